@@ -1,0 +1,104 @@
+"""Deterministic synthetic LiDAR scans (no KITTI in the build/bench environment).
+
+A rotating multi-ring sensor is ray-cast inside a box room with a ground plane and a few
+box obstacles; the second scan of a pair re-observes the same scene from a pose moved by
+a known small SE(3).  Only numpy (``default_rng(seed)``) is used, so the same seed gives
+the same scans in the build container and on the GPU box.  The layout matches what the
+reference reads from disk: a scan is ``[3,N]`` fp32, x forward / y left / z up, sensor at
+the origin (src/data/dataset.py:94-102 loads ``[M,3]`` npy and permutes to ``[1,3,M]``).
+"""
+import math
+
+import numpy as np
+
+
+def _rot_zyx(yaw, pitch, roll):
+    cy, sy, cp, sp, cr, sr = math.cos(yaw), math.sin(yaw), math.cos(pitch), math.sin(pitch), math.cos(roll), math.sin(roll)
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1.0]])
+    Ry = np.array([[cp, 0, sp], [0, 1.0, 0], [-sp, 0, cp]])
+    Rx = np.array([[1.0, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    return Rz @ Ry @ Rx
+
+
+class Scene:
+    """Axis-aligned room [-ax,ax]x[-ay,ay], ground z=-h, ceiling z=+c, plus solid boxes."""
+
+    def __init__(self, rng, half_x=22.0, half_y=9.0, sensor_height=1.73, ceiling=6.0, n_boxes=6):
+        self.half_x, self.half_y = half_x, half_y
+        self.ground, self.ceiling = -sensor_height, ceiling
+        boxes = []
+        for _ in range(n_boxes):
+            cx = rng.uniform(-0.8 * half_x, 0.8 * half_x)
+            cy = rng.uniform(-0.8 * half_y, 0.8 * half_y)
+            if abs(cx) < 3.0 and abs(cy) < 3.0:           # keep the sensor in free space
+                cx += 6.0 * (1 if cx >= 0 else -1)
+            sx, sy, sz = rng.uniform(0.6, 2.5), rng.uniform(0.6, 2.5), rng.uniform(0.8, 2.5)
+            boxes.append((cx - sx, cx + sx, cy - sy, cy + sy, self.ground, self.ground + sz))
+        self.boxes = boxes
+
+    def cast(self, origin, dirs):
+        """Distance along each unit ray (``dirs[K,3]``) to the first surface; inf if none."""
+        o = origin.reshape(1, 3)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = 1.0 / dirs
+        t_best = np.full(dirs.shape[0], np.inf)
+        # room: we are inside, take the exit distance of the slab intersection
+        lo = np.array([-self.half_x, -self.half_y, self.ground])
+        hi = np.array([self.half_x, self.half_y, self.ceiling])
+        t1 = (lo - o) * inv
+        t2 = (hi - o) * inv
+        t_exit = np.nanmin(np.maximum(t1, t2), axis=1)
+        t_best = np.minimum(t_best, np.where(t_exit > 0, t_exit, np.inf))
+        for (x0, x1, y0, y1, z0, z1) in self.boxes:
+            lo = np.array([x0, y0, z0])
+            hi = np.array([x1, y1, z1])
+            t1 = (lo - o) * inv
+            t2 = (hi - o) * inv
+            t_in = np.nanmax(np.minimum(t1, t2), axis=1)
+            t_out = np.nanmin(np.maximum(t1, t2), axis=1)
+            hit = (t_in > 0) & (t_in <= t_out)
+            t_best = np.where(hit & (t_in < t_best), t_in, t_best)
+        return t_best
+
+
+def scan_scene(scene, rng, rings=64, azimuth_steps=2250, vfov_deg=(-24.5, 2.0), pose=None,
+               noise=0.01, min_range=1.0, max_range=80.0, dropout=0.02):
+    """One revolution: ``rings`` x ``azimuth_steps`` rays, returns ``[3,N]`` fp32 in the sensor frame."""
+    R, t = (np.eye(3), np.zeros(3)) if pose is None else pose
+    el = np.deg2rad(np.linspace(vfov_deg[0], vfov_deg[1], rings))
+    el = el + rng.normal(0, 2e-4, size=rings)
+    az0 = rng.uniform(0, 2 * math.pi / azimuth_steps, size=rings)
+    az = (np.arange(azimuth_steps) * (2 * math.pi / azimuth_steps))[None, :] + az0[:, None] - math.pi
+    elg = np.broadcast_to(el[:, None], az.shape)
+    d = np.stack([np.cos(elg) * np.cos(az), np.cos(elg) * np.sin(az), np.sin(elg)], axis=-1).reshape(-1, 3)
+    dist = scene.cast(t, d @ R.T)
+    dist = dist + rng.normal(0, noise, size=dist.shape)
+    ok = np.isfinite(dist) & (dist > min_range) & (dist < max_range) & (rng.uniform(size=dist.shape) > dropout)
+    pts = d[ok] * dist[ok, None]
+    order = rng.permutation(pts.shape[0])        # raw driver order is not range- or ring-sorted
+    return np.ascontiguousarray(pts[order].T.astype(np.float32))
+
+
+def make_pair(seed, rings=64, azimuth_steps=2250, vfov_deg=(-24.5, 2.0), max_shift=1.0, max_rot_deg=3.0, **kw):
+    """(scan_1, scan_2, T_21) with T_21 mapping scan-2 coordinates into the scan-1 frame (what the
+    network is asked to predict: target = scan 1, source = scan 2, src/deploy/deployer.py:294-307)."""
+    rng = np.random.default_rng(seed)
+    scene = Scene(rng)
+    s1 = scan_scene(scene, rng, rings, azimuth_steps, vfov_deg, None, **kw)
+    yaw, pitch, roll = np.deg2rad(rng.uniform(-max_rot_deg, max_rot_deg)), np.deg2rad(rng.uniform(-0.3, 0.3)), np.deg2rad(rng.uniform(-0.3, 0.3))
+    R = _rot_zyx(yaw, pitch, roll)
+    t = np.array([rng.uniform(0.2, max_shift), rng.uniform(-0.1, 0.1), rng.uniform(-0.02, 0.02)])
+    s2 = scan_scene(scene, rng, rings, azimuth_steps, vfov_deg, (R, t), **kw)
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, t
+    return s1, s2, T.astype(np.float32)
+
+
+def pad_or_trim(scan, n, rng=None):
+    """Fixed-size ``[3,n]`` variant (clean byte counts for the bench): trims, or repeats points."""
+    N = scan.shape[1]
+    if N >= n:
+        return np.ascontiguousarray(scan[:, :n])
+    rng = rng or np.random.default_rng(0)
+    extra = scan[:, rng.integers(0, N, size=n - N)]
+    return np.ascontiguousarray(np.concatenate([scan, extra], axis=1))

@@ -1,0 +1,355 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE.
+
+Runs only in the build container (needs /root/reference, which never travels to the GPU
+box).  The reference's hot-path modules are imported unmodified; third-party modules that
+are absent here get harness-side stubs:
+  numba.njit      -> identity decorator (the loop then runs interpreted, same semantics)
+  torch.symeig    -> torch.linalg.eigh(UPLO="U")  (removed from torch >= 1.13)
+  kornia          -> quaternion_to_rotation_matrix restated from kornia 0.3.0 (the one boundary the
+                     reference itself cannot pin; see oracle/delora_oracle.py)
+  mlflow, qqdm, cv2, pykitti -> empty modules (not touched by the step)
+While writing each fixture the script also asserts that oracle/delora_oracle.py reproduces the
+reference output (bit-exact for indices and fp32 values computed by identical torch ops).
+
+Usage:  python tests/golden/make_golden.py        (writes tests/golden/*.npz)
+"""
+import copy
+import hashlib
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+import yaml
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle import delora_oracle as orc                      # noqa: E402
+from delora_amd.data import synthetic                         # noqa: E402
+
+
+# ----------------------------------------------------------------------------- stubs
+def install_stubs():
+    numba = types.ModuleType("numba")
+    numba.njit = lambda f=None, **kw: f if f is not None else (lambda g: g)
+    sys.modules["numba"] = numba
+    kornia = types.ModuleType("kornia")
+    kornia.quaternion_to_rotation_matrix = lambda quaternion: orc.quaternion_to_rotation_matrix(quaternion)
+    sys.modules["kornia"] = kornia
+    for name in ("mlflow", "mlflow.pytorch", "mlflow.tracking", "qqdm", "cv2", "pykitti"):
+        sys.modules[name] = types.ModuleType(name)
+    sys.modules["mlflow"].pytorch = sys.modules["mlflow.pytorch"]
+    def symeig(a, eigenvectors=False, upper=True):       # torch >= 1.13 only keeps a raising stub
+        w, v = torch.linalg.eigh(a, UPLO="U" if upper else "L")
+        return w, v
+    torch.symeig = symeig
+    sys.path.insert(0, os.path.join(REF, "src"))
+
+
+def reference_config(H, W, dataset="kitti", **over):
+    cfg = {}
+    for f in ("config_datasets.yaml", "deployment_options.yaml", "hyperparameters.yaml"):
+        cfg.update(yaml.load(open(os.path.join(REF, "config", f)), Loader=yaml.FullLoader))
+    cfg["device"] = torch.device("cpu")
+    for ds in ("kitti", "darpa"):
+        cfg[ds]["vertical_field_of_view"][0] *= (np.pi / 180.0)
+        cfg[ds]["vertical_field_of_view"][1] *= (np.pi / 180.0)
+        cfg[ds]["data_identifiers"] = cfg[ds]["training_identifiers"]
+    cfg["horizontal_field_of_view"][0] *= (np.pi / 180.0)
+    cfg["horizontal_field_of_view"][1] *= (np.pi / 180.0)
+    cfg[dataset]["vertical_cells"] = H
+    cfg[dataset]["horizontal_cells"] = W
+    cfg["datasets"] = [dataset]
+    cfg["mode"] = "training"
+    cfg["checkpoint"] = None
+    cfg["training_run_name"] = cfg["run_name"] = "golden"
+    cfg.update(over)
+    return cfg
+
+
+def sensor_of(cfg, dataset="kitti"):
+    return orc.Sensor(cfg[dataset]["vertical_cells"], cfg[dataset]["horizontal_cells"],
+                      cfg[dataset]["vertical_field_of_view"], cfg["horizontal_field_of_view"])
+
+
+def t2n(x):
+    return x.detach().cpu().numpy()
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def ambiguity_mask(scan, sensor, tol=2e-3):
+    """Points whose fp64 image coordinate lies within ``tol`` px of a rounding boundary (or of the
+    field-of-view edge): the only points whose pixel may legitimately differ between two correct
+    fp32 atan2 implementations."""
+    p = scan.astype(np.float64)
+    u = (np.arctan2(p[1], p[0]) - sensor.hfov[0]) / (sensor.hfov[1] - sensor.hfov[0]) * (sensor.W - 1)
+    v = (np.arctan2(p[2], np.hypot(p[0], p[1])) - sensor.vfov[0]) / (sensor.vfov[1] - sensor.vfov[0]) * (sensor.H - 1)
+    fu = np.abs(u - np.floor(u) - 0.5)
+    fv = np.abs(v - np.floor(v) - 0.5)
+    return (fu < tol) | (fv < tol)
+
+
+def assert_same(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert np.array_equal(a, b), (what, float(np.abs(a.astype(np.float64) - b.astype(np.float64)).max()))
+
+
+# ----------------------------------------------------------------------------- fixtures
+def fx_projection(out):
+    import utility.projection as rproj
+    cases = {}
+    # small synthetic scans, C=3 and C=6 (extra channels ride along, deployer.py:75-86 uses C=6/9)
+    for name, (H, W, rings, az, C, seed) in {
+        "small": (16, 128, 16, 160, 3, 11), "small_c6": (16, 128, 16, 160, 6, 12),
+        "mid": (64, 512, 64, 600, 3, 13),
+    }.items():
+        cfg = reference_config(H, W)
+        s1, _, _ = synthetic.make_pair(seed, rings=rings, azimuth_steps=az)
+        if C == 6:
+            rng = np.random.default_rng(seed)
+            s1 = np.concatenate([s1, rng.normal(size=s1.shape).astype(np.float32)], axis=0)
+        cases[name] = (cfg, s1)
+    # hand-made edge cases: same-pixel collisions (nearest wins), range ties on distinct pixels, points
+    # outside the vertical FoV, azimuth at +-pi (falls outside the +-179.9 deg window), exact-zero coords
+    cfg = reference_config(8, 32)
+    sen = sensor_of(cfg)
+    el = 0.5 * (sen.vfov[0] + sen.vfov[1])
+    def sph(r, az_, el_):
+        return [r * np.cos(el_) * np.cos(az_), r * np.cos(el_) * np.sin(az_), r * np.sin(el_)]
+    pts = [sph(10.0, 0.3, el), sph(7.0, 0.3, el), sph(12.0, 0.3, el), sph(5.0, 0.3001, el),   # collisions
+           sph(6.0, -1.0, el), sph(6.0, 1.0, el),                                            # equal range, different pixels
+           sph(9.0, 0.1, 0.5), sph(9.0, 0.1, -0.9),                                          # outside vFoV
+           sph(4.0, np.pi, el), sph(4.0, -np.pi + 1e-4, el), sph(4.0, np.pi - 1e-4, el),     # azimuth wrap edge
+           [0.0, 3.0, -0.5], [3.0, 0.0, -0.5], [2.0, 2.0, 0.0],                               # exact-zero coordinates
+           sph(20.0, 2.0, sen.vfov[0] + 1e-3), sph(20.0, 2.0, sen.vfov[1] - 1e-3)]           # FoV borders
+    cases["edge"] = (cfg, np.asarray(pts, dtype=np.float32).T.copy())
+    # empty-after-filter input: everything outside the FoV
+    cases["all_outside"] = (reference_config(8, 32), np.asarray([sph(9.0, 0.1, 0.6), sph(3.0, 1.0, 0.7)], dtype=np.float32).T.copy())
+
+    for name, (cfg, scan) in cases.items():
+        layer = rproj.ImageProjectionLayer(config=cfg)
+        x = torch.from_numpy(scan).view(1, scan.shape[0], -1)
+        image, u, v, idx, pix = layer(input=x, dataset="kitti")
+        sen = sensor_of(cfg)
+        o = orc.project_to_img(x, sen)
+        for a, b, w in zip((image, u, v, idx, pix), o, ("image", "u", "v", "idx", "pix")):
+            assert_same(t2n(a), t2n(b), f"projection/{name}/{w}")
+        out[f"proj_{name}"] = dict(scan=scan, H=sen.H, W=sen.W, vfov=np.asarray(sen.vfov), hfov=np.asarray(sen.hfov),
+                                   image=t2n(image), u=t2n(u), v=t2n(v), idx=t2n(idx), pix=t2n(pix),
+                                   ambiguous=ambiguity_mask(scan[:3], sen))
+        print(f"  projection {name}: N={scan.shape[1]} kept={len(idx)} ambiguous={int(out[f'proj_{name}']['ambiguous'].sum())}")
+
+    # full-size digest: 64x2048, only compact data (pixel->point map as int32, sha of the float image)
+    cfg = reference_config(64, 2048)
+    s1, _, _ = synthetic.make_pair(2001)
+    layer = rproj.ImageProjectionLayer(config=cfg)
+    x = torch.from_numpy(s1).view(1, 3, -1)
+    image, u, v, idx, pix = layer(input=x, dataset="kitti")
+    sen = sensor_of(cfg)
+    o = orc.project_to_img(x, sen)
+    assert_same(t2n(idx), t2n(o[3]), "projection/full/idx")
+    assert_same(t2n(image), t2n(o[0]), "projection/full/image")
+    pix2pt = -np.ones((sen.H, sen.W), dtype=np.int32)
+    p = t2n(pix)[0]
+    pix2pt[p[:, 0], p[:, 1]] = t2n(idx).astype(np.int32)
+    amb = ambiguity_mask(s1, sen)
+    out["proj_full_digest"] = dict(seed=2001, H=sen.H, W=sen.W, vfov=np.asarray(sen.vfov), hfov=np.asarray(sen.hfov),
+                                   N=s1.shape[1], scan_sha=sha(s1), pix2pt=pix2pt, kept=len(idx),
+                                   ambiguous_idx=np.nonzero(amb)[0].astype(np.int32),
+                                   range_sum=float(t2n(image)[0, 3].astype(np.float64).sum()))
+    print(f"  projection full: N={s1.shape[1]} kept={len(idx)} ambiguous={int(amb.sum())}")
+
+
+def fx_normals(out):
+    import utility.projection as rproj
+    import preprocessing.normal_computation as rnorm
+    for name, (H, W, rings, az, seed) in {"small": (16, 128, 16, 140, 21), "mid": (64, 256, 64, 280, 22)}.items():
+        cfg = reference_config(H, W)
+        s1, _, _ = synthetic.make_pair(seed, rings=rings, azimuth_steps=az, dropout=0.08)
+        layer = rproj.ImageProjectionLayer(config=cfg)
+        image, *_ = layer(input=torch.from_numpy(s1).view(1, 3, -1), dataset="kitti")
+        if name == "small":        # plant exact-zero coordinates and a hole block (a4: AND-validity, a6: absent neighbours)
+            image[0, 0, 3, 10] = 0.0
+            image[0, :, 5:9, 40:50] = 0.0
+        nc = rnorm.NormalsComputer(config=cfg, dataset_name="kitti")
+        normals, has, pts = nc.compute_normal_vectors(image=image.clone())
+        sen = sensor_of(cfg)
+        on, oh, op, aux = orc.compute_normal_vectors(image.clone(), sen, side=cfg["kitti"]["neighborhood_side_length"],
+                                                     epsilon_range=cfg["epsilon_range"],
+                                                     min_neighbors=cfg["min_num_points_in_neighborhood_to_determine_point_class"],
+                                                     return_aux=True)
+        assert_same(t2n(has), t2n(oh), f"normals/{name}/has")
+        assert_same(t2n(pts), t2n(op), f"normals/{name}/pts")
+        assert_same(t2n(normals), t2n(on), f"normals/{name}/normals")
+        out[f"normals_{name}"] = dict(image=t2n(image), H=H, W=W, side=np.asarray(cfg["kitti"]["neighborhood_side_length"]),
+                                      epsilon_range=cfg["epsilon_range"],
+                                      min_neighbors=cfg["min_num_points_in_neighborhood_to_determine_point_class"],
+                                      normals=t2n(normals), has=t2n(has), points=t2n(pts),
+                                      count=t2n(aux["count"]).astype(np.int32), eigenvalues=t2n(aux["eigenvalues"]),
+                                      v=t2n(aux["v"]).astype(np.int32), u=t2n(aux["u"]).astype(np.int32))
+        print(f"  normals {name}: valid={len(pts)} with_normal={int(has.sum())}")
+
+
+def preprocessed_lists(seed, H_pre, W_pre, rings, az, cfg_base):
+    """What bin/preprocess_data.py stores for a pair: projected points [M,3] + normals [M,3]
+    (src/preprocessing/preprocesser.py:50-68), produced here by the reference's own classes."""
+    import utility.projection as rproj
+    import preprocessing.normal_computation as rnorm
+    cfg = copy.deepcopy(cfg_base)
+    cfg["kitti"]["vertical_cells"], cfg["kitti"]["horizontal_cells"] = H_pre, W_pre
+    s1, s2, T = synthetic.make_pair(seed, rings=rings, azimuth_steps=az)
+    layer = rproj.ImageProjectionLayer(config=cfg)
+    nc = rnorm.NormalsComputer(config=cfg, dataset_name="kitti")
+    res = []
+    for s in (s1, s2):
+        image, *_ = layer(input=torch.from_numpy(s).view(1, 3, -1), dataset="kitti")
+        normals, _, pts = nc.compute_normal_vectors(image=image)
+        res.append((t2n(pts).copy(), t2n(normals).copy()))
+    return res, T
+
+
+def fx_loss(out):
+    import losses.icp_losses as rloss
+    import models.model_parts as rparts
+    cfg0 = reference_config(16, 128)
+    (l1, l2), T_true = preprocessed_lists(31, 16, 160, 16, 200, cfg0)
+    tgt = torch.from_numpy(l1[0]).permute(1, 0).view(1, 3, -1)
+    tgt_n = torch.from_numpy(l1[1]).permute(1, 0).view(1, 3, -1)
+    src = torch.from_numpy(l2[0]).permute(1, 0).view(1, 3, -1)
+    src_n = torch.from_numpy(l2[1]).permute(1, 0).view(1, 3, -1)
+    rng = np.random.default_rng(5)
+    qs = {"identity": np.array([0, 0, 0, 1.0]), "true": None, "random": rng.normal(size=4)}
+    entry = dict(tgt=l1[0], tgt_n=l1[1], src=l2[0], src_n=l2[1], T_true=T_true)
+    for mode in ("squared", "linear"):
+        for p2p in (False, True):
+            cfg = reference_config(16, 128, normal_loss=mode, point_to_point_loss=p2p)
+            ref = rloss.ICPLosses(config=cfg)
+            for qname, qv in qs.items():
+                if qv is None:
+                    # quaternion of the true motion, perturbed a little
+                    from scipy.spatial.transform import Rotation
+                    qv = Rotation.from_matrix(T_true[:3, :3].astype(np.float64)).as_quat() + rng.normal(0, 1e-3, 4)
+                    tv = T_true[:3, 3] + rng.normal(0, 0.02, 3)
+                elif qname == "identity":
+                    tv = np.zeros(3)
+                else:
+                    tv = rng.normal(0, 1.0, 3)
+                t = torch.tensor(tv, dtype=torch.float32).view(1, 3).requires_grad_(True)
+                q = torch.tensor(qv, dtype=torch.float32).view(1, 4).requires_grad_(True)
+                T = rparts.GeometryHandler.get_transformation_matrix_quaternion(translation=t, quaternion=q, device=torch.device("cpu"))
+                T.retain_grad()
+                s_t = T[:, :3, :3].matmul(src) + T[:, :3, 3].view(-1, 3, 1)
+                n_t = T[:, :3, :3].matmul(src_n)
+                losses, plotting = ref(source_point_cloud_transformed=s_t, source_normal_list_transformed=n_t,
+                                       target_point_cloud=tgt, target_normal_list=tgt_n, compute_pointwise_loss_bool=False)
+                total = losses["loss_po2po"] + 2.0 * losses["loss_po2pl"] + 0.5 * losses["loss_pl2pl"]
+                total.backward()
+                o, aux = orc.icp_losses(orc.transform_points(T.detach(), src), orc.rotate_points(T.detach(), src_n), tgt, tgt_n,
+                                        normal_loss=mode, point_to_point=p2p, return_aux=True)
+                for k in ("loss_po2po", "loss_po2pl", "loss_pl2pl"):
+                    assert_same(t2n(losses[k]), t2n(o[k]), f"loss/{mode}/{p2p}/{qname}/{k}")
+                key = f"{mode}_{'p2p' if p2p else 'nop2p'}_{qname}"
+                entry[key + "_t"] = t2n(t)
+                entry[key + "_q"] = t2n(q)
+                entry[key + "_T"] = t2n(T)
+                entry[key + "_losses"] = np.array([t2n(losses[k]).item() for k in ("loss_po2po", "loss_po2pl", "loss_pl2pl")], dtype=np.float64)
+                entry[key + "_gradT"] = t2n(T.grad)          # d(po2po + 2 po2pl + 0.5 pl2pl)/dT
+                entry[key + "_nn"] = t2n(aux["nn_with_normals"]).astype(np.int32)
+                entry[key + "_pairs"] = aux["pairs"]
+                print(f"  loss {key}: pairs={aux['pairs']} losses={entry[key + '_losses']}")
+    out["loss_pair"] = entry
+
+
+def fx_geometry(out):
+    import models.model_parts as rparts
+    rng = np.random.default_rng(9)
+    q = np.concatenate([np.array([[0, 0, 0, 1.0], [0, 0, 1.0, 0], [1.0, 0, 0, 0], [0.5, 0.5, 0.5, 0.5]]), rng.normal(size=(12, 4))]).astype(np.float32)
+    t = rng.normal(size=(16, 3)).astype(np.float32)
+    T = rparts.GeometryHandler.get_transformation_matrix_quaternion(translation=torch.from_numpy(t), quaternion=torch.from_numpy(q), device=torch.device("cpu"))
+    assert_same(t2n(T), t2n(orc.transformation_matrix(torch.from_numpy(t), torch.from_numpy(q))), "geometry/T")
+    out["geometry"] = dict(q=q, t=t, T=t2n(T), note="kornia 0.3.0 restated: parity unpinned by the reference")
+
+
+def fx_model_and_step(out):
+    """Reference OdometryModel forward and full Trainer.step (projection -> CNN -> T -> losses -> backward -> Adam)
+    on a small configuration; the initial state_dict is part of the fixture."""
+    import deploy.trainer as rtrainer
+    H, W = 16, 128
+    small = dict(factor_fewer_resnet_channels=8, resnet_outputs=64, unsupervised_at_start=True, inference_only=False,
+                 batch_size=2, store_dataset_in_RAM=False)
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg = reference_config(H, W, **small)
+        cfg["kitti"]["preprocessed_path"] = tmp
+        cfg["kitti"]["data_identifiers"] = cfg["kitti"]["training_identifiers"] = [0]
+        os.makedirs(os.path.join(tmp, "00", "scans"))
+        os.makedirs(os.path.join(tmp, "00", "normals"))
+        scans = []
+        for k, seed in enumerate((41, 42)):
+            (l1, l2), _ = preprocessed_lists(seed, 16, 160, 16, 200, cfg)
+            scans += [l1, l2]
+        for i, (pts, nrm) in enumerate(scans):
+            np.save(os.path.join(tmp, "00", "scans", f"{i:06d}.npy"), pts)
+            np.save(os.path.join(tmp, "00", "normals", f"{i:06d}.npy"), nrm)
+        torch.manual_seed(1234)
+        trainer = rtrainer.Trainer(config=cfg)
+        state0 = {k: t2n(v).copy() for k, v in trainer.model.state_dict().items()}
+        ds = trainer.dataset
+        # -- model forward alone (a7)
+        sen = sensor_of(cfg)
+        d0 = ds[0]
+        img1, img2, _ = orc.filter_to_projected(d0, sen)
+        with torch.no_grad():
+            tr, qr = trainer.model(image_1=img1.unsqueeze(0), image_2=img2.unsqueeze(0))
+        out["model_small"] = dict(H=H, W=W, image_1=t2n(img1), image_2=t2n(img2), translation=t2n(tr), quaternion=t2n(qr),
+                                  **{"sd::" + k: v for k, v in state0.items()},
+                                  **{"cfg::" + k: np.asarray(v) for k, v in small.items() if k in ("factor_fewer_resnet_channels", "resnet_outputs")})
+        # -- full step, B=2 (samples 0 and 2 are the two independent pairs; sample 1 pairs scan 1 with scan 2)
+        for name, picks in {"b1": [0], "b2": [0, 2]}.items():
+            torch.manual_seed(1234)
+            cfg_s = copy.deepcopy(cfg)
+            cfg_s["batch_size"] = len(picks)
+            trn = rtrainer.Trainer(config=cfg_s)
+            trn.model.load_state_dict({k: torch.from_numpy(v) for k, v in state0.items()})
+            dicts = [ds[i] for i in picks]
+            raw = [{k: (t2n(v).copy() if hasattr(v, "numpy") else v) for k, v in d.items()} for d in dicts]
+            ep = {k: 0.0 for k in ("loss_epoch", "loss_point_cloud_epoch", "loss_po2po_epoch", "loss_po2pl_epoch", "loss_pl2pl_epoch", "visible_pixels_epoch")}
+            trn.optimizer.zero_grad()
+            ep, T = trn.step(preprocessed_dicts=dicts, epoch_losses=ep, log_images_bool=False)
+            grads = {k: t2n(p.grad).copy() for k, p in trn.model.named_parameters()}
+            state1 = {k: t2n(v).copy() for k, v in trn.model.state_dict().items()}
+            e = dict(H=H, W=W, picks=np.asarray(picks), T=t2n(T),
+                     **{"ep::" + k: float(np.asarray(v).sum()) for k, v in ep.items()},
+                     **{"gradnorm::" + k: float(np.linalg.norm(v.astype(np.float64))) for k, v in grads.items()},
+                     **{"delta::" + k: (state1[k].astype(np.float64) - state0[k].astype(np.float64)).sum() for k in state0})
+            for j, r in enumerate(raw):
+                for k in ("scan_1", "scan_2", "normal_list_1", "normal_list_2"):
+                    e[f"s{j}::{k}"] = r[k]
+            out[f"step_{name}"] = e
+            print(f"  step {name}: loss={e['ep::loss_epoch']:.6f} po2pl={e['ep::loss_po2pl_epoch']:.6f} pl2pl={e['ep::loss_pl2pl_epoch']:.6f} vis={e['ep::visible_pixels_epoch']}")
+
+
+def main():
+    install_stubs()
+    torch.set_num_threads(8)
+    out = {}
+    for f in (fx_projection, fx_normals, fx_geometry, fx_loss, fx_model_and_step):
+        print(f.__name__)
+        f(out)
+    for name, d in out.items():
+        path = os.path.join(HERE, name + ".npz")
+        np.savez_compressed(path, **{k: np.asarray(v) for k, v in d.items()})
+        print(f"wrote {os.path.relpath(path, ROOT)}  {os.path.getsize(path) / 1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()
