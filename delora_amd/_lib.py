@@ -1,0 +1,73 @@
+"""ctypes binding of libdelora_hip.so (include/delora_hip.h).
+
+The library is the only implementation of the geometry path: if it is missing or cannot be
+loaded this module raises -- there is no CPU or torch fallback.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdelora_hip.so")
+ABI_VERSION = 1
+
+
+class DeloraHipError(RuntimeError):
+    pass
+
+
+class SensorStruct(ctypes.Structure):
+    """``dl_sensor`` of include/delora_hip.h."""
+    _fields_ = [("H", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("hfov0", ctypes.c_double), ("hfov1", ctypes.c_double),
+                ("vfov0", ctypes.c_double), ("vfov1", ctypes.c_double)]
+
+
+_vp, _i32, _i64, _u32, _f32, _sz = (ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_uint32,
+                                    ctypes.c_float, ctypes.c_size_t)
+_SP = ctypes.POINTER(SensorStruct)
+
+# name -> (restype, argtypes); mirrors the declarations of include/delora_hip.h one to one
+SIGNATURES = {
+    "dl_abi_version": (_i32, []),
+    "dl_last_error": (ctypes.c_char_p, []),
+    "dl_project_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "dl_project": (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _SP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dl_normals": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
+    "dl_nn_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "dl_nn_correspond": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _SP, _i32, _vp, _vp, _vp, _vp]),
+    "dl_icp_loss_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "dl_icp_loss_fwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _u32,
+                               _vp, _vp, _vp, _vp, _vp]),
+    "dl_icp_loss_bwd": (_i32, [_vp, _vp, _i32, _vp, _vp]),
+    "dl_nn_bruteforce": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the bound library; raises DeloraHipError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DeloraHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C delora_amd/csrc`. The geometry path has no fallback implementation.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise DeloraHipError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dl_abi_version() != ABI_VERSION:
+        raise DeloraHipError(f"libdelora_hip.so ABI {lib.dl_abi_version()} != expected {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        raise DeloraHipError(f"{what} failed ({status}): {load().dl_last_error().decode()}")

@@ -1,0 +1,59 @@
+// Shared device helpers for the DeLORA geometry kernels (gfx950 only, wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/delora_hip.h"
+
+#define DL_WAVE 64
+#define DL_BLOCK 256
+
+// Sensor constants resolved on the host once per call (passed to kernels by value).
+struct SensorK {
+  int H, W, HW;
+  // fp32 constants of the reference expression ((atan2 - f0) / (f1 - f0)) * (cells - 1),
+  // src/utility/projection.py:23-30: torch casts the python-float scalars to fp32.
+  float hf0f, hspanf, wm1f;
+  float vf0f, vspanf, hm1f;
+  // fp64 geometry for the nearest-neighbour window bounds: radians per pixel and origins.
+  double hf0, hres, vf0, vres;
+};
+
+static inline SensorK make_sensor(const dl_sensor* s) {
+  SensorK k;
+  k.H = s->H; k.W = s->W; k.HW = s->H * s->W;
+  k.hf0f = (float)s->hfov0; k.hspanf = (float)(s->hfov1 - s->hfov0); k.wm1f = (float)(s->W - 1);
+  k.vf0f = (float)s->vfov0; k.vspanf = (float)(s->vfov1 - s->vfov0); k.hm1f = (float)(s->H - 1);
+  k.hf0 = s->hfov0; k.hres = (s->hfov1 - s->hfov0) / (double)(s->W - 1);
+  k.vf0 = s->vfov0; k.vres = (s->vfov1 - s->vfov0) / (double)(s->H - 1);
+  return k;
+}
+
+// torch.norm(x[:3], dim=0) on the reference's CPU build rounds as sqrt(fma(z,z,fma(y,y,x*x))).
+__device__ __forceinline__ float norm3f(float x, float y, float z) {
+  return __fsqrt_rn(__fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x))));
+}
+__device__ __forceinline__ float norm2f(float x, float y) {
+  return __fsqrt_rn(__fmaf_rn(y, y, __fmul_rn(x, x)));
+}
+
+// fp32 image coordinates exactly in the reference's operation order; the atan2 itself is evaluated
+// in fp64 and rounded once (a correctly rounded fp32 atan2 up to double rounding).
+__device__ __forceinline__ float coord_u(float x, float y, const SensorK& s) {
+  float a = (float)atan2((double)y, (double)x);
+  return __fmul_rn(__fdiv_rn(__fsub_rn(a, s.hf0f), s.hspanf), s.wm1f);
+}
+__device__ __forceinline__ float coord_v(float x, float y, float z, const SensorK& s) {
+  float e = (float)atan2((double)z, (double)norm2f(x, y));
+  return __fmul_rn(__fdiv_rn(__fsub_rn(e, s.vf0f), s.vspanf), s.hm1f);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, DL_WAVE);
+  return v;
+}
+
+extern thread_local char g_dl_err[256];
+int dl_fail(int code, const char* fmt, ...);
+int dl_check_launch(const char* what);

@@ -1,0 +1,182 @@
+"""Batched geometry of the DeLORA training step on MI355X: thin torch wrappers over the C ABI.
+
+Every function takes/returns CUDA(HIP) tensors, allocates outputs with torch's caching allocator,
+passes raw device pointers plus torch's *current stream* to libdelora_hip.so, and never
+synchronises.  Layouts are those of include/delora_hip.h: planar fp32 range images
+``[S,4,H,W]`` (x,y,z,range), planar normals ``[S,3,H,W]``, int32 pixel maps.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+
+LOSS_POINT_TO_POINT, LOSS_POINT_TO_PLANE, LOSS_PLANE_TO_PLANE, LOSS_NORMAL_LINEAR = 1, 2, 4, 8
+
+
+class Sensor:
+    """Projection parameters of one dataset, resolved once from the reference's flat config
+    (``config[dataset]["vertical_cells"|"horizontal_cells"|"vertical_field_of_view"]`` and
+    ``config["horizontal_field_of_view"]``, radians; reference src/utility/projection.py:16,50-52)."""
+
+    def __init__(self, height, width, vfov, hfov):
+        self.H, self.W = int(height), int(width)
+        self.vfov = (float(vfov[0]), float(vfov[1]))
+        self.hfov = (float(hfov[0]), float(hfov[1]))
+        self.struct = _lib.SensorStruct(self.H, self.W, self.hfov[0], self.hfov[1], self.vfov[0], self.vfov[1])
+
+    @classmethod
+    def from_config(cls, config, dataset):
+        d = config[dataset]
+        return cls(d["vertical_cells"], d["horizontal_cells"], d["vertical_field_of_view"],
+                   config["horizontal_field_of_view"])
+
+    def key(self):
+        return (self.H, self.W, self.vfov, self.hfov)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise _lib.DeloraHipError("delora_amd geometry needs tensors on the GPU (no CPU implementation)")
+
+
+def _planar(t, channels):
+    """(data_ptr tensor, scan stride) of a ``[S,channels,H,W]`` tensor whose inner three dims are dense."""
+    S, C, H, W = t.shape
+    if C < channels or t.stride(3) != 1 or t.stride(2) != W or t.stride(1) != H * W or t.dtype != torch.float32:
+        raise ValueError(f"expected planar fp32 [S,>={channels},H,W] with dense inner dims, got {tuple(t.shape)} / {t.stride()}")
+    return t, t.stride(0)
+
+
+def project(points, offsets, max_points, sensor, want_uv=False):
+    """Range images of S scans.  points ``[C,sumN]`` fp32 (rows 0..2 = xyz), offsets ``[S+1]`` int32 (device).
+    Returns dict(image4 [S,4,H,W], aux [S,C-3,H,W]|None, pix2pt [S,H,W] int32, kept [S] int32, uv [2,sumN]|None)."""
+    lib = _lib.load()
+    _require_cuda(points, offsets)
+    if points.dtype != torch.float32 or points.dim() != 2 or points.stride(1) != 1:
+        raise ValueError("points must be fp32 [C,sumN] with unit inner stride")
+    if offsets.dtype != torch.int32:
+        raise ValueError("offsets must be int32")
+    C, S = points.shape[0], offsets.numel() - 1
+    H, W, dev = sensor.H, sensor.W, points.device
+    image4 = torch.empty((S, 4, H, W), dtype=torch.float32, device=dev)
+    aux = torch.empty((S, C - 3, H, W), dtype=torch.float32, device=dev) if C > 3 else None
+    pix2pt = torch.empty((S, H, W), dtype=torch.int32, device=dev)
+    kept = torch.empty((S,), dtype=torch.int32, device=dev)
+    keys = torch.empty((lib.dl_project_workspace_bytes(S, H, W) // 8,), dtype=torch.int64, device=dev)
+    uv = torch.empty((2, points.shape[1]), dtype=torch.float32, device=dev) if want_uv else None
+    if uv is not None and points.stride(0) != uv.stride(0):
+        raise ValueError("want_uv needs a dense points buffer")
+    _lib.check(lib.dl_project(_ptr(points), points.stride(0), _ptr(offsets), S, C, int(max_points),
+                              ctypes.byref(sensor.struct), _ptr(image4), _ptr(aux), _ptr(pix2pt), _ptr(keys),
+                              _ptr(kept), _ptr(uv), _stream()), "dl_project")
+    return {"image4": image4, "aux": aux, "pix2pt": pix2pt, "kept": kept, "uv": uv}
+
+
+def normals(image4, half_rows=3, half_cols=5, epsilon_range=0.5, min_neighbors=10):
+    """Normals ``[S,3,H,W]`` of range images ``[S,>=3,H,W]`` (zero vector = no normal)."""
+    lib = _lib.load()
+    _require_cuda(image4)
+    t, ss = _planar(image4, 3)
+    S, _, H, W = t.shape
+    out = torch.empty((S, 3, H, W), dtype=torch.float32, device=t.device)
+    _lib.check(lib.dl_normals(_ptr(t), ss, S, H, W, int(half_rows), int(half_cols), float(epsilon_range),
+                              int(min_neighbors), _ptr(out), _stream()), "dl_normals")
+    return out
+
+
+def nn_correspond(src_image4, src_normals, tgt_image4, T, sensor, need_without_normals=False, want_visible=True):
+    """Exact nearest target pixel of every transformed source point.  Returns (nn_pix [B,H,W] int32, visible [B]|None)."""
+    lib = _lib.load()
+    _require_cuda(src_image4, tgt_image4, T)
+    s, s_ss = _planar(src_image4, 3)
+    t, t_ss = _planar(tgt_image4, 3)
+    n, n_ss = _planar(src_normals, 3) if src_normals is not None else (None, 0)
+    B, H, W = s.shape[0], sensor.H, sensor.W
+    Tc = T.detach().contiguous().float()
+    nn = torch.empty((B, H, W), dtype=torch.int32, device=s.device)
+    vis = torch.empty((B,), dtype=torch.int32, device=s.device) if want_visible else None
+    ws = torch.empty((lib.dl_nn_workspace_bytes(B, H, W) // 8 + 1,), dtype=torch.int64, device=s.device)
+    _lib.check(lib.dl_nn_correspond(_ptr(s), s_ss, _ptr(n), n_ss, _ptr(t), t_ss, _ptr(Tc), B,
+                                    ctypes.byref(sensor.struct), int(bool(need_without_normals)), _ptr(nn),
+                                    _ptr(vis), _ptr(ws), _stream()), "dl_nn_correspond")
+    return nn, vis
+
+
+class _IcpLoss(torch.autograd.Function):
+    """loss_terms[B,3] = (po2po, po2pl, pl2pl) as a differentiable function of T[B,4,4]; the
+    correspondences are constants, exactly as the gather indices are in the reference."""
+
+    @staticmethod
+    def forward(ctx, T, src_image4, src_normals, tgt_image4, tgt_normals, nn_pix, flags):
+        lib = _lib.load()
+        s, s_ss = _planar(src_image4, 3)
+        sn, sn_ss = _planar(src_normals, 3)
+        t, t_ss = _planar(tgt_image4, 3)
+        tn, tn_ss = _planar(tgt_normals, 3)
+        B, _, H, W = s.shape
+        dev = s.device
+        Tc = T.detach().contiguous().float()
+        loss_terms = torch.empty((B, 3), dtype=torch.float32, device=dev)
+        counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
+        grad_terms = torch.empty((B, 3, 12), dtype=torch.float32, device=dev)
+        ws = torch.empty((lib.dl_icp_loss_workspace_bytes(B, H, W) // 4,), dtype=torch.float32, device=dev)
+        _lib.check(lib.dl_icp_loss_fwd(_ptr(s), s_ss, _ptr(sn), sn_ss, _ptr(t), t_ss, _ptr(tn), tn_ss, _ptr(nn_pix),
+                                       _ptr(Tc), B, H, W, int(flags), _ptr(loss_terms), _ptr(counts),
+                                       _ptr(grad_terms), _ptr(ws), _stream()), "dl_icp_loss_fwd")
+        ctx.save_for_backward(grad_terms)
+        ctx.mark_non_differentiable(counts)
+        return loss_terms, counts
+
+    @staticmethod
+    def backward(ctx, g_terms, _g_counts):
+        lib = _lib.load()
+        (grad_terms,) = ctx.saved_tensors
+        B = grad_terms.shape[0]
+        g = g_terms.contiguous().float()
+        grad_T = torch.empty((B, 4, 4), dtype=torch.float32, device=g.device)
+        _lib.check(lib.dl_icp_loss_bwd(_ptr(grad_terms), _ptr(g), B, _ptr(grad_T), _stream()), "dl_icp_loss_bwd")
+        return grad_T, None, None, None, None, None, None
+
+
+def icp_loss(T, src_image4, src_normals, tgt_image4, tgt_normals, nn_pix, flags):
+    """(loss_terms [B,3], pair_counts [B,2]); loss_terms is differentiable with respect to T."""
+    _require_cuda(T, src_image4, src_normals, tgt_image4, tgt_normals, nn_pix)
+    return _IcpLoss.apply(T, src_image4, src_normals, tgt_image4, tgt_normals, nn_pix, flags)
+
+
+def loss_flags(config):
+    """Flag word of dl_icp_loss_fwd from the reference's hyper-parameters (config/hyperparameters.yaml:14-19)."""
+    f = 0
+    if config["point_to_point_loss"]:
+        f |= LOSS_POINT_TO_POINT
+    if config["point_to_plane_loss"]:
+        f |= LOSS_POINT_TO_PLANE
+    if config["plane_to_plane_loss"]:
+        f |= LOSS_PLANE_TO_PLANE
+    if config["normal_loss"] == "linear":
+        f |= LOSS_NORMAL_LINEAR
+    elif config["normal_loss"] != "squared":
+        raise Exception("The normal loss which is defined here is not admissible.")
+    return f
+
+
+def nn_bruteforce(src, tgt):
+    """Exact NN index into ``tgt [3,Mt]`` for every column of ``src [3,Ms]`` (free-form lists)."""
+    lib = _lib.load()
+    _require_cuda(src, tgt)
+    src, tgt = src.detach().contiguous().float(), tgt.detach().contiguous().float()
+    Ms, Mt = src.shape[1], tgt.shape[1]
+    nn = torch.empty((Ms,), dtype=torch.int32, device=src.device)
+    _lib.check(lib.dl_nn_bruteforce(_ptr(src), max(Ms, 1), Ms, _ptr(tgt), max(Mt, 1), Mt, _ptr(nn), _stream()),
+               "dl_nn_bruteforce")
+    return nn

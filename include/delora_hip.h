@@ -1,0 +1,158 @@
+/*
+ * delora_hip.h -- C ABI of libdelora_hip.so: the MI355X (gfx950) geometry kernels of the DeLORA
+ * per-scan-pair training step.
+ *
+ * The reference (leggedrobotics/delora) has no native layer; its boundary for this path is the
+ * Python module API.  Each entry point below replaces the torch-op sequence of one reference
+ * function (file:line into the reference tree) and is what a ctypes binding of the reference would
+ * call (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, sizes, strides in ELEMENTS; no torch/HIP types in signatures
+ *     (dl_stream is the hipStream_t handle passed as void*, e.g. torch's current stream).
+ *   - the caller owns every buffer; the library allocates nothing, keeps no mutable global state,
+ *     never synchronises the device: all work is enqueued on the given stream (graph-capturable).
+ *   - return 0 on success, negative dl_status otherwise; dl_last_error() (thread-local) has the text.
+ *   - data layout: a batch of S scans is a planar fp32 buffer pts[C][sumN] + CSR offsets offs[S+1];
+ *     a range image is planar fp32 [S][4][H][W] = (x, y, z, range), empty pixels are all-zero;
+ *     normals are planar fp32 [S][3][H][W], the zero vector meaning "no normal"; pixel indices are
+ *     int32 row-major v*W+u, -1 = none.  Row 0 is the lowest elevation, column 0 azimuth hfov[0].
+ *   - results are deterministic: no floating-point atomics, order-independent integer atomics only.
+ */
+#ifndef DELORA_HIP_H
+#define DELORA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DL_ABI_VERSION 1
+
+typedef void* dl_stream;
+
+typedef enum {
+  DL_OK = 0,
+  DL_ERR_INVALID_ARGUMENT = -1,
+  DL_ERR_LAUNCH = -2,
+  DL_ERR_UNSUPPORTED = -3
+} dl_status;
+
+/* Projection model of one sensor (radians).  The fp64 fields are the exact config values; the
+ * kernels derive the fp32 constants the reference's torch expression uses from them:
+ * fp32(f0) and fp32(f1 - f0), the difference formed in fp64 (src/utility/projection.py:23-30). */
+typedef struct {
+  int32_t H;          /* vertical_cells   (config/config_datasets.yaml:20)  */
+  int32_t W;          /* horizontal_cells (config/config_datasets.yaml:21)  */
+  double hfov0, hfov1; /* horizontal_field_of_view (config_datasets.yaml:3, after deg->rad) */
+  double vfov0, vfov1; /* <dataset>.vertical_field_of_view (config_datasets.yaml:19)        */
+} dl_sensor;
+
+/* Flags of dl_icp_loss_fwd (config/hyperparameters.yaml:14-19). */
+#define DL_LOSS_POINT_TO_POINT 1u   /* point_to_point_loss */
+#define DL_LOSS_POINT_TO_PLANE 2u   /* point_to_plane_loss */
+#define DL_LOSS_PLANE_TO_PLANE 4u   /* plane_to_plane_loss */
+#define DL_LOSS_NORMAL_LINEAR  8u   /* normal_loss == "linear" (default "squared") */
+
+int dl_abi_version(void);
+const char* dl_last_error(void);
+
+/* Bytes of the uint64 key workspace dl_project needs for S scans of H x W pixels. */
+size_t dl_project_workspace_bytes(int32_t S, int32_t H, int32_t W);
+
+/*
+ * Spherical projection of S scans into range images, nearest point per pixel.
+ * Replaces ImageProjectionLayer.project_to_img (src/utility/projection.py:48-106): range channel
+ * (:55-60), argsort by range + sequential first-wins dedup on the host (:63-67, :34-43, :80-91)
+ * and the index scatter (:98-103) become one atomicMin pass over (range_bits << 32 | point_index)
+ * keys plus one resolve pass; u,v follow compute_2D_coordinates (:21-31) with round-half-even.
+ *   pts      [C][pts_cs]   planar fp32, channels 0..2 = x,y,z; scan s owns columns offs[s]..offs[s+1)
+ *   offs     [S+1]         int32 CSR offsets (device); max_n = largest scan length (host value)
+ *   image4   [S][4][H][W]  out: x,y,z,range of the winning point, zeros elsewhere
+ *   aux      [S][C-3][H][W] out (may be NULL when C == 3): the remaining channels of the winner
+ *   pix2pt   [S][H][W]     out: index of the winning point relative to its scan start, -1 if empty
+ *   keys_ws  dl_project_workspace_bytes(S,H,W) bytes of scratch
+ *   kept     [S]           out: number of occupied pixels per scan
+ *   uv       [2][pts_cs]   out (may be NULL): fp32 u and v of EVERY input point, input order
+ */
+int dl_project(const float* pts, int64_t pts_cs, const int32_t* offs, int32_t S, int32_t C,
+               int32_t max_n, const dl_sensor* sensor, float* image4, float* aux, int32_t* pix2pt,
+               uint64_t* keys_ws, int32_t* kept, float* uv, dl_stream stream);
+
+/*
+ * Per-pixel surface normals of S range images.
+ * Replaces NormalsComputer.compute_normal_vectors + covariance_eigen_decomposition + linalg.cov
+ * (src/preprocessing/normal_computation.py:89-122, :53-87; src/utility/linalg.py:33-56): the
+ * (2a+1)x(2b+1) clamped-neighbour gather, range gate, masked covariance, n >= min_n gate, CPU
+ * symeig and viewpoint flip become one LDS-tiled kernel with an in-register 3x3 eigen solve.
+ *   image4  [S][4][H][W] in (scan stride image_ss elements, channel stride H*W)
+ *   normals [S][3][H][W] out (scan stride 3*H*W), zeros where no normal
+ * A pixel is processed iff x != 0 && y != 0 && z != 0 (normal_computation.py:35).
+ */
+int dl_normals(const float* image4, int64_t image_ss, int32_t S, int32_t H, int32_t W,
+               int32_t half_rows, int32_t half_cols, float epsilon_range, int32_t min_neighbors,
+               float* normals, dl_stream stream);
+
+/* Bytes of scratch dl_nn_correspond needs (hard-query list + counters). */
+size_t dl_nn_workspace_bytes(int32_t B, int32_t H, int32_t W);
+
+/*
+ * Exact 3-D nearest target point of every transformed source point (k=1, Euclidean, fp64 distances).
+ * Replaces the CPU cKDTree build + queries of ICPLosses.forward (src/losses/icp_losses.py:24-26,
+ * :34, :63-80) together with the source transform of Deployer.step (src/deploy/deployer.py:294-296).
+ * Target points are the occupied pixels of tgt_image4, source points those of src_image4.
+ *   T          [B][4][4]  fp32 row-major source->target transforms
+ *   nn_pix     [B][H][W]  out: target pixel index of the nearest target point per source pixel
+ *                         (-1 for empty source pixels or an empty target image)
+ *   visible    [B]        out (may be NULL): number of source points with round(v) < H and v > 0 in the
+ *                         target frame (the visible_pixels metric, deployer.py:349-352,365-367)
+ *   src_normals may be NULL; when given and need_without_normals == 0, source pixels without a normal
+ *   are skipped (their correspondences are only used by the point-to-point term).
+ */
+int dl_nn_correspond(const float* src_image4, int64_t src_ss, const float* src_normals, int64_t srcn_ss,
+                     const float* tgt_image4, int64_t tgt_ss, const float* T, int32_t B,
+                     const dl_sensor* sensor, int32_t need_without_normals, int32_t* nn_pix,
+                     int32_t* visible, void* workspace, dl_stream stream);
+
+/* Bytes of scratch dl_icp_loss_fwd needs (per-block partial sums). */
+size_t dl_icp_loss_workspace_bytes(int32_t B, int32_t H, int32_t W);
+
+/*
+ * Fused source transform + point-to-plane / plane-to-plane / point-to-point residuals + reduction,
+ * and the moments of the analytic gradient with respect to T.
+ * Replaces Deployer.step's R@p+t, R@n (src/deploy/deployer.py:294-299) and
+ * KDPointToPlaneLoss / KDPlaneToPlaneLoss / KDPointToPointLoss (src/losses/icp_losses.py:196-206,
+ * :224-240, :168-179) with the pair selection of ICPLosses.forward (:48-60, :102-121).
+ *   loss_terms [B][3]      out: loss_po2po, loss_po2pl, loss_pl2pl (means; 0 for disabled terms,
+ *                          NaN when an enabled term has no pairs, as torch's MSELoss of an empty set)
+ *   pair_counts[B][2]      out: pairs with normals (K), pairs without normals (K', po2po)
+ *   grad_terms [B][3][12]  out: d loss_term / d T[:3,:4] (row-major 3x4), correspondences held fixed
+ */
+int dl_icp_loss_fwd(const float* src_image4, int64_t src_ss, const float* src_normals, int64_t srcn_ss,
+                    const float* tgt_image4, int64_t tgt_ss, const float* tgt_normals, int64_t tgtn_ss,
+                    const int32_t* nn_pix, const float* T, int32_t B, int32_t H, int32_t W,
+                    uint32_t flags, float* loss_terms, int32_t* pair_counts, float* grad_terms,
+                    void* workspace, dl_stream stream);
+
+/*
+ * Backward of dl_icp_loss_fwd: grad_T[b][:3,:4] = sum_k grad_loss_terms[b][k] * grad_terms[b][k]
+ * (row 3 of grad_T is zero).  grad_T is [B][4][4].
+ */
+int dl_icp_loss_bwd(const float* grad_terms, const float* grad_loss_terms, int32_t B, float* grad_T,
+                    dl_stream stream);
+
+/*
+ * Exact nearest neighbour between two free-form point lists (no range-image structure), fp64
+ * distances, LDS-tiled brute force.  Backs the list-based ICPLosses.forward signature
+ * (src/losses/icp_losses.py:28-33) when the caller has lists rather than images.
+ *   src [3][ms_cs], tgt [3][mt_cs] planar fp32; nn [Ms] out (index into tgt, -1 if Mt == 0)
+ */
+int dl_nn_bruteforce(const float* src, int64_t ms_cs, int32_t Ms, const float* tgt, int64_t mt_cs,
+                     int32_t Mt, int32_t* nn, dl_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DELORA_HIP_H */

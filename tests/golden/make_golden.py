@@ -222,14 +222,22 @@ def fx_loss(out):
     import losses.icp_losses as rloss
     import models.model_parts as rparts
     cfg0 = reference_config(16, 128)
+    import utility.projection as rproj
     (l1, l2), T_true = preprocessed_lists(31, 16, 160, 16, 200, cfg0)
-    tgt = torch.from_numpy(l1[0]).permute(1, 0).view(1, 3, -1)
-    tgt_n = torch.from_numpy(l1[1]).permute(1, 0).view(1, 3, -1)
-    src = torch.from_numpy(l2[0]).permute(1, 0).view(1, 3, -1)
-    src_n = torch.from_numpy(l2[1]).permute(1, 0).view(1, 3, -1)
+    # as Deployer.step does (deployer.py:252-261): re-project the stored lists at the training resolution and keep
+    # only the projected points; those filtered lists are what ICPLosses sees.
+    layer = rproj.ImageProjectionLayer(config=cfg0)
+    filt = []
+    for pts, nrm in (l1, l2):
+        x = torch.from_numpy(pts).permute(1, 0).view(1, 3, -1)
+        n = torch.from_numpy(nrm).permute(1, 0).view(1, 3, -1)
+        _, _, _, idx, _ = layer(input=x, dataset="kitti")
+        filt.append((x[:, :, idx].contiguous(), n[:, :, idx].contiguous()))
+    (tgt, tgt_n), (src, src_n) = filt
     rng = np.random.default_rng(5)
     qs = {"identity": np.array([0, 0, 0, 1.0]), "true": None, "random": rng.normal(size=4)}
-    entry = dict(tgt=l1[0], tgt_n=l1[1], src=l2[0], src_n=l2[1], T_true=T_true)
+    entry = dict(raw_tgt=l1[0], raw_tgt_n=l1[1], raw_src=l2[0], raw_src_n=l2[1], T_true=T_true, H=16, W=128,
+                 tgt=t2n(tgt[0]), tgt_n=t2n(tgt_n[0]), src=t2n(src[0]), src_n=t2n(src_n[0]))
     for mode in ("squared", "linear"):
         for p2p in (False, True):
             cfg = reference_config(16, 128, normal_loss=mode, point_to_point_loss=p2p)

@@ -1,0 +1,434 @@
+"""Parity of the HIP geometry kernels (through the C ABI) against the oracle and the golden vectors.
+
+Bars: pixel indices / correspondences bit-exact (projection: outside the documented atan2 ambiguity mask),
+fp32 values exact where the same arithmetic is specified, loss terms and gradients within 1e-4 relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+from tests.util import orc
+
+pytestmark = pytest.mark.gpu
+
+REL = 1e-4       # tolerance of the north star for floating-point results
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _geo():
+    from delora_amd import geometry
+    return geometry
+
+
+def gpu_sensor(H, W, vfov, hfov):
+    return _geo().Sensor(int(H), int(W), [float(v) for v in vfov], [float(h) for h in hfov])
+
+
+def run_project(scans, sensor, want_uv=True):
+    """scans: list of [C,N] numpy arrays -> dict of CPU numpy outputs (batched in one launch)."""
+    dev = _dev()
+    C = scans[0].shape[0]
+    pts = torch.from_numpy(np.concatenate(scans, axis=1)).to(dev)
+    lens = [s.shape[1] for s in scans]
+    offs = torch.tensor(np.concatenate([[0], np.cumsum(lens)]), dtype=torch.int32, device=dev)
+    if pts.shape[1] == 0:
+        pts = torch.zeros((C, 1), device=dev)[:, :0]
+    out = _geo().project(pts, offs, max(lens), sensor, want_uv=want_uv)
+    torch.cuda.synchronize()
+    return out
+
+
+def check_projection(scan, out, s, o_sensor, expect_pix2pt=None, expect_image=None):
+    """The projection contract for scan ``s`` of a batched result."""
+    ref_pix, ref_u, ref_v = util.reference_pixels(scan, o_sensor)
+    n0 = 0 if s == 0 else None
+    H, W = o_sensor.H, o_sensor.W
+    pix2pt = out["pix2pt"][s].cpu().numpy()
+    image = out["image4"][s].cpu().numpy()
+    N = scan.shape[1]
+    if out["uv"] is not None and n0 is not None and N:
+        uv = out["uv"].cpu().numpy()[:, :N]
+        assert np.nanmax(np.abs(uv[0] - ref_u)) < 2e-3 and np.nanmax(np.abs(uv[1] - ref_v)) < 2e-3
+        ru, rv = np.rint(uv[0]), np.rint(uv[1])
+        inside = (ru <= W - 1) & (ru >= 0) & (rv <= H - 1) & (rv >= 0)
+        gpu_pix = np.where(inside, rv.astype(np.int64) * W + ru.astype(np.int64), -1)
+        differ = gpu_pix != ref_pix
+        amb = util.ambiguity_mask(scan, o_sensor)
+        assert not np.any(differ & ~amb), "pixel index differs outside the ambiguity mask"
+    else:
+        differ = np.zeros(N, dtype=bool)
+        gpu_pix = ref_pix
+    # expected map from the reference semantics: nearest range per pixel, ties to the lower index
+    rng = torch.norm(torch.from_numpy(np.ascontiguousarray(scan[:3])).view(1, 3, -1), dim=1)[0].numpy()
+    exp = -np.ones(H * W, dtype=np.int64)
+    order = np.lexsort((np.arange(N), rng))
+    keep = ref_pix[order] >= 0
+    po, oo = ref_pix[order][keep], order[keep]
+    _, first = np.unique(po, return_index=True)
+    exp[po[first]] = oo[first]
+    touched = np.zeros(H * W, dtype=bool)
+    for arr in (gpu_pix[differ], ref_pix[differ]):
+        touched[arr[arr >= 0]] = True
+    ok = ~touched
+    assert np.array_equal(pix2pt.reshape(-1)[ok], exp[ok]), "pixel -> point map mismatch"
+    if expect_pix2pt is not None and not differ.any():
+        assert np.array_equal(pix2pt, expect_pix2pt)
+    # image content: xyz are copies, range follows torch.norm's rounding
+    occ = exp >= 0
+    sel = ok & occ
+    for c in range(3):
+        assert np.array_equal(image[c].reshape(-1)[sel], scan[c][exp[sel]])
+    assert np.array_equal(image[3].reshape(-1)[sel], rng[exp[sel]])
+    assert np.all(image.reshape(4, -1)[:, ok & ~occ] == 0)
+    assert int(out["kept"][s].item()) == int((pix2pt >= 0).sum())
+    if expect_image is not None and not differ.any():
+        assert np.array_equal(image, expect_image)
+    return differ
+
+
+@pytest.mark.parametrize("name", ["small", "small_c6", "mid", "edge", "all_outside"])
+def test_projection_golden(name):
+    g = util.load_golden("proj_" + name)
+    o_sensor = util.oracle_sensor(g["H"], g["W"], g["vfov"], g["hfov"])
+    sensor = gpu_sensor(g["H"], g["W"], g["vfov"], g["hfov"])
+    scan = g["scan"]
+    out = run_project([scan], sensor)
+    H, W = o_sensor.H, o_sensor.W
+    exp_map = -np.ones((H, W), dtype=np.int64)
+    pix = g["pix"][0]
+    exp_map[pix[:, 0], pix[:, 1]] = g["idx"]
+    C = scan.shape[0]
+    ref_img = g["image"][0]                                   # [C+1,H,W], last = range
+    exp_img4 = np.concatenate([ref_img[:3], ref_img[C:C + 1]], axis=0)
+    differ = check_projection(scan, out, 0, o_sensor, exp_map, exp_img4)
+    if C > 3 and not differ.any():
+        assert np.array_equal(out["aux"][0].cpu().numpy(), ref_img[3:C])
+
+
+def test_projection_batched_ragged_and_deterministic():
+    """Several scans of different length (one empty) in one launch; results independent of batching and run."""
+    from delora_amd.data import synthetic
+    vf, hf = util.kitti_fov()
+    o_sensor, sensor = util.oracle_sensor(32, 256, vf, hf), gpu_sensor(32, 256, vf, hf)
+    scans = [synthetic.make_pair(100 + i, rings=32, azimuth_steps=300 + 17 * i)[0] for i in range(3)]
+    scans.insert(1, np.zeros((3, 0), dtype=np.float32))
+    out = run_project(scans, sensor, want_uv=False)
+    for s, scan in enumerate(scans):
+        check_projection(scan, out, s, o_sensor)
+    again = run_project(scans, sensor, want_uv=False)
+    for k in ("image4", "pix2pt", "kept"):
+        assert torch.equal(out[k], again[k])
+    solo = run_project([scans[2]], sensor, want_uv=False)
+    assert torch.equal(solo["pix2pt"][0], out["pix2pt"][2]) and torch.equal(solo["image4"][0], out["image4"][2])
+
+
+def test_projection_full_size_digest():
+    """64x2048 KITTI-shaped scan: pixel->point map equals the reference's (committed as int32 digest)."""
+    from delora_amd.data import synthetic
+    g = util.load_golden("proj_full_digest")
+    s1, _, _ = synthetic.make_pair(int(g["seed"]))
+    assert s1.shape[1] == int(g["N"])
+    o_sensor = util.oracle_sensor(g["H"], g["W"], g["vfov"], g["hfov"])
+    sensor = gpu_sensor(g["H"], g["W"], g["vfov"], g["hfov"])
+    out = run_project([s1], sensor)
+    differ = check_projection(s1, out, 0, o_sensor, g["pix2pt"].astype(np.int64))
+    assert set(np.nonzero(differ)[0]).issubset(set(g["ambiguous_idx"].tolist()))
+    if not differ.any():
+        assert abs(float(out["image4"][0, 3].double().sum().item()) - float(g["range_sum"])) < 1e-6 * float(g["range_sum"])
+
+
+def test_projection_idempotent_full_size():
+    """Projecting the kept points again reproduces the image (size-independent property, batch of 8)."""
+    from delora_amd.data import synthetic
+    vf, hf = util.kitti_fov()
+    sensor = gpu_sensor(64, 2048, vf, hf)
+    scans = [synthetic.make_pair(300 + i)[i % 2] for i in range(8)]
+    out = run_project(scans, sensor, want_uv=False)
+    relists = []
+    for s in range(8):
+        img = out["image4"][s].cpu().numpy().reshape(4, -1)
+        occ = out["pix2pt"][s].cpu().numpy().reshape(-1) >= 0
+        relists.append(np.ascontiguousarray(img[:3, occ]))
+    out2 = run_project(relists, sensor, want_uv=False)
+    assert torch.equal(out["image4"], out2["image4"])
+    assert torch.equal(out["kept"], out2["kept"])
+
+
+# ------------------------------------------------------------------------------------------ normals
+def _angle(a, b):
+    c = np.clip(np.sum(a * b, axis=1), -1.0, 1.0)
+    return np.arccos(c)
+
+
+def check_normals(image, got, ref_normals, ref_has, ref_v, ref_u, eigenvalues, pts):
+    """Compare normals at the reference's valid pixels, conditioning-aware."""
+    g = got[:, ref_v, ref_u].T                                  # [M,3]
+    got_has = np.any(g != 0, axis=1)
+    mism = got_has != ref_has
+    assert mism.mean() <= 2e-3, f"has-normal mask differs on {mism.sum()} of {len(mism)} pixels"
+    both = got_has & ref_has
+    lam = eigenvalues[both].astype(np.float64)
+    gap = (lam[:, 1] - lam[:, 0]) / np.maximum(lam[:, 2], 1e-30)
+    p = pts[both].astype(np.float64)
+    graze = np.abs(np.sum(ref_normals[both] * p, axis=1)) / np.linalg.norm(p, axis=1) < 1e-3
+    a, b = g[both].astype(np.float64), ref_normals[both].astype(np.float64)
+    assert np.allclose(np.linalg.norm(a, axis=1), 1.0, atol=1e-5)
+    ang = _angle(a, b)
+    ang_unsigned = np.minimum(ang, np.pi - ang)
+    ang = np.where(graze, ang_unsigned, ang)
+    well = gap > 1e-3
+    # fp32 LAPACK error of the reference scales like eps32 * lambda_max / gap
+    bound = 2e-4 + 50 * 6e-8 / np.maximum(gap, 1e-12)
+    frac_bad = np.mean(ang[well] > bound[well])
+    assert frac_bad <= 1e-3, f"{frac_bad:.2e} of well-conditioned normals off (max {ang[well].max():.3e} rad)"
+    assert np.median(ang) < 1e-5
+    # pixels that are not valid in the reference carry no normal
+    mask = np.ones(got.shape[1:], dtype=bool)
+    mask[ref_v, ref_u] = False
+    assert np.all(got[:, mask] == 0)
+    return ang
+
+
+@pytest.mark.parametrize("name", ["small", "mid"])
+def test_normals_golden(name):
+    g = util.load_golden("normals_" + name)
+    dev = _dev()
+    image = torch.from_numpy(g["image"]).to(dev)                # [1,4,H,W]
+    a, b = int(g["side"][0] / 2), int(g["side"][1] / 2)
+    got = _geo().normals(image, a, b, float(g["epsilon_range"]), int(g["min_neighbors"]))[0].cpu().numpy()
+    check_normals(g["image"], got, g["normals"], g["has"], g["v"], g["u"], g["eigenvalues"], g["points"])
+
+
+def test_normals_vs_oracle_batched_128_rings():
+    """Ouster-style 128-row images, batch of 3 (BASELINE config 4 shape class, reduced width for oracle time)."""
+    from delora_amd.data import synthetic
+    dev = _dev()
+    vf = (-22.5 * np.pi / 180.0, 22.5 * np.pi / 180.0)
+    hf = util.kitti_fov()[1]
+    sensor, o_sensor = gpu_sensor(128, 256, vf, hf), util.oracle_sensor(128, 256, vf, hf)
+    scans = [synthetic.make_pair(500 + i, rings=128, azimuth_steps=290, vfov_deg=(-22.5, 22.5))[0] for i in range(3)]
+    out = run_project(scans, sensor, want_uv=False)
+    got = _geo().normals(out["image4"]).cpu().numpy()
+    for s in range(3):
+        img = out["image4"][s:s + 1].cpu()
+        n, has, pts, aux = orc.compute_normal_vectors(img.clone(), o_sensor, return_aux=True)
+        check_normals(None, got[s], n.numpy(), has.numpy(), aux["v"].numpy(), aux["u"].numpy(),
+                      aux["eigenvalues"].numpy(), pts.numpy())
+
+
+# ------------------------------------------------------------------------------------ correspondences
+def _pair_images(seed, H, W, rings, az, vfov_deg=(-24.5, 2.0), online_normals=True):
+    from delora_amd.data import synthetic
+    vf = (vfov_deg[0] * np.pi / 180.0, vfov_deg[1] * np.pi / 180.0)
+    hf = util.kitti_fov()[1]
+    sensor = gpu_sensor(H, W, vf, hf)
+    s1, s2, T = synthetic.make_pair(seed, rings=rings, azimuth_steps=az, vfov_deg=vfov_deg)
+    out = run_project([s1, s2], sensor, want_uv=False)
+    nrm = _geo().normals(out["image4"])
+    return sensor, out["image4"], nrm, T
+
+
+def _random_T(rng, scale_t=1.0):
+    q = torch.tensor(rng.normal(size=(1, 4)), dtype=torch.float32)
+    t = torch.tensor(rng.normal(0, scale_t, size=(1, 3)), dtype=torch.float32)
+    return orc.transformation_matrix(t, q)
+
+
+def oracle_nn_pixels(tgt_img, src_img, src_nrm, T, need_wo):
+    """Oracle correspondences expressed as target pixel ids per source pixel (-1 where none is requested)."""
+    tp, _, tpix = util.lists_from_images(tgt_img, torch.zeros(3, *tgt_img.shape[1:]))
+    sp, sn, spix = util.lists_from_images(src_img, src_nrm)
+    has = (sn[0] != 0).any(dim=0)
+    sel = torch.ones_like(has) if need_wo else has
+    q = orc.transform_points(T, sp[:, :, sel])
+    nn = orc.nearest_target_indices(tp, q)
+    out = -torch.ones(src_img.shape[1] * src_img.shape[2], dtype=torch.long)
+    out[spix[sel]] = tpix[nn]
+    return out, q, tp, tpix
+
+
+@pytest.mark.parametrize("case", ["identity", "true", "small_error", "random", "random_far"])
+@pytest.mark.parametrize("shape", [(16, 128, 16, 160), (64, 512, 64, 600)])
+def test_nn_matches_kdtree(case, shape):
+    H, W, rings, az = shape
+    sensor, img, nrm, T_true = _pair_images(77, H, W, rings, az)
+    rng = np.random.default_rng(3)
+    if case == "identity":
+        T = torch.eye(4).view(1, 4, 4)
+    elif case == "true":
+        T = torch.from_numpy(T_true).view(1, 4, 4)
+    elif case == "small_error":
+        T = torch.from_numpy(T_true).view(1, 4, 4).clone()
+        T[0, :3, 3] += torch.tensor([0.15, -0.1, 0.05])
+    elif case == "random":
+        T = _random_T(rng)
+    else:
+        T = _random_T(rng, scale_t=30.0)
+    for need_wo in (False, True):
+        nn, vis = _geo().nn_correspond(img[1:2], nrm[1:2], img[0:1], T.to(img.device), sensor, need_without_normals=need_wo)
+        torch.cuda.synchronize()
+        exp, q, tp, tpix = oracle_nn_pixels(img[0].cpu(), img[1].cpu(), nrm[1].cpu(), T, need_wo)
+        got = nn[0].reshape(-1).cpu().long()
+        if not torch.equal(got, exp):
+            # only exact distance ties may differ: compare the fp64 distances of the two answers
+            bad = torch.nonzero(got != exp).reshape(-1)
+            assert ((got[bad] >= 0) & (exp[bad] >= 0)).all()
+            tflat = img[0, :3].reshape(3, -1).cpu().double()
+            sflat = img[1, :3].reshape(3, -1).cpu()
+            qq = orc.transform_points(T, sflat[:, bad].view(1, 3, -1))[0].double()
+            d_got = (qq - tflat[:, got[bad]]).norm(dim=0)
+            d_exp = (qq - tflat[:, exp[bad]]).norm(dim=0)
+            assert torch.all(d_got <= d_exp * (1 + 1e-12)), f"{len(bad)} non-tie mismatches"
+        sp, _, _ = util.lists_from_images(img[1].cpu(), nrm[1].cpu())
+        assert int(vis[0].item()) == orc.visible_pixels(orc.transform_points(T, sp), util.oracle_sensor(H, W, sensor.vfov, sensor.hfov))
+
+
+def test_nn_full_size_against_bruteforce_kernel():
+    """64x2048, batch 2: the windowed search equals the exhaustive kernel (and the KD-tree on sample 0)."""
+    sensor, img, nrm, T_true = _pair_images(2024, 64, 2048, 64, 2250)
+    dev = img.device
+    imgs_t = torch.stack([img[0], img[0]])
+    imgs_s = torch.stack([img[1], img[1]])
+    nrm_s = torch.stack([nrm[1], nrm[1]])
+    T = torch.stack([torch.from_numpy(T_true), torch.eye(4)]).to(dev)
+    nn, _ = _geo().nn_correspond(imgs_s, nrm_s, imgs_t, T, sensor, need_without_normals=True)
+    for b in range(2):
+        tp, _, tpix = util.lists_from_images(imgs_t[b].cpu(), torch.zeros(3, 64, 2048))
+        sp, _, spix = util.lists_from_images(imgs_s[b].cpu(), nrm_s[b].cpu())
+        q = orc.transform_points(T[b:b + 1].cpu(), sp)
+        bf = _geo().nn_bruteforce(q[0].to(dev), tp[0].to(dev)).cpu().long()
+        got = nn[b].reshape(-1).cpu().long()[spix]
+        exp = tpix[bf]
+        if not torch.equal(got, exp):
+            bad = torch.nonzero(got != exp).reshape(-1)
+            tflat = imgs_t[b, :3].reshape(3, -1).cpu().double()
+            d_got = (q[0][:, bad].double() - tflat[:, got[bad]]).norm(dim=0)
+            d_exp = (q[0][:, bad].double() - tflat[:, exp[bad]]).norm(dim=0)
+            assert torch.all(d_got <= d_exp * (1 + 1e-12)), f"{len(bad)} non-tie mismatches"
+        if b == 0:
+            kd = orc.nearest_target_indices(tp, q)
+            assert (tpix[kd] != got).sum() <= 2          # exact ties only
+
+
+def test_nn_empty_target_and_empty_source():
+    vf, hf = util.kitti_fov()
+    sensor = gpu_sensor(16, 128, vf, hf)
+    dev = _dev()
+    z = torch.zeros((1, 4, 16, 128), device=dev)
+    _, img, nrm, _ = _pair_images(5, 16, 128, 16, 160)
+    T = torch.eye(4, device=dev).view(1, 4, 4)
+    nn, vis = _geo().nn_correspond(img[1:2], nrm[1:2], z, T, sensor)
+    assert (nn == -1).all()
+    nn, vis = _geo().nn_correspond(z, z[:, :3], img[0:1], T, sensor)
+    assert (nn == -1).all() and int(vis[0].item()) == 0
+
+
+# ------------------------------------------------------------------------------------------- losses
+def _flags(mode, p2p):
+    G = _geo()
+    f = G.LOSS_POINT_TO_PLANE | G.LOSS_PLANE_TO_PLANE
+    if p2p:
+        f |= G.LOSS_POINT_TO_POINT
+    if mode == "linear":
+        f |= G.LOSS_NORMAL_LINEAR
+    return f
+
+
+def _close(a, b, rel=REL, what=""):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    scale = np.maximum(np.abs(b).max(), 1e-30)
+    assert np.all(np.abs(a - b) <= rel * scale + 1e-9), f"{what}: {a} vs {b}"
+
+
+@pytest.mark.parametrize("mode", ["squared", "linear"])
+@pytest.mark.parametrize("p2p", [False, True])
+def test_loss_golden_from_reference(mode, p2p):
+    """Raw preprocessed lists -> projection with normals as extra channels -> correspondences -> loss terms and
+    dL/dT, against the numbers the reference's ICPLosses + autograd produced on the same lists."""
+    g = util.load_golden("loss_pair")
+    G, dev = _geo(), _dev()
+    vf, hf = util.kitti_fov()
+    sensor = gpu_sensor(g["H"], g["W"], vf, hf)
+    scans = [np.concatenate([g["raw_tgt"].T, g["raw_tgt_n"].T], axis=0).astype(np.float32),
+             np.concatenate([g["raw_src"].T, g["raw_src_n"].T], axis=0).astype(np.float32)]
+    out = run_project(scans, sensor, want_uv=False)
+    img, nrm = out["image4"], out["aux"]
+    # the kept sets must be the reference's filtered lists (deployer.py:258-261)
+    assert int(out["kept"][0]) == g["tgt"].shape[1] and int(out["kept"][1]) == g["src"].shape[1]
+    for qname in ("identity", "true", "random"):
+        key = f"{mode}_{'p2p' if p2p else 'nop2p'}_{qname}"
+        T = torch.from_numpy(g[key + "_T"]).to(dev).requires_grad_(True)
+        nn, _ = G.nn_correspond(img[1:2], nrm[1:2], img[0:1], T, sensor, need_without_normals=p2p)
+        terms, counts = G.icp_loss(T, img[1:2], nrm[1:2], img[0:1], nrm[0:1], nn, _flags(mode, p2p))
+        total = terms[0, 0] + 2.0 * terms[0, 1] + 0.5 * terms[0, 2]
+        total.backward()
+        assert int(counts[0, 0]) == int(g[key + "_pairs"])
+        _close(terms[0].detach().cpu().numpy(), g[key + "_losses"], what=key + " losses")
+        _close(T.grad[0, :3].cpu().numpy(), g[key + "_gradT"][0, :3], what=key + " dL/dT")
+        assert torch.all(T.grad[0, 3] == 0)
+
+
+@pytest.mark.parametrize("mode,p2p", [("squared", False), ("linear", True)])
+def test_loss_vs_oracle_batched(mode, p2p):
+    """Batch of 4 different pairs (64x512) in one launch against the oracle per sample, values and gradients."""
+    G, dev = _geo(), _dev()
+    imgs, nrms, Ts = [], [], []
+    rng = np.random.default_rng(8)
+    for i in range(4):
+        sensor, img, nrm, T_true = _pair_images(900 + i, 64, 512, 64, 600)
+        imgs.append(img)
+        nrms.append(nrm)
+        T = torch.from_numpy(T_true).clone()
+        T[:3, 3] += torch.tensor(rng.normal(0, 0.05, 3), dtype=torch.float32)
+        Ts.append(T if i != 3 else _random_T(rng)[0])
+    tgt = torch.stack([im[0] for im in imgs]); src = torch.stack([im[1] for im in imgs])
+    tgt_n = torch.stack([n[0] for n in nrms]); src_n = torch.stack([n[1] for n in nrms])
+    T = torch.stack(Ts).to(dev).requires_grad_(True)
+    nn, _ = G.nn_correspond(src, src_n, tgt, T, sensor, need_without_normals=p2p)
+    terms, counts = G.icp_loss(T, src, src_n, tgt, tgt_n, nn, _flags(mode, p2p))
+    w = torch.tensor([[1.0, 2.0, 0.5]], device=dev) * torch.arange(1, 5, device=dev).view(4, 1)
+    (terms * w).sum().backward()
+    for b in range(4):
+        tp, tn, _ = util.lists_from_images(tgt[b].cpu(), tgt_n[b].cpu())
+        sp, sn, _ = util.lists_from_images(src[b].cpu(), src_n[b].cpu())
+        Tb = Ts[b].view(1, 4, 4).clone().requires_grad_(True)
+        l, aux = orc.icp_losses(orc.transform_points(Tb, sp), orc.rotate_points(Tb, sn), tp, tn, normal_loss=mode,
+                                point_to_point=p2p, return_aux=True)
+        exp = torch.stack([l["loss_po2po"].reshape(()), l["loss_po2pl"].reshape(()), l["loss_pl2pl"].reshape(())])
+        (exp * w[b].cpu()).sum().backward()
+        assert int(counts[b, 0]) == aux["pairs"]
+        _close(terms[b].detach().cpu().numpy(), exp.detach().numpy(), what=f"sample {b} losses")
+        _close(T.grad[b, :3].cpu().numpy(), Tb.grad[0, :3].numpy(), what=f"sample {b} dL/dT")
+
+
+def test_loss_identity_on_same_image_is_zero_and_deterministic():
+    """Size-independent properties at the full 64x2048 size, batch 8: with T = I and source == target every
+    point is its own neighbour and all terms vanish; two runs are bit-identical."""
+    G, dev = _geo(), _dev()
+    sensor, img, nrm, _ = _pair_images(4242, 64, 2048, 64, 2250)
+    tgt = img[0:1].expand(8, -1, -1, -1).contiguous()
+    tn = nrm[0:1].expand(8, -1, -1, -1).contiguous()
+    T = torch.eye(4, device=dev).repeat(8, 1, 1)
+    nn, vis = G.nn_correspond(tgt, tn, tgt, T, sensor, need_without_normals=True)
+    own = torch.arange(64 * 2048, device=dev, dtype=torch.int32).view(1, 64, 2048).expand(8, -1, -1)
+    occ = ~((tgt[:, 0] == 0) & (tgt[:, 1] == 0) & (tgt[:, 2] == 0))
+    assert torch.equal(nn[occ], own[occ]) and (nn[~occ] == -1).all()
+    terms, counts = G.icp_loss(T, tgt, tn, tgt, tn, nn, _flags("squared", True))
+    assert torch.all(terms[:, 1:] == 0)
+    has = (tn != 0).any(dim=1)
+    assert int(counts[0, 0]) == int(has[0].sum())
+    # determinism with a non-trivial transform
+    T2 = T.clone(); T2[:, :3, 3] = torch.tensor([0.3, -0.2, 0.05], device=dev)
+    r = []
+    for _ in range(2):
+        nn2, _ = G.nn_correspond(tgt, tn, tgt, T2, sensor)
+        t2, c2 = G.icp_loss(T2, tgt, tn, tgt, tn, nn2, _flags("squared", False))
+        r.append((nn2.clone(), t2.clone()))
+    assert torch.equal(r[0][0], r[1][0]) and torch.equal(r[0][1], r[1][1])
+    assert torch.allclose(r[0][1][0], r[0][1][7])
