@@ -29,23 +29,28 @@ static inline SensorK make_sensor(const dl_sensor* s) {
   return k;
 }
 
+// NOTE on rounding: this library is compiled with -ffp-contract=off, so `a * b + c` is never fused behind
+// our back; fused multiply-adds are written as fmaf().  sqrtf() and `/` are correctly rounded (hipcc's default
+// -fhip-fp32-correctly-rounded-divide-sqrt).  HIP's __fsqrt_rn/__fmul_rn-style intrinsics are NOT used: without
+// OCML_BASIC_ROUNDED_OPERATIONS they lower to the native approximations.
+//
 // torch.norm(x[:3], dim=0) on the reference's CPU build rounds as sqrt(fma(z,z,fma(y,y,x*x))).
 __device__ __forceinline__ float norm3f(float x, float y, float z) {
-  return __fsqrt_rn(__fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x))));
+  return sqrtf(fmaf(z, z, fmaf(y, y, (x * x))));
 }
 __device__ __forceinline__ float norm2f(float x, float y) {
-  return __fsqrt_rn(__fmaf_rn(y, y, __fmul_rn(x, x)));
+  return sqrtf(fmaf(y, y, (x * x)));
 }
 
 // fp32 image coordinates exactly in the reference's operation order; the atan2 itself is evaluated
 // in fp64 and rounded once (a correctly rounded fp32 atan2 up to double rounding).
 __device__ __forceinline__ float coord_u(float x, float y, const SensorK& s) {
   float a = (float)atan2((double)y, (double)x);
-  return __fmul_rn(__fdiv_rn(__fsub_rn(a, s.hf0f), s.hspanf), s.wm1f);
+  return ((a - s.hf0f) / s.hspanf) * s.wm1f;
 }
 __device__ __forceinline__ float coord_v(float x, float y, float z, const SensorK& s) {
   float e = (float)atan2((double)z, (double)norm2f(x, y));
-  return __fmul_rn(__fdiv_rn(__fsub_rn(e, s.vf0f), s.vspanf), s.hm1f);
+  return ((e - s.vf0f) / s.vspanf) * s.hm1f;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

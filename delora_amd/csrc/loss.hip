@@ -61,9 +61,9 @@ __global__ __launch_bounds__(DL_BLOCK) void k_icp_loss(
     if (has_s != has_t) continue;
     if (!P2P && !has_s) continue;
     const float tx = tp[j], ty = tp[HW + j], tz = tp[2 * HW + j];
-    const float qx = __fadd_rn(__fmaf_rn(m[2], z, __fmaf_rn(m[1], y, __fmul_rn(m[0], x))), m[3]);
-    const float qy = __fadd_rn(__fmaf_rn(m[6], z, __fmaf_rn(m[5], y, __fmul_rn(m[4], x))), m[7]);
-    const float qz = __fadd_rn(__fmaf_rn(m[10], z, __fmaf_rn(m[9], y, __fmul_rn(m[8], x))), m[11]);
+    const float qx = (fmaf(m[2], z, fmaf(m[1], y, (m[0] * x))) + m[3]);
+    const float qy = (fmaf(m[6], z, fmaf(m[5], y, (m[4] * x))) + m[7]);
+    const float qz = (fmaf(m[10], z, fmaf(m[9], y, (m[8] * x))) + m[11]);
     const float dx = qx - tx, dy = qy - ty, dz = qz - tz;
     if (has_s) {
       // point-to-plane (:196-203)

@@ -59,9 +59,9 @@ __device__ __forceinline__ void load_T(const float* __restrict__ T, int b, float
 // q = R p + t in fp32 (deployer.py:181-189)
 __device__ __forceinline__ void transform_point(const float (&m)[12], float x, float y, float z, float& qx,
                                                 float& qy, float& qz) {
-  qx = __fadd_rn(__fmaf_rn(m[2], z, __fmaf_rn(m[1], y, __fmul_rn(m[0], x))), m[3]);
-  qy = __fadd_rn(__fmaf_rn(m[6], z, __fmaf_rn(m[5], y, __fmul_rn(m[4], x))), m[7]);
-  qz = __fadd_rn(__fmaf_rn(m[10], z, __fmaf_rn(m[9], y, __fmul_rn(m[8], x))), m[11]);
+  qx = (fmaf(m[2], z, fmaf(m[1], y, (m[0] * x))) + m[3]);
+  qy = (fmaf(m[6], z, fmaf(m[5], y, (m[4] * x))) + m[7]);
+  qz = (fmaf(m[10], z, fmaf(m[9], y, (m[8] * x))) + m[11]);
 }
 
 __device__ __forceinline__ Query make_query(float fx, float fy, float fz, const SensorK& sen) {

@@ -92,10 +92,10 @@ __global__ __launch_bounds__(NTH * NTW) void k_normals(
       for (int j = 0; j <= 2 * b; ++j) {
         const float x = sx[row + j], y = sy[row + j], z = sz[row + j], r = sr[row + j];
         // gated out iff |range - centre range| > eps (:55-59); present iff any component != 0 (linalg.py:34-37)
-        const bool present = !(fabsf(__fsub_rn(r, cr)) > eps_range) && (x != 0.f || y != 0.f || z != 0.f);
+        const bool present = !(fabsf(r - cr) > eps_range) && (x != 0.f || y != 0.f || z != 0.f);
         if (present) {
-          const double dx = (double)__fsub_rn(x, cx), dy = (double)__fsub_rn(y, cy),
-                       dz = (double)__fsub_rn(z, cz);
+          const double dx = (double)(x - cx), dy = (double)(y - cy),
+                       dz = (double)(z - cz);
           ++n;
           m0 += dx; m1 += dy; m2 += dz;
           c00 = fma(dx, dx, c00); c01 = fma(dx, dy, c01); c02 = fma(dx, dz, c02);

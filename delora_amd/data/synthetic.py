@@ -102,3 +102,20 @@ def pad_or_trim(scan, n, rng=None):
     rng = rng or np.random.default_rng(0)
     extra = scan[:, rng.integers(0, N, size=n - N)]
     return np.ascontiguousarray(np.concatenate([scan, extra], axis=1))
+
+
+def portable_cloud(seed, n):
+    """``[3,n]`` fp32 cloud built from the PCG64 bit stream with +,-,*,/ only (no libm calls), hence bit-identical
+    on every machine; used where a committed digest must be reproduced from a seed.  Ground disc plus four walls,
+    roughly the range/elevation statistics of a 64-ring scan."""
+    rng = np.random.default_rng(seed)
+    u = rng.random((6, n))
+    ground = u[0] < 0.55
+    gx, gy = (u[1] - 0.5) * 90.0, (u[2] - 0.5) * 90.0
+    gz = -1.73 + (u[3] - 0.5) * 0.04
+    side = u[4]
+    wx = np.where(side < 0.25, 22.0, np.where(side < 0.5, -22.0, (u[1] - 0.5) * 44.0)) + (u[3] - 0.5) * 0.03
+    wy = np.where(side < 0.5, (u[2] - 0.5) * 18.0, np.where(side < 0.75, 9.0, -9.0)) + (u[5] - 0.5) * 0.03
+    wz = -1.73 + u[5] * 2.4
+    pts = np.where(ground[None, :], np.stack([gx, gy, gz]), np.stack([wx, wy, wz]))
+    return np.ascontiguousarray(pts.astype(np.float32))

@@ -151,7 +151,7 @@ def fx_projection(out):
 
     # full-size digest: 64x2048, only compact data (pixel->point map as int32, sha of the float image)
     cfg = reference_config(64, 2048)
-    s1, _, _ = synthetic.make_pair(2001)
+    s1 = synthetic.portable_cloud(2001, 140000)     # libm-free generator: the same bits on every machine
     layer = rproj.ImageProjectionLayer(config=cfg)
     x = torch.from_numpy(s1).view(1, 3, -1)
     image, u, v, idx, pix = layer(input=x, dataset="kitti")

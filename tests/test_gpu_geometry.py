@@ -77,8 +77,10 @@ def check_projection(scan, out, s, o_sensor, expect_pix2pt=None, expect_image=No
         touched[arr[arr >= 0]] = True
     ok = ~touched
     assert np.array_equal(pix2pt.reshape(-1)[ok], exp[ok]), "pixel -> point map mismatch"
-    if expect_pix2pt is not None and not differ.any():
-        assert np.array_equal(pix2pt, expect_pix2pt)
+    if expect_pix2pt is not None:
+        # the golden map was produced on another CPU (different Sleef path): compare away from ambiguous points
+        clean = ~util.tainted_pixels(scan, o_sensor)
+        assert np.array_equal(pix2pt[clean], np.asarray(expect_pix2pt)[clean])
     # image content: xyz are copies, range follows torch.norm's rounding
     occ = exp >= 0
     sel = ok & occ
@@ -87,8 +89,9 @@ def check_projection(scan, out, s, o_sensor, expect_pix2pt=None, expect_image=No
     assert np.array_equal(image[3].reshape(-1)[sel], rng[exp[sel]])
     assert np.all(image.reshape(4, -1)[:, ok & ~occ] == 0)
     assert int(out["kept"][s].item()) == int((pix2pt >= 0).sum())
-    if expect_image is not None and not differ.any():
-        assert np.array_equal(image, expect_image)
+    if expect_image is not None:
+        clean = ~util.tainted_pixels(scan, o_sensor)
+        assert np.array_equal(image[:, clean], expect_image[:, clean])
     return differ
 
 
@@ -107,8 +110,9 @@ def test_projection_golden(name):
     ref_img = g["image"][0]                                   # [C+1,H,W], last = range
     exp_img4 = np.concatenate([ref_img[:3], ref_img[C:C + 1]], axis=0)
     differ = check_projection(scan, out, 0, o_sensor, exp_map, exp_img4)
-    if C > 3 and not differ.any():
-        assert np.array_equal(out["aux"][0].cpu().numpy(), ref_img[3:C])
+    if C > 3:
+        clean = ~util.tainted_pixels(scan, o_sensor)
+        assert np.array_equal(out["aux"][0].cpu().numpy()[:, clean], ref_img[3:C][:, clean])
 
 
 def test_projection_batched_ragged_and_deterministic():
@@ -132,15 +136,16 @@ def test_projection_full_size_digest():
     """64x2048 KITTI-shaped scan: pixel->point map equals the reference's (committed as int32 digest)."""
     from delora_amd.data import synthetic
     g = util.load_golden("proj_full_digest")
-    s1, _, _ = synthetic.make_pair(int(g["seed"]))
-    assert s1.shape[1] == int(g["N"])
+    import hashlib
+    s1 = synthetic.portable_cloud(int(g["seed"]), int(g["N"]))
+    assert hashlib.sha256(s1.tobytes()).hexdigest() == str(g["scan_sha"]), "portable_cloud is not bit-reproducible here"
     o_sensor = util.oracle_sensor(g["H"], g["W"], g["vfov"], g["hfov"])
     sensor = gpu_sensor(g["H"], g["W"], g["vfov"], g["hfov"])
     out = run_project([s1], sensor)
     differ = check_projection(s1, out, 0, o_sensor, g["pix2pt"].astype(np.int64))
     assert set(np.nonzero(differ)[0]).issubset(set(g["ambiguous_idx"].tolist()))
-    if not differ.any():
-        assert abs(float(out["image4"][0, 3].double().sum().item()) - float(g["range_sum"])) < 1e-6 * float(g["range_sum"])
+    if True:
+        assert abs(float(out["image4"][0, 3].double().sum().item()) - float(g["range_sum"])) < 1e-4 * float(g["range_sum"])
 
 
 def test_projection_idempotent_full_size():
@@ -162,8 +167,8 @@ def test_projection_idempotent_full_size():
 
 # ------------------------------------------------------------------------------------------ normals
 def _angle(a, b):
-    c = np.clip(np.sum(a * b, axis=1), -1.0, 1.0)
-    return np.arccos(c)
+    # atan2(|a x b|, a.b): arccos of the dot product has a noise floor of sqrt(2 eps32) ~ 3e-4 rad on fp32 unit vectors
+    return np.arctan2(np.linalg.norm(np.cross(a, b), axis=1), np.sum(a * b, axis=1))
 
 
 def check_normals(image, got, ref_normals, ref_has, ref_v, ref_u, eigenvalues, pts):
@@ -240,6 +245,12 @@ def _random_T(rng, scale_t=1.0):
     return orc.transformation_matrix(t, q)
 
 
+def _q_slack(q):
+    """Two candidates whose distances differ by less than the fp32 rounding of the transformed point q = R p + t
+    (a few ulp of |q|; the GPU forms q with an fmaf chain, torch's CPU bmm with its own order) are a tie."""
+    return 8 * 6e-8 * q.norm(dim=0) + 1e-12
+
+
 def oracle_nn_pixels(tgt_img, src_img, src_nrm, T, need_wo):
     """Oracle correspondences expressed as target pixel ids per source pixel (-1 where none is requested)."""
     tp, _, tpix = util.lists_from_images(tgt_img, torch.zeros(3, *tgt_img.shape[1:]))
@@ -284,7 +295,8 @@ def test_nn_matches_kdtree(case, shape):
             qq = orc.transform_points(T, sflat[:, bad].view(1, 3, -1))[0].double()
             d_got = (qq - tflat[:, got[bad]]).norm(dim=0)
             d_exp = (qq - tflat[:, exp[bad]]).norm(dim=0)
-            assert torch.all(d_got <= d_exp * (1 + 1e-12)), f"{len(bad)} non-tie mismatches"
+            assert torch.all(d_got <= d_exp + _q_slack(qq)), f"{len(bad)} non-tie mismatches"
+            assert len(bad) <= 1e-4 * len(got) + 1
         sp, _, _ = util.lists_from_images(img[1].cpu(), nrm[1].cpu())
         assert int(vis[0].item()) == orc.visible_pixels(orc.transform_points(T, sp), util.oracle_sensor(H, W, sensor.vfov, sensor.hfov))
 
@@ -310,7 +322,8 @@ def test_nn_full_size_against_bruteforce_kernel():
             tflat = imgs_t[b, :3].reshape(3, -1).cpu().double()
             d_got = (q[0][:, bad].double() - tflat[:, got[bad]]).norm(dim=0)
             d_exp = (q[0][:, bad].double() - tflat[:, exp[bad]]).norm(dim=0)
-            assert torch.all(d_got <= d_exp * (1 + 1e-12)), f"{len(bad)} non-tie mismatches"
+            assert torch.all(d_got <= d_exp + _q_slack(q[0][:, bad].double())), f"{len(bad)} non-tie mismatches"
+            assert len(bad) <= 1e-4 * len(got) + 1
         if b == 0:
             kd = orc.nearest_target_indices(tp, q)
             assert (tpix[kd] != got).sum() <= 2          # exact ties only
@@ -355,8 +368,8 @@ def test_loss_golden_from_reference(mode, p2p):
     G, dev = _geo(), _dev()
     vf, hf = util.kitti_fov()
     sensor = gpu_sensor(g["H"], g["W"], vf, hf)
-    scans = [np.concatenate([g["raw_tgt"].T, g["raw_tgt_n"].T], axis=0).astype(np.float32),
-             np.concatenate([g["raw_src"].T, g["raw_src_n"].T], axis=0).astype(np.float32)]
+    scans = [np.ascontiguousarray(np.concatenate([g["raw_tgt"].T, g["raw_tgt_n"].T], axis=0), dtype=np.float32),
+             np.ascontiguousarray(np.concatenate([g["raw_src"].T, g["raw_src_n"].T], axis=0), dtype=np.float32)]
     out = run_project(scans, sensor, want_uv=False)
     img, nrm = out["image4"], out["aux"]
     # the kept sets must be the reference's filtered lists (deployer.py:258-261)

@@ -1,0 +1,122 @@
+"""The oracle (oracle/delora_oracle.py) against the golden vectors produced by running the reference
+(tests/golden/make_golden.py).  CPU only; this is what pins the oracle before it judges the HIP path.
+
+Integer/index outputs must match exactly.  fp32 values computed by the same torch ops match exactly on the
+machine that generated the vectors; on another CPU, vectorised libm paths (Sleef atan2f) may differ in the
+last place, which is exactly the ambiguity the projection contract documents -- so index comparisons are made
+away from ambiguous points and float comparisons use a few-ulp tolerance.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+from tests.util import orc
+
+
+def _t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+@pytest.mark.parametrize("name", ["small", "small_c6", "mid", "edge", "all_outside"])
+def test_projection(name):
+    g = util.load_golden("proj_" + name)
+    sensor = util.oracle_sensor(g["H"], g["W"], g["vfov"], g["hfov"])
+    scan = g["scan"]
+    image, u, v, idx, pix = orc.project_to_img(_t(scan).view(1, scan.shape[0], -1), sensor)
+    clean = ~util.tainted_pixels(scan, sensor)
+    assert np.array_equal(image.numpy()[0][:, clean], g["image"][0][:, clean])
+    if np.array_equal(idx.numpy(), g["idx"]):          # same CPU path: everything is bit-identical
+        assert np.array_equal(pix.numpy(), g["pix"])
+        assert np.array_equal(u.numpy(), g["u"]) and np.array_equal(v.numpy(), g["v"])
+    else:                                                # only ambiguous points may move
+        amb = set(np.nonzero(util.ambiguity_mask(scan, sensor))[0].tolist())
+        assert set(idx.numpy().tolist()) ^ set(g["idx"].tolist()) <= amb
+    assert np.allclose(u.numpy(), g["u"], atol=1e-3, equal_nan=True) or u.shape != g["u"].shape
+
+
+def test_projection_full_digest():
+    from delora_amd.data import synthetic
+    import hashlib
+    g = util.load_golden("proj_full_digest")
+    s1 = synthetic.portable_cloud(int(g["seed"]), int(g["N"]))
+    assert hashlib.sha256(s1.tobytes()).hexdigest() == str(g["scan_sha"])
+    sensor = util.oracle_sensor(g["H"], g["W"], g["vfov"], g["hfov"])
+    image, _, _, idx, pix = orc.project_to_img(_t(s1).view(1, 3, -1), sensor)
+    m = -np.ones((sensor.H, sensor.W), dtype=np.int32)
+    p = pix.numpy()[0]
+    m[p[:, 0], p[:, 1]] = idx.numpy().astype(np.int32)
+    clean = ~util.tainted_pixels(s1, sensor)
+    assert np.array_equal(m[clean], g["pix2pt"][clean])
+
+
+@pytest.mark.parametrize("name", ["small", "mid"])
+def test_normals(name):
+    g = util.load_golden("normals_" + name)
+    sensor = util.oracle_sensor(g["H"], g["W"], *util.kitti_fov())
+    n, has, pts, aux = orc.compute_normal_vectors(_t(g["image"]).clone(), sensor, side=tuple(g["side"]),
+                                                  epsilon_range=float(g["epsilon_range"]),
+                                                  min_neighbors=int(g["min_neighbors"]), return_aux=True)
+    assert np.array_equal(has.numpy(), g["has"])
+    assert np.array_equal(pts.numpy(), g["points"])
+    assert np.array_equal(aux["count"].numpy(), g["count"])
+    assert np.allclose(n.numpy(), g["normals"], atol=2e-3)
+    ang = np.arctan2(np.linalg.norm(np.cross(n.numpy(), g["normals"]), axis=1), np.sum(n.numpy() * g["normals"], axis=1))
+    assert np.median(ang[g["has"]]) < 1e-6
+
+
+def test_quaternion_to_T_known_answers():
+    g = util.load_golden("geometry")
+    T = orc.transformation_matrix(_t(g["t"]), _t(g["q"]))
+    assert np.allclose(T.numpy(), g["T"], atol=1e-6)
+    # known answers of the (x,y,z,w) convention: identity and a half turn about z
+    R = orc.quaternion_to_rotation_matrix(torch.tensor([[0.0, 0, 0, 1], [0, 0, 1, 0]]))
+    assert torch.allclose(R[0], torch.eye(3)) and torch.allclose(R[1], torch.diag(torch.tensor([-1.0, -1.0, 1.0])))
+    Rr = orc.quaternion_to_rotation_matrix(_t(g["q"]))
+    assert torch.allclose(torch.linalg.det(Rr), torch.ones(len(Rr)), atol=1e-5)
+    assert torch.allclose(Rr @ Rr.transpose(1, 2), torch.eye(3).expand(len(Rr), 3, 3), atol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["squared", "linear"])
+@pytest.mark.parametrize("p2p", [False, True])
+def test_losses_and_gradients(mode, p2p):
+    g = util.load_golden("loss_pair")
+    tgt, tgt_n = _t(g["tgt"]).view(1, 3, -1), _t(g["tgt_n"]).view(1, 3, -1)
+    src, src_n = _t(g["src"]).view(1, 3, -1), _t(g["src_n"]).view(1, 3, -1)
+    for qname in ("identity", "true", "random"):
+        key = f"{mode}_{'p2p' if p2p else 'nop2p'}_{qname}"
+        t = _t(g[key + "_t"]).requires_grad_(True)
+        q = _t(g[key + "_q"]).requires_grad_(True)
+        T = orc.transformation_matrix(t, q)
+        T.retain_grad()
+        assert np.allclose(T.detach().numpy(), g[key + "_T"], atol=1e-6)
+        l, aux = orc.icp_losses(orc.transform_points(T, src), orc.rotate_points(T, src_n), tgt, tgt_n,
+                                normal_loss=mode, point_to_point=p2p, return_aux=True)
+        (l["loss_po2po"] + 2.0 * l["loss_po2pl"] + 0.5 * l["loss_pl2pl"]).backward()
+        got = np.array([float(l[k]) for k in ("loss_po2po", "loss_po2pl", "loss_pl2pl")])
+        assert np.allclose(got, g[key + "_losses"], rtol=1e-5, atol=1e-9)
+        assert aux["pairs"] == int(g[key + "_pairs"])
+        assert np.array_equal(aux["nn_with_normals"].numpy(), g[key + "_nn"])
+        assert np.allclose(T.grad.numpy(), g[key + "_gradT"], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["b1", "b2"])
+def test_step_loss_accumulation_quirk(name):
+    """Deployer.step's loss_pc (sample j weighted (B-j)/B) from the reference step vectors, given the reference T."""
+    g = util.load_golden("step_" + name)
+    sensor = util.oracle_sensor(g["H"], g["W"], *util.kitti_fov())
+    B = len(g["picks"])
+    lists = []
+    for j in range(B):
+        sample = {k: _t(g[f"s{j}::{k}"]) for k in ("scan_1", "scan_2", "normal_list_1", "normal_list_2")}
+        _, _, l = orc.filter_to_projected(sample, sensor)
+        lists.append(l)
+    out, per = orc.step_losses(lists, _t(g["T"]))
+    assert np.isclose(float(out["loss_pc"]), g["ep::loss_point_cloud_epoch"], rtol=2e-5)
+    assert np.isclose(float(out["loss_po2pl"]), g["ep::loss_po2pl_epoch"], rtol=2e-5)
+    assert np.isclose(float(out["loss_pl2pl"]), g["ep::loss_pl2pl_epoch"], rtol=2e-5)
+    # the data-parallel formulation (global sample weights) is the same number
+    halves = [orc.step_losses(lists[r:r + 1], _t(g["T"])[r:r + 1], batch_offset=r, global_batch=B)[0]["loss_pc"] for r in range(B)]
+    assert np.isclose(float(sum(halves)), float(out["loss_pc"]), rtol=1e-6)
+    sp = orc.transform_points(_t(g["T"])[B - 1:B], lists[B - 1]["scan_2"])
+    assert orc.visible_pixels(sp, sensor) == int(g["ep::visible_pixels_epoch"])

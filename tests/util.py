@@ -52,3 +52,20 @@ def lists_from_images(image4, normals):
     pts = img[:3].reshape(3, -1)[:, pix].contiguous().view(1, 3, -1)
     nrm = normals.detach().cpu().reshape(3, -1)[:, pix].contiguous().view(1, 3, -1)
     return pts, nrm, pix
+
+
+def tainted_pixels(xyz, sensor, tol=2e-3):
+    """Pixels an ambiguous point (see ambiguity_mask) may or may not land in: both rounding candidates in u and v.
+    Two correct fp32 evaluations of the projection (different CPUs' Sleef paths, or the GPU's) can only differ there."""
+    p = np.asarray(xyz[:3], dtype=np.float64)
+    amb = ambiguity_mask(xyz, sensor, tol)
+    u = (np.arctan2(p[1], p[0]) - sensor.hfov[0]) / (sensor.hfov[1] - sensor.hfov[0]) * (sensor.W - 1)
+    v = (np.arctan2(p[2], np.hypot(p[0], p[1])) - sensor.vfov[0]) / (sensor.vfov[1] - sensor.vfov[0]) * (sensor.H - 1)
+    t = np.zeros((sensor.H, sensor.W), dtype=bool)
+    ua, va = u[amb], v[amb]
+    for du in (-tol * 2, tol * 2):
+        for dv in (-tol * 2, tol * 2):
+            uu, vv = np.rint(ua + du).astype(np.int64), np.rint(va + dv).astype(np.int64)
+            ok = (uu >= 0) & (uu < sensor.W) & (vv >= 0) & (vv < sensor.H)
+            t[vv[ok], uu[ok]] = True
+    return t
