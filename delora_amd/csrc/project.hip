@@ -15,7 +15,7 @@
 
 __global__ __launch_bounds__(DL_BLOCK) void k_project_scatter(
     const float* __restrict__ pts, int64_t cs, const int32_t* __restrict__ offs, SensorK sen,
-    unsigned long long* __restrict__ keys, float* __restrict__ uv) {
+    unsigned long long* __restrict__ keys, float* __restrict__ uvr) {
   const int s = blockIdx.y;
   const int n0 = offs[s];
   const int n = offs[s + 1] - n0;
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(DL_BLOCK) void k_project_scatter(
     const float r = norm3f(x, y, z);
     const float u = coord_u(x, y, sen);
     const float v = coord_v(x, y, z, sen);
-    if (uv) { uv[g] = u; uv[cs + g] = v; }
+    if (uvr) { uvr[g] = u; uvr[cs + g] = v; uvr[2 * cs + g] = r; }
     const float ru = rintf(u), rv = rintf(v);   // torch.round: half to even
     if (ru <= sen.wm1f && ru >= 0.0f && rv <= sen.hm1f && rv >= 0.0f) {   // projection.py:74-75
       const unsigned long long key = ((unsigned long long)__float_as_uint(r) << 32) | (unsigned int)i;
@@ -72,7 +72,7 @@ extern "C" size_t dl_project_workspace_bytes(int32_t S, int32_t H, int32_t W) {
 
 extern "C" int dl_project(const float* pts, int64_t pts_cs, const int32_t* offs, int32_t S, int32_t C,
                           int32_t max_n, const dl_sensor* sensor, float* image4, float* aux,
-                          int32_t* pix2pt, uint64_t* keys_ws, int32_t* kept, float* uv,
+                          int32_t* pix2pt, uint64_t* keys_ws, int32_t* kept, float* uvr,
                           dl_stream stream) {
   if ((!pts && max_n > 0) || !offs || !sensor || !image4 || !pix2pt || !keys_ws || !kept)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_project: null pointer argument");
@@ -88,7 +88,7 @@ extern "C" int dl_project(const float* pts, int64_t pts_cs, const int32_t* offs,
     int gx = (max_n + DL_BLOCK - 1) / DL_BLOCK;
     if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL(k_project_scatter, dim3(gx, S), dim3(DL_BLOCK), 0, st, pts, pts_cs, offs, sen,
-                       (unsigned long long*)keys_ws, uv);
+                       (unsigned long long*)keys_ws, uvr);
   }
   hipLaunchKernelGGL(k_project_resolve, dim3((sen.HW + DL_BLOCK - 1) / DL_BLOCK, S), dim3(DL_BLOCK), 0,
                      st, pts, pts_cs, offs, C, sen, (const unsigned long long*)keys_ws, image4, aux,

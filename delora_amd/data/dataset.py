@@ -1,0 +1,103 @@
+"""Datasets of consecutive scan pairs.
+
+``PreprocessedPointCloudDataset`` reads the reference's on-disk format
+(``<preprocessed_path>/<seq:02d>/{scans,normals}/<idx:06d>.npy``, ``[M,3]`` fp32, written by
+src/preprocessing/preprocesser.py:64-68) and yields the same sample dict as src/data/dataset.py:124-154.
+``SyntheticPairDataset`` produces pairs from delora_amd.data.synthetic when no dataset is on disk
+(build container, bench); its samples carry raw scans and, unless asked otherwise, no normal lists --
+the step then estimates normals online from the projected images.
+"""
+import glob
+import os
+
+import numpy as np
+import torch
+
+from . import synthetic
+
+
+def _as_list_tensor(array):
+    """``[M,3]`` array -> ``[1,3,M]`` tensor (the reference's view of a stored list, dataset.py:94-102)."""
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(array, dtype=np.float32).T)).unsqueeze(0)
+
+
+class PreprocessedPointCloudDataset(torch.utils.data.Dataset):
+    def __init__(self, config):
+        super().__init__()
+        self.config = config
+        self.store_dataset_in_RAM = config["store_dataset_in_RAM"]
+        self.scans_files_in_datasets, self.normals_files_in_datasets = [], []
+        table = []                                   # rows: (dataset index, sequence index, scan index)
+        for i_ds, name in enumerate(config["datasets"]):
+            scans_seq, normals_seq = [], []
+            for i_seq, ident in enumerate(config[name]["data_identifiers"]):
+                root = os.path.join(config[name]["preprocessed_path"], format(ident, "02d") + "/")
+                if not os.path.exists(root):
+                    raise Exception("The specified path and dataset " + root + "does not exist.")
+                scans = sorted(glob.glob(os.path.join(root, "scans/", "*.npy")))
+                normals = sorted(glob.glob(os.path.join(root, "normals/", "*.npy")))
+                scans_seq.append(scans)
+                normals_seq.append(normals)
+                # a sample is the pair (t, t+1): the last scan of a sequence only ever appears as "t+1"
+                table += [(i_ds, i_seq, k) for k in range(len(normals) - 1)]
+            self.scans_files_in_datasets.append(scans_seq)
+            self.normals_files_in_datasets.append(normals_seq)
+        table = np.asarray(table, dtype=int).reshape(-1, 3)
+        self.indices_dataset, self.indices_sequence, self.indices_scan = table[:, 0], table[:, 1], table[:, 2]
+        self.num_scans_overall = len(table)
+        self._ram = {}
+        if self.store_dataset_in_RAM:
+            print("Loading all scans and normals into the RAM / SWAP... Disable this if you do not have enough RAM.")
+            for i_ds, seqs in enumerate(self.scans_files_in_datasets):
+                for i_seq, files in enumerate(seqs):
+                    for k in range(len(files)):
+                        self._ram[(i_ds, i_seq, k)] = self.load_files_from_disk(i_ds, i_seq, k)
+            print("Loaded " + str(len(self._ram)) + " scans to RAM/swap.")
+        else:
+            print("Dataset will be kept on disk. For higher performance enable RAM loading.")
+
+    def load_files_from_disk(self, index_dataset, index_sequence, index_scan):
+        normals = _as_list_tensor(np.load(self.normals_files_in_datasets[index_dataset][index_sequence][index_scan]))
+        scan = _as_list_tensor(np.load(self.scans_files_in_datasets[index_dataset][index_sequence][index_scan]))
+        return normals, scan
+
+    def _get(self, i_ds, i_seq, k):
+        if self.store_dataset_in_RAM:
+            return self._ram[(i_ds, i_seq, k)]
+        return self.load_files_from_disk(i_ds, i_seq, k)
+
+    def __getitem__(self, index):
+        i_ds, i_seq, k = int(self.indices_dataset[index]), int(self.indices_sequence[index]), int(self.indices_scan[index])
+        normal_list_1, scan_1 = self._get(i_ds, i_seq, k)
+        normal_list_2, scan_2 = self._get(i_ds, i_seq, k + 1)
+        return {"index": index, "index_dataset": i_ds, "index_sequence": i_seq, "index_scan": k,
+                "dataset": self.config["datasets"][i_ds],
+                "normal_list_1": normal_list_1, "normal_list_2": normal_list_2, "scan_1": scan_1, "scan_2": scan_2}
+
+    def __len__(self):
+        return self.num_scans_overall
+
+
+class SyntheticPairDataset(torch.utils.data.Dataset):
+    """``length`` deterministic synthetic pairs for dataset block ``dataset`` (seed = base_seed + index)."""
+
+    def __init__(self, config, dataset, length, base_seed=1000, rings=None, azimuth_steps=None, points=None):
+        self.config, self.dataset, self.length, self.base_seed = config, dataset, int(length), int(base_seed)
+        block = config[dataset]
+        self.rings = rings or block["vertical_cells"]
+        self.azimuth_steps = azimuth_steps or block.get("horizontal_cells_preprocessing", block["horizontal_cells"])
+        vf = block["vertical_field_of_view"]
+        self.vfov_deg = (float(np.rad2deg(vf[0])), float(np.rad2deg(vf[1])))
+        self.points = points
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, index):
+        s1, s2, T = synthetic.make_pair(self.base_seed + index, rings=self.rings, azimuth_steps=self.azimuth_steps,
+                                        vfov_deg=self.vfov_deg)
+        if self.points:
+            s1, s2 = synthetic.pad_or_trim(s1, self.points), synthetic.pad_or_trim(s2, self.points)
+        return {"index": index, "index_dataset": 0, "index_sequence": 0, "index_scan": index, "dataset": self.dataset,
+                "scan_1": torch.from_numpy(s1).unsqueeze(0), "scan_2": torch.from_numpy(s2).unsqueeze(0),
+                "normal_list_1": None, "normal_list_2": None, "T_true": torch.from_numpy(T)}

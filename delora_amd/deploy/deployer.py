@@ -1,0 +1,156 @@
+"""``Deployer``: model + geometry + one optimisation step over a batch of scan pairs.
+
+Mirror of the reference's Deployer (src/deploy/deployer.py:21-375) for the training/inference step:
+same constructor argument, same ``step(preprocessed_dicts, epoch_losses, log_images_bool)`` contract and
+the same loss bookkeeping -- including its accumulation order, which gives sample j of a batch the weight
+(B-j)/B in the back-propagated ``loss_pc`` (deployer.py:309-312,329) -- but the per-sample Python loops are
+replaced by batched HIP launches (deploy/step_geometry.py) and nothing synchronises with the host inside a step.
+Plotting / MLflow image logging (deployer.py:73-162) is outside the hot path and not provided.
+"""
+import torch
+
+from .. import geometry
+from ..data import dataset as dataset_module
+from ..models import model as model_module
+from ..models import model_parts
+from ..utility import projection
+from . import step_geometry
+
+
+class Deployer(object):
+
+    def __init__(self, config, dataset=None, geometry_backend=None):
+        self.config = config
+        self.device = config["device"]
+        self.batch_size = config["batch_size"]
+        self.dataset = dataset if dataset is not None else dataset_module.PreprocessedPointCloudDataset(config=config)
+        self.steps_per_epoch = int(len(self.dataset) / self.batch_size)
+        self.img_projection = projection.ImageProjectionLayer(config=config)
+        self.model = model_module.OdometryModel(config=config).to(self.device)
+        if config.get("channels_last", False):
+            self.model = self.model.to(memory_format=torch.channels_last)
+        if config["use_jit"]:
+            first = config["datasets"][0]
+            example = torch.zeros((1, 4, config[first]["vertical_cells"], config[first]["horizontal_cells"]), device=self.device)
+            self.model = torch.jit.trace(self.model, example_inputs=(example, example))
+        self.geometry_handler = model_parts.GeometryHandler(config=config)
+        self.geo = geometry_backend if geometry_backend is not None else step_geometry.HipStepGeometry()
+        self.lossTransformation = torch.nn.MSELoss()
+        self.training_bool = False
+        # data-parallel placement of this process' slice inside the global batch (single process: 0 of 1)
+        self.rank, self.world_size = 0, 1
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            self.rank, self.world_size = torch.distributed.get_rank(), torch.distributed.get_world_size()
+
+    @staticmethod
+    def list_collate(batch_dicts):
+        return list(batch_dicts)
+
+    # ------------------------------------------------------------------ point cloud helpers (deployer.py:181-189)
+    def rotate_point_cloud_transformation_matrix(self, transformation_matrix, point_cloud):
+        return transformation_matrix[:, :3, :3].matmul(point_cloud[:, :3, :])
+
+    def transform_point_cloud_transformation_matrix(self, transformation_matrix, point_cloud):
+        return (self.rotate_point_cloud_transformation_matrix(transformation_matrix, point_cloud)
+                + transformation_matrix[:, :3, 3].view(-1, 3, 1))
+
+    def augment_input(self, preprocessed_data):
+        if self.config["random_point_cloud_rotations"]:
+            raise Exception("Needs to be verified for larger batches")   # the reference refuses too (deployer.py:203-204)
+        return preprocessed_data
+
+    def normalize_input(self, preprocessed_data):
+        """Optional range normalisation (deployer.py:222-235): both scans divided by the mean of their mean ranges."""
+        m1 = torch.norm(preprocessed_data["scan_1"], dim=1).mean(dim=1, keepdim=True)
+        m2 = torch.norm(preprocessed_data["scan_2"], dim=1).mean(dim=1, keepdim=True)
+        mean = torch.cat((m1, m2), dim=1).mean(dim=1)
+        preprocessed_data["scan_1"] = preprocessed_data["scan_1"] / mean
+        preprocessed_data["scan_2"] = preprocessed_data["scan_2"] / mean
+        preprocessed_data["scaling_factor"] = mean
+        return preprocessed_data, mean
+
+    def _normal_params(self, dataset):
+        side = self.config[dataset]["neighborhood_side_length"]
+        return (int(side[0] / 2), int(side[1] / 2), float(self.config["epsilon_range"]),
+                int(self.config["min_num_points_in_neighborhood_to_determine_point_class"]))
+
+    def _run_model(self, stacked):
+        amp = self.config.get("amp_dtype")
+        if self.config.get("channels_last", False):
+            stacked = stacked.contiguous(memory_format=torch.channels_last)
+        args = (stacked[:, :4], stacked[:, 4:]) if self.config["use_jit"] else (stacked,)
+        if amp:
+            with torch.autocast("cuda", dtype=getattr(torch, amp)):
+                t, q = self.model(*args)
+            return t.float(), q.float()
+        return self.model(*args)
+
+    # ------------------------------------------------------------------------------------------------ the step
+    def step(self, preprocessed_dicts, epoch_losses=None, log_images_bool=False):
+        cfg = self.config
+        B = len(preprocessed_dicts)
+        if B != self.batch_size:
+            # the reference indexes batch_size transforms against the list and fails on a short last batch
+            # (deployer.py:240,290-292); make that explicit
+            raise ValueError(f"step() needs exactly batch_size={self.batch_size} samples, got {B} (use drop_last)")
+        dataset = preprocessed_dicts[0]["dataset"]
+        sensor = self.img_projection.sensor(dataset)
+        for i, d in enumerate(preprocessed_dicts):
+            if d["dataset"] != dataset and geometry.Sensor.from_config(cfg, d["dataset"]).key() != sensor.key():
+                raise ValueError("all samples of a batch must share one image geometry (reference: hyperparameters.yaml:3)")
+            if self.training_bool:
+                d = self.augment_input(preprocessed_data=d)
+            if cfg["normalization_scaling"]:
+                d, _ = self.normalize_input(preprocessed_data=d)
+            preprocessed_dicts[i] = d
+        prepared = self.geo.prepare(preprocessed_dicts, sensor, self._normal_params(dataset))
+        translations, rotation_representation = self._run_model(prepared["stacked"])
+        computed_transformations = self.geometry_handler.get_transformation_matrix_quaternion(
+            translation=translations, quaternion=rotation_representation, device=self.device)
+
+        def rescale(T):
+            if cfg["normalization_scaling"]:
+                T = T.clone()
+                for i, d in enumerate(preprocessed_dicts):
+                    T[i, :3, 3] = T[i, :3, 3] * d["scaling_factor"]
+            return T
+
+        if cfg["inference_only"]:
+            return rescale(computed_transformations)
+
+        flags = geometry.loss_flags(cfg)
+        terms, counts, visible = self.geo.losses(computed_transformations, prepared, flags,
+                                                 need_without_normals=bool(cfg["point_to_point_loss"]))
+        # global batch bookkeeping: this rank holds samples [rank*B, (rank+1)*B) of a batch of world_size*B
+        Bg = B * self.world_size
+        j_global = torch.arange(B, device=terms.device, dtype=terms.dtype) + float(self.rank * B)
+        lam = torch.tensor([1.0, float(cfg["lambda_po2pl"]), 1.0], device=terms.device, dtype=terms.dtype)
+        weighted = terms * lam                                                   # deployer.py:309-311
+        sums = weighted.sum(dim=0)
+        losses = {"loss_po2po": sums[0] / Bg, "loss_po2pl": sums[1] / Bg, "loss_pl2pl": sums[2] / Bg,
+                  # running sums added inside the sample loop (:312) <=> weight (Bg - j) on sample j; then /Bg (:329)
+                  "loss_pc": ((Bg - j_global) * weighted.sum(dim=1)).sum() / Bg}
+        if not cfg["unsupervised_at_start"]:
+            # identity pre-training (:324-338): the reference overwrites loss_transformation in every loop pass, so
+            # only the LAST sample of the batch is fitted to the identity
+            eye = torch.eye(4, device=self.device).view(1, 4, 4)
+            loss = self.lossTransformation(input=computed_transformations[B - 1:B], target=eye) / Bg
+            if self.world_size > 1 and self.rank != self.world_size - 1:
+                loss = loss * 0.0
+        else:
+            loss = losses["loss_pc"]
+        if self.training_bool:
+            # DDP averages gradients over ranks; the reference's loss is a SUM over the global batch
+            (loss * float(self.world_size)).backward()
+            self.optimizer.step()
+        computed_transformations = rescale(computed_transformations)
+        if epoch_losses is not None:
+            epoch_losses["loss_epoch"] += loss.detach()
+            epoch_losses["loss_point_cloud_epoch"] += losses["loss_pc"].detach()
+            epoch_losses["loss_po2po_epoch"] += losses["loss_po2po"].detach()
+            epoch_losses["loss_po2pl_epoch"] += losses["loss_po2pl"].detach()
+            epoch_losses["loss_pl2pl_epoch"] += losses["loss_pl2pl"].detach()
+            if visible is not None:
+                epoch_losses["visible_pixels_epoch"] += visible[B - 1].detach()   # last sample only (:349-352)
+        self.last_step = {"loss_terms": terms.detach(), "pair_counts": counts, "losses": {k: v.detach() for k, v in losses.items()}}
+        return epoch_losses, computed_transformations

@@ -1,0 +1,68 @@
+"""Geometry of one training step, batched: every sample of the batch goes through ONE launch per kernel.
+
+The reference loops over the samples in Python and crosses to the host several times per sample
+(src/deploy/deployer.py:245-268, :290-327).  Here the 2B scans of a batch are concatenated (CSR offsets),
+projected together into a ``[2B,4,H,W]`` buffer laid out as [b0.scan_1, b0.scan_2, b1.scan_1, ...] -- which
+*is* the network input ``[B,8,H,W]`` without a copy -- and normals, correspondences and losses are batched
+the same way.  Nothing in here synchronises with the host.
+"""
+import torch
+
+from .. import geometry
+
+
+class HipStepGeometry:
+    """Default (and only product) backend; raises through delora_amd._lib when libdelora_hip.so is missing."""
+
+    def __init__(self):
+        self._offsets = {}
+
+    def _offsets_for(self, lengths, device):
+        key = (tuple(lengths), str(device))
+        t = self._offsets.get(key)
+        if t is None:
+            offs = [0]
+            for n in lengths:
+                offs.append(offs[-1] + n)
+            t = torch.tensor(offs, dtype=torch.int32, device=device)
+            if len(self._offsets) > 64:
+                self._offsets.clear()
+            self._offsets[key] = t
+        return t
+
+    def prepare(self, samples, sensor, normal_params):
+        """samples: list of dicts with ``scan_1``/``scan_2`` ``[1,3,N]`` on the GPU and optional ``normal_list_*``.
+        Returns dict(stacked [B,8,H,W] network input, images [B,2,4,H,W] view, normals [B,2,3,H,W])."""
+        B = len(samples)
+        with_lists = samples[0].get("normal_list_1") is not None
+        chunks, lengths = [], []
+        for s in samples:
+            for k in ("1", "2"):
+                scan = s["scan_" + k][0]
+                if with_lists:
+                    scan = torch.cat((scan[:3], s["normal_list_" + k][0]), dim=0)
+                chunks.append(scan)
+                lengths.append(scan.shape[1])
+        pts = torch.cat(chunks, dim=1).contiguous().float()
+        offs = self._offsets_for(lengths, pts.device)
+        out = geometry.project(pts, offs, max(lengths), sensor)
+        image4 = out["image4"]
+        H, W = sensor.H, sensor.W
+        if with_lists:
+            normals = out["aux"][:, :3]                 # stored normals ride along as extra channels (deployer.py:258-261)
+            if normals.shape[1] != 3 or not normals.is_contiguous():
+                normals = normals.contiguous()
+        else:
+            a, b, eps, min_n = normal_params
+            normals = geometry.normals(image4, a, b, eps, min_n)
+        return {"stacked": image4.view(B, 8, H, W), "images": image4.view(B, 2, 4, H, W),
+                "normals": normals.view(B, 2, 3, H, W), "kept": out["kept"].view(B, 2), "sensor": sensor}
+
+    def losses(self, T, prepared, flags, need_without_normals):
+        """(loss_terms [B,3] differentiable w.r.t. T, pair_counts [B,2], visible [B]) for target = scan 1, source = scan 2."""
+        img, nrm, sensor = prepared["images"], prepared["normals"], prepared["sensor"]
+        tgt, src = img[:, 0], img[:, 1]
+        tgt_n, src_n = nrm[:, 0], nrm[:, 1]
+        nn, visible = geometry.nn_correspond(src, src_n, tgt, T, sensor, need_without_normals=need_without_normals)
+        terms, counts = geometry.icp_loss(T, src, src_n, tgt, tgt_n, nn, flags)
+        return terms, counts, visible

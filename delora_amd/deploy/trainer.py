@@ -1,0 +1,150 @@
+"""``Trainer``: optimiser, epochs, checkpoints, logging.  Mirror of src/deploy/trainer.py:18-186.
+
+Differences that the MI355X design needs and the reference does not have:
+  * data parallelism: when torch.distributed is initialised (``torchrun``; backend "nccl" = RCCL over xGMI) the
+    model is wrapped in DistributedDataParallel and the sampler shards the dataset; the loss weights follow the
+    sample's position in the GLOBAL batch so that N ranks x B samples reproduce one process with N*B samples;
+  * metrics stay on the device and are read back once per epoch (the reference syncs five scalars per step);
+  * mlflow / qqdm are optional: if they are not installed, metrics are printed and checkpoints still written.
+Checkpoint files keep the reference's layout (trainer.py:155-161): epoch, model_state_dict, optimizer_state_dict,
+loss, parameters.
+"""
+import os
+
+import numpy as np
+import torch
+
+from . import deployer
+
+try:                                  # optional third-party logging, absent in the build/bench image
+    import mlflow
+    import mlflow.pytorch
+except ImportError:                   # pragma: no cover
+    mlflow = None
+try:
+    import qqdm
+except ImportError:                   # pragma: no cover
+    qqdm = None
+
+
+class Trainer(deployer.Deployer):
+
+    def __init__(self, config, dataset=None, geometry_backend=None):
+        super().__init__(config=config, dataset=dataset, geometry_backend=geometry_backend)
+        self.training_bool = True
+        self.raw_model = self.model
+        if self.world_size > 1:
+            ids = [self.device.index] if getattr(self.device, "type", "cpu") == "cuda" else None
+            self.model = torch.nn.parallel.DistributedDataParallel(
+                self.model, device_ids=ids, gradient_as_bucket_view=True,
+                bucket_cap_mb=config.get("ddp_bucket_cap_mb", 25))
+        self.optimizer = torch.optim.Adam(params=self.raw_model.parameters(), lr=config["learning_rate"])
+        if config["checkpoint"]:
+            checkpoint = torch.load(config["checkpoint"], map_location=self.device, weights_only=False)
+            self.raw_model.load_state_dict(checkpoint["model_state_dict"])
+            print("Model weights loaded from " + config["checkpoint"])
+            self.optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
+            print("Optimizer parameters loaded from " + config["checkpoint"])
+            config["unsupervised_at_start"] = True      # a pretrained model continues unsupervised (trainer.py:35-36)
+        if config["inference_only"]:
+            print("Config error: Inference only does not make sense during training. Changing to inference_only=False.")
+            config["inference_only"] = False
+
+    @staticmethod
+    def new_epoch_losses():
+        return {"loss_epoch": 0.0, "loss_point_cloud_epoch": 0.0, "loss_field_of_view_epoch": 0.0,
+                "loss_po2po_epoch": 0.0, "loss_po2pl_epoch": 0.0, "loss_pl2pl_epoch": 0.0,
+                "visible_pixels_epoch": 0.0, "loss_yaw_pitch_roll_epoch": np.zeros(3), "loss_true_trafo_epoch": 0.0}
+
+    def to_device(self, preprocessed_dicts):
+        for d in preprocessed_dicts:
+            for key, value in d.items():
+                if hasattr(value, "to"):
+                    d[key] = value.to(self.device, non_blocking=True)
+        return preprocessed_dicts
+
+    def train_epoch(self, epoch, dataloader):
+        epoch_losses = self.new_epoch_losses()
+        iterator = dataloader
+        show = self.rank == 0 and qqdm is not None
+        if show:
+            iterator = qqdm.qqdm(dataloader, desc=qqdm.format_str("blue", "Epoch " + str(epoch)))
+        every = max(1, int(self.config.get("progress_every", 50)))
+        for counter, preprocessed_dicts in enumerate(iterator):
+            self.to_device(preprocessed_dicts)
+            self.optimizer.zero_grad(set_to_none=True)
+            epoch_losses, _ = self.step(preprocessed_dicts=preprocessed_dicts, epoch_losses=epoch_losses,
+                                        log_images_bool=False)
+            if show and counter % every == 0:          # one host sync per `every` steps instead of one per step
+                iterator.set_infos({"loss": f'{float(epoch_losses["loss_epoch"]) / (counter + 1):.6f}',
+                                    "loss_po2pl": f'{float(epoch_losses["loss_po2pl_epoch"]) / (counter + 1):.6f}',
+                                    "loss_pl2pl": f'{float(epoch_losses["loss_pl2pl_epoch"]) / (counter + 1):.6f}'})
+        return epoch_losses
+
+    def _reduce_metrics(self, epoch_losses):
+        keys = ("loss_epoch", "loss_point_cloud_epoch", "loss_po2po_epoch", "loss_po2pl_epoch", "loss_pl2pl_epoch",
+                "visible_pixels_epoch")
+        vec = torch.stack([torch.as_tensor(epoch_losses[k], dtype=torch.float32, device=self.device).reshape(()) for k in keys])
+        if self.world_size > 1:
+            # loss terms are already normalised by the global batch on every rank: the global value is the SUM
+            torch.distributed.all_reduce(vec, op=torch.distributed.ReduceOp.SUM)
+        vals = (vec / max(self.steps_per_epoch_effective, 1)).tolist()
+        return dict(zip(keys, vals))
+
+    def save_checkpoint(self, path, epoch, loss):
+        torch.save({"epoch": epoch, "model_state_dict": self.raw_model.state_dict(),
+                    "optimizer_state_dict": self.optimizer.state_dict(), "loss": float(loss),
+                    "parameters": self.config}, path)
+
+    def make_dataloader(self):
+        sampler = None
+        if self.world_size > 1:
+            sampler = torch.utils.data.distributed.DistributedSampler(self.dataset, num_replicas=self.world_size,
+                                                                      rank=self.rank, shuffle=True, drop_last=True)
+        loader = torch.utils.data.DataLoader(dataset=self.dataset, batch_size=self.batch_size, shuffle=sampler is None,
+                                             sampler=sampler, collate_fn=Trainer.list_collate, drop_last=True,
+                                             num_workers=self.config["num_dataloader_workers"],
+                                             pin_memory=getattr(self.device, "type", "cpu") == "cuda")
+        return loader, sampler
+
+    def train(self, max_epochs=10000):
+        dataloader, sampler = self.make_dataloader()
+        self.steps_per_epoch_effective = len(dataloader)
+        out_dir = self.config.get("checkpoint_dir", "/tmp")
+        run = None
+        if mlflow is not None and self.rank == 0:
+            mlflow.set_experiment(self.config["experiment"])
+            run = mlflow.start_run(run_name="Training: " + self.config["training_run_name"])
+            for k, v in self.config.items():
+                mlflow.log_param(k, v)
+        try:
+            for epoch in range(max_epochs):
+                if sampler is not None:
+                    sampler.set_epoch(epoch)
+                metrics = self._reduce_metrics(self.train_epoch(epoch=epoch, dataloader=dataloader))
+                if self.rank == 0:
+                    print("--------------------------")
+                    print("Epoch Summary: " + format(epoch, "05d") + ", loss: " + str(metrics["loss_epoch"]) +
+                          ", unsupervised: " + str(self.config["unsupervised_at_start"]))
+                    names = {"loss": "loss_epoch", "loss point cloud": "loss_point_cloud_epoch", "loss po2po": "loss_po2po_epoch",
+                             "loss po2pl": "loss_po2pl_epoch", "loss pl2pl": "loss_pl2pl_epoch", "visible pixels": "visible_pixels_epoch"}
+                    if mlflow is not None:
+                        for shown, key in names.items():
+                            mlflow.log_metric(shown, float(metrics[key]), step=epoch)
+                    else:
+                        print({shown: metrics[key] for shown, key in names.items()})
+                    latest = os.path.join(out_dir, self.config["training_run_name"] + "_latest_checkpoint.pth")
+                    self.save_checkpoint(latest, epoch, metrics["loss_epoch"])            # every epoch (trainer.py:155-162)
+                    if not epoch % 5:                                                       # and a kept copy every 5 (:164-173)
+                        self.save_checkpoint(os.path.join(out_dir, self.config["training_run_name"] + "_checkpoint_epoch_" + str(epoch) + ".pth"),
+                                             epoch, metrics["loss_epoch"])
+                    if mlflow is not None:
+                        mlflow.log_artifact(latest)
+                # identity pre-training ends once its loss is small (trainer.py:184-186); all ranks see the same reduced value
+                if not self.config["unsupervised_at_start"] and metrics["loss_epoch"] < 1e-2:
+                    self.config["unsupervised_at_start"] = True
+                    if self.rank == 0:
+                        print("Loss has decreased sufficiently. Switching to unsupervised mode.")
+        finally:
+            if run is not None:
+                mlflow.end_run()

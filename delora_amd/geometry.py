@@ -59,7 +59,8 @@ def _planar(t, channels):
 
 def project(points, offsets, max_points, sensor, want_uv=False):
     """Range images of S scans.  points ``[C,sumN]`` fp32 (rows 0..2 = xyz), offsets ``[S+1]`` int32 (device).
-    Returns dict(image4 [S,4,H,W], aux [S,C-3,H,W]|None, pix2pt [S,H,W] int32, kept [S] int32, uv [2,sumN]|None)."""
+    Returns dict(image4 [S,4,H,W], aux [S,C-3,H,W]|None, pix2pt [S,H,W] int32, kept [S] int32,
+    uv [3,sumN]|None = u, v and range of every point)."""
     lib = _lib.load()
     _require_cuda(points, offsets)
     if points.dtype != torch.float32 or points.dim() != 2 or points.stride(1) != 1:
@@ -73,7 +74,7 @@ def project(points, offsets, max_points, sensor, want_uv=False):
     pix2pt = torch.empty((S, H, W), dtype=torch.int32, device=dev)
     kept = torch.empty((S,), dtype=torch.int32, device=dev)
     keys = torch.empty((lib.dl_project_workspace_bytes(S, H, W) // 8,), dtype=torch.int64, device=dev)
-    uv = torch.empty((2, points.shape[1]), dtype=torch.float32, device=dev) if want_uv else None
+    uv = torch.empty((3, points.shape[1]), dtype=torch.float32, device=dev) if want_uv else None
     if uv is not None and points.stride(0) != uv.stride(0):
         raise ValueError("want_uv needs a dense points buffer")
     _lib.check(lib.dl_project(_ptr(points), points.stride(0), _ptr(offsets), S, C, int(max_points),

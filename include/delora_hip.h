@@ -75,11 +75,11 @@ size_t dl_project_workspace_bytes(int32_t S, int32_t H, int32_t W);
  *   pix2pt   [S][H][W]     out: index of the winning point relative to its scan start, -1 if empty
  *   keys_ws  dl_project_workspace_bytes(S,H,W) bytes of scratch
  *   kept     [S]           out: number of occupied pixels per scan
- *   uv       [2][pts_cs]   out (may be NULL): fp32 u and v of EVERY input point, input order
+ *   uvr      [3][pts_cs]   out (may be NULL): fp32 u, v and range of EVERY input point, input order
  */
 int dl_project(const float* pts, int64_t pts_cs, const int32_t* offs, int32_t S, int32_t C,
                int32_t max_n, const dl_sensor* sensor, float* image4, float* aux, int32_t* pix2pt,
-               uint64_t* keys_ws, int32_t* kept, float* uv, dl_stream stream);
+               uint64_t* keys_ws, int32_t* kept, float* uvr, dl_stream stream);
 
 /*
  * Per-pixel surface normals of S range images.

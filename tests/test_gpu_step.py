@@ -1,0 +1,219 @@
+"""The full training step (projection -> CNN -> T -> correspondences -> losses -> backward -> Adam) on the GPU against
+the vectors recorded from the reference's own ``Trainer.step`` (tests/golden/step_b{1,2}.npz), and the mirrors of
+the reference's module API against golden vectors / the oracle."""
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+from tests.util import orc
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _small_model_cfg(g, H, W, **over):
+    return util.repo_config(H, W, device="cuda:0", factor_fewer_resnet_channels=int(g["cfg::factor_fewer_resnet_channels"]),
+                            resnet_outputs=int(g["cfg::resnet_outputs"]), unsupervised_at_start=True, inference_only=False, **over)
+
+
+def _state_dict(g, dev):
+    return {k[4:]: torch.from_numpy(v).to(dev) for k, v in g.items() if k.startswith("sd::")}
+
+
+def test_model_forward_matches_reference():
+    from delora_amd.models.model import OdometryModel
+    dev = _dev()
+    g = util.load_golden("model_small")
+    cfg = _small_model_cfg(g, int(g["H"]), int(g["W"]))
+    m = OdometryModel(cfg).to(dev)
+    assert set(m.state_dict().keys()) == set(_state_dict(g, dev).keys())
+    m.load_state_dict(_state_dict(g, dev))
+    i1, i2 = torch.from_numpy(g["image_1"]).to(dev).unsqueeze(0), torch.from_numpy(g["image_2"]).to(dev).unsqueeze(0)
+    with torch.no_grad():
+        t, q = m(i1, i2)
+        t2, q2 = m(torch.cat((i1, i2), dim=1))
+    assert torch.equal(t, t2) and torch.equal(q, q2)
+    assert np.allclose(t.cpu().numpy(), g["translation"], rtol=REL, atol=1e-6)
+    assert np.allclose(q.cpu().numpy(), g["quaternion"], rtol=REL, atol=1e-6)
+
+
+def test_full_model_has_reference_parameter_layout():
+    from delora_amd.models.model import OdometryModel
+    cfg = util.repo_config(64, 2048)
+    m = OdometryModel(cfg)
+    sd = m.state_dict()
+    assert sum(p.numel() for p in m.parameters()) == 11876019
+    assert len(sd) == 30 and tuple(sd["resnet.conv1.weight"].shape) == (64, 8, 3, 3)
+    assert tuple(sd["fully_connected_rotation.3.weight"].shape) == (4, 100)
+
+
+@pytest.mark.parametrize("name", ["b1", "b2"])
+def test_training_step_matches_reference(name):
+    from delora_amd.deploy.trainer import Trainer
+    dev = _dev()
+    g = util.load_golden("step_" + name)
+    gm = util.load_golden("model_small")
+    B = len(g["picks"])
+    cfg = _small_model_cfg(gm, int(g["H"]), int(g["W"]), batch_size=B)
+    samples = []
+    for j in range(B):
+        s = {k: torch.from_numpy(g[f"s{j}::{k}"]).to(dev) for k in ("scan_1", "scan_2", "normal_list_1", "normal_list_2")}
+        s["dataset"] = "kitti"
+        samples.append(s)
+    trainer = Trainer(cfg, dataset=util.ListDataset(samples))
+    trainer.raw_model.load_state_dict(_state_dict(gm, dev))
+    before = {k: v.detach().clone() for k, v in trainer.raw_model.state_dict().items()}
+    ep = trainer.new_epoch_losses()
+    trainer.optimizer.zero_grad()
+    ep, T = trainer.step(preprocessed_dicts=[dict(s) for s in samples], epoch_losses=ep)
+    torch.cuda.synchronize()
+    T_ref = g["T"]
+    assert np.allclose(T.detach().cpu().numpy(), T_ref, rtol=REL, atol=REL * np.abs(T_ref).max()), "poses"
+    for key in ("loss_epoch", "loss_point_cloud_epoch", "loss_po2pl_epoch", "loss_pl2pl_epoch", "loss_po2po_epoch"):
+        assert np.isclose(float(ep[key]), g["ep::" + key], rtol=REL, atol=1e-7), key
+    assert int(ep["visible_pixels_epoch"]) == int(g["ep::visible_pixels_epoch"])
+    for k, p in trainer.raw_model.named_parameters():
+        ref = float(g["gradnorm::" + k])
+        assert np.isclose(float(p.grad.double().norm()), ref, rtol=2e-3, atol=1e-9), f"grad norm {k}"
+    after = trainer.raw_model.state_dict()
+    for k in before:                                        # Adam's first step moves every weight by ~lr*sign(grad)
+        got = float((after[k].double() - before[k].double()).sum())
+        n = before[k].numel()
+        assert abs(got - float(g["delta::" + k])) <= 1e-5 * max(2.0, 0.005 * n), f"Adam update {k}"
+
+
+def test_identity_pretraining_loss_uses_last_sample_only():
+    """deployer.py:324-338: with unsupervised_at_start False the loss is MSE(T_last, I)/B."""
+    from delora_amd.deploy.trainer import Trainer
+    dev = _dev()
+    g, gm = util.load_golden("step_b2"), util.load_golden("model_small")
+    cfg = _small_model_cfg(gm, int(g["H"]), int(g["W"]), batch_size=2)
+    cfg["unsupervised_at_start"] = False
+    samples = [{**{k: torch.from_numpy(g[f"s{j}::{k}"]).to(dev) for k in ("scan_1", "scan_2", "normal_list_1", "normal_list_2")},
+                "dataset": "kitti"} for j in range(2)]
+    trainer = Trainer(cfg, dataset=util.ListDataset(samples))
+    trainer.raw_model.load_state_dict(_state_dict(gm, dev))
+    ep, T = trainer.step(preprocessed_dicts=[dict(s) for s in samples], epoch_losses=trainer.new_epoch_losses())
+    expect = float(((T[1].detach() - torch.eye(4, device=dev)) ** 2).mean() / 2)
+    assert np.isclose(float(ep["loss_epoch"]), expect, rtol=1e-5)
+    assert np.isclose(float(ep["loss_point_cloud_epoch"]), g["ep::loss_point_cloud_epoch"], rtol=REL)   # still computed (quirk f)
+
+
+def test_online_normals_step_runs_and_learns():
+    """No normal lists in the samples: normals come from the projected images; a few steps reduce the loss."""
+    from delora_amd.data.dataset import SyntheticPairDataset
+    from delora_amd.deploy.trainer import Trainer
+    dev = _dev()
+    cfg = util.repo_config(32, 256, device="cuda:0", factor_fewer_resnet_channels=4, resnet_outputs=128,
+                           unsupervised_at_start=True, inference_only=False, batch_size=2, learning_rate=1e-4)
+    ds = SyntheticPairDataset(cfg, "kitti", 2, rings=32, azimuth_steps=300)
+    trainer = Trainer(cfg, dataset=ds)
+    torch.manual_seed(0)
+    batch = trainer.to_device([ds[0], ds[1]])
+    first = None
+    for it in range(12):
+        ep = trainer.new_epoch_losses()
+        trainer.optimizer.zero_grad()
+        ep, T = trainer.step(preprocessed_dicts=[dict(b) for b in batch], epoch_losses=ep)
+        val = float(ep["loss_epoch"])
+        assert np.isfinite(val)
+        first = val if first is None else first
+    assert val < first
+
+
+def test_checkpoint_layout_roundtrip(tmp_path):
+    from delora_amd.deploy.trainer import Trainer
+    dev = _dev()
+    gm = util.load_golden("model_small")
+    cfg = _small_model_cfg(gm, 16, 128, batch_size=1)
+    tr = Trainer(cfg, dataset=util.ListDataset([]))
+    path = str(tmp_path / "ckpt.pth")
+    tr.save_checkpoint(path, epoch=3, loss=0.5)
+    ck = torch.load(path, map_location="cpu", weights_only=False)
+    assert set(ck.keys()) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss", "parameters"}   # trainer.py:155-161
+    cfg2 = _small_model_cfg(gm, 16, 128, batch_size=1)
+    cfg2["checkpoint"] = path
+    cfg2["unsupervised_at_start"] = False
+    tr2 = Trainer(cfg2, dataset=util.ListDataset([]))
+    assert cfg2["unsupervised_at_start"] is True
+    for k, v in tr.raw_model.state_dict().items():
+        assert torch.equal(v, tr2.raw_model.state_dict()[k])
+
+
+# ------------------------------------------------------------------------------------ reference module API mirrors
+def test_image_projection_layer_returns_reference_tuple():
+    from delora_amd.utility.projection import ImageProjectionLayer
+    dev = _dev()
+    for name in ("small", "small_c6"):
+        g = util.load_golden("proj_" + name)
+        cfg = util.repo_config(int(g["H"]), int(g["W"]), device="cuda:0")
+        layer = ImageProjectionLayer(cfg)
+        scan = g["scan"]
+        x = torch.from_numpy(scan).to(dev).view(1, scan.shape[0], -1)
+        image, u, v, idx, pix = layer(input=x, dataset="kitti")
+        o_sensor = util.oracle_sensor(g["H"], g["W"], g["vfov"], g["hfov"])
+        clean = ~util.tainted_pixels(scan, o_sensor)
+        assert image.shape == g["image"].shape and u.shape == g["u"].shape and pix.shape[0] == 1 and pix.shape[2] == 2
+        assert np.array_equal(image.cpu().numpy()[0][:, clean], g["image"][0][:, clean])
+        assert np.allclose(u.cpu().numpy(), g["u"], atol=2e-3) and np.allclose(v.cpu().numpy(), g["v"], atol=2e-3)
+        amb = set(np.nonzero(util.ambiguity_mask(scan, o_sensor))[0].tolist())
+        got_idx = idx.cpu().numpy()
+        assert set(got_idx.tolist()) ^ set(g["idx"].tolist()) <= amb
+        if np.array_equal(np.sort(got_idx), np.sort(g["idx"])):
+            assert np.array_equal(got_idx, g["idx"])                      # ascending range, the reference's order
+            assert np.array_equal(pix.cpu().numpy(), g["pix"])
+        # the kept points, gathered the way Deployer.step does, sit at the returned pixels
+        p = pix[0].cpu().numpy()
+        assert np.array_equal(image.cpu().numpy()[0, :3, p[:, 0], p[:, 1]].T if False else image.cpu().numpy()[0][:3][:, p[:, 0], p[:, 1]],
+                              scan[:3][:, got_idx])
+
+
+def test_normals_computer_returns_reference_triple():
+    from delora_amd.preprocessing.normal_computation import NormalsComputer
+    dev = _dev()
+    g = util.load_golden("normals_small")
+    cfg = util.repo_config(int(g["H"]), int(g["W"]), device="cuda:0")
+    nc = NormalsComputer(config=cfg, dataset_name="kitti")
+    normals, has, pts = nc.compute_normal_vectors(image=torch.from_numpy(g["image"]).to(dev))
+    assert np.array_equal(pts.cpu().numpy(), g["points"])
+    assert (has.cpu().numpy() != g["has"]).mean() <= 2e-3
+    both = has.cpu().numpy() & g["has"]
+    a, b = normals.cpu().numpy()[both].astype(np.float64), g["normals"][both].astype(np.float64)
+    ang = np.arctan2(np.linalg.norm(np.cross(a, b), axis=1), np.sum(a * b, axis=1))
+    assert np.median(ang) < 1e-5 and np.mean(ang > 5e-3) < 2e-3
+
+
+@pytest.mark.parametrize("mode,p2p", [("squared", False), ("linear", True)])
+def test_icp_losses_module_on_lists(mode, p2p):
+    from delora_amd.losses.icp_losses import ICPLosses
+    from delora_amd.models.model_parts import GeometryHandler
+    dev = _dev()
+    g = util.load_golden("loss_pair")
+    cfg = util.repo_config(16, 128, device="cuda:0", normal_loss=mode, point_to_point_loss=p2p)
+    mod = ICPLosses(cfg)
+    tgt, tgt_n = (torch.from_numpy(g[k]).to(dev).view(1, 3, -1) for k in ("tgt", "tgt_n"))
+    src, src_n = (torch.from_numpy(g[k]).to(dev).view(1, 3, -1) for k in ("src", "src_n"))
+    for qname in ("identity", "true", "random"):
+        key = f"{mode}_{'p2p' if p2p else 'nop2p'}_{qname}"
+        t = torch.from_numpy(g[key + "_t"]).to(dev).requires_grad_(True)
+        q = torch.from_numpy(g[key + "_q"]).to(dev).requires_grad_(True)
+        T = GeometryHandler.get_transformation_matrix_quaternion(translation=t, quaternion=q, device=dev)
+        assert np.allclose(T.detach().cpu().numpy(), g[key + "_T"], atol=2e-6)
+        T.retain_grad()
+        s_t = T[:, :3, :3].matmul(src) + T[:, :3, 3].view(-1, 3, 1)
+        n_t = T[:, :3, :3].matmul(src_n)
+        losses, plotting = mod(source_point_cloud_transformed=s_t, source_normal_list_transformed=n_t,
+                               target_point_cloud=tgt, target_normal_list=tgt_n, compute_pointwise_loss_bool=False)
+        (losses["loss_po2po"] + 2.0 * losses["loss_po2pl"] + 0.5 * losses["loss_pl2pl"]).sum().backward()
+        got = np.array([float(losses[k]) for k in ("loss_po2po", "loss_po2pl", "loss_pl2pl")])
+        assert np.allclose(got, g[key + "_losses"], rtol=REL, atol=1e-8), key
+        ref_g = g[key + "_gradT"]
+        assert np.allclose(T.grad.cpu().numpy(), ref_g, rtol=1e-3, atol=1e-4 * np.abs(ref_g).max()), key
+        assert plotting["scan_2_transformed"].shape[2] == int(g[key + "_pairs"])

@@ -69,3 +69,32 @@ def tainted_pixels(xyz, sensor, tol=2e-3):
             ok = (uu >= 0) & (uu < sensor.W) & (vv >= 0) & (vv < sensor.H)
             t[vv[ok], uu[ok]] = True
     return t
+
+
+def repo_config(H, W, dataset="kitti", device="cpu", **over):
+    """The flat run config built from THIS repo's config/*.yaml the way bin/run_training.py builds it."""
+    import copy
+    from delora_amd import config as cfgmod
+    from tests.conftest import ROOT
+    cfg = cfgmod.load_yaml_config(os.path.join(ROOT, "config"))
+    cfg["datasets"] = [dataset]
+    cfgmod.degrees_to_radians(cfg)
+    cfg[dataset]["data_identifiers"] = cfg[dataset]["training_identifiers"]
+    cfg[dataset]["vertical_cells"], cfg[dataset]["horizontal_cells"] = int(H), int(W)
+    cfg["device"] = torch.device(device)
+    cfg["checkpoint"] = None
+    cfg["training_run_name"] = cfg["run_name"] = "test"
+    cfg["mode"] = "training"
+    cfg.update(over)
+    return copy.deepcopy(cfg)
+
+
+class ListDataset(torch.utils.data.Dataset):
+    def __init__(self, samples):
+        self.samples = samples
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __getitem__(self, i):
+        return dict(self.samples[i])
