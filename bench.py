@@ -1,0 +1,291 @@
+#!/usr/bin/env python3
+"""Headline benchmark: DeLORA training scan-pairs/s on synthetic KITTI-shaped 64x2048 input.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A "step" is one full training step over a batch of B scan pairs per GPU (BASELINE.json configs[1]: 64x2048, B=8,
+fp32): spherical projection of the 2B raw scans, per-pixel normals from the projected images, the pose CNN forward,
+quaternion -> T, exact nearest-neighbour correspondences, the fused point-to-plane/plane-to-plane loss, backward
+through loss and CNN, gradient all-reduce (N>1) and the Adam update.  Inputs (raw scan point lists) are resident in
+HBM when the timed region starts.  Rank 0 prints ONE JSON line (contract in the task statement) that also carries
+  "roofline":     the fused ICP loss launch, algorithmic bytes / HIP-event time inside the timed steps, vs 8 TB/s HBM
+  "cpu_baseline": the same step evaluated by the CPU oracle (oracle/delora_oracle.py + torch CPU ops) on a bounded
+                  sample, on this box's host cores (kind "port")
+  "kernels":      per-launch HIP-event times and achieved bandwidth of every geometry kernel (back-to-back launches).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s measured copy rate)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="scan pairs per GPU per step")
+    ap.add_argument("--height", type=int, default=64)
+    ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--amp", default="", help="optional autocast dtype for the CNN (bfloat16/float16); default fp32 = parity mode")
+    ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs evaluated by the CPU baseline")
+    ap.add_argument("--kernel-reps", type=int, default=50)
+    return ap.parse_args()
+
+
+def build_config(args, device):
+    from delora_amd import config as cfgmod
+    cfg = cfgmod.load_yaml_config(os.path.join(ROOT, "config"))
+    cfg["datasets"] = ["kitti"]
+    cfgmod.degrees_to_radians(cfg)
+    cfg["kitti"]["data_identifiers"] = cfg["kitti"]["training_identifiers"]
+    cfg["kitti"]["vertical_cells"], cfg["kitti"]["horizontal_cells"] = args.height, args.width
+    cfg.update(device=device, batch_size=args.batch, unsupervised_at_start=True, inference_only=False, checkpoint=None,
+               training_run_name="bench", run_name="bench", mode="training")
+    if args.amp:
+        cfg["amp_dtype"] = args.amp
+    if args.channels_last:
+        cfg["channels_last"] = True
+    return cfg
+
+
+def make_batch(args, rank, device=None):
+    """B synthetic pairs for this rank (seed = 1000*config + global sample index; config = 2)."""
+    from delora_amd.data import synthetic
+    samples = []
+    for j in range(args.batch):
+        s1, s2, T = synthetic.make_pair(2000 + rank * args.batch + j, rings=args.height, azimuth_steps=2250)
+        d = {"dataset": "kitti", "scan_1": torch.from_numpy(s1).unsqueeze(0), "scan_2": torch.from_numpy(s2).unsqueeze(0),
+             "normal_list_1": None, "normal_list_2": None}
+        if device is not None:
+            d["scan_1"], d["scan_2"] = d["scan_1"].to(device), d["scan_2"].to(device)
+        samples.append(d)
+    return samples
+
+
+def identity_pretrained_state(model):
+    """Put the randomly initialised network into the state the reference's own first training phase leaves it in
+    (identity fitting until its loss < 1e-2, src/deploy/trainer.py:184-186): it predicts T = I.  Done by zeroing the last
+    linear layer of both heads and biasing the quaternion to (0,0,0,1); every other weight keeps its random value, so
+    the forward/backward cost is unchanged.  Without this an untrained network predicts a random rotation, and the
+    correspondence search of every step degenerates to its exhaustive fallback -- a regime real training never sees."""
+    with torch.no_grad():
+        rot, tra = model.fully_connected_rotation[-1], model.fully_connected_translation[-1]
+        rot.weight.zero_(); rot.bias.copy_(torch.tensor([0.0, 0.0, 0.0, 1.0]))
+        tra.weight.zero_(); tra.bias.zero_()
+
+
+class _Events:
+    """HIP events on torch's current stream -- the stream every delora kernel is launched on."""
+
+    def __init__(self):
+        self.pairs = []
+
+    def __enter__(self):
+        self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.a.record()
+        return self
+
+    def __exit__(self, *exc):
+        self.b.record()
+        self.pairs.append((self.a, self.b))
+
+    def mean_ms(self):
+        return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) if self.pairs else float("nan")
+
+
+def kernel_table(trainer, batch, reps):
+    """Per-launch time of each geometry entry point on the bench batch: `reps` back-to-back launches between two HIP
+    events (launch gaps included), with the algorithmic bytes of DESIGN.md."""
+    from delora_amd import geometry as G
+    cfg = trainer.config
+    sensor = trainer.img_projection.sensor("kitti")
+    B, HW = len(batch), sensor.H * sensor.W
+    prepared = trainer.geo.prepare(batch, sensor, trainer._normal_params("kitti"))
+    img, nrm = prepared["images"], prepared["normals"]
+    with torch.no_grad():
+        t, q = trainer._run_model(prepared["stacked"])
+        T = trainer.geometry_handler.get_transformation_matrix_quaternion(t, q, trainer.device)
+    # a realistic pose (small residual motion) for the correspondence / loss kernels
+    T_small = torch.eye(4, device=trainer.device).repeat(B, 1, 1)
+    T_small[:, 0, 3] = 0.4
+    pts = torch.cat([torch.cat((s["scan_1"][0], s["scan_2"][0]), dim=1) for s in batch], dim=1).contiguous()
+    lengths = [n for s in batch for n in (s["scan_1"].shape[2], s["scan_2"].shape[2])]
+    offs = trainer.geo._offsets_for(lengths, pts.device)
+    n_pts = int(sum(lengths))
+    nn, _ = G.nn_correspond(img[:, 1], nrm[:, 1], img[:, 0], T_small, sensor)
+    flags = G.loss_flags(cfg)
+    terms, counts = G.icp_loss(T_small, img[:, 1], nrm[:, 1], img[:, 0], nrm[:, 0], nn, flags)
+    M = int((nn >= 0).sum())
+    K = int(counts[:, 0].sum())
+    kept = int(prepared["kept"].sum())
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / reps
+
+    rows = []
+
+    def row(name, ms, nbytes, bound, note):
+        rows.append({"kernel": name, "ms": round(ms, 5), "algorithmic_MB": round(nbytes / 1e6, 3),
+                     "GB_s": round(nbytes / ms / 1e6, 1), "frac_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
+                     "bound": bound, "note": note})
+
+    row("dl_project", timed(lambda: G.project(pts, offs, max(lengths), sensor)), 12 * n_pts + 20 * 2 * B * HW, "hbm",
+        f"{2 * B} scans, {n_pts} points -> {2 * B}x{sensor.H}x{sensor.W}; 12 B/point + 20 B/pixel")
+    row("dl_normals", timed(lambda: G.normals(prepared["stacked"].view(2 * B, 4, sensor.H, sensor.W))), 24 * 2 * B * HW, "valu",
+        "7x11 stencil + fp64 3x3 eigen; 24 B/pixel")
+    row("dl_nn_correspond", timed(lambda: G.nn_correspond(img[:, 1], nrm[:, 1], img[:, 0], T_small, sensor)), 28 * B * HW + 12 * B * HW, "l2+valu",
+        f"{M} queries, residual motion 0.4 m")
+    row("dl_icp_loss_fwd", timed(lambda: G.icp_loss(T_small, img[:, 1], nrm[:, 1], img[:, 0], nrm[:, 0], nn, flags)), 40 * M + 12 * K, "hbm",
+        f"{M} source points, {K} pairs; 40 B/point + 12 B/pair")
+    return rows, {"M": M, "K": K, "kept": kept}
+
+
+def cpu_baseline(args, cfg):
+    """The same training step on the host: oracle geometry (torch CPU ops + scipy cKDTree) + the CNN on CPU threads.
+    Bounded sample: `cpu_pairs` pairs at B=1 (the reference's own batch size), same 64x2048 synthetic generator."""
+    from oracle import delora_oracle as orc
+    from delora_amd.models.model import OdometryModel
+    from delora_amd.models.model_parts import GeometryHandler
+    cores = torch.get_num_threads()
+    ccfg = dict(cfg)
+    ccfg["device"] = torch.device("cpu")
+    torch.manual_seed(0)
+    model = OdometryModel(ccfg)
+    opt = torch.optim.Adam(model.parameters(), lr=cfg["learning_rate"])
+    sensor = orc.Sensor(args.height, args.width, cfg["kitti"]["vertical_field_of_view"], cfg["horizontal_field_of_view"])
+    side = cfg["kitti"]["neighborhood_side_length"]
+    from delora_amd.data import synthetic
+    t_total = 0.0
+    for k in range(args.cpu_pairs):
+        s1, s2, _ = synthetic.make_pair(2000 + k, rings=args.height, azimuth_steps=2250)
+        t0 = time.perf_counter()
+        lists, images = {}, []
+        for name, s in (("1", s1), ("2", s2)):
+            img, _, _, _, _ = orc.project_to_img(torch.from_numpy(s).view(1, 3, -1), sensor)
+            nrm, has, pts = orc.compute_normal_vectors(img.clone(), sensor, side=side, epsilon_range=cfg["epsilon_range"],
+                                                       min_neighbors=cfg["min_num_points_in_neighborhood_to_determine_point_class"])
+            lists["scan_" + name] = pts.t().contiguous().view(1, 3, -1)
+            lists["normal_list_" + name] = nrm.t().contiguous().view(1, 3, -1)
+            images.append(img)
+        opt.zero_grad()
+        t, q = model(images[0], images[1])
+        T = GeometryHandler.get_transformation_matrix_quaternion(t, q, torch.device("cpu"))
+        out, _ = orc.step_losses([lists], T, lambda_po2pl=cfg["lambda_po2pl"], normal_loss=cfg["normal_loss"])
+        out["loss_pc"].sum().backward()
+        opt.step()
+        t_total += time.perf_counter() - t0
+    return {"value": round(args.cpu_pairs / t_total, 4), "unit": "scan-pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{args.cpu_pairs} pairs, B=1, {args.height}x{args.width}, oracle geometry (torch CPU + scipy cKDTree) + CNN fwd/bwd + Adam on {cores} threads",
+            "s_per_pair": round(t_total / args.cpu_pairs, 3)}
+
+
+def main():
+    args = parse()
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        torch.distributed.init_process_group(backend="nccl", device_id=device)
+    from delora_amd.deploy.trainer import Trainer
+    from delora_amd.data.dataset import ListDataset
+    cfg = build_config(args, device)
+    torch.manual_seed(1234)
+    batch = make_batch(args, rank, device)
+    trainer = Trainer(cfg, dataset=ListDataset(batch))
+    identity_pretrained_state(trainer.raw_model)
+    ev_loss = _Events()
+    orig_losses = trainer.geo.losses
+
+    def run_step(timed):
+        trainer.optimizer.zero_grad(set_to_none=True)
+        ep = trainer.new_epoch_losses()
+        ep, T = trainer.step(preprocessed_dicts=[dict(s) for s in batch], epoch_losses=ep)
+        return ep
+
+    for _ in range(args.warmup):
+        run_step(False)
+    # in-situ HIP events around the fused loss launch of every timed step
+    from delora_amd import geometry as G
+    real_icp = G.icp_loss
+
+    def timed_icp(*a, **k):
+        with ev_loss:
+            return real_icp(*a, **k)
+
+    G.icp_loss = timed_icp
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ep = run_step(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    elapsed = time.perf_counter() - t0
+    G.icp_loss = real_icp
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    final_loss = float(ep["loss_epoch"])
+    pairs = world * args.batch * args.steps
+    result = {
+        "metric": "training scan-pairs/sec, KITTI 64x2048 range images", "value": round(pairs / elapsed, 3), "unit": "scan-pairs/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if not args.amp else args.amp,
+        "data": "synthetic",
+        "config": {"workload": f"KITTI-shaped {args.height}x{args.width}, batch={args.batch} pairs/GPU, raw scans of ~141k points, "
+                               f"online normals, ResNet pose CNN (11.9M params, identity-pretrained state) on PyTorch-ROCm, Adam; BASELINE configs[1]",
+                   "global_batch": world * args.batch, "parallelism": f"dp{world}", "cnn": "fp32" if not args.amp else "autocast " + args.amp,
+                   "channels_last": bool(args.channels_last)},
+        "final_loss": final_loss,
+    }
+    if rank == 0:
+        rows, counts = kernel_table(trainer, batch, args.kernel_reps)
+        loss_ms = ev_loss.mean_ms()
+        # in-situ measurement uses the poses the network actually predicted in the timed steps
+        last = trainer.last_step
+        K_live = int(last["pair_counts"][:, 0].sum())
+        alg = next(r for r in rows if r["kernel"] == "dl_icp_loss_fwd")
+        live_bytes = 40 * counts["M"] + 12 * K_live
+        result["roofline"] = {"kernel": "dl_icp_loss_fwd (k_icp_loss + k_icp_finalize)", "bound": "hbm",
+                              "achieved": round(live_bytes / loss_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": round(live_bytes / loss_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
+                              "ms_per_launch_in_step": round(loss_ms, 5), "ms_per_launch_back_to_back": alg["ms"],
+                              "algorithmic_bytes": live_bytes,
+                              "note": "HIP events on the launch stream around each of the K timed launches; traffic (PMC) in profiles/"}
+        result["kernels"] = rows
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args, cfg)
+        print(json.dumps(result))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

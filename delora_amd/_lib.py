@@ -54,6 +54,9 @@ def load():
         raise DeloraHipError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C delora_amd/csrc`. The geometry path has no fallback implementation.")
+    # torch ships its own HIP runtime (libamdhip64); it must be resident BEFORE this library is mapped so that both
+    # share one runtime -- loading ours first would pull a second copy from /opt/rocm and split the device context.
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:

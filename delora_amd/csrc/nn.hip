@@ -11,10 +11,10 @@
 //     (2*RV+1)x(2*RU+1) window, then CERTIFY the result: if the angular bound of the best distance found,
 //     widened by the half-pixel rounding of the projection plus a safety margin, lies inside the scanned
 //     window, the neighbour is exact.  Otherwise the query goes to a compact "hard" list.
-//   pass B (one wave per hard query): rows are visited outward from q's row; a row is skipped as soon as
-//     |q| sin(elevation gap) >= best distance, and the column span of each row follows from the spherical-cap
-//     bound for the current best distance (wrapping through the azimuth seam).  With no usable bound
-//     (d >= |q|) this degrades to an exhaustive scan, so the result is exact in every regime.
+//   pass B (one wave per hard query): the 64 lanes stride over the flattened (rows x columns) window that the
+//     spherical-cap bound of the best distance so far allows (columns wrap through the azimuth seam); when that
+//     bound is weak (holes, occlusions) a moderate window is probed first and the bound recomputed.  With no usable
+//     bound (d >= |q|) this degrades to an exhaustive scan, so the result is exact in every regime.
 //
 // Distances are accumulated in fp64 from the fp32 coordinates, as the KD-tree does; ties resolve to the lower
 // pixel index.  Bound: L2/LDS + VALU (candidates are re-read from cache), reported separately from the
@@ -22,33 +22,46 @@
 #include "common.h"
 
 #define NN_RV 2
-#define NN_RU 3
-#define NN_MARGIN 0.01   // pixels: slack on the fp32 rounding of the stored points' image coordinates
-#define NN_PI 3.14159265358979323846
+#define NN_RU 5
+#define NN_MARGIN 0.01f        // pixels: slack on the rounding of the stored points' (and our own) image coordinates
+#define NN_PI_F 3.14159265358979323846f
+#define NN_UP (1.0f + 4e-6f)   // round-up factor for quantities that must not be under-estimated in fp32
+#define NN_CLIP_ROWS 8         // pass B, first probe when the bound from pass A is useless: +-8 rows x +-40 columns
+#define NN_CLIP_COLS 40
+#define NN_CLIP_LIMIT 2048     // candidates above which pass B probes before trusting a bound
 
-struct NNWorkspace {
-  int32_t* counter;     // [64] ints, counter[0] = number of hard queries
-  int32_t* hard_slot;   // [B*HW]
-  int32_t* hard_idx;    // [B*HW]
-  double* hard_d2;      // [B*HW]
+struct NNHard {                // one record per query that pass A could not certify
+  double d2;                   // best squared distance found so far (1e300 = none)
+  int32_t slot;                // b*HW + source pixel
+  int32_t idx;                 // target pixel of that best (-1 = none)
+  float qx, qy, qz;            // transformed source point
+  int32_t pad;
 };
 
-static inline NNWorkspace carve_nn(void* ws, size_t slots) {
+struct NNWorkspace {
+  int32_t* counter;            // counter[0] = number of hard queries
+  NNHard* hard;                // [B*HW]
+};
+
+static inline NNWorkspace carve_nn(void* ws) {
   NNWorkspace w;
-  char* p = (char*)ws;
-  w.counter = (int32_t*)p; p += 256;
-  w.hard_d2 = (double*)p; p += slots * sizeof(double);
-  w.hard_slot = (int32_t*)p; p += slots * sizeof(int32_t);
-  w.hard_idx = (int32_t*)p;
+  w.counter = (int32_t*)ws;
+  w.hard = (NNHard*)((char*)ws + 256);
   return w;
 }
 
 extern "C" size_t dl_nn_workspace_bytes(int32_t B, int32_t H, int32_t W) {
-  return 256 + (size_t)B * H * W * (sizeof(double) + 2 * sizeof(int32_t));
+  return 256 + (size_t)B * H * W * sizeof(NNHard);
 }
 
-struct Query {
-  double qx, qy, qz, rxy, nq, az, el, uq, vq;
+// Angular description of a query in fp32.  The image is only a spatial index here: these values pick WHICH pixels
+// are examined, with explicit safety margins; the distances that decide the neighbour are exact fp64.
+struct QueryF {
+  float qx, qy, qz, rxy, nq, az, el, uq, vq, cosE;
+};
+
+struct Window {                // rows [r0, r1], circular column range [c0, c0 + nc)
+  int r0, r1, c0, nc;
 };
 
 __device__ __forceinline__ void load_T(const float* __restrict__ T, int b, float (&m)[12]) {
@@ -64,20 +77,21 @@ __device__ __forceinline__ void transform_point(const float (&m)[12], float x, f
   qz = (fmaf(m[10], z, fmaf(m[9], y, (m[8] * x))) + m[11]);
 }
 
-__device__ __forceinline__ Query make_query(float fx, float fy, float fz, const SensorK& sen) {
-  Query q;
+__device__ __forceinline__ QueryF make_query(float fx, float fy, float fz, const SensorK& sen) {
+  QueryF q;
   q.qx = fx; q.qy = fy; q.qz = fz;
-  q.rxy = sqrt(q.qx * q.qx + q.qy * q.qy);
-  q.nq = sqrt(q.rxy * q.rxy + q.qz * q.qz);
-  q.az = atan2(q.qy, q.qx);
-  q.el = atan2(q.qz, q.rxy);
-  q.uq = (q.az - sen.hf0) / sen.hres;
-  q.vq = (q.el - sen.vf0) / sen.vres;
+  q.rxy = sqrtf(fx * fx + fy * fy);
+  q.nq = sqrtf(q.rxy * q.rxy + fz * fz);
+  q.az = atan2f(fy, fx);
+  q.el = atan2f(fz, q.rxy);
+  q.uq = (q.az - (float)sen.hf0) / (float)sen.hres;
+  q.vq = (q.el - (float)sen.vf0) / (float)sen.vres;
+  q.cosE = q.nq > 0.f ? q.rxy / q.nq : 0.f;
   return q;
 }
 
-__device__ __forceinline__ double dist2(const Query& q, float x, float y, float z) {
-  const double dx = q.qx - (double)x, dy = q.qy - (double)y, dz = q.qz - (double)z;
+__device__ __forceinline__ double dist2(float qx, float qy, float qz, float x, float y, float z) {
+  const double dx = (double)qx - (double)x, dy = (double)qy - (double)y, dz = (double)qz - (double)z;
   return dx * dx + dy * dy + dz * dz;
 }
 
@@ -86,20 +100,33 @@ __device__ __forceinline__ int wrap_col(int u, int W) {
   return u < 0 ? u + W : u;
 }
 
-// Columns that can hold a target within angle theta (sin theta = s) of q: circular range [start, start+n).
-__device__ __forceinline__ void column_span(const Query& q, double s, const SensorK& sen, int& start, int& n) {
-  const int W = sen.W;
-  const double cosE = q.nq > 0.0 ? q.rxy / q.nq : 0.0;
-  if (!(s < cosE * (1.0 - 1e-12))) { start = 0; n = W; return; }   // the cap contains a pole (or no bound)
-  const double daz = asin(s / cosE);
-  if (2.0 * daz / sen.hres + 4.0 >= (double)W) { start = 0; n = W; return; }
-  double a_lo = q.az - daz, a_hi = q.az + daz;
-  if (a_lo < -NN_PI) a_lo += 2.0 * NN_PI;
-  if (a_hi > NN_PI) a_hi -= 2.0 * NN_PI;
-  const int cl = (int)ceil((a_lo - sen.hf0) / sen.hres - 0.5 - NN_MARGIN);
-  const int cr = (int)floor((a_hi - sen.hf0) / sen.hres + 0.5 + NN_MARGIN);
-  start = wrap_col(cl, W);
-  n = wrap_col(cr - cl, W) + 1;
+// All pixels that can hold a target point closer than d to q (conservative).  A target within distance d < |q|
+// subtends at most theta = asin(d/|q|) with q: its elevation differs by at most theta and its azimuth by at most
+// asin(sin(theta)/cos(el_q)) (all azimuths once the cap reaches a pole).  Pixels are widened by half a pixel plus
+// NN_MARGIN for the rounding of the projection.  d >= |q| gives no bound: the whole image.
+__device__ __forceinline__ Window bound_window(const QueryF& q, float d, const SensorK& sen) {
+  Window w;
+  const int H = sen.H, W = sen.W;
+  w.r0 = 0; w.r1 = H - 1; w.c0 = 0; w.nc = W;
+  if (!(d * NN_UP < q.nq)) return w;
+  const float s = fminf(d / q.nq * NN_UP, 1.0f);
+  const float theta = asinf(s) * NN_UP + 1e-6f;
+  const float av = theta / (float)sen.vres + 0.5f + NN_MARGIN;
+  int r0 = (int)ceilf(q.vq - av), r1 = (int)floorf(q.vq + av);
+  w.r0 = r0 < 0 ? 0 : r0;
+  w.r1 = r1 > H - 1 ? H - 1 : r1;
+  if (!(s < q.cosE * (1.0f - 1e-5f))) return w;                 // cap reaches a pole: every column
+  const float daz = asinf(fminf(s / q.cosE * NN_UP, 1.0f)) * NN_UP + 1e-6f;
+  const float hres = (float)sen.hres;
+  if (2.0f * daz / hres + 4.0f >= (float)W) return w;
+  float a_lo = q.az - daz, a_hi = q.az + daz;
+  if (a_lo < -NN_PI_F) a_lo += 2.0f * NN_PI_F;
+  if (a_hi > NN_PI_F) a_hi -= 2.0f * NN_PI_F;
+  const int cl = (int)ceilf((a_lo - (float)sen.hf0) / hres - 0.5f - NN_MARGIN);
+  const int cr = (int)floorf((a_hi - (float)sen.hf0) / hres + 0.5f + NN_MARGIN);
+  w.c0 = wrap_col(cl, W);
+  w.nc = wrap_col(cr - cl, W) + 1;
+  return w;
 }
 
 __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
@@ -113,6 +140,7 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
   load_T(T, b, m);
   bool occupied = false, active = false, vis = false;
   float fx = 0, fy = 0, fz = 0;
+  QueryF q;
   if (px < HW) {
     const float* sp = src + (size_t)b * src_ss + px;
     const float x = sp[0], y = sp[HW], z = sp[2 * HW];
@@ -124,8 +152,14 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
     }
     if (occupied) {
       transform_point(m, x, y, z, fx, fy, fz);
-      const float v = coord_v(fx, fy, fz, sen);             // deployer.py:365-367
-      vis = (rintf(v) < (float)H) && (v > 0.f);
+      q = make_query(fx, fy, fz, sen);
+      if (visible) {
+        // visible_pixels metric (deployer.py:365-367): round(v) < H and v > 0 with the reference's fp32 v.  The fast
+        // fp32 estimate decides unless it is close to one of the two thresholds, then the exact expression is used.
+        float v = ((q.el - sen.vf0f) / sen.vspanf) * sen.hm1f;
+        if (fabsf(v) < 1e-2f || fabsf(v - ((float)H - 0.5f)) < 1e-2f) v = coord_v(fx, fy, fz, sen);
+        vis = (rintf(v) < (float)H) && (v > 0.f);
+      }
     }
   }
   if (visible) {
@@ -135,10 +169,9 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
   if (px >= HW) return;
   if (!active) { nn_pix[(size_t)b * HW + px] = -1; return; }
 
-  const Query q = make_query(fx, fy, fz, sen);
   const float* tp = tgt + (size_t)b * tgt_ss;
-  const int u0 = (int)rint(q.uq);
-  int v0 = (int)rint(q.vq);
+  const int u0 = (int)rintf(q.uq);
+  int v0 = (int)rintf(q.vq);
   v0 = v0 < 0 ? 0 : (v0 > H - 1 ? H - 1 : v0);
   double best = 1e300;
   int bidx = -1;
@@ -151,43 +184,28 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
       const int p = v * W + wrap_col(u0 + du, W);
       const float x = tp[p], y = tp[HW + p], z = tp[2 * HW + p];
       if (x == 0.f && y == 0.f && z == 0.f) continue;
-      const double d2 = dist2(q, x, y, z);
+      const double d2 = dist2(fx, fy, fz, x, y, z);
       if (d2 < best || (d2 == best && p < bidx)) { best = d2; bidx = p; }
     }
   }
-  // certificate: every pixel that can hold a closer target lies inside the scanned window
+  // certificate: every pixel that can hold a closer target lies inside the scanned window (and the needed columns do
+  // not run through the azimuth seam, where the scanned columns were wrapped)
   bool exact = false;
   if (bidx >= 0) {
-    const double d = sqrt(best);
-    if (d < q.nq) {
-      const double s = d / q.nq;
-      const double theta = asin(s);
-      const double av = theta / sen.vres + 0.5 + NN_MARGIN;
-      int row_lo = (int)ceil(q.vq - av), row_hi = (int)floor(q.vq + av);
-      row_lo = row_lo < 0 ? 0 : row_lo;
-      row_hi = row_hi > H - 1 ? H - 1 : row_hi;
-      const bool rows_ok = (row_lo >= v0 - NN_RV) && (row_hi <= v0 + NN_RV);
-      const double cosE = q.rxy / q.nq;
-      if (rows_ok && s < cosE * (1.0 - 1e-12)) {
-        const double daz = asin(s / cosE);
-        const double a_lo = q.az - daz, a_hi = q.az + daz;
-        if (a_lo > -NN_PI + 1e-9 && a_hi < NN_PI - 1e-9) {   // no seam crossing
-          int col_lo = (int)ceil((a_lo - sen.hf0) / sen.hres - 0.5 - NN_MARGIN);
-          int col_hi = (int)floor((a_hi - sen.hf0) / sen.hres + 0.5 + NN_MARGIN);
-          col_lo = col_lo < 0 ? 0 : col_lo;
-          col_hi = col_hi > W - 1 ? W - 1 : col_hi;
-          exact = (col_lo >= u0 - NN_RU) && (col_hi <= u0 + NN_RU);
-        }
-      }
-    }
+    const float d = (float)sqrt(best) * NN_UP;
+    const Window w = bound_window(q, d, sen);
+    const bool rows_ok = (w.r0 >= v0 - NN_RV) && (w.r1 <= v0 + NN_RV);
+    const bool cols_ok = (w.nc <= 2 * NN_RU + 1) && (w.c0 >= u0 - NN_RU) && (w.c0 + w.nc - 1 <= u0 + NN_RU) &&
+                         (w.c0 + w.nc - 1 <= W - 1);
+    exact = rows_ok && cols_ok;
   }
   if (exact) {
     nn_pix[(size_t)b * HW + px] = bidx;
   } else {
     const int pos = atomicAdd(ws.counter, 1);
-    ws.hard_slot[pos] = b * HW + px;
-    ws.hard_idx[pos] = bidx;
-    ws.hard_d2[pos] = best;
+    NNHard h;
+    h.d2 = best; h.slot = b * HW + px; h.idx = bidx; h.qx = fx; h.qy = fy; h.qz = fz; h.pad = 0;
+    ws.hard[pos] = h;
   }
 }
 
@@ -200,61 +218,61 @@ __device__ __forceinline__ void wave_argmin(double& d2, int& idx) {
   }
 }
 
-__global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(
-    const float* __restrict__ src, int64_t src_ss, const float* __restrict__ tgt, int64_t tgt_ss,
-    const float* __restrict__ T, SensorK sen, int32_t* __restrict__ nn_pix, NNWorkspace ws) {
+// Scan a window with the 64 lanes striding over its flattened (row, column) candidates.
+__device__ __forceinline__ void scan_window(const Window& w, const float* __restrict__ tp, int HW, int W, float qx,
+                                            float qy, float qz, int lane, double& best, int& bidx) {
+  const int nrows = w.r1 - w.r0 + 1;
+  if (nrows <= 0 || w.nc <= 0) return;
+  const int total = nrows * w.nc;
+  const float inv = 1.0f / (float)w.nc;
+  double lbest = 1e300;
+  int lidx = -1;
+  for (int k = lane; k < total; k += DL_WAVE) {
+    int r = (int)(((float)k + 0.5f) * inv);
+    int c = k - r * w.nc;
+    if (c < 0) { --r; c += w.nc; } else if (c >= w.nc) { ++r; c -= w.nc; }
+    c += w.c0;
+    c = c >= W ? c - W : c;
+    const int p = (w.r0 + r) * W + c;
+    const float x = tp[p], y = tp[HW + p], z = tp[2 * HW + p];
+    if (x == 0.f && y == 0.f && z == 0.f) continue;
+    const double d2 = dist2(qx, qy, qz, x, y, z);
+    if (d2 < lbest || (d2 == lbest && p < lidx)) { lbest = d2; lidx = p; }
+  }
+  wave_argmin(lbest, lidx);
+  if (lidx >= 0 && (lbest < best || (lbest == best && (bidx < 0 || lidx < bidx)))) { best = lbest; bidx = lidx; }
+}
+
+__global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float* __restrict__ tgt, int64_t tgt_ss, SensorK sen,
+                                                      int32_t* __restrict__ nn_pix, NNWorkspace ws) {
   const int lane = threadIdx.x & (DL_WAVE - 1);
   const int wave = (blockIdx.x * DL_BLOCK + threadIdx.x) / DL_WAVE;
   const int nwaves = gridDim.x * DL_BLOCK / DL_WAVE;
   const int count = ws.counter[0];
   const int HW = sen.HW, H = sen.H, W = sen.W;
   for (int h = wave; h < count; h += nwaves) {
-    const int slot = ws.hard_slot[h];
-    const int b = slot / HW, px = slot - b * HW;
-    float m[12];
-    load_T(T, b, m);
-    const float* sp = src + (size_t)b * src_ss + px;
-    float fx, fy, fz;
-    transform_point(m, sp[0], sp[HW], sp[2 * HW], fx, fy, fz);
-    const Query q = make_query(fx, fy, fz, sen);
+    const NNHard rec = ws.hard[h];
+    const int b = rec.slot / HW;
     const float* tp = tgt + (size_t)b * tgt_ss;
-    double best = ws.hard_d2[h];
-    int bidx = ws.hard_idx[h];
-    int v0 = (int)rint(q.vq);
-    v0 = v0 < 0 ? 0 : (v0 > H - 1 ? H - 1 : v0);
-    bool done_dn = false, done_up = false;
-    for (int r = 0; r < H && !(done_dn && done_up); ++r) {
-      for (int side = 0; side < 2; ++side) {
-        if (r == 0 && side == 1) continue;
-        const int v = side == 0 ? v0 - r : v0 + r;
-        if (side == 0 ? done_dn : done_up) continue;
-        if (v < 0 || v >= H) { if (side == 0) done_dn = true; else done_up = true; continue; }
-        const double d = bidx >= 0 ? sqrt(best) : 1e300;
-        // smallest angle between q and any point stored in row v
-        const double el_v = sen.vf0 + (double)v * sen.vres;
-        double gap = fabs(q.el - el_v) - (0.5 + NN_MARGIN) * sen.vres;
-        gap = gap < 0.0 ? 0.0 : gap;
-        const double lb = gap >= 0.5 * NN_PI ? q.nq : q.nq * sin(gap);
-        if (lb >= d && r > 0) { if (side == 0) done_dn = true; else done_up = true; continue; }
-        int start, n;
-        if (d < q.nq) column_span(q, d / q.nq, sen, start, n);
-        else { start = 0; n = W; }
-        double lbest = 1e300;
-        int lidx = -1;
-        for (int k = lane; k < n; k += DL_WAVE) {
-          int c = start + k;
-          c = c >= W ? c - W : c;
-          const int p = v * W + c;
-          const float x = tp[p], y = tp[HW + p], z = tp[2 * HW + p];
-          if (x == 0.f && y == 0.f && z == 0.f) continue;
-          const double d2 = dist2(q, x, y, z);
-          if (d2 < lbest || (d2 == lbest && p < lidx)) { lbest = d2; lidx = p; }
-        }
-        wave_argmin(lbest, lidx);
-        if (lidx >= 0 && (lbest < best || (lbest == best && (bidx < 0 || lidx < bidx)))) { best = lbest; bidx = lidx; }
-      }
+    const QueryF q = make_query(rec.qx, rec.qy, rec.qz, sen);
+    double best = rec.d2;
+    int bidx = rec.idx;
+    Window w = bound_window(q, bidx >= 0 ? (float)sqrt(best) * NN_UP : 3.0e38f, sen);
+    if ((w.r1 - w.r0 + 1) * w.nc > NN_CLIP_LIMIT) {
+      // the bound from pass A is weak (hole / occlusion around the projected pixel): probe a moderate window first,
+      // then bound again with what was found
+      Window c;
+      int v0 = (int)rintf(q.vq);
+      v0 = v0 < 0 ? 0 : (v0 > H - 1 ? H - 1 : v0);
+      c.r0 = v0 - NN_CLIP_ROWS < 0 ? 0 : v0 - NN_CLIP_ROWS;
+      c.r1 = v0 + NN_CLIP_ROWS > H - 1 ? H - 1 : v0 + NN_CLIP_ROWS;
+      c.nc = 2 * NN_CLIP_COLS + 1 < W ? 2 * NN_CLIP_COLS + 1 : W;
+      c.c0 = wrap_col((int)rintf(q.uq) - NN_CLIP_COLS, W);
+      scan_window(c, tp, HW, W, rec.qx, rec.qy, rec.qz, lane, best, bidx);
+      w = bound_window(q, bidx >= 0 ? (float)sqrt(best) * NN_UP : 3.0e38f, sen);
     }
-    if (lane == 0) nn_pix[slot] = bidx;
+    scan_window(w, tp, HW, W, rec.qx, rec.qy, rec.qz, lane, best, bidx);
+    if (lane == 0) nn_pix[rec.slot] = bidx;
   }
 }
 
@@ -264,18 +282,17 @@ extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const f
                                 int32_t* nn_pix, int32_t* visible, void* workspace, dl_stream stream) {
   if (!src_image4 || !tgt_image4 || !T || !sensor || !nn_pix || !workspace)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_nn_correspond: null pointer argument");
-  if (B <= 0 || sensor->H < 2 || sensor->W < 2)
+  if (B <= 0 || sensor->H < 2 || sensor->W < 2 * NN_RU + 2)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_nn_correspond: bad sizes B=%d H=%d W=%d", B, sensor->H, sensor->W);
   hipStream_t st = (hipStream_t)stream;
   const SensorK sen = make_sensor(sensor);
-  NNWorkspace ws = carve_nn(workspace, (size_t)B * sen.HW);
+  NNWorkspace ws = carve_nn(workspace);
   (void)hipMemsetAsync(ws.counter, 0, 256, st);
   if (visible) (void)hipMemsetAsync(visible, 0, sizeof(int32_t) * B, st);
   hipLaunchKernelGGL(k_nn_window, dim3((sen.HW + DL_BLOCK - 1) / DL_BLOCK, B), dim3(DL_BLOCK), 0, st,
                      src_image4, src_ss, src_normals, srcn_ss, tgt_image4, tgt_ss, T, sen,
                      need_without_normals, nn_pix, visible, ws);
-  hipLaunchKernelGGL(k_nn_hard, dim3(2048), dim3(DL_BLOCK), 0, st, src_image4, src_ss, tgt_image4, tgt_ss, T,
-                     sen, nn_pix, ws);
+  hipLaunchKernelGGL(k_nn_hard, dim3(2048), dim3(DL_BLOCK), 0, st, tgt_image4, tgt_ss, sen, nn_pix, ws);
   return dl_check_launch("dl_nn_correspond");
 }
 

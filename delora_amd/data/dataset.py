@@ -101,3 +101,16 @@ class SyntheticPairDataset(torch.utils.data.Dataset):
         return {"index": index, "index_dataset": 0, "index_sequence": 0, "index_scan": index, "dataset": self.dataset,
                 "scan_1": torch.from_numpy(s1).unsqueeze(0), "scan_2": torch.from_numpy(s2).unsqueeze(0),
                 "normal_list_1": None, "normal_list_2": None, "T_true": torch.from_numpy(T)}
+
+
+class ListDataset(torch.utils.data.Dataset):
+    """A dataset over an in-memory list of sample dicts (bench, smoke test, unit tests)."""
+
+    def __init__(self, samples):
+        self.samples = list(samples)
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __getitem__(self, index):
+        return dict(self.samples[index])
