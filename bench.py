@@ -114,6 +114,7 @@ def kernel_table(trainer, batch, reps):
     B, HW = len(batch), sensor.H * sensor.W
     prepared = trainer.geo.prepare(batch, sensor, trainer._normal_params("kitti"))
     img, nrm = prepared["images"], prepared["normals"]
+    tgt_pk, tgt_n_pk = prepared["packed"][:, 0], prepared["normals_packed"][:, 0]
     with torch.no_grad():
         t, q = trainer._run_model(prepared["stacked"])
         T = trainer.geometry_handler.get_transformation_matrix_quaternion(t, q, trainer.device)
@@ -124,12 +125,12 @@ def kernel_table(trainer, batch, reps):
     lengths = [n for s in batch for n in (s["scan_1"].shape[2], s["scan_2"].shape[2])]
     offs = trainer.geo._offsets_for(lengths, pts.device)
     n_pts = int(sum(lengths))
-    nn, _ = G.nn_correspond(img[:, 1], nrm[:, 1], img[:, 0], T_small, sensor)
+    nn, _, match = G.nn_correspond(img[:, 1], nrm[:, 1], tgt_pk, tgt_n_pk, T_small, sensor)
     flags = G.loss_flags(cfg)
-    terms, counts = G.icp_loss(T_small, img[:, 1], nrm[:, 1], img[:, 0], nrm[:, 0], nn, flags)
+    terms, counts = G.icp_loss(T_small, img[:, 1], nrm[:, 1], match, nn, flags)
     M = int((nn >= 0).sum())
     K = int(counts[:, 0].sum())
-    kept = int(prepared["kept"].sum())
+    kept = int((prepared["pix2pt"] >= 0).sum())
 
     def timed(fn):
         fn()
@@ -149,14 +150,14 @@ def kernel_table(trainer, batch, reps):
                      "GB_s": round(nbytes / ms / 1e6, 1), "frac_hbm_peak": round(nbytes / ms / 1e6 / HBM_PEAK_GBS, 4),
                      "bound": bound, "note": note})
 
-    row("dl_project", timed(lambda: G.project(pts, offs, max(lengths), sensor)), 12 * n_pts + 20 * 2 * B * HW, "hbm",
-        f"{2 * B} scans, {n_pts} points -> {2 * B}x{sensor.H}x{sensor.W}; 12 B/point + 20 B/pixel")
-    row("dl_normals", timed(lambda: G.normals(prepared["stacked"].view(2 * B, 4, sensor.H, sensor.W))), 24 * 2 * B * HW, "valu",
-        "7x11 stencil + fp64 3x3 eigen; 24 B/pixel")
-    row("dl_nn_correspond", timed(lambda: G.nn_correspond(img[:, 1], nrm[:, 1], img[:, 0], T_small, sensor)), 28 * B * HW + 12 * B * HW, "l2+valu",
+    row("dl_project", timed(lambda: G.project(pts, offs, max(lengths), sensor, want_kept=False)), 12 * n_pts + 36 * 2 * B * HW, "hbm",
+        f"{2 * B} scans, {n_pts} points -> {2 * B}x{sensor.H}x{sensor.W}; 12 B/point + 36 B/pixel (planar + packed image, map)")
+    row("dl_normals", timed(lambda: G.normals(prepared["stacked"].view(2 * B, 4, sensor.H, sensor.W), want_packed=True)), 40 * 2 * B * HW, "valu",
+        "7x11 stencil + fp64 3x3 eigen; 40 B/pixel (read xyz, write planar + packed normals)")
+    row("dl_nn_correspond", timed(lambda: G.nn_correspond(img[:, 1], nrm[:, 1], tgt_pk, tgt_n_pk, T_small, sensor)), 28 * B * HW + 12 * B * HW, "l2+valu",
         f"{M} queries, residual motion 0.4 m")
-    row("dl_icp_loss_fwd", timed(lambda: G.icp_loss(T_small, img[:, 1], nrm[:, 1], img[:, 0], nrm[:, 0], nn, flags)), 40 * M + 12 * K, "hbm",
-        f"{M} source points, {K} pairs; 40 B/point + 12 B/pair")
+    row("dl_icp_loss_fwd", timed(lambda: G.icp_loss(T_small, img[:, 1], nrm[:, 1], match, nn, flags)), 40 * M + 12 * K, "hbm",
+        f"{M} source points, {K} pairs; 40 B/point + 12 B/pair (algorithmic; the packed gathers move 16 B each)")
     return rows, {"M": M, "K": K, "kept": kept}
 
 

@@ -31,13 +31,15 @@ SIGNATURES = {
     "dl_abi_version": (_i32, []),
     "dl_last_error": (ctypes.c_char_p, []),
     "dl_project_workspace_bytes": (_sz, [_i32, _i32, _i32]),
-    "dl_project": (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _SP, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "dl_normals": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp]),
+    "dl_project": (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _SP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dl_normals": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
     "dl_nn_workspace_bytes": (_sz, [_i32, _i32, _i32]),
-    "dl_nn_correspond": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _SP, _i32, _vp, _vp, _vp, _vp]),
+    "dl_nn_correspond": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _SP, _i32, _vp, _vp, _vp, _vp, _vp]),
     "dl_icp_loss_workspace_bytes": (_sz, [_i32, _i32, _i32]),
-    "dl_icp_loss_fwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _u32,
+    "dl_icp_loss_fwd": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _u32,
                                _vp, _vp, _vp, _vp, _vp]),
+    "dl_icp_loss_partial": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _u32, _vp, _vp]),
+    "dl_icp_loss_reduce": (_i32, [_vp, _i32, _i32, _i32, _u32, _vp, _vp, _vp, _vp]),
     "dl_icp_loss_bwd": (_i32, [_vp, _vp, _i32, _vp, _vp]),
     "dl_nn_bruteforce": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp]),
 }

@@ -5,8 +5,8 @@
 // the pair selection of ICPLosses.forward (src/losses/icp_losses.py:48-60, :102-121) and the three loss
 // modules (:168-179 point-to-point, :196-206 point-to-plane, :224-240 plane-to-plane).  The reference
 // materialises the transformed cloud, six gathered/compacted copies and per-pair tensors; this kernel
-// streams the source planes once (coalesced), gathers the matched target point/normal through the
-// correspondence map and keeps everything else in registers:
+// streams the source planes and the matched target point/normal planes (written in source pixel order by the
+// correspondence kernel, which has the winning target in registers anyway) once and keeps everything else in registers:
 //     po2pl = 1/K  sum r^2,            r = n_t . (R p + t - p_t)
 //     pl2pl = 1/K  sum |R n - n_t|^2   ("squared")   or  1/K sum (1 - (R n).n_t)^2   ("linear")
 //     po2po = 1/3K' sum |R p + t - p_t|^2   over pairs where neither side has a normal
@@ -15,29 +15,189 @@
 // same pass:  d po2pl = 2/K sum r n_t [p^T | 1],  d pl2pl = 2/K sum (R n - n_t) n^T  (resp. -(1-c) n_t n^T),
 // d po2po = 2/3K' sum (q - p_t) [p^T | 1].  The backward is then O(B) work (dl_icp_loss_bwd).
 //
-// Reduction: per-lane fp32 partial sums -> wave shuffle tree -> one partial row per workgroup (no float
-// atomics: deterministic) -> a small second kernel sums the rows of a sample in fp64 and finalises.
+// Reduction: per-lane fp32 partial sums -> wave shuffle tree -> one partial row per wave (no float atomics:
+// deterministic) -> a second, tiny launch sums each sample's rows in fp64 in a fixed order and writes the outputs.
+// (An in-kernel hand-off to the last-arriving workgroup was measured slower: the write-through drain + ticket round
+// trip sit on every workgroup's critical path, +8 us on a 17 us kernel; a kernel boundary costs ~1.5 us.)
 //
-// HBM-bound: algorithmic traffic per matched source point = 24 B (p, n) + 4 B (correspondence) + 24 B
-// (gathered p_t, n_t) = 52 B.
+// HBM-bound: algorithmic traffic per source pixel = 24 B (p, n) + 4 B (correspondence) + 24 B (matched p_t, n_t)
+// = 52 B, all of it coalesced 16-byte loads.
 #include "common.h"
 
-#define LOSS_BX 64          // workgroups per sample
+#define LOSS_PX 4            // consecutive pixels per lane (16-byte loads of every streamed plane)
 #define ACC_N 24            // po2pl: 0 rr, 1-3 r*nt, 4-12 r*nt p^T ; pl2pl: 13 ss, 14-22 G ; 23 K
 #define ACC_P2P 14          // 24 dd, 25-27 diff, 28-36 diff p^T, 37 K'
 #define ACC_MAX (ACC_N + ACC_P2P)
+#define ACC_PITCH 40        // floats per partial row
+
+#ifndef LOSS_WG_PER_SAMPLE
+#define LOSS_WG_PER_SAMPLE 128  // workgroups (4 waves each) per sample: 512 waves, 1 chunk per wave at 64x2048
+#endif
+static inline int loss_blocks(int HW) {
+  const int chunks = (HW + DL_WAVE * LOSS_PX - 1) / (DL_WAVE * LOSS_PX);
+  int wg = (chunks + 3) / 4;
+  return wg < LOSS_WG_PER_SAMPLE ? wg : LOSS_WG_PER_SAMPLE;
+}
+static inline int loss_rows(int HW) { return loss_blocks(HW) * (DL_BLOCK / DL_WAVE); }
 
 extern "C" size_t dl_icp_loss_workspace_bytes(int32_t B, int32_t H, int32_t W) {
-  (void)H; (void)W;
-  return (size_t)B * LOSS_BX * ACC_MAX * sizeof(float);
+  return (size_t)B * loss_rows(H * W) * ACC_PITCH * sizeof(float);   // one partial row per wave
 }
 
+struct LossOut {
+  float* loss_terms;
+  int32_t* pair_counts;
+  float* grad_terms;
+  uint32_t flags;
+};
+
+// One matched pair, branch-free: `w` (0 or 1) masks pairs that do not count, so that the loads of several
+// pixels can be issued before any of them is consumed.
+template <bool P2P, bool LINEAR, int NA>
+__device__ __forceinline__ void accumulate_pair(float (&acc)[NA], const float (&m)[12], bool valid, float x, float y,
+                                                float z, float nx, float ny, float nz, float tx, float ty, float tz,
+                                                float tnx, float tny, float tnz) {
+  const bool has_s = (nx != 0.f) || (ny != 0.f) || (nz != 0.f);               // icp_losses.py:48-50
+  const bool has_t = (tnx != 0.f) || (tny != 0.f) || (tnz != 0.f);            // :51-52
+  const float w = (valid && has_s && has_t) ? 1.f : 0.f;                       // :110-121
+  const float qx = (fmaf(m[2], z, fmaf(m[1], y, (m[0] * x))) + m[3]);
+  const float qy = (fmaf(m[6], z, fmaf(m[5], y, (m[4] * x))) + m[7]);
+  const float qz = (fmaf(m[10], z, fmaf(m[9], y, (m[8] * x))) + m[11]);
+  const float dx = qx - tx, dy = qy - ty, dz = qz - tz;
+  {
+    // point-to-plane (:196-203)
+    const float r = w * fmaf(dz, tnz, fmaf(dy, tny, dx * tnx));
+    acc[0] = fmaf(r, r, acc[0]);
+    const float gx = r * tnx, gy = r * tny, gz = r * tnz;
+    acc[1] += gx; acc[2] += gy; acc[3] += gz;
+    acc[4] = fmaf(gx, x, acc[4]); acc[5] = fmaf(gx, y, acc[5]); acc[6] = fmaf(gx, z, acc[6]);
+    acc[7] = fmaf(gy, x, acc[7]); acc[8] = fmaf(gy, y, acc[8]); acc[9] = fmaf(gy, z, acc[9]);
+    acc[10] = fmaf(gz, x, acc[10]); acc[11] = fmaf(gz, y, acc[11]); acc[12] = fmaf(gz, z, acc[12]);
+    // plane-to-plane (:224-238) on the rotated source normal (deployer.py:297-299)
+    const float rx = fmaf(m[2], nz, fmaf(m[1], ny, m[0] * nx));
+    const float ry = fmaf(m[6], nz, fmaf(m[5], ny, m[4] * nx));
+    const float rz = fmaf(m[10], nz, fmaf(m[9], ny, m[8] * nx));
+    float ex, ey, ez;
+    if (LINEAR) {
+      const float c1 = w * (1.f - fmaf(rz, tnz, fmaf(ry, tny, rx * tnx)));
+      acc[13] = fmaf(c1, c1, acc[13]);
+      ex = -c1 * tnx; ey = -c1 * tny; ez = -c1 * tnz;
+    } else {
+      ex = w * (rx - tnx); ey = w * (ry - tny); ez = w * (rz - tnz);
+      acc[13] += fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+    }
+    acc[14] = fmaf(ex, nx, acc[14]); acc[15] = fmaf(ex, ny, acc[15]); acc[16] = fmaf(ex, nz, acc[16]);
+    acc[17] = fmaf(ey, nx, acc[17]); acc[18] = fmaf(ey, ny, acc[18]); acc[19] = fmaf(ey, nz, acc[19]);
+    acc[20] = fmaf(ez, nx, acc[20]); acc[21] = fmaf(ez, ny, acc[21]); acc[22] = fmaf(ez, nz, acc[22]);
+    acc[23] += w;
+  }
+  if (P2P) {
+    // point-to-point on pairs without normals on either side (:85-100, :168-172)
+    const float w2 = (valid && !has_s && !has_t) ? 1.f : 0.f;
+    const float ux = w2 * dx, uy = w2 * dy, uz = w2 * dz;
+    acc[ACC_N + 0] += fmaf(uz, uz, fmaf(uy, uy, ux * ux));
+    acc[ACC_N + 1] += ux; acc[ACC_N + 2] += uy; acc[ACC_N + 3] += uz;
+    acc[ACC_N + 4] = fmaf(ux, x, acc[ACC_N + 4]); acc[ACC_N + 5] = fmaf(ux, y, acc[ACC_N + 5]); acc[ACC_N + 6] = fmaf(ux, z, acc[ACC_N + 6]);
+    acc[ACC_N + 7] = fmaf(uy, x, acc[ACC_N + 7]); acc[ACC_N + 8] = fmaf(uy, y, acc[ACC_N + 8]); acc[ACC_N + 9] = fmaf(uy, z, acc[ACC_N + 9]);
+    acc[ACC_N + 10] = fmaf(uz, x, acc[ACC_N + 10]); acc[ACC_N + 11] = fmaf(uz, y, acc[ACC_N + 11]); acc[ACC_N + 12] = fmaf(uz, z, acc[ACC_N + 12]);
+    acc[ACC_N + 13] += w2;
+  }
+}
+
+// Sum of the partial rows of one sample in fp64 (fixed order) and the final means / gradient moments.  Runs in the
+// LAST workgroup of a sample to arrive, all DL_BLOCK threads: thread t owns one 16-byte column group (t % 10) and
+// every 25th row, so that all of its loads are independent and issued back to back.
+#define FIN_GROUPS (ACC_PITCH / 4)            // 10 float4 per row
+#define FIN_SLICES 25                          // 250 of the 256 threads take part
+__device__ __forceinline__ void finalize_sample(const float* __restrict__ rows, int nrows, int b, const LossOut& out,
+                                                double* tot /* LDS [FIN_SLICES][ACC_PITCH] */) {
+  const int t = threadIdx.x;
+  const int cg = t % FIN_GROUPS, slice = t / FIN_GROUPS;
+  const bool p2p = out.flags & DL_LOSS_POINT_TO_POINT;
+  if (slice < FIN_SLICES) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const float4* r4 = reinterpret_cast<const float4*>(rows);
+#pragma unroll 8
+    for (int i = slice; i < nrows; i += FIN_SLICES) {
+      const float4 v = r4[(size_t)i * FIN_GROUPS + cg];
+      s0 += (double)v.x; s1 += (double)v.y; s2 += (double)v.z; s3 += (double)v.w;
+    }
+    double* dst = tot + slice * ACC_PITCH + cg * 4;
+    dst[0] = s0; dst[1] = s1; dst[2] = s2; dst[3] = s3;
+  }
+  __syncthreads();
+  double mine = 0.0;
+  if (t < ACC_PITCH) {
+#pragma unroll
+    for (int p = 0; p < FIN_SLICES; ++p) mine += tot[p * ACC_PITCH + t];
+  }
+  __syncthreads();
+  if (t < ACC_PITCH) tot[t] = (t < ACC_N || (p2p && t < ACC_MAX)) ? mine : 0.0;
+  __syncthreads();
+  const double K = tot[23], K2 = tot[ACC_N + 13];
+  float* lt = out.loss_terms + b * 3;
+  float* g = out.grad_terms + b * 36;
+  if (t == 0) {
+    out.pair_counts[b * 2 + 0] = (int)K;
+    out.pair_counts[b * 2 + 1] = (int)K2;
+    // means as torch's MSELoss: an enabled term over an empty set is 0/0 = NaN
+    lt[0] = p2p ? (float)(tot[ACC_N] / (3.0 * K2)) : 0.f;
+    lt[1] = (out.flags & DL_LOSS_POINT_TO_PLANE) ? (float)(tot[0] / K) : 0.f;
+    lt[2] = (out.flags & DL_LOSS_PLANE_TO_PLANE) ? (float)(tot[13] / K) : 0.f;
+  }
+  if (t < 12) {
+    const int i = t / 4, j = t % 4;
+    // row-major [R | t]: column 3 is d/dt
+    const double po2pl = j < 3 ? tot[4 + i * 3 + j] : tot[1 + i];
+    const double pl2pl = j < 3 ? tot[14 + i * 3 + j] : 0.0;
+    const double po2po = j < 3 ? tot[ACC_N + 4 + i * 3 + j] : tot[ACC_N + 1 + i];
+    g[0 * 12 + t] = p2p ? (float)(2.0 * po2po / (3.0 * K2)) : 0.f;
+    g[1 * 12 + t] = (out.flags & DL_LOSS_POINT_TO_PLANE) ? (float)(2.0 * po2pl / K) : 0.f;
+    g[2 * 12 + t] = (out.flags & DL_LOSS_PLANE_TO_PLANE) ? (float)(2.0 * pl2pl / K) : 0.f;
+  }
+}
+
+// Streamed operands of one 256-pixel chunk as a wave loads them: lane l holds pixels 4l..4l+3 of every plane.
+struct StreamRegs {
+  int4 j;                       // correspondence (validity)
+  float4 x, y, z, a, b, c;      // source point and normal
+  float4 tx, ty, tz, ta, tb, tc; // matched target point and normal
+};
+
+__device__ __forceinline__ StreamRegs load_stream(const int32_t* __restrict__ nn, const float* __restrict__ sp,
+                                                  const float* __restrict__ sn, const float* __restrict__ mt, int q4,
+                                                  int g4) {
+  StreamRegs r;
+  r.j = reinterpret_cast<const int4*>(nn)[g4];
+  r.x = reinterpret_cast<const float4*>(sp)[g4];
+  r.y = reinterpret_cast<const float4*>(sp)[q4 + g4];
+  r.z = reinterpret_cast<const float4*>(sp)[2 * q4 + g4];
+  r.a = reinterpret_cast<const float4*>(sn)[g4];
+  r.b = reinterpret_cast<const float4*>(sn)[q4 + g4];
+  r.c = reinterpret_cast<const float4*>(sn)[2 * q4 + g4];
+  r.tx = reinterpret_cast<const float4*>(mt)[g4];
+  r.ty = reinterpret_cast<const float4*>(mt)[q4 + g4];
+  r.tz = reinterpret_cast<const float4*>(mt)[2 * q4 + g4];
+  r.ta = reinterpret_cast<const float4*>(mt)[3 * q4 + g4];
+  r.tb = reinterpret_cast<const float4*>(mt)[4 * q4 + g4];
+  r.tc = reinterpret_cast<const float4*>(mt)[5 * q4 + g4];
+  return r;
+}
+
+// A pure streaming pass: thirteen fp32 planes per sample -- the correspondence map (validity), the source point and
+// normal, and the matched target point and normal that the correspondence kernel wrote in SOURCE pixel order -- are
+// read once with 16-byte loads, 52 bytes per source pixel, no dependent gather.  Every wave is an independent worker
+// that walks 256-pixel chunks of one sample with a stride of `waves per sample` (one chunk per wave at 64x2048: the
+// thirteen loads of a chunk are all in flight before the first use, and 16 waves per CU overlap each other).  One
+// reduction and one partial row per WAVE at the end.  (A software-pipelined two-chunks-per-wave variant was measured
+// slower: 200+ VGPRs halve the occupancy.)
 template <bool P2P, bool LINEAR>
 __global__ __launch_bounds__(DL_BLOCK) void k_icp_loss(
     const float* __restrict__ src, int64_t src_ss, const float* __restrict__ srcn, int64_t srcn_ss,
-    const float* __restrict__ tgt, int64_t tgt_ss, const float* __restrict__ tgtn, int64_t tgtn_ss,
-    const int32_t* __restrict__ nn_pix, const float* __restrict__ T, int HW, float* __restrict__ partials) {
+    const float* __restrict__ match, int64_t match_ss, const int32_t* __restrict__ nn_pix,
+    const float* __restrict__ T, int HW, float* __restrict__ partials) {
   constexpr int NA = P2P ? ACC_MAX : ACC_N;
+  constexpr int CHUNK = DL_WAVE * LOSS_PX;                       // 256 pixels
   const int b = blockIdx.y;
   float m[12];
 #pragma unroll
@@ -47,110 +207,46 @@ __global__ __launch_bounds__(DL_BLOCK) void k_icp_loss(
   for (int i = 0; i < NA; ++i) acc[i] = 0.f;
   const float* sp = src + (size_t)b * src_ss;
   const float* sn = srcn + (size_t)b * srcn_ss;
-  const float* tp = tgt + (size_t)b * tgt_ss;
-  const float* tn = tgtn + (size_t)b * tgtn_ss;
+  const float* mt = match + (size_t)b * match_ss;
   const int32_t* nn = nn_pix + (size_t)b * HW;
-  for (int px = blockIdx.x * DL_BLOCK + threadIdx.x; px < HW; px += LOSS_BX * DL_BLOCK) {
-    const int j = nn[px];
-    const float x = sp[px], y = sp[HW + px], z = sp[2 * HW + px];
-    const float nx = sn[px], ny = sn[HW + px], nz = sn[2 * HW + px];
-    if (j < 0) continue;
-    const bool has_s = (nx != 0.f) || (ny != 0.f) || (nz != 0.f);               // icp_losses.py:48-50
-    const float tnx = tn[j], tny = tn[HW + j], tnz = tn[2 * HW + j];
-    const bool has_t = (tnx != 0.f) || (tny != 0.f) || (tnz != 0.f);            // :51-52
-    if (has_s != has_t) continue;
-    if (!P2P && !has_s) continue;
-    const float tx = tp[j], ty = tp[HW + j], tz = tp[2 * HW + j];
-    const float qx = (fmaf(m[2], z, fmaf(m[1], y, (m[0] * x))) + m[3]);
-    const float qy = (fmaf(m[6], z, fmaf(m[5], y, (m[4] * x))) + m[7]);
-    const float qz = (fmaf(m[10], z, fmaf(m[9], y, (m[8] * x))) + m[11]);
-    const float dx = qx - tx, dy = qy - ty, dz = qz - tz;
-    if (has_s) {
-      // point-to-plane (:196-203)
-      const float r = fmaf(dz, tnz, fmaf(dy, tny, dx * tnx));
-      acc[0] = fmaf(r, r, acc[0]);
-      const float gx = r * tnx, gy = r * tny, gz = r * tnz;
-      acc[1] += gx; acc[2] += gy; acc[3] += gz;
-      acc[4] = fmaf(gx, x, acc[4]); acc[5] = fmaf(gx, y, acc[5]); acc[6] = fmaf(gx, z, acc[6]);
-      acc[7] = fmaf(gy, x, acc[7]); acc[8] = fmaf(gy, y, acc[8]); acc[9] = fmaf(gy, z, acc[9]);
-      acc[10] = fmaf(gz, x, acc[10]); acc[11] = fmaf(gz, y, acc[11]); acc[12] = fmaf(gz, z, acc[12]);
-      // plane-to-plane (:224-238) on the rotated source normal (deployer.py:297-299)
-      const float rx = fmaf(m[2], nz, fmaf(m[1], ny, m[0] * nx));
-      const float ry = fmaf(m[6], nz, fmaf(m[5], ny, m[4] * nx));
-      const float rz = fmaf(m[10], nz, fmaf(m[9], ny, m[8] * nx));
-      float ex, ey, ez;
-      if (LINEAR) {
-        const float c1 = 1.f - fmaf(rz, tnz, fmaf(ry, tny, rx * tnx));
-        acc[13] = fmaf(c1, c1, acc[13]);
-        ex = -c1 * tnx; ey = -c1 * tny; ez = -c1 * tnz;
-      } else {
-        ex = rx - tnx; ey = ry - tny; ez = rz - tnz;
-        acc[13] += fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+  const int lane = threadIdx.x & (DL_WAVE - 1), wv = threadIdx.x / DL_WAVE;
+  const int waves = gridDim.x * (DL_BLOCK / DL_WAVE);
+  const int gw = blockIdx.x * (DL_BLOCK / DL_WAVE) + wv;
+  const int nchunks = (HW + CHUNK - 1) / CHUNK;
+  const int q4 = HW / 4;
+  const bool vec = (HW & 3) == 0;
+  for (int c = gw; c < nchunks; c += waves) {
+    if (vec && c * CHUNK + CHUNK <= HW) {
+      const StreamRegs cur = load_stream(nn, sp, sn, mt, q4, c * DL_WAVE + lane);
+#define DL_PAIR(C) accumulate_pair<P2P, LINEAR, NA>(acc, m, cur.j.C >= 0, cur.x.C, cur.y.C, cur.z.C, cur.a.C, cur.b.C, \
+                                                    cur.c.C, cur.tx.C, cur.ty.C, cur.tz.C, cur.ta.C, cur.tb.C, cur.tc.C)
+      DL_PAIR(x); DL_PAIR(y); DL_PAIR(z); DL_PAIR(w);
+#undef DL_PAIR
+    } else {                                                     // ragged tail / unaligned image: scalar loads
+      for (int k = 0; k < LOSS_PX; ++k) {
+        const int px = c * CHUNK + lane * LOSS_PX + k;
+        if (px < HW)
+          accumulate_pair<P2P, LINEAR, NA>(acc, m, nn[px] >= 0, sp[px], sp[HW + px], sp[2 * HW + px], sn[px], sn[HW + px],
+                                           sn[2 * HW + px], mt[px], mt[HW + px], mt[2 * HW + px], mt[3 * HW + px],
+                                           mt[4 * HW + px], mt[5 * HW + px]);
       }
-      acc[14] = fmaf(ex, nx, acc[14]); acc[15] = fmaf(ex, ny, acc[15]); acc[16] = fmaf(ex, nz, acc[16]);
-      acc[17] = fmaf(ey, nx, acc[17]); acc[18] = fmaf(ey, ny, acc[18]); acc[19] = fmaf(ey, nz, acc[19]);
-      acc[20] = fmaf(ez, nx, acc[20]); acc[21] = fmaf(ez, ny, acc[21]); acc[22] = fmaf(ez, nz, acc[22]);
-      acc[23] += 1.f;
-    } else if (P2P) {
-      // point-to-point on pairs without normals on either side (:85-100, :168-172)
-      acc[ACC_N + 0] += fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-      acc[ACC_N + 1] += dx; acc[ACC_N + 2] += dy; acc[ACC_N + 3] += dz;
-      acc[ACC_N + 4] = fmaf(dx, x, acc[ACC_N + 4]); acc[ACC_N + 5] = fmaf(dx, y, acc[ACC_N + 5]); acc[ACC_N + 6] = fmaf(dx, z, acc[ACC_N + 6]);
-      acc[ACC_N + 7] = fmaf(dy, x, acc[ACC_N + 7]); acc[ACC_N + 8] = fmaf(dy, y, acc[ACC_N + 8]); acc[ACC_N + 9] = fmaf(dy, z, acc[ACC_N + 9]);
-      acc[ACC_N + 10] = fmaf(dz, x, acc[ACC_N + 10]); acc[ACC_N + 11] = fmaf(dz, y, acc[ACC_N + 11]); acc[ACC_N + 12] = fmaf(dz, z, acc[ACC_N + 12]);
-      acc[ACC_N + 13] += 1.f;
     }
   }
-  // wave tree, then the four waves of the workgroup through LDS
-  __shared__ float red[DL_BLOCK / DL_WAVE][ACC_MAX];
-  const int lane = threadIdx.x & (DL_WAVE - 1), wv = threadIdx.x / DL_WAVE;
+  // one partial row per wave
+  float* row = partials + ((size_t)b * waves + gw) * ACC_PITCH;
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const float v = wave_sum(acc[i]);
-    if (lane == 0) red[wv][i] = v;
+    if (lane == i) row[i] = v;
   }
-  __syncthreads();
-  if (threadIdx.x < NA) {
-    const float v = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
-    partials[((size_t)b * LOSS_BX + blockIdx.x) * ACC_MAX + threadIdx.x] = v;
-  }
+  if (lane >= NA && lane < ACC_PITCH) row[lane] = 0.f;
 }
 
-__global__ __launch_bounds__(DL_WAVE) void k_icp_finalize(const float* __restrict__ partials, uint32_t flags,
-                                                          float* __restrict__ loss_terms,
-                                                          int32_t* __restrict__ pair_counts,
-                                                          float* __restrict__ grad_terms) {
-  __shared__ double tot[ACC_MAX];
-  const int b = blockIdx.x, k = threadIdx.x;
-  const bool p2p = flags & DL_LOSS_POINT_TO_POINT;
-  if (k < ACC_MAX) {
-    double s = 0.0;
-    if (k < ACC_N || p2p)
-      for (int i = 0; i < LOSS_BX; ++i) s += (double)partials[((size_t)b * LOSS_BX + i) * ACC_MAX + k];
-    tot[k] = s;
-  }
-  __syncthreads();
-  const double K = tot[23], K2 = tot[ACC_N + 13];
-  float* lt = loss_terms + b * 3;
-  float* g = grad_terms + b * 36;
-  if (k == 0) {
-    pair_counts[b * 2 + 0] = (int)K;
-    pair_counts[b * 2 + 1] = (int)K2;
-    // means as torch's MSELoss: an enabled term over an empty set is 0/0 = NaN
-    lt[0] = p2p ? (float)(tot[ACC_N] / (3.0 * K2)) : 0.f;
-    lt[1] = (flags & DL_LOSS_POINT_TO_PLANE) ? (float)(tot[0] / K) : 0.f;
-    lt[2] = (flags & DL_LOSS_PLANE_TO_PLANE) ? (float)(tot[13] / K) : 0.f;
-  }
-  if (k < 12) {
-    const int i = k / 4, j = k % 4;
-    // row-major [R | t]: column 3 is d/dt
-    const double po2pl = j < 3 ? tot[4 + i * 3 + j] : tot[1 + i];
-    const double pl2pl = j < 3 ? tot[14 + i * 3 + j] : 0.0;
-    const double po2po = j < 3 ? tot[ACC_N + 4 + i * 3 + j] : tot[ACC_N + 1 + i];
-    g[0 * 12 + k] = p2p ? (float)(2.0 * po2po / (3.0 * K2)) : 0.f;
-    g[1 * 12 + k] = (flags & DL_LOSS_POINT_TO_PLANE) ? (float)(2.0 * po2pl / K) : 0.f;
-    g[2 * 12 + k] = (flags & DL_LOSS_PLANE_TO_PLANE) ? (float)(2.0 * pl2pl / K) : 0.f;
-  }
+// Second (tiny) launch: one workgroup per sample sums that sample's partial rows in fp64, in a fixed order.
+__global__ __launch_bounds__(DL_BLOCK) void k_icp_reduce(const float* __restrict__ partials, int nrows, LossOut out) {
+  __shared__ double tot[FIN_SLICES * ACC_PITCH];
+  const int b = blockIdx.x;
+  finalize_sample(partials + (size_t)b * nrows * ACC_PITCH, nrows, b, out, tot);
 }
 
 __global__ void k_icp_bwd(const float* __restrict__ grad_terms, const float* __restrict__ grad_loss, int B,
@@ -167,31 +263,50 @@ __global__ void k_icp_bwd(const float* __restrict__ grad_terms, const float* __r
   grad_T[t] = v;
 }
 
-extern "C" int dl_icp_loss_fwd(const float* src_image4, int64_t src_ss, const float* src_normals,
-                               int64_t srcn_ss, const float* tgt_image4, int64_t tgt_ss,
-                               const float* tgt_normals, int64_t tgtn_ss, const int32_t* nn_pix,
-                               const float* T, int32_t B, int32_t H, int32_t W, uint32_t flags,
-                               float* loss_terms, int32_t* pair_counts, float* grad_terms, void* workspace,
-                               dl_stream stream) {
-  if (!src_image4 || !src_normals || !tgt_image4 || !tgt_normals || !nn_pix || !T || !loss_terms ||
-      !pair_counts || !grad_terms || !workspace)
-    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_icp_loss_fwd: null pointer argument");
-  if (B <= 0 || H <= 0 || W <= 0) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_icp_loss_fwd: bad sizes");
+extern "C" int dl_icp_loss_partial(const float* src_image4, int64_t src_ss, const float* src_normals,
+                                   int64_t srcn_ss, const float* match, int64_t match_ss, const int32_t* nn_pix,
+                                   const float* T, int32_t B, int32_t H, int32_t W, uint32_t flags, void* workspace,
+                                   dl_stream stream) {
+  if (!src_image4 || !src_normals || !match || !nn_pix || !T || !workspace)
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_icp_loss_partial: null pointer argument");
+  if (B <= 0 || H <= 0 || W <= 0) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_icp_loss_partial: bad sizes");
+  if ((H * W) % 4 == 0 && ((src_ss | srcn_ss | match_ss) % 4 ||
+                           (((uintptr_t)src_image4 | (uintptr_t)src_normals | (uintptr_t)match | (uintptr_t)nn_pix) & 15)))
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_icp_loss_partial: planes and nn_pix must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
   float* partials = (float*)workspace;
-  const dim3 grid(LOSS_BX, B), block(DL_BLOCK);
+  const dim3 grid(loss_blocks(H * W), B), block(DL_BLOCK);
   const bool p2p = flags & DL_LOSS_POINT_TO_POINT, lin = flags & DL_LOSS_NORMAL_LINEAR;
 #define DL_LAUNCH_LOSS(P, L)                                                                               \
   hipLaunchKernelGGL((k_icp_loss<P, L>), grid, block, 0, st, src_image4, src_ss, src_normals, srcn_ss,     \
-                     tgt_image4, tgt_ss, tgt_normals, tgtn_ss, nn_pix, T, H * W, partials)
+                     match, match_ss, nn_pix, T, H * W, partials)
   if (p2p && lin) DL_LAUNCH_LOSS(true, true);
   else if (p2p) DL_LAUNCH_LOSS(true, false);
   else if (lin) DL_LAUNCH_LOSS(false, true);
   else DL_LAUNCH_LOSS(false, false);
 #undef DL_LAUNCH_LOSS
-  hipLaunchKernelGGL(k_icp_finalize, dim3(B), dim3(DL_WAVE), 0, st, partials, flags, loss_terms, pair_counts,
-                     grad_terms);
-  return dl_check_launch("dl_icp_loss_fwd");
+  return dl_check_launch("dl_icp_loss_partial");
+}
+
+extern "C" int dl_icp_loss_reduce(const void* workspace, int32_t B, int32_t H, int32_t W, uint32_t flags,
+                                  float* loss_terms, int32_t* pair_counts, float* grad_terms, dl_stream stream) {
+  if (!workspace || !loss_terms || !pair_counts || !grad_terms || B <= 0 || H <= 0 || W <= 0)
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_icp_loss_reduce: bad argument");
+  LossOut out{loss_terms, pair_counts, grad_terms, flags};
+  hipLaunchKernelGGL(k_icp_reduce, dim3(B), dim3(DL_BLOCK), 0, (hipStream_t)stream, (const float*)workspace,
+                     loss_rows(H * W), out);
+  return dl_check_launch("dl_icp_loss_reduce");
+}
+
+extern "C" int dl_icp_loss_fwd(const float* src_image4, int64_t src_ss, const float* src_normals,
+                               int64_t srcn_ss, const float* match, int64_t match_ss, const int32_t* nn_pix,
+                               const float* T, int32_t B, int32_t H, int32_t W, uint32_t flags,
+                               float* loss_terms, int32_t* pair_counts, float* grad_terms, void* workspace,
+                               dl_stream stream) {
+  const int rc = dl_icp_loss_partial(src_image4, src_ss, src_normals, srcn_ss, match, match_ss, nn_pix, T, B, H, W,
+                                     flags, workspace, stream);
+  if (rc != DL_OK) return rc;
+  return dl_icp_loss_reduce(workspace, B, H, W, flags, loss_terms, pair_counts, grad_terms, stream);
 }
 
 extern "C" int dl_icp_loss_bwd(const float* grad_terms, const float* grad_loss_terms, int32_t B, float* grad_T,

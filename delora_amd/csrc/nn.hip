@@ -16,8 +16,8 @@
 //     bound is weak (holes, occlusions) a moderate window is probed first and the bound recomputed.  With no usable
 //     bound (d >= |q|) this degrades to an exhaustive scan, so the result is exact in every regime.
 //
-// Distances are accumulated in fp64 from the fp32 coordinates, as the KD-tree does; ties resolve to the lower
-// pixel index.  Bound: L2/LDS + VALU (candidates are re-read from cache), reported separately from the
+// The target image is read in its packed form (one 16-byte load per candidate pixel).  Distances are accumulated
+// in fp64 from the fp32 coordinates, as the KD-tree does; ties resolve to the lower pixel index.  Bound: L2/LDS + VALU (candidates are re-read from cache), reported separately from the
 // HBM-bound residual kernel.
 #include "common.h"
 
@@ -131,8 +131,9 @@ __device__ __forceinline__ Window bound_window(const QueryF& q, float d, const S
 
 __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
     const float* __restrict__ src, int64_t src_ss, const float* __restrict__ srcn, int64_t srcn_ss,
-    const float* __restrict__ tgt, int64_t tgt_ss, const float* __restrict__ T, SensorK sen, int need_wo,
-    int32_t* __restrict__ nn_pix, int32_t* __restrict__ visible, NNWorkspace ws) {
+    const float4* __restrict__ tgt, int64_t tgt_ss4, const float4* __restrict__ tgtn, int64_t tgtn_ss4,
+    const float* __restrict__ T, SensorK sen, int need_wo, int32_t* __restrict__ nn_pix, float* __restrict__ match,
+    int32_t* __restrict__ visible, NNWorkspace ws) {
   const int b = blockIdx.y;
   const int px = blockIdx.x * DL_BLOCK + threadIdx.x;
   const int HW = sen.HW, H = sen.H, W = sen.W;
@@ -167,27 +168,41 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
     if ((threadIdx.x & (DL_WAVE - 1)) == 0 && vm) atomicAdd(&visible[b], (int)__popcll(vm));
   }
   if (px >= HW) return;
-  if (!active) { nn_pix[(size_t)b * HW + px] = -1; return; }
+  float* mp = match ? match + (size_t)b * 6 * HW + px : nullptr;
+  if (!active) {
+    nn_pix[(size_t)b * HW + px] = -1;
+    if (mp) { mp[0] = 0.f; mp[HW] = 0.f; mp[2 * HW] = 0.f; mp[3 * HW] = 0.f; mp[4 * HW] = 0.f; mp[5 * HW] = 0.f; }
+    return;
+  }
 
-  const float* tp = tgt + (size_t)b * tgt_ss;
+  const float4* tp = tgt + (size_t)b * tgt_ss4;
   const int u0 = (int)rintf(q.uq);
   int v0 = (int)rintf(q.vq);
   v0 = v0 < 0 ? 0 : (v0 > H - 1 ? H - 1 : v0);
   double best = 1e300;
   int bidx = -1;
+  const int cbase = wrap_col(u0 - NN_RU, W);
 #pragma unroll
   for (int dv = -NN_RV; dv <= NN_RV; ++dv) {
     const int v = v0 + dv;
     if (v < 0 || v >= H) continue;
+    float4 cc[2 * NN_RU + 1];
+    int cp[2 * NN_RU + 1];
 #pragma unroll
-    for (int du = -NN_RU; du <= NN_RU; ++du) {
-      const int p = v * W + wrap_col(u0 + du, W);
-      const float x = tp[p], y = tp[HW + p], z = tp[2 * HW + p];
-      if (x == 0.f && y == 0.f && z == 0.f) continue;
-      const double d2 = dist2(fx, fy, fz, x, y, z);
-      if (d2 < best || (d2 == best && p < bidx)) { best = d2; bidx = p; }
+    for (int i = 0; i <= 2 * NN_RU; ++i) {       // one row of candidates: all (16-byte) loads first
+      int c = cbase + i;
+      c = c >= W ? c - W : c;
+      cp[i] = v * W + c;
+      cc[i] = tp[cp[i]];
+    }
+#pragma unroll
+    for (int i = 0; i <= 2 * NN_RU; ++i) {
+      const bool empty = (cc[i].x == 0.f && cc[i].y == 0.f && cc[i].z == 0.f);
+      const double d2 = empty ? 1e300 : dist2(fx, fy, fz, cc[i].x, cc[i].y, cc[i].z);
+      if (d2 < best || (d2 == best && d2 < 1e299 && cp[i] < bidx)) { best = d2; bidx = cp[i]; }
     }
   }
+  if (best >= 1e299) bidx = -1;
   // certificate: every pixel that can hold a closer target lies inside the scanned window (and the needed columns do
   // not run through the azimuth seam, where the scanned columns were wrapped)
   bool exact = false;
@@ -201,6 +216,11 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
   }
   if (exact) {
     nn_pix[(size_t)b * HW + px] = bidx;
+    if (mp) {      // matched target point and normal in source pixel order: the loss pass streams them
+      const float4 p4 = tp[bidx];
+      const float4 n4 = tgtn ? (tgtn + (size_t)b * tgtn_ss4)[bidx] : make_float4(0.f, 0.f, 0.f, 0.f);
+      mp[0] = p4.x; mp[HW] = p4.y; mp[2 * HW] = p4.z; mp[3 * HW] = n4.x; mp[4 * HW] = n4.y; mp[5 * HW] = n4.z;
+    }
   } else {
     const int pos = atomicAdd(ws.counter, 1);
     NNHard h;
@@ -219,7 +239,7 @@ __device__ __forceinline__ void wave_argmin(double& d2, int& idx) {
 }
 
 // Scan a window with the 64 lanes striding over its flattened (row, column) candidates.
-__device__ __forceinline__ void scan_window(const Window& w, const float* __restrict__ tp, int HW, int W, float qx,
+__device__ __forceinline__ void scan_window(const Window& w, const float4* __restrict__ tp, int HW, int W, float qx,
                                             float qy, float qz, int lane, double& best, int& bidx) {
   const int nrows = w.r1 - w.r0 + 1;
   if (nrows <= 0 || w.nc <= 0) return;
@@ -227,24 +247,37 @@ __device__ __forceinline__ void scan_window(const Window& w, const float* __rest
   const float inv = 1.0f / (float)w.nc;
   double lbest = 1e300;
   int lidx = -1;
-  for (int k = lane; k < total; k += DL_WAVE) {
-    int r = (int)(((float)k + 0.5f) * inv);
-    int c = k - r * w.nc;
-    if (c < 0) { --r; c += w.nc; } else if (c >= w.nc) { ++r; c -= w.nc; }
-    c += w.c0;
-    c = c >= W ? c - W : c;
-    const int p = (w.r0 + r) * W + c;
-    const float x = tp[p], y = tp[HW + p], z = tp[2 * HW + p];
-    if (x == 0.f && y == 0.f && z == 0.f) continue;
-    const double d2 = dist2(qx, qy, qz, x, y, z);
-    if (d2 < lbest || (d2 == lbest && p < lidx)) { lbest = d2; lidx = p; }
+  constexpr int UN = 4;                       // candidates per lane per trip: 12 loads in flight
+  for (int k0 = lane; k0 < total; k0 += DL_WAVE * UN) {
+    float4 c4[UN];
+    int p[UN];
+#pragma unroll
+    for (int i = 0; i < UN; ++i) {
+      const int k = k0 + i * DL_WAVE;
+      const int kk = k < total ? k : 0;
+      int r = (int)(((float)kk + 0.5f) * inv);
+      int c = kk - r * w.nc;
+      if (c < 0) { --r; c += w.nc; } else if (c >= w.nc) { ++r; c -= w.nc; }
+      c += w.c0;
+      c = c >= W ? c - W : c;
+      p[i] = k < total ? (w.r0 + r) * W + c : -1;
+      c4[i] = tp[p[i] < 0 ? 0 : p[i]];
+    }
+#pragma unroll
+    for (int i = 0; i < UN; ++i) {
+      if (p[i] < 0 || (c4[i].x == 0.f && c4[i].y == 0.f && c4[i].z == 0.f)) continue;
+      const double d2 = dist2(qx, qy, qz, c4[i].x, c4[i].y, c4[i].z);
+      if (d2 < lbest || (d2 == lbest && p[i] < lidx)) { lbest = d2; lidx = p[i]; }
+    }
   }
   wave_argmin(lbest, lidx);
   if (lidx >= 0 && (lbest < best || (lbest == best && (bidx < 0 || lidx < bidx)))) { best = lbest; bidx = lidx; }
 }
 
-__global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float* __restrict__ tgt, int64_t tgt_ss, SensorK sen,
-                                                      int32_t* __restrict__ nn_pix, NNWorkspace ws) {
+__global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float4* __restrict__ tgt, int64_t tgt_ss4,
+                                                      const float4* __restrict__ tgtn, int64_t tgtn_ss4, SensorK sen,
+                                                      int32_t* __restrict__ nn_pix, float* __restrict__ match,
+                                                      NNWorkspace ws) {
   const int lane = threadIdx.x & (DL_WAVE - 1);
   const int wave = (blockIdx.x * DL_BLOCK + threadIdx.x) / DL_WAVE;
   const int nwaves = gridDim.x * DL_BLOCK / DL_WAVE;
@@ -253,7 +286,7 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float* __restrict__ 
   for (int h = wave; h < count; h += nwaves) {
     const NNHard rec = ws.hard[h];
     const int b = rec.slot / HW;
-    const float* tp = tgt + (size_t)b * tgt_ss;
+    const float4* tp = tgt + (size_t)b * tgt_ss4;
     const QueryF q = make_query(rec.qx, rec.qy, rec.qz, sen);
     double best = rec.d2;
     int bidx = rec.idx;
@@ -272,16 +305,31 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float* __restrict__ 
       w = bound_window(q, bidx >= 0 ? (float)sqrt(best) * NN_UP : 3.0e38f, sen);
     }
     scan_window(w, tp, HW, W, rec.qx, rec.qy, rec.qz, lane, best, bidx);
-    if (lane == 0) nn_pix[rec.slot] = bidx;
+    if (lane == 0) {
+      nn_pix[rec.slot] = bidx;
+      if (match) {
+        const int px = rec.slot - b * HW;
+        float* mp = match + (size_t)b * 6 * HW + px;
+        float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f), n4 = p4;
+        if (bidx >= 0) {
+          p4 = tp[bidx];
+          if (tgtn) n4 = (tgtn + (size_t)b * tgtn_ss4)[bidx];
+        }
+        mp[0] = p4.x; mp[HW] = p4.y; mp[2 * HW] = p4.z; mp[3 * HW] = n4.x; mp[4 * HW] = n4.y; mp[5 * HW] = n4.z;
+      }
+    }
   }
 }
 
 extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const float* src_normals,
-                                int64_t srcn_ss, const float* tgt_image4, int64_t tgt_ss, const float* T,
-                                int32_t B, const dl_sensor* sensor, int32_t need_without_normals,
-                                int32_t* nn_pix, int32_t* visible, void* workspace, dl_stream stream) {
-  if (!src_image4 || !tgt_image4 || !T || !sensor || !nn_pix || !workspace)
+                                int64_t srcn_ss, const float* tgt_packed, int64_t tgt_ss,
+                                const float* tgt_normals_packed, int64_t tgtn_ss, const float* T, int32_t B,
+                                const dl_sensor* sensor, int32_t need_without_normals, int32_t* nn_pix,
+                                float* match, int32_t* visible, void* workspace, dl_stream stream) {
+  if (!src_image4 || !tgt_packed || !T || !sensor || !nn_pix || !workspace)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_nn_correspond: null pointer argument");
+  if (tgt_ss % 4 != 0 || ((uintptr_t)tgt_packed & 15) || tgtn_ss % 4 != 0 || ((uintptr_t)tgt_normals_packed & 15))
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_nn_correspond: packed targets must be 16-byte aligned");
   if (B <= 0 || sensor->H < 2 || sensor->W < 2 * NN_RU + 2)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_nn_correspond: bad sizes B=%d H=%d W=%d", B, sensor->H, sensor->W);
   hipStream_t st = (hipStream_t)stream;
@@ -290,9 +338,11 @@ extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const f
   (void)hipMemsetAsync(ws.counter, 0, 256, st);
   if (visible) (void)hipMemsetAsync(visible, 0, sizeof(int32_t) * B, st);
   hipLaunchKernelGGL(k_nn_window, dim3((sen.HW + DL_BLOCK - 1) / DL_BLOCK, B), dim3(DL_BLOCK), 0, st,
-                     src_image4, src_ss, src_normals, srcn_ss, tgt_image4, tgt_ss, T, sen,
-                     need_without_normals, nn_pix, visible, ws);
-  hipLaunchKernelGGL(k_nn_hard, dim3(2048), dim3(DL_BLOCK), 0, st, tgt_image4, tgt_ss, sen, nn_pix, ws);
+                     src_image4, src_ss, src_normals, srcn_ss, (const float4*)tgt_packed, tgt_ss / 4,
+                     (const float4*)tgt_normals_packed, tgtn_ss / 4, T, sen, need_without_normals, nn_pix, match, visible,
+                     ws);
+  hipLaunchKernelGGL(k_nn_hard, dim3(2048), dim3(DL_BLOCK), 0, st, (const float4*)tgt_packed, tgt_ss / 4,
+                     (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, ws);
   return dl_check_launch("dl_nn_correspond");
 }
 

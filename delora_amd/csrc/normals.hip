@@ -54,7 +54,7 @@ __device__ __forceinline__ void smallest_eigenvector(double a00, double a01, dou
 
 __global__ __launch_bounds__(NTH * NTW) void k_normals(
     const float* __restrict__ image4, int64_t image_ss, int H, int W, int a, int b, float eps_range,
-    int min_n, float* __restrict__ normals) {
+    int min_n, float* __restrict__ normals, float4* __restrict__ packed) {
   extern __shared__ float lds[];
   const int tw = NTW + 2 * b, th = NTH + 2 * a, tn = tw * th;
   float* sx = lds;
@@ -119,11 +119,12 @@ __global__ __launch_bounds__(NTH * NTW) void k_normals(
   }
   float* out = normals + (size_t)s * 3 * HW + v * W + u;
   out[0] = ox; out[HW] = oy; out[2 * HW] = oz;
+  if (packed) packed[(size_t)s * HW + v * W + u] = make_float4(ox, oy, oz, 0.f);
 }
 
 extern "C" int dl_normals(const float* image4, int64_t image_ss, int32_t S, int32_t H, int32_t W,
                           int32_t half_rows, int32_t half_cols, float epsilon_range,
-                          int32_t min_neighbors, float* normals, dl_stream stream) {
+                          int32_t min_neighbors, float* normals, float* packed_normals, dl_stream stream) {
   if (!image4 || !normals) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_normals: null pointer argument");
   if (S <= 0 || H <= 0 || W <= 0 || half_rows < 0 || half_cols < 0 || half_rows > 15 || half_cols > 31)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_normals: bad sizes S=%d H=%d W=%d a=%d b=%d", S, H, W,
@@ -131,6 +132,6 @@ extern "C" int dl_normals(const float* image4, int64_t image_ss, int32_t S, int3
   const size_t lds = (size_t)(NTH + 2 * half_rows) * (NTW + 2 * half_cols) * 4 * sizeof(float);
   dim3 grid((W + NTW - 1) / NTW, (H + NTH - 1) / NTH, S);
   hipLaunchKernelGGL(k_normals, grid, dim3(NTH * NTW), lds, (hipStream_t)stream, image4, image_ss, H, W,
-                     half_rows, half_cols, epsilon_range, min_neighbors, normals);
+                     half_rows, half_cols, epsilon_range, min_neighbors, normals, (float4*)packed_normals);
   return dl_check_launch("dl_normals");
 }

@@ -38,7 +38,8 @@ __global__ __launch_bounds__(DL_BLOCK) void k_project_scatter(
 __global__ __launch_bounds__(DL_BLOCK) void k_project_resolve(
     const float* __restrict__ pts, int64_t cs, const int32_t* __restrict__ offs, int C, SensorK sen,
     const unsigned long long* __restrict__ keys, float* __restrict__ image4, float* __restrict__ aux,
-    int32_t* __restrict__ pix2pt, int32_t* __restrict__ kept) {
+    float4* __restrict__ packed, float4* __restrict__ packed_aux, int32_t* __restrict__ pix2pt,
+    int32_t* __restrict__ kept) {
   const int s = blockIdx.y;
   const int px = blockIdx.x * DL_BLOCK + threadIdx.x;
   const int HW = sen.HW;
@@ -50,20 +51,35 @@ __global__ __launch_bounds__(DL_BLOCK) void k_project_resolve(
     if (occupied) {
       const int idx = (int)(unsigned int)(key & 0xffffffffu);
       const int64_t g = (int64_t)offs[s] + idx;
-      img[0] = pts[g];
-      img[HW] = pts[cs + g];
-      img[2 * HW] = pts[2 * cs + g];
-      img[3 * HW] = __uint_as_float((unsigned int)(key >> 32));
-      for (int c = 3; c < C; ++c) aux[((size_t)s * (C - 3) + (c - 3)) * HW + px] = pts[c * cs + g];
+      const float x = pts[g], y = pts[cs + g], z = pts[2 * cs + g];
+      const float r = __uint_as_float((unsigned int)(key >> 32));
+      img[0] = x; img[HW] = y; img[2 * HW] = z; img[3 * HW] = r;
+      if (packed) packed[(size_t)s * HW + px] = make_float4(x, y, z, r);
+      float a3[3] = {0.f, 0.f, 0.f};
+      for (int c = 3; c < C; ++c) {
+        const float v = pts[c * cs + g];
+        aux[((size_t)s * (C - 3) + (c - 3)) * HW + px] = v;
+        if (c < 6) a3[c - 3] = v;
+      }
+      if (packed_aux) packed_aux[(size_t)s * HW + px] = make_float4(a3[0], a3[1], a3[2], 0.f);
       pix2pt[(size_t)s * HW + px] = idx;
     } else {
       img[0] = 0.f; img[HW] = 0.f; img[2 * HW] = 0.f; img[3 * HW] = 0.f;
+      if (packed) packed[(size_t)s * HW + px] = make_float4(0.f, 0.f, 0.f, 0.f);
       for (int c = 3; c < C; ++c) aux[((size_t)s * (C - 3) + (c - 3)) * HW + px] = 0.f;
+      if (packed_aux) packed_aux[(size_t)s * HW + px] = make_float4(0.f, 0.f, 0.f, 0.f);
       pix2pt[(size_t)s * HW + px] = -1;
     }
   }
-  const unsigned long long m = __ballot(occupied);
-  if ((threadIdx.x & (DL_WAVE - 1)) == 0 && m) atomicAdd(&kept[s], (int)__popcll(m));
+  if (kept) {   // optional statistic: one atomic per workgroup (the training step passes NULL)
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const unsigned long long m = __ballot(occupied);
+    if ((threadIdx.x & (DL_WAVE - 1)) == 0 && m) atomicAdd(&s_cnt, (int)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(&kept[s], s_cnt);
+  }
 }
 
 extern "C" size_t dl_project_workspace_bytes(int32_t S, int32_t H, int32_t W) {
@@ -71,19 +87,20 @@ extern "C" size_t dl_project_workspace_bytes(int32_t S, int32_t H, int32_t W) {
 }
 
 extern "C" int dl_project(const float* pts, int64_t pts_cs, const int32_t* offs, int32_t S, int32_t C,
-                          int32_t max_n, const dl_sensor* sensor, float* image4, float* aux,
-                          int32_t* pix2pt, uint64_t* keys_ws, int32_t* kept, float* uvr,
+                          int32_t max_n, const dl_sensor* sensor, float* image4, float* aux, float* packed,
+                          float* packed_aux, int32_t* pix2pt, uint64_t* keys_ws, int32_t* kept, float* uvr,
                           dl_stream stream) {
-  if ((!pts && max_n > 0) || !offs || !sensor || !image4 || !pix2pt || !keys_ws || !kept)
+  if ((!pts && max_n > 0) || !offs || !sensor || !image4 || !pix2pt || !keys_ws)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_project: null pointer argument");
   if (S <= 0 || C < 3 || sensor->H < 2 || sensor->W < 2 || max_n < 0)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_project: bad sizes S=%d C=%d H=%d W=%d max_n=%d", S, C,
                    sensor->H, sensor->W, max_n);
   if (C > 3 && !aux) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_project: C=%d needs an aux image", C);
+  if (packed_aux && C < 6) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_project: packed_aux needs C >= 6 (got %d)", C);
   hipStream_t st = (hipStream_t)stream;
   const SensorK sen = make_sensor(sensor);
   (void)hipMemsetAsync(keys_ws, 0xff, dl_project_workspace_bytes(S, sen.H, sen.W), st);
-  (void)hipMemsetAsync(kept, 0, sizeof(int32_t) * S, st);
+  if (kept) (void)hipMemsetAsync(kept, 0, sizeof(int32_t) * S, st);
   if (max_n > 0) {
     int gx = (max_n + DL_BLOCK - 1) / DL_BLOCK;
     if (gx > 4096) gx = 4096;
@@ -92,6 +109,6 @@ extern "C" int dl_project(const float* pts, int64_t pts_cs, const int32_t* offs,
   }
   hipLaunchKernelGGL(k_project_resolve, dim3((sen.HW + DL_BLOCK - 1) / DL_BLOCK, S), dim3(DL_BLOCK), 0,
                      st, pts, pts_cs, offs, C, sen, (const unsigned long long*)keys_ws, image4, aux,
-                     pix2pt, kept);
+                     (float4*)packed, (float4*)packed_aux, pix2pt, kept);
   return dl_check_launch("dl_project");
 }

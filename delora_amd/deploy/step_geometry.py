@@ -32,7 +32,8 @@ class HipStepGeometry:
 
     def prepare(self, samples, sensor, normal_params):
         """samples: list of dicts with ``scan_1``/``scan_2`` ``[1,3,N]`` on the GPU and optional ``normal_list_*``.
-        Returns dict(stacked [B,8,H,W] network input, images [B,2,4,H,W] view, normals [B,2,3,H,W])."""
+        Returns dict(stacked [B,8,H,W] network input, images [B,2,4,H,W] view, normals [B,2,3,H,W], their packed twins
+        packed / normals_packed [B,2,H,W,4], pix2pt [B,2,H,W])."""
         B = len(samples)
         with_lists = samples[0].get("normal_list_1") is not None
         chunks, lengths = [], []
@@ -45,24 +46,28 @@ class HipStepGeometry:
                 lengths.append(scan.shape[1])
         pts = torch.cat(chunks, dim=1).contiguous().float()
         offs = self._offsets_for(lengths, pts.device)
-        out = geometry.project(pts, offs, max(lengths), sensor)
+        out = geometry.project(pts, offs, max(lengths), sensor, want_kept=False)
         image4 = out["image4"]
         H, W = sensor.H, sensor.W
         if with_lists:
             normals = out["aux"][:, :3]                 # stored normals ride along as extra channels (deployer.py:258-261)
             if normals.shape[1] != 3 or not normals.is_contiguous():
                 normals = normals.contiguous()
+            normals_pk = out["packed_aux"]
         else:
             a, b, eps, min_n = normal_params
-            normals = geometry.normals(image4, a, b, eps, min_n)
+            normals, normals_pk = geometry.normals(image4, a, b, eps, min_n, want_packed=True)
         return {"stacked": image4.view(B, 8, H, W), "images": image4.view(B, 2, 4, H, W),
-                "normals": normals.view(B, 2, 3, H, W), "kept": out["kept"].view(B, 2), "sensor": sensor}
+                "normals": normals.view(B, 2, 3, H, W), "packed": out["packed"].view(B, 2, H, W, 4),
+                "normals_packed": normals_pk.view(B, 2, H, W, 4), "pix2pt": out["pix2pt"].view(B, 2, H, W),
+                "sensor": sensor}
 
     def losses(self, T, prepared, flags, need_without_normals):
         """(loss_terms [B,3] differentiable w.r.t. T, pair_counts [B,2], visible [B]) for target = scan 1, source = scan 2."""
-        img, nrm, sensor = prepared["images"], prepared["normals"], prepared["sensor"]
-        tgt, src = img[:, 0], img[:, 1]
-        tgt_n, src_n = nrm[:, 0], nrm[:, 1]
-        nn, visible = geometry.nn_correspond(src, src_n, tgt, T, sensor, need_without_normals=need_without_normals)
-        terms, counts = geometry.icp_loss(T, src, src_n, tgt, tgt_n, nn, flags)
+        sensor = prepared["sensor"]
+        src, src_n = prepared["images"][:, 1], prepared["normals"][:, 1]            # streamed: planar
+        tgt_pk, tgt_n_pk = prepared["packed"][:, 0], prepared["normals_packed"][:, 0]   # gathered (by the search): packed
+        nn, visible, match = geometry.nn_correspond(src, src_n, tgt_pk, tgt_n_pk, T, sensor,
+                                                    need_without_normals=need_without_normals)
+        terms, counts = geometry.icp_loss(T, src, src_n, match, nn, flags)
         return terms, counts, visible

@@ -3,7 +3,8 @@
 Every function takes/returns CUDA(HIP) tensors, allocates outputs with torch's caching allocator,
 passes raw device pointers plus torch's *current stream* to libdelora_hip.so, and never
 synchronises.  Layouts are those of include/delora_hip.h: planar fp32 range images
-``[S,4,H,W]`` (x,y,z,range), planar normals ``[S,3,H,W]``, int32 pixel maps.
+``[S,4,H,W]`` (x,y,z,range) and normals ``[S,3,H,W]`` for everything that is streamed, packed
+``[S,H,W,4]`` twins ((x,y,z,range) / (nx,ny,nz,0)) for everything that is gathered from, int32 pixel maps.
 """
 import ctypes
 
@@ -57,10 +58,10 @@ def _planar(t, channels):
     return t, t.stride(0)
 
 
-def project(points, offsets, max_points, sensor, want_uv=False):
+def project(points, offsets, max_points, sensor, want_uv=False, want_kept=True, want_packed=True):
     """Range images of S scans.  points ``[C,sumN]`` fp32 (rows 0..2 = xyz), offsets ``[S+1]`` int32 (device).
-    Returns dict(image4 [S,4,H,W], aux [S,C-3,H,W]|None, pix2pt [S,H,W] int32, kept [S] int32,
-    uv [3,sumN]|None = u, v and range of every point)."""
+    Returns dict(image4 [S,4,H,W], aux [S,C-3,H,W]|None, packed [S,H,W,4]|None, packed_aux [S,H,W,4]|None (C >= 6: the
+    stored normals), pix2pt [S,H,W] int32, kept [S] int32|None, uv [3,sumN]|None = u, v and range of every point)."""
     lib = _lib.load()
     _require_cuda(points, offsets)
     if points.dtype != torch.float32 or points.dim() != 2 or points.stride(1) != 1:
@@ -71,46 +72,77 @@ def project(points, offsets, max_points, sensor, want_uv=False):
     H, W, dev = sensor.H, sensor.W, points.device
     image4 = torch.empty((S, 4, H, W), dtype=torch.float32, device=dev)
     aux = torch.empty((S, C - 3, H, W), dtype=torch.float32, device=dev) if C > 3 else None
+    packed = torch.empty((S, H, W, 4), dtype=torch.float32, device=dev) if want_packed else None
+    packed_aux = torch.empty((S, H, W, 4), dtype=torch.float32, device=dev) if (want_packed and C >= 6) else None
     pix2pt = torch.empty((S, H, W), dtype=torch.int32, device=dev)
-    kept = torch.empty((S,), dtype=torch.int32, device=dev)
+    kept = torch.empty((S,), dtype=torch.int32, device=dev) if want_kept else None
     keys = torch.empty((lib.dl_project_workspace_bytes(S, H, W) // 8,), dtype=torch.int64, device=dev)
     uv = torch.empty((3, points.shape[1]), dtype=torch.float32, device=dev) if want_uv else None
     if uv is not None and points.stride(0) != uv.stride(0):
         raise ValueError("want_uv needs a dense points buffer")
     _lib.check(lib.dl_project(_ptr(points), points.stride(0), _ptr(offsets), S, C, int(max_points),
-                              ctypes.byref(sensor.struct), _ptr(image4), _ptr(aux), _ptr(pix2pt), _ptr(keys),
-                              _ptr(kept), _ptr(uv), _stream()), "dl_project")
-    return {"image4": image4, "aux": aux, "pix2pt": pix2pt, "kept": kept, "uv": uv}
+                              ctypes.byref(sensor.struct), _ptr(image4), _ptr(aux), _ptr(packed), _ptr(packed_aux),
+                              _ptr(pix2pt), _ptr(keys), _ptr(kept), _ptr(uv), _stream()), "dl_project")
+    return {"image4": image4, "aux": aux, "packed": packed, "packed_aux": packed_aux, "pix2pt": pix2pt, "kept": kept,
+            "uv": uv}
 
 
-def normals(image4, half_rows=3, half_cols=5, epsilon_range=0.5, min_neighbors=10):
-    """Normals ``[S,3,H,W]`` of range images ``[S,>=3,H,W]`` (zero vector = no normal)."""
+def normals(image4, half_rows=3, half_cols=5, epsilon_range=0.5, min_neighbors=10, want_packed=False):
+    """Normals ``[S,3,H,W]`` of range images ``[S,>=3,H,W]`` (zero vector = no normal); with ``want_packed`` also the
+    packed twin ``[S,H,W,4]`` -> (planar, packed)."""
     lib = _lib.load()
     _require_cuda(image4)
     t, ss = _planar(image4, 3)
     S, _, H, W = t.shape
     out = torch.empty((S, 3, H, W), dtype=torch.float32, device=t.device)
+    pk = torch.empty((S, H, W, 4), dtype=torch.float32, device=t.device) if want_packed else None
     _lib.check(lib.dl_normals(_ptr(t), ss, S, H, W, int(half_rows), int(half_cols), float(epsilon_range),
-                              int(min_neighbors), _ptr(out), _stream()), "dl_normals")
+                              int(min_neighbors), _ptr(out), _ptr(pk), _stream()), "dl_normals")
+    return (out, pk) if want_packed else out
+
+
+def pack_image(planar):
+    """Packed twin ``[S,H,W,4]`` of a planar ``[S,3|4,H,W]`` tensor (torch ops; for callers that did not get it from
+    project()/normals())."""
+    S, C, H, W = planar.shape
+    out = torch.zeros((S, H, W, 4), dtype=torch.float32, device=planar.device)
+    out[..., :min(C, 4)] = planar[:, :4].permute(0, 2, 3, 1)
     return out
 
 
-def nn_correspond(src_image4, src_normals, tgt_image4, T, sensor, need_without_normals=False, want_visible=True):
-    """Exact nearest target pixel of every transformed source point.  Returns (nn_pix [B,H,W] int32, visible [B]|None)."""
+def _packed(t):
+    S, H, W, C = t.shape
+    if C != 4 or t.stride(3) != 1 or t.stride(2) != 4 or t.stride(1) != 4 * W or t.dtype != torch.float32:
+        raise ValueError(f"expected packed fp32 [S,H,W,4] with dense inner dims, got {tuple(t.shape)} / {t.stride()}")
+    return t, t.stride(0)
+
+
+def nn_correspond(src_image4, src_normals, tgt_packed, tgt_normals_packed, T, sensor, need_without_normals=False,
+                  want_visible=True, want_match=True):
+    """Exact nearest target pixel of every transformed source point (source planar, target packed ``[B,H,W,4]``).
+    Returns (nn_pix [B,H,W] int32, visible [B]|None, match [B,6,H,W]|None): ``match`` holds, per SOURCE pixel, the matched
+    target point (planes 0..2) and normal (planes 3..5) -- the operand stream of icp_loss()."""
     lib = _lib.load()
-    _require_cuda(src_image4, tgt_image4, T)
+    _require_cuda(src_image4, tgt_packed, T)
     s, s_ss = _planar(src_image4, 3)
-    t, t_ss = _planar(tgt_image4, 3)
+    t, t_ss = _packed(tgt_packed)
+    tn, tn_ss = _packed(tgt_normals_packed) if tgt_normals_packed is not None else (None, 0)
     n, n_ss = _planar(src_normals, 3) if src_normals is not None else (None, 0)
     B, H, W = s.shape[0], sensor.H, sensor.W
     Tc = T.detach().contiguous().float()
     nn = torch.empty((B, H, W), dtype=torch.int32, device=s.device)
+    match = torch.empty((B, 6, H, W), dtype=torch.float32, device=s.device) if want_match else None
     vis = torch.empty((B,), dtype=torch.int32, device=s.device) if want_visible else None
     ws = torch.empty((lib.dl_nn_workspace_bytes(B, H, W) // 8 + 1,), dtype=torch.int64, device=s.device)
-    _lib.check(lib.dl_nn_correspond(_ptr(s), s_ss, _ptr(n), n_ss, _ptr(t), t_ss, _ptr(Tc), B,
+    _lib.check(lib.dl_nn_correspond(_ptr(s), s_ss, _ptr(n), n_ss, _ptr(t), t_ss, _ptr(tn), tn_ss, _ptr(Tc), B,
                                     ctypes.byref(sensor.struct), int(bool(need_without_normals)), _ptr(nn),
-                                    _ptr(vis), _ptr(ws), _stream()), "dl_nn_correspond")
-    return nn, vis
+                                    _ptr(match), _ptr(vis), _ptr(ws), _stream()), "dl_nn_correspond")
+    return nn, vis, match
+
+
+# bench.py sets this to a callable that records a HIP event on the current stream: it is invoked immediately before
+# and after the launch of the streaming loss kernel, so that its duration can be measured inside real training steps
+PARTIAL_HOOK = None
 
 
 class _IcpLoss(torch.autograd.Function):
@@ -118,12 +150,11 @@ class _IcpLoss(torch.autograd.Function):
     correspondences are constants, exactly as the gather indices are in the reference."""
 
     @staticmethod
-    def forward(ctx, T, src_image4, src_normals, tgt_image4, tgt_normals, nn_pix, flags):
+    def forward(ctx, T, src_image4, src_normals, match, nn_pix, flags):
         lib = _lib.load()
         s, s_ss = _planar(src_image4, 3)
         sn, sn_ss = _planar(src_normals, 3)
-        t, t_ss = _planar(tgt_image4, 3)
-        tn, tn_ss = _planar(tgt_normals, 3)
+        mt, mt_ss = _planar(match, 6)
         B, _, H, W = s.shape
         dev = s.device
         Tc = T.detach().contiguous().float()
@@ -131,9 +162,14 @@ class _IcpLoss(torch.autograd.Function):
         counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
         grad_terms = torch.empty((B, 3, 12), dtype=torch.float32, device=dev)
         ws = torch.empty((lib.dl_icp_loss_workspace_bytes(B, H, W) // 4,), dtype=torch.float32, device=dev)
-        _lib.check(lib.dl_icp_loss_fwd(_ptr(s), s_ss, _ptr(sn), sn_ss, _ptr(t), t_ss, _ptr(tn), tn_ss, _ptr(nn_pix),
-                                       _ptr(Tc), B, H, W, int(flags), _ptr(loss_terms), _ptr(counts),
-                                       _ptr(grad_terms), _ptr(ws), _stream()), "dl_icp_loss_fwd")
+        if PARTIAL_HOOK is not None:
+            PARTIAL_HOOK()
+        _lib.check(lib.dl_icp_loss_partial(_ptr(s), s_ss, _ptr(sn), sn_ss, _ptr(mt), mt_ss, _ptr(nn_pix),
+                                           _ptr(Tc), B, H, W, int(flags), _ptr(ws), _stream()), "dl_icp_loss_partial")
+        if PARTIAL_HOOK is not None:
+            PARTIAL_HOOK()
+        _lib.check(lib.dl_icp_loss_reduce(_ptr(ws), B, H, W, int(flags), _ptr(loss_terms), _ptr(counts),
+                                          _ptr(grad_terms), _stream()), "dl_icp_loss_reduce")
         ctx.save_for_backward(grad_terms)
         ctx.mark_non_differentiable(counts)
         return loss_terms, counts
@@ -146,13 +182,14 @@ class _IcpLoss(torch.autograd.Function):
         g = g_terms.contiguous().float()
         grad_T = torch.empty((B, 4, 4), dtype=torch.float32, device=g.device)
         _lib.check(lib.dl_icp_loss_bwd(_ptr(grad_terms), _ptr(g), B, _ptr(grad_T), _stream()), "dl_icp_loss_bwd")
-        return grad_T, None, None, None, None, None, None
+        return grad_T, None, None, None, None, None
 
 
-def icp_loss(T, src_image4, src_normals, tgt_image4, tgt_normals, nn_pix, flags):
-    """(loss_terms [B,3], pair_counts [B,2]); loss_terms is differentiable with respect to T."""
-    _require_cuda(T, src_image4, src_normals, tgt_image4, tgt_normals, nn_pix)
-    return _IcpLoss.apply(T, src_image4, src_normals, tgt_image4, tgt_normals, nn_pix, flags)
+def icp_loss(T, src_image4, src_normals, match, nn_pix, flags):
+    """(loss_terms [B,3], pair_counts [B,2]); loss_terms is differentiable with respect to T.  Source planes
+    ``[B,>=3,H,W]`` / ``[B,3,H,W]``, ``match`` ``[B,6,H,W]`` and ``nn_pix`` from nn_correspond()."""
+    _require_cuda(T, src_image4, src_normals, match, nn_pix)
+    return _IcpLoss.apply(T, src_image4, src_normals, match, nn_pix, flags)
 
 
 def loss_flags(config):

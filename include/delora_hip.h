@@ -17,6 +17,9 @@
  *     a range image is planar fp32 [S][4][H][W] = (x, y, z, range), empty pixels are all-zero;
  *     normals are planar fp32 [S][3][H][W], the zero vector meaning "no normal"; pixel indices are
  *     int32 row-major v*W+u, -1 = none.  Row 0 is the lowest elevation, column 0 azimuth hfov[0].
+ *     Planar images are what is STREAMED (network input, source side of the loss); images that are
+ *     GATHERED from (the target side of correspondence search and loss) additionally exist in a packed
+ *     form [S][H][W][4] fp32 -- (x,y,z,range) and (nx,ny,nz,0) -- so that one pixel is one 16-byte load.
  *   - results are deterministic: no floating-point atomics, order-independent integer atomics only.
  */
 #ifndef DELORA_HIP_H
@@ -72,14 +75,17 @@ size_t dl_project_workspace_bytes(int32_t S, int32_t H, int32_t W);
  *   offs     [S+1]         int32 CSR offsets (device); max_n = largest scan length (host value)
  *   image4   [S][4][H][W]  out: x,y,z,range of the winning point, zeros elsewhere
  *   aux      [S][C-3][H][W] out (may be NULL when C == 3): the remaining channels of the winner
+ *   packed   [S][H][W][4]  out (may be NULL): x,y,z,range of the winner, pixel-interleaved
+ *   packed_aux [S][H][W][4] out (may be NULL; needs C >= 6): channels 3..5 of the winner + 0 (stored normals)
  *   pix2pt   [S][H][W]     out: index of the winning point relative to its scan start, -1 if empty
  *   keys_ws  dl_project_workspace_bytes(S,H,W) bytes of scratch
- *   kept     [S]           out: number of occupied pixels per scan
+ *   kept     [S]           out (may be NULL): number of occupied pixels per scan
  *   uvr      [3][pts_cs]   out (may be NULL): fp32 u, v and range of EVERY input point, input order
  */
 int dl_project(const float* pts, int64_t pts_cs, const int32_t* offs, int32_t S, int32_t C,
-               int32_t max_n, const dl_sensor* sensor, float* image4, float* aux, int32_t* pix2pt,
-               uint64_t* keys_ws, int32_t* kept, float* uvr, dl_stream stream);
+               int32_t max_n, const dl_sensor* sensor, float* image4, float* aux, float* packed,
+               float* packed_aux, int32_t* pix2pt, uint64_t* keys_ws, int32_t* kept, float* uvr,
+               dl_stream stream);
 
 /*
  * Per-pixel surface normals of S range images.
@@ -89,11 +95,12 @@ int dl_project(const float* pts, int64_t pts_cs, const int32_t* offs, int32_t S,
  * symeig and viewpoint flip become one LDS-tiled kernel with an in-register 3x3 eigen solve.
  *   image4  [S][4][H][W] in (scan stride image_ss elements, channel stride H*W)
  *   normals [S][3][H][W] out (scan stride 3*H*W), zeros where no normal
+ *   packed_normals [S][H][W][4] out (may be NULL): (nx,ny,nz,0), pixel-interleaved
  * A pixel is processed iff x != 0 && y != 0 && z != 0 (normal_computation.py:35).
  */
 int dl_normals(const float* image4, int64_t image_ss, int32_t S, int32_t H, int32_t W,
                int32_t half_rows, int32_t half_cols, float epsilon_range, int32_t min_neighbors,
-               float* normals, dl_stream stream);
+               float* normals, float* packed_normals, dl_stream stream);
 
 /* Bytes of scratch dl_nn_correspond needs (hard-query list + counters). */
 size_t dl_nn_workspace_bytes(int32_t B, int32_t H, int32_t W);
@@ -102,8 +109,14 @@ size_t dl_nn_workspace_bytes(int32_t B, int32_t H, int32_t W);
  * Exact 3-D nearest target point of every transformed source point (k=1, Euclidean, fp64 distances).
  * Replaces the CPU cKDTree build + queries of ICPLosses.forward (src/losses/icp_losses.py:24-26,
  * :34, :63-80) together with the source transform of Deployer.step (src/deploy/deployer.py:294-296).
- * Target points are the occupied pixels of tgt_image4, source points those of src_image4.
+ * Target points are the occupied pixels of the target image (given in packed form, as produced by dl_project
+ * with THE SAME sensor: the search relies on every stored point lying in the pixel it projects to), source
+ * points those of src_image4.
+ *   tgt_packed [B][H][W][4] packed target image (scan stride tgt_ss elements)
+ *   tgt_normals_packed [B][H][W][4] packed target normals (may be NULL: matched normals are then zero)
  *   T          [B][4][4]  fp32 row-major source->target transforms
+ *   match      [B][6][H][W] out (may be NULL): per SOURCE pixel the matched target point (planes 0..2) and its
+ *                         normal (planes 3..5), zeros where nn_pix is -1 -- what dl_icp_loss_* streams
  *   nn_pix     [B][H][W]  out: target pixel index of the nearest target point per source pixel
  *                         (-1 for empty source pixels or an empty target image)
  *   visible    [B]        out (may be NULL): number of source points with round(v) < H and v > 0 in the
@@ -112,9 +125,9 @@ size_t dl_nn_workspace_bytes(int32_t B, int32_t H, int32_t W);
  *   are skipped (their correspondences are only used by the point-to-point term).
  */
 int dl_nn_correspond(const float* src_image4, int64_t src_ss, const float* src_normals, int64_t srcn_ss,
-                     const float* tgt_image4, int64_t tgt_ss, const float* T, int32_t B,
-                     const dl_sensor* sensor, int32_t need_without_normals, int32_t* nn_pix,
-                     int32_t* visible, void* workspace, dl_stream stream);
+                     const float* tgt_packed, int64_t tgt_ss, const float* tgt_normals_packed, int64_t tgtn_ss,
+                     const float* T, int32_t B, const dl_sensor* sensor, int32_t need_without_normals,
+                     int32_t* nn_pix, float* match, int32_t* visible, void* workspace, dl_stream stream);
 
 /* Bytes of scratch dl_icp_loss_fwd needs (per-block partial sums). */
 size_t dl_icp_loss_workspace_bytes(int32_t B, int32_t H, int32_t W);
@@ -125,16 +138,25 @@ size_t dl_icp_loss_workspace_bytes(int32_t B, int32_t H, int32_t W);
  * Replaces Deployer.step's R@p+t, R@n (src/deploy/deployer.py:294-299) and
  * KDPointToPlaneLoss / KDPlaneToPlaneLoss / KDPointToPointLoss (src/losses/icp_losses.py:196-206,
  * :224-240, :168-179) with the pair selection of ICPLosses.forward (:48-60, :102-121).
+ *   src_image4 / src_normals   planar source planes; match [B][6][H][W] from dl_nn_correspond; nn_pix its map
+ *                          (only the sign is used: validity).  All thirteen planes are streamed once.
  *   loss_terms [B][3]      out: loss_po2po, loss_po2pl, loss_pl2pl (means; 0 for disabled terms,
  *                          NaN when an enabled term has no pairs, as torch's MSELoss of an empty set)
  *   pair_counts[B][2]      out: pairs with normals (K), pairs without normals (K', po2po)
  *   grad_terms [B][3][12]  out: d loss_term / d T[:3,:4] (row-major 3x4), correspondences held fixed
  */
 int dl_icp_loss_fwd(const float* src_image4, int64_t src_ss, const float* src_normals, int64_t srcn_ss,
-                    const float* tgt_image4, int64_t tgt_ss, const float* tgt_normals, int64_t tgtn_ss,
-                    const int32_t* nn_pix, const float* T, int32_t B, int32_t H, int32_t W,
+                    const float* match, int64_t match_ss, const int32_t* nn_pix, const float* T, int32_t B, int32_t H, int32_t W,
                     uint32_t flags, float* loss_terms, int32_t* pair_counts, float* grad_terms,
                     void* workspace, dl_stream stream);
+
+/* The two launches of dl_icp_loss_fwd as separate entry points (same arguments): the streaming pass that leaves one
+ * partial row per workgroup in the workspace, and the per-sample fp64 reduction of those rows. */
+int dl_icp_loss_partial(const float* src_image4, int64_t src_ss, const float* src_normals, int64_t srcn_ss,
+                        const float* match, int64_t match_ss, const int32_t* nn_pix, const float* T, int32_t B, int32_t H, int32_t W, uint32_t flags,
+                        void* workspace, dl_stream stream);
+int dl_icp_loss_reduce(const void* workspace, int32_t B, int32_t H, int32_t W, uint32_t flags, float* loss_terms,
+                       int32_t* pair_counts, float* grad_terms, dl_stream stream);
 
 /*
  * Backward of dl_icp_loss_fwd: grad_T[b][:3,:4] = sum_k grad_loss_terms[b][k] * grad_terms[b][k]

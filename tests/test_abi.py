@@ -41,7 +41,7 @@ def test_argument_validation_reports_through_last_error():
     lib = _lib.load()
     rc = lib.dl_icp_loss_bwd(None, None, 0, None, None)
     assert rc < 0 and b"dl_icp_loss_bwd" in lib.dl_last_error()
-    rc = lib.dl_normals(None, 0, 1, 4, 4, 3, 5, 0.5, 10, None, None)
+    rc = lib.dl_normals(None, 0, 1, 4, 4, 3, 5, 0.5, 10, None, None, None)
     assert rc < 0 and b"null" in lib.dl_last_error()
 
 

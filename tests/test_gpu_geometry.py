@@ -288,7 +288,7 @@ def test_nn_matches_kdtree(case, shape):
     else:
         T = _random_T(rng, scale_t=30.0)
     for need_wo in (False, True):
-        nn, vis = _geo().nn_correspond(img[1:2], nrm[1:2], img[0:1], T.to(img.device), sensor, need_without_normals=need_wo)
+        nn, vis, _ = _geo().nn_correspond(img[1:2], nrm[1:2], _geo().pack_image(img[0:1]), None, T.to(img.device), sensor, need_without_normals=need_wo)
         torch.cuda.synchronize()
         exp, q, tp, tpix = oracle_nn_pixels(img[0].cpu(), img[1].cpu(), nrm[1].cpu(), T, need_wo)
         got = nn[0].reshape(-1).cpu().long()
@@ -315,7 +315,7 @@ def test_nn_full_size_against_bruteforce_kernel():
     imgs_s = torch.stack([img[1], img[1]])
     nrm_s = torch.stack([nrm[1], nrm[1]])
     T = torch.stack([torch.from_numpy(T_true), torch.eye(4)]).to(dev)
-    nn, _ = _geo().nn_correspond(imgs_s, nrm_s, imgs_t, T, sensor, need_without_normals=True)
+    nn, _, _ = _geo().nn_correspond(imgs_s, nrm_s, _geo().pack_image(imgs_t), None, T, sensor, need_without_normals=True)
     for b in range(2):
         tp, _, tpix = util.lists_from_images(imgs_t[b].cpu(), torch.zeros(3, 64, 2048))
         sp, _, spix = util.lists_from_images(imgs_s[b].cpu(), nrm_s[b].cpu())
@@ -342,9 +342,9 @@ def test_nn_empty_target_and_empty_source():
     z = torch.zeros((1, 4, 16, 128), device=dev)
     _, img, nrm, _ = _pair_images(5, 16, 128, 16, 160)
     T = torch.eye(4, device=dev).view(1, 4, 4)
-    nn, vis = _geo().nn_correspond(img[1:2], nrm[1:2], z, T, sensor)
+    nn, vis, _ = _geo().nn_correspond(img[1:2], nrm[1:2], _geo().pack_image(z), None, T, sensor)
     assert (nn == -1).all()
-    nn, vis = _geo().nn_correspond(z, z[:, :3], img[0:1], T, sensor)
+    nn, vis, _ = _geo().nn_correspond(z, z[:, :3], _geo().pack_image(img[0:1]), None, T, sensor)
     assert (nn == -1).all() and int(vis[0].item()) == 0
 
 
@@ -383,8 +383,8 @@ def test_loss_golden_from_reference(mode, p2p):
     for qname in ("identity", "true", "random"):
         key = f"{mode}_{'p2p' if p2p else 'nop2p'}_{qname}"
         T = torch.from_numpy(g[key + "_T"]).to(dev).requires_grad_(True)
-        nn, _ = G.nn_correspond(img[1:2], nrm[1:2], img[0:1], T, sensor, need_without_normals=p2p)
-        terms, counts = G.icp_loss(T, img[1:2], nrm[1:2], img[0:1], nrm[0:1], nn, _flags(mode, p2p))
+        nn, _, match = G.nn_correspond(img[1:2], nrm[1:2], out["packed"][0:1], out["packed_aux"][0:1], T, sensor, need_without_normals=p2p)
+        terms, counts = G.icp_loss(T, img[1:2], nrm[1:2], match, nn, _flags(mode, p2p))
         total = terms[0, 0] + 2.0 * terms[0, 1] + 0.5 * terms[0, 2]
         total.backward()
         assert int(counts[0, 0]) == int(g[key + "_pairs"])
@@ -409,8 +409,8 @@ def test_loss_vs_oracle_batched(mode, p2p):
     tgt = torch.stack([im[0] for im in imgs]); src = torch.stack([im[1] for im in imgs])
     tgt_n = torch.stack([n[0] for n in nrms]); src_n = torch.stack([n[1] for n in nrms])
     T = torch.stack(Ts).to(dev).requires_grad_(True)
-    nn, _ = G.nn_correspond(src, src_n, tgt, T, sensor, need_without_normals=p2p)
-    terms, counts = G.icp_loss(T, src, src_n, tgt, tgt_n, nn, _flags(mode, p2p))
+    nn, _, match = G.nn_correspond(src, src_n, G.pack_image(tgt), G.pack_image(tgt_n), T, sensor, need_without_normals=p2p)
+    terms, counts = G.icp_loss(T, src, src_n, match, nn, _flags(mode, p2p))
     w = torch.tensor([[1.0, 2.0, 0.5]], device=dev) * torch.arange(1, 5, device=dev).view(4, 1)
     (terms * w).sum().backward()
     for b in range(4):
@@ -434,11 +434,14 @@ def test_loss_identity_on_same_image_is_zero_and_deterministic():
     tgt = img[0:1].expand(8, -1, -1, -1).contiguous()
     tn = nrm[0:1].expand(8, -1, -1, -1).contiguous()
     T = torch.eye(4, device=dev).repeat(8, 1, 1)
-    nn, vis = G.nn_correspond(tgt, tn, tgt, T, sensor, need_without_normals=True)
+    tgt_pk, tn_pk = G.pack_image(tgt), G.pack_image(tn)
+    nn, vis, match = G.nn_correspond(tgt, tn, tgt_pk, tn_pk, T, sensor, need_without_normals=True)
     own = torch.arange(64 * 2048, device=dev, dtype=torch.int32).view(1, 64, 2048).expand(8, -1, -1)
     occ = ~((tgt[:, 0] == 0) & (tgt[:, 1] == 0) & (tgt[:, 2] == 0))
     assert torch.equal(nn[occ], own[occ]) and (nn[~occ] == -1).all()
-    terms, counts = G.icp_loss(T, tgt, tn, tgt, tn, nn, _flags("squared", True))
+    terms, counts = G.icp_loss(T, tgt, tn, match, nn, _flags("squared", True))
+    occ6 = occ.unsqueeze(1).expand(-1, 3, -1, -1)
+    assert torch.equal(match[:, :3][occ6], tgt[:, :3][occ6]) and torch.equal(match[:, 3:][occ6], tn[occ6])
     assert torch.all(terms[:, 1:] == 0)
     has = (tn != 0).any(dim=1)
     assert int(counts[0, 0]) == int(has[0].sum())
@@ -446,8 +449,8 @@ def test_loss_identity_on_same_image_is_zero_and_deterministic():
     T2 = T.clone(); T2[:, :3, 3] = torch.tensor([0.3, -0.2, 0.05], device=dev)
     r = []
     for _ in range(2):
-        nn2, _ = G.nn_correspond(tgt, tn, tgt, T2, sensor)
-        t2, c2 = G.icp_loss(T2, tgt, tn, tgt, tn, nn2, _flags("squared", False))
+        nn2, _, m2 = G.nn_correspond(tgt, tn, tgt_pk, tn_pk, T2, sensor)
+        t2, c2 = G.icp_loss(T2, tgt, tn, m2, nn2, _flags("squared", False))
         r.append((nn2.clone(), t2.clone()))
     assert torch.equal(r[0][0], r[1][0]) and torch.equal(r[0][1], r[1][1])
     assert torch.allclose(r[0][1][0], r[0][1][7])

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of the geometry kernels on the bench batch (B=8, 64x2048); meant to run under rocprofv3.
+usage: python tools/geo_bench.py [reps] [shift_m]"""
+import os, sys, time
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import bench
+from delora_amd import geometry as G
+from delora_amd.deploy.step_geometry import HipStepGeometry
+
+class A: batch=8; height=64; width=2048
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+shift = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
+dev = torch.device("cuda:0")
+args = A()
+cfg = bench.build_config(argparse_like := type("X", (), dict(height=64, width=2048, batch=8, amp="", channels_last=False))(), dev)
+batch = bench.make_batch(args, 0, dev)
+sensor = G.Sensor.from_config(cfg, "kitti")
+geo = HipStepGeometry()
+prep = geo.prepare(batch, sensor, (3, 5, 0.5, 10))
+img, nrm = prep["images"], prep["normals"]
+tpk, tnpk = prep["packed"][:, 0], prep["normals_packed"][:, 0]
+B = 8
+T = torch.eye(4, device=dev).repeat(B, 1, 1); T[:, 0, 3] = shift
+flags = G.LOSS_POINT_TO_PLANE | G.LOSS_PLANE_TO_PLANE
+for _ in range(reps):
+    prep = geo.prepare(batch, sensor, (3, 5, 0.5, 10))
+    nn, vis, match = G.nn_correspond(img[:, 1], nrm[:, 1], tpk, tnpk, T, sensor)
+    terms, counts = G.icp_loss(T, img[:, 1], nrm[:, 1], match, nn, flags)
+# calibration: plain torch streaming kernels over the same number of bytes as the loss kernel moves (53 MB)
+xa = torch.randn(53_000_000 // 4, device=dev); xb = torch.empty(53_000_000 // 8, device=dev); xc = torch.randn(53_000_000 // 8, device=dev)
+for _ in range(reps):
+    xa.sum(); xb.copy_(xc)
+torch.cuda.synchronize()
+ws = torch.empty(64, dtype=torch.int32, device=dev)
+print("pairs", counts[:, 0].tolist(), "terms", terms[0].tolist())
