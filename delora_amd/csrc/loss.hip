@@ -15,7 +15,7 @@
 // same pass:  d po2pl = 2/K sum r n_t [p^T | 1],  d pl2pl = 2/K sum (R n - n_t) n^T  (resp. -(1-c) n_t n^T),
 // d po2po = 2/3K' sum (q - p_t) [p^T | 1].  The backward is then O(B) work (dl_icp_loss_bwd).
 //
-// Reduction: per-lane fp32 partial sums -> wave shuffle tree -> one partial row per wave (no float atomics:
+// Reduction: per-lane fp32 partial sums -> wave shuffle tree -> LDS -> one partial row per workgroup (no float atomics:
 // deterministic) -> a second, tiny launch sums each sample's rows in fp64 in a fixed order and writes the outputs.
 // (An in-kernel hand-off to the last-arriving workgroup was measured slower: the write-through drain + ticket round
 // trip sit on every workgroup's critical path, +8 us on a 17 us kernel; a kernel boundary costs ~1.5 us.)
@@ -38,10 +38,10 @@ static inline int loss_blocks(int HW) {
   int wg = (chunks + 3) / 4;
   return wg < LOSS_WG_PER_SAMPLE ? wg : LOSS_WG_PER_SAMPLE;
 }
-static inline int loss_rows(int HW) { return loss_blocks(HW) * (DL_BLOCK / DL_WAVE); }
+static inline int loss_rows(int HW) { return loss_blocks(HW); }
 
 extern "C" size_t dl_icp_loss_workspace_bytes(int32_t B, int32_t H, int32_t W) {
-  return (size_t)B * loss_rows(H * W) * ACC_PITCH * sizeof(float);   // one partial row per wave
+  return (size_t)B * loss_rows(H * W) * ACC_PITCH * sizeof(float);   // one partial row per workgroup
 }
 
 struct LossOut {
@@ -189,7 +189,7 @@ __device__ __forceinline__ StreamRegs load_stream(const int32_t* __restrict__ nn
 // read once with 16-byte loads, 52 bytes per source pixel, no dependent gather.  Every wave is an independent worker
 // that walks 256-pixel chunks of one sample with a stride of `waves per sample` (one chunk per wave at 64x2048: the
 // thirteen loads of a chunk are all in flight before the first use, and 16 waves per CU overlap each other).  One
-// reduction and one partial row per WAVE at the end.  (A software-pipelined two-chunks-per-wave variant was measured
+// reduction and one partial row per workgroup at the end.  (A software-pipelined two-chunks-per-wave variant was measured
 // slower: 200+ VGPRs halve the occupancy.)
 template <bool P2P, bool LINEAR>
 __global__ __launch_bounds__(DL_BLOCK) void k_icp_loss(
@@ -232,14 +232,19 @@ __global__ __launch_bounds__(DL_BLOCK) void k_icp_loss(
       }
     }
   }
-  // one partial row per wave
-  float* row = partials + ((size_t)b * waves + gw) * ACC_PITCH;
+  // wave shuffle tree, then the four waves of the workgroup through LDS: one partial row per workgroup
+  __shared__ float red[(DL_BLOCK / DL_WAVE) * ACC_PITCH];
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const float v = wave_sum(acc[i]);
-    if (lane == i) row[i] = v;
+    if (lane == 0) red[wv * ACC_PITCH + i] = v;
   }
-  if (lane >= NA && lane < ACC_PITCH) row[lane] = 0.f;
+  __syncthreads();
+  if (threadIdx.x < ACC_PITCH) {
+    const int t = threadIdx.x;
+    partials[((size_t)b * gridDim.x + blockIdx.x) * ACC_PITCH + t] =
+        t < NA ? (red[t] + red[ACC_PITCH + t]) + (red[2 * ACC_PITCH + t] + red[3 * ACC_PITCH + t]) : 0.f;
+  }
 }
 
 // Second (tiny) launch: one workgroup per sample sums that sample's partial rows in fp64, in a fixed order.
