@@ -1,0 +1,188 @@
+"""Host-side logic that needs no GPU: config surface, model layout, the step's loss bookkeeping against the reference
+vectors (geometry evaluated by the oracle backend), and data parallelism over 2 gloo ranks."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from tests import util
+from tests.conftest import ROOT
+
+
+def _small_cfg(H, W, B, **over):
+    gm = util.load_golden("model_small")
+    cfg = util.repo_config(H, W, device="cpu", factor_fewer_resnet_channels=int(gm["cfg::factor_fewer_resnet_channels"]),
+                           resnet_outputs=int(gm["cfg::resnet_outputs"]), unsupervised_at_start=True, inference_only=False,
+                           batch_size=B, **over)
+    sd = {k[4:]: torch.from_numpy(v) for k, v in gm.items() if k.startswith("sd::")}
+    return cfg, sd
+
+
+def _samples(g, B):
+    out = []
+    for j in range(B):
+        s = {k: torch.from_numpy(g[f"s{j}::{k}"]) for k in ("scan_1", "scan_2", "normal_list_1", "normal_list_2")}
+        s["dataset"] = "kitti"
+        out.append(s)
+    return out
+
+
+def test_config_files_have_the_reference_surface():
+    from delora_amd import config as cfgmod
+    cfg = cfgmod.load_yaml_config(os.path.join(ROOT, "config"))
+    for key in ("horizontal_field_of_view", "epsilon_range", "min_num_points_in_neighborhood_to_determine_point_class",
+                "datasets", "device", "store_dataset_in_RAM", "num_dataloader_workers", "unsupervised_at_start",
+                "inference_only", "use_jit", "batch_size", "learning_rate", "lambda_po2pl", "use_dropout",
+                "random_point_cloud_rotations", "normal_loss", "point_to_point_loss", "point_to_plane_loss",
+                "plane_to_plane_loss", "po2po_alone", "normalization_scaling", "activation_fct", "resnet_outputs",
+                "pre_feature_extraction", "layers", "factor_fewer_resnet_channels", "use_single_mlp_at_output", "experiment"):
+        assert key in cfg, key
+    k = cfg["kitti"]
+    assert (k["vertical_cells"], k["horizontal_cells"], k["horizontal_cells_preprocessing"]) == (64, 720, 2250)
+    assert k["vertical_field_of_view"] == [-24.5, 2.0] and k["neighborhood_side_length"] == [7, 11]
+    assert cfg["learning_rate"] == 1e-5 and cfg["batch_size"] == 1 and cfg["normal_loss"] == "squared"
+    cfgmod.degrees_to_radians(cfg)
+    assert np.isclose(cfg["kitti"]["vertical_field_of_view"][0], -24.5 * np.pi / 180.0)
+
+
+def test_reference_import_names_resolve():
+    import delora_amd.compat  # noqa: F401
+    import deploy.trainer, losses.icp_losses, models.model, preprocessing.normal_computation, utility.projection  # noqa: E401,F401
+    assert deploy.trainer.Trainer.__mro__[1].__name__ == "Deployer"
+
+
+def test_model_matches_reference_on_cpu():
+    from delora_amd.models.model import OdometryModel
+    g = util.load_golden("model_small")
+    cfg, sd = _small_cfg(int(g["H"]), int(g["W"]), 1)
+    m = OdometryModel(cfg)
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        t, q = m(torch.from_numpy(g["image_1"]).unsqueeze(0), torch.from_numpy(g["image_2"]).unsqueeze(0))
+    assert np.allclose(t.numpy(), g["translation"], atol=1e-6) and np.allclose(q.numpy(), g["quaternion"], atol=1e-6)
+
+
+def test_geometry_handler_matches_reference_vectors():
+    from delora_amd.models.model_parts import GeometryHandler
+    g = util.load_golden("geometry")
+    T = GeometryHandler.get_transformation_matrix_quaternion(torch.from_numpy(g["t"]), torch.from_numpy(g["q"]), torch.device("cpu"))
+    assert np.allclose(T.numpy(), g["T"], atol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["b1", "b2"])
+def test_step_bookkeeping_matches_reference(name):
+    """Trainer.step with the oracle geometry backend reproduces the reference step: poses, loss terms (incl. the
+    (B-j)/B weighting), gradient norms."""
+    from delora_amd.deploy.trainer import Trainer
+    g = util.load_golden("step_" + name)
+    B = len(g["picks"])
+    cfg, sd = _small_cfg(int(g["H"]), int(g["W"]), B)
+    tr = Trainer(cfg, dataset=util.ListDataset([]), geometry_backend=util.OracleStepGeometry())
+    tr.raw_model.load_state_dict(sd)
+    ep = tr.new_epoch_losses()
+    tr.optimizer.zero_grad()
+    ep, T = tr.step(preprocessed_dicts=_samples(g, B), epoch_losses=ep)
+    assert np.allclose(T.detach().numpy(), g["T"], atol=1e-5)
+    for key in ("loss_epoch", "loss_point_cloud_epoch", "loss_po2pl_epoch", "loss_pl2pl_epoch"):
+        assert np.isclose(float(ep[key]), g["ep::" + key], rtol=2e-5), key
+    assert int(ep["visible_pixels_epoch"]) == int(g["ep::visible_pixels_epoch"])
+    for k, p in tr.raw_model.named_parameters():
+        assert np.isclose(float(p.grad.double().norm()), float(g["gradnorm::" + k]), rtol=1e-3, atol=1e-9), k
+
+
+def _ddp_worker(rank, world, port, return_dict):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from delora_amd.deploy.trainer import Trainer
+        torch.set_num_threads(2)
+        g = util.load_golden("step_b2")
+        cfg, sd = _small_cfg(int(g["H"]), int(g["W"]), 1)
+        tr = Trainer(cfg, dataset=util.ListDataset([]), geometry_backend=util.OracleStepGeometry())
+        tr.raw_model.load_state_dict(sd)
+        assert tr.world_size == 2 and tr.rank == rank
+        ep = tr.new_epoch_losses()
+        tr.optimizer.zero_grad()
+        ep, T = tr.step(preprocessed_dicts=[_samples(g, 2)[rank]], epoch_losses=ep)
+        tr.steps_per_epoch_effective = 1
+        red = tr._reduce_metrics(ep)
+        grads = {k: p.grad.clone() for k, p in tr.raw_model.named_parameters()}
+        after = {k: v.clone() for k, v in tr.raw_model.state_dict().items()}
+        return_dict[rank] = {"T": T.detach().clone(), "grads": grads, "after": after, "reduced": red,
+                             "local_loss": float(ep["loss_epoch"])}
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_reproduce_the_single_process_batch():
+    """2 ranks x B=1 (gloo) == 1 process x B=2: same poses, same averaged gradients, same Adam update, same loss --
+    i.e. the loss weights follow the sample's index in the GLOBAL batch."""
+    from delora_amd.deploy.trainer import Trainer
+    g = util.load_golden("step_b2")
+    cfg, sd = _small_cfg(int(g["H"]), int(g["W"]), 2)
+    tr = Trainer(cfg, dataset=util.ListDataset([]), geometry_backend=util.OracleStepGeometry())
+    tr.raw_model.load_state_dict(sd)
+    ep = tr.new_epoch_losses()
+    tr.optimizer.zero_grad()
+    ep, T = tr.step(preprocessed_dicts=_samples(g, 2), epoch_losses=ep)
+    single_grads = {k: p.grad.clone() for k, p in tr.raw_model.named_parameters()}
+    single_after = tr.raw_model.state_dict()
+    port = 29500 + (os.getpid() % 2000)
+    ret = mp.Manager().dict()
+    mp.spawn(_ddp_worker, args=(2, port, ret), nprocs=2, join=True)
+    for r in (0, 1):
+        assert torch.allclose(ret[r]["T"][0], T[r].detach(), atol=1e-6)
+        for k in single_grads:
+            # DDP averages; the step scales each rank's loss by world_size so that the average equals the global sum.
+            # (tolerance: the CNN runs with batch 1 per rank vs batch 2, i.e. different CPU conv summation orders)
+            a, b = ret[r]["grads"][k], single_grads[k]
+            assert torch.allclose(a, b, rtol=2e-3, atol=2e-4 * float(b.abs().max())), k
+        for k in single_after:
+            # Adam's first step is +-lr per weight: only weights whose gradient is ~0 may move differently
+            off = (ret[r]["after"][k] - single_after[k]).abs() > 2e-7
+            assert float(off.float().mean()) < 0.01, k
+        assert np.isclose(ret[r]["reduced"]["loss_epoch"], float(ep["loss_epoch"]), rtol=1e-5)
+    assert np.isclose(ret[0]["local_loss"] + ret[1]["local_loss"], float(ep["loss_epoch"]), rtol=1e-5)
+
+
+def test_short_batch_is_rejected_explicitly():
+    from delora_amd.deploy.trainer import Trainer
+    g = util.load_golden("step_b2")
+    cfg, sd = _small_cfg(int(g["H"]), int(g["W"]), 2)
+    tr = Trainer(cfg, dataset=util.ListDataset([]), geometry_backend=util.OracleStepGeometry())
+    with pytest.raises(ValueError):
+        tr.step(preprocessed_dicts=_samples(g, 1), epoch_losses=tr.new_epoch_losses())
+
+
+def test_product_deployer_defaults_to_the_hip_backend_and_refuses_cpu():
+    from delora_amd import _lib
+    from delora_amd.deploy.deployer import Deployer
+    from delora_amd.deploy.step_geometry import HipStepGeometry
+    g = util.load_golden("step_b1")
+    cfg, sd = _small_cfg(int(g["H"]), int(g["W"]), 1)
+    dep = Deployer(cfg, dataset=util.ListDataset([]))
+    assert isinstance(dep.geo, HipStepGeometry)
+    with pytest.raises(_lib.DeloraHipError):                    # CPU tensors: no fallback
+        dep.step(preprocessed_dicts=_samples(g, 1), epoch_losses=None)
+
+
+def test_preprocessed_dataset_reads_reference_layout(tmp_path):
+    from delora_amd.data.dataset import PreprocessedPointCloudDataset
+    root = tmp_path / "seq"
+    for sub in ("scans", "normals"):
+        os.makedirs(root / "03" / sub)
+    rng = np.random.default_rng(0)
+    for i in range(4):
+        np.save(root / "03" / "scans" / f"{i:06d}.npy", rng.normal(size=(50 + i, 3)).astype(np.float32))
+        np.save(root / "03" / "normals" / f"{i:06d}.npy", rng.normal(size=(50 + i, 3)).astype(np.float32))
+    cfg = util.repo_config(16, 128)
+    cfg["kitti"]["preprocessed_path"] = str(root)
+    cfg["kitti"]["data_identifiers"] = [3]
+    ds = PreprocessedPointCloudDataset(cfg)
+    assert len(ds) == 3                                         # pairs (t, t+1)
+    s = ds[1]
+    assert s["scan_1"].shape == (1, 3, 51) and s["scan_2"].shape == (1, 3, 52) and s["dataset"] == "kitti"
+    assert set(s) >= {"index", "index_dataset", "index_sequence", "index_scan", "dataset", "scan_1", "scan_2",
+                      "normal_list_1", "normal_list_2"}

@@ -98,3 +98,43 @@ class ListDataset(torch.utils.data.Dataset):
 
     def __getitem__(self, i):
         return dict(self.samples[i])
+
+
+class OracleStepGeometry:
+    """Test-only geometry backend with the interface of delora_amd.deploy.step_geometry.HipStepGeometry, evaluated by
+    the CPU oracle.  It lets the host logic of the step (loss weighting, DDP, optimiser) be exercised without a GPU;
+    the product never constructs it (Deployer defaults to the HIP backend and fails without the library)."""
+
+    def prepare(self, samples, sensor, normal_params):
+        o_sensor = orc.Sensor(sensor.H, sensor.W, sensor.vfov, sensor.hfov)
+        stacked, lists = [], []
+        a, b, eps, min_n = normal_params
+        for s in samples:
+            entry, imgs = {}, []
+            for k in ("1", "2"):
+                scan = s["scan_" + k].detach().cpu()
+                img, _, _, idx, _ = orc.project_to_img(scan, o_sensor)
+                imgs.append(img[0])
+                if s.get("normal_list_" + k) is not None:
+                    entry["scan_" + k] = scan[:, :, idx]
+                    entry["normal_list_" + k] = s["normal_list_" + k].detach().cpu()[:, :, idx]
+                else:
+                    n, has, pts = orc.compute_normal_vectors(img.clone(), o_sensor, side=(2 * a + 1, 2 * b + 1),
+                                                             epsilon_range=eps, min_neighbors=min_n)
+                    entry["scan_" + k] = pts.t().contiguous().view(1, 3, -1)
+                    entry["normal_list_" + k] = n.t().contiguous().view(1, 3, -1)
+            stacked.append(torch.cat(imgs, dim=0))
+            lists.append(entry)
+        return {"stacked": torch.stack(stacked), "lists": lists, "sensor": o_sensor}
+
+    def losses(self, T, prepared, flags, need_without_normals):
+        rows, vis = [], []
+        for j, L in enumerate(prepared["lists"]):
+            Tj = T[j:j + 1]
+            s_t = orc.transform_points(Tj, L["scan_2"])
+            l = orc.icp_losses(s_t, orc.rotate_points(Tj, L["normal_list_2"]), L["scan_1"], L["normal_list_1"],
+                               normal_loss="linear" if flags & 8 else "squared", point_to_point=bool(flags & 1),
+                               point_to_plane=bool(flags & 2), plane_to_plane=bool(flags & 4))
+            rows.append(torch.stack([l["loss_po2po"].reshape(()), l["loss_po2pl"].reshape(()), l["loss_pl2pl"].reshape(())]))
+            vis.append(orc.visible_pixels(s_t, prepared["sensor"]))
+        return torch.stack(rows), None, torch.tensor(vis)
