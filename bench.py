@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs evaluated by the CPU baseline")
+    ap.add_argument("--cpu-threads", type=int, default=16, help="torch CPU threads of the baseline (more is slower on a 256-thread host: "
+                    "the step is a chain of small ops; 128 threads measured 190 s/pair vs ~10 s/pair)")
     ap.add_argument("--kernel-reps", type=int, default=50)
     return ap.parse_args()
 
@@ -167,6 +169,7 @@ def cpu_baseline(args, cfg):
     from oracle import delora_oracle as orc
     from delora_amd.models.model import OdometryModel
     from delora_amd.models.model_parts import GeometryHandler
+    torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
     cores = torch.get_num_threads()
     ccfg = dict(cfg)
     ccfg["device"] = torch.device("cpu")
