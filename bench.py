@@ -107,6 +107,19 @@ class _Events:
         return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) if self.pairs else float("nan")
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC profile of this workload (profiles/*_geometry_pmc.json:
+    separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction); None when absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_geometry_pmc.json")))
+    if not files:
+        return None
+    try:
+        return int(json.load(open(files[-1]))["kernels"][kernel]["hbm_bytes_per_launch"])
+    except (KeyError, ValueError):
+        return None
+
+
 def kernel_table(trainer, batch, reps):
     """Per-launch time of each geometry entry point on the bench batch: `reps` back-to-back launches between two HIP
     events (launch gaps included), with the algorithmic bytes of DESIGN.md."""
@@ -272,7 +285,7 @@ def main():
         live_bytes = 52 * counts["M"]
         result["roofline"] = {"kernel": "k_icp_loss (dl_icp_loss_partial: fused transform + residuals + reduction, 13 planes streamed)", "bound": "hbm",
                               "achieved": round(live_bytes / loss_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(live_bytes / loss_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": None,
+                              "frac": round(live_bytes / loss_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("k_icp_loss"),
                               "ms_per_launch_in_step": round(loss_ms, 5), "ms_per_launch_back_to_back": alg["ms"],
                               "algorithmic_bytes": live_bytes,
                               "note": "HIP events on the launch stream around the kernel launch in each of the K timed steps; 52 B x source points with a correspondence"}
