@@ -42,6 +42,8 @@ SIGNATURES = {
     "dl_icp_loss_reduce": (_i32, [_vp, _i32, _i32, _i32, _u32, _vp, _vp, _vp, _vp]),
     "dl_icp_loss_bwd": (_i32, [_vp, _vp, _i32, _vp, _vp]),
     "dl_nn_bruteforce": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp]),
+    "dl_ring_act_pad_fwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "dl_ring_act_pad_bwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
 }
 
 _lib = None

@@ -3,47 +3,50 @@
 Same topology and parameter names as the reference so that its checkpoints load unchanged
 (``conv1``, ``layer{1..4}.{i}.conv{1,2}``, ``layer{2,3,4}.0.downsample.0``, ``fc``): no normalisation layers,
 tanh (or relu) activations, every 3x3 convolution sees one wrapped column on each side of W and one zero row on
-each side of H, strides (1,2) in the stem/pool/layer2/layer3 and (2,2) in layer4.  The wrap-around is folded
-into the convolution module (``RingConv2d``) instead of a separate padding call per layer.
+each side of H, strides (1,2) in the stem/pool/layer2/layer3 and (2,2) in layer4.  Activations travel between
+convolutions in wrapped form: activation (+ residual add) and the wrap-around padding are ONE fused HIP elementwise
+op (``ring_ops.ring_act_pad``) instead of the reference's separate tanh, add and three-copy F.pad per layer.
 """
 import torch
-import torch.nn.functional as F
+
+from .ring_ops import ring_act_pad
 
 
 class RingConv2d(torch.nn.Conv2d):
-    """Bias-free convolution whose input is first wrapped by one column on each side of W (circular) while H
-    gets ordinary zero padding; parameters are those of the wrapped nn.Conv2d (key ``<name>.weight``).
-    Reference: F.pad(..., (1,1,0,0), 'circular') followed by Conv2d(padding=(1,0)), resnet_modified.py:97-98,162-168."""
+    """Bias-free 3x3 convolution of a 360-degree image whose input is ALREADY wrapped by one column on each side of W
+    (see ring_ops.ring_act_pad); H gets ordinary zero padding.  Parameters are those of nn.Conv2d (key
+    ``<name>.weight``).  Reference: F.pad(..., (1,1,0,0), 'circular') followed by Conv2d(padding=(1,0)),
+    resnet_modified.py:97-98,162-168."""
 
     def __init__(self, in_planes, out_planes, stride=1):
         super().__init__(in_planes, out_planes, kernel_size=3, stride=stride, padding=(1, 0), bias=False)
 
-    def forward(self, x):
-        return super().forward(F.pad(x, (1, 1, 0, 0), mode="circular"))
-
-
-def _activation(name):
-    return torch.nn.ReLU(inplace=True) if name == "relu" else torch.nn.Tanh()
-
 
 class BasicBlock(torch.nn.Module):
-    """Two ring convolutions with a residual connection (reference resnet_modified.py:136-177)."""
+    """Two ring convolutions with a residual connection (reference resnet_modified.py:136-177).  Activations travel
+    between convolutions in wrapped ("padded") form: the block takes a padded, activated input and returns a padded,
+    activated output, and each of its two elementwise stages -- activation, and residual add + activation -- is fused
+    with the wrap-around padding of the next convolution's input."""
     expansion = 1
 
     def __init__(self, inplanes, planes, stride=1, downsample=None, activation_fct="relu"):
         super().__init__()
         self.conv1 = RingConv2d(inplanes, planes, stride=stride)
         self.conv2 = RingConv2d(planes, planes)
-        self.activation = _activation(activation_fct)
+        self.activation = torch.nn.ReLU(inplace=True) if activation_fct == "relu" else torch.nn.Tanh()
+        self.act_name = "relu" if activation_fct == "relu" else "tanh"
         self.downsample = downsample
         self.stride = stride
+        self.pad_out = True             # the last block of the network returns an unpadded tensor
 
-    def forward(self, x):
-        shortcut = x if self.downsample is None else self.downsample(x)
-        y = self.activation(self.conv1(x))
-        y = self.conv2(y)
-        y = y + shortcut
-        return self.activation(y)
+    def forward(self, p_in):
+        p_mid = ring_act_pad(self.conv1(p_in), self.act_name, pad=True)
+        v = self.conv2(p_mid)
+        if self.downsample is None:
+            shortcut = p_in                                         # padded tensor: its interior is the residual
+        else:
+            shortcut = self.downsample(p_in[..., 1:-1])             # 1x1 strided convolution of the unpadded input
+        return ring_act_pad(v, self.act_name, pad=self.pad_out, residual=shortcut)
 
 
 class ResNetModified(torch.nn.Module):
@@ -65,6 +68,7 @@ class ResNetModified(torch.nn.Module):
         self.layer4 = self._make_layer(widths[3], layers[3], stride=(2, 2))
         self.avgpool = torch.nn.AdaptiveAvgPool2d((1, 1))
         self.fc = torch.nn.Linear(widths[3] * BasicBlock.expansion, num_outputs)
+        self.layer4[-1].pad_out = False
         for m in self.modules():                       # resnet_modified.py:64-66
             if isinstance(m, torch.nn.Conv2d):
                 torch.nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity=activation_fct)
@@ -80,12 +84,14 @@ class ResNetModified(torch.nn.Module):
         return torch.nn.Sequential(*stack)
 
     def forward(self, x):
-        act = self.relu if self.activation_fct == "relu" else self.tanh
-        x = act(self.conv1(self.dropout_values(x)))
-        x = self.maxpool(F.pad(x, (1, 1, 0, 0), mode="circular"))
-        x1 = self.layer1(x)
-        x2 = self.layer2(x1)
-        x3 = self.dropout_channels(self.layer3(x2))
-        x4 = self.layer4(x3)
+        act = "relu" if self.activation_fct == "relu" else "tanh"
+        p = ring_act_pad(self.dropout_values(x), "none", pad=True)
+        p = ring_act_pad(self.conv1(p), act, pad=True)
+        p = ring_act_pad(self.maxpool(p), "none", pad=True)
+        p1 = self.layer1(p)
+        p2 = self.layer2(p1)
+        p3 = self.dropout_channels(self.layer3(p2))
+        x4 = self.layer4(p3)                                         # unpadded (last block)
         out = self.dropout_values(self.fc(torch.flatten(self.avgpool(x4), 1)))
-        return [x1, x2, x3, x4, out]
+        # the reference returns the four feature maps as well; they are views of the padded tensors here
+        return [p1[..., 1:-1], p2[..., 1:-1], p3[..., 1:-1], x4, out]

@@ -1,0 +1,82 @@
+"""Fused [residual add] + activation + wrap-around width padding for the pose CNN (autograd Function over
+``dl_ring_act_pad_fwd/bwd`` of libdelora_hip.so).
+
+``ring_act_pad(x, act, pad=True, residual=None)`` returns ``act(x + residual)`` padded by one wrapped column on each
+side of W (``pad=False``: unpadded).  ``residual`` may be a *padded* tensor ``[N,C,H,W+2]`` whose interior is the
+residual -- the natural form of a block input here, because every activation lives in padded form between
+convolutions -- or a dense ``[N,C,H,W]`` tensor (the 1x1 down-sampling branch).  On CUDA tensors the HIP kernels are mandatory (the call raises if the library is
+missing); on CPU tensors -- the CPU baseline and the CPU unit tests, where the device itself is the user's choice --
+the same function is evaluated with torch ops.
+"""
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from .. import _lib
+
+ACT = {"none": 0, "tanh": 1, "relu": 2}
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _RingActPad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, act, pad):
+        lib = _lib.load()
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        rows = N * C * H
+        out = torch.empty((N, C, H, W + 2 * pad), dtype=x.dtype, device=x.device)
+        res_pitch = res_off = 0
+        res_kind = 0                                   # 0 none, 1 dense [N,C,H,W], 2 padded [N,C,H,W+2] (interior used)
+        if residual is not None:
+            residual = residual.contiguous()
+            if residual.shape == (N, C, H, W):
+                res_pitch, res_off, res_kind = W, 0, 1
+            elif residual.shape == (N, C, H, W + 2):
+                res_pitch, res_off, res_kind = W + 2, 1, 2
+            else:
+                raise ValueError(f"residual shape {tuple(residual.shape)} fits neither [N,C,H,W] nor [N,C,H,W+2]")
+        _lib.check(lib.dl_ring_act_pad_fwd(_ptr(x), _ptr(residual), res_pitch, res_off, rows, W, pad, act,
+                                           _ptr(out), _stream()), "dl_ring_act_pad_fwd")
+        ctx.save_for_backward(out)
+        ctx.meta = (rows, W, pad, act, res_kind)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        (y,) = ctx.saved_tensors
+        rows, W, pad, act, res_kind = ctx.meta
+        grad_out = grad_out.contiguous()
+        N, C, H = y.shape[:3]
+        grad_x = torch.empty((N, C, H, W), dtype=y.dtype, device=y.device)
+        grad_res = torch.empty((N, C, H, W + 2), dtype=y.dtype, device=y.device) if res_kind == 2 else None
+        _lib.check(lib.dl_ring_act_pad_bwd(_ptr(grad_out), _ptr(y), rows, W, pad, act, _ptr(grad_x), _ptr(grad_res),
+                                           _stream()), "dl_ring_act_pad_bwd")
+        if res_kind == 1:
+            grad_res = grad_x                          # d(x + r)/dr = d/dx: the same tensor serves both
+        return grad_x, grad_res, None, None
+
+
+def ring_act_pad(x, act="none", pad=True, residual=None):
+    """``act(x + residual)`` with one wrapped column added on each side of W (``pad=False``: unpadded).  ``residual`` is
+    either dense ``[N,C,H,W]`` or a padded ``[N,C,H,W+2]`` tensor whose interior is the residual."""
+    if x.is_cuda and x.dtype == torch.float32 and (residual is None or residual.dtype == torch.float32):
+        return _RingActPad.apply(x, residual, ACT[act], 1 if pad else 0)
+    # CPU device (or autocast dtypes): plain torch ops, same function
+    v = x
+    if residual is not None:
+        v = x + (residual if residual.shape[-1] == x.shape[-1] else residual[..., 1:-1]).to(x.dtype)
+    if act == "tanh":
+        v = torch.tanh(v)
+    elif act == "relu":
+        v = torch.relu(v)
+    return F.pad(v, (1, 1, 0, 0), mode="circular") if pad else v

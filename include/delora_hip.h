@@ -174,6 +174,21 @@ int dl_icp_loss_bwd(const float* grad_terms, const float* grad_loss_terms, int32
 int dl_nn_bruteforce(const float* src, int64_t ms_cs, int32_t Ms, const float* tgt, int64_t mt_cs,
                      int32_t Mt, int32_t* nn, dl_stream stream);
 
+/*
+ * Fused elementwise glue of the pose CNN: out[r][pad + w] = act(x[r][w] + res[r][w]) plus, for pad == 1, the two
+ * wrap-around columns out[r][0] = out[r][W], out[r][W+1] = out[r][1]  (rows r = n*C*H + c*H + h).
+ * Replaces the separate activation, residual add and F.pad(..., (1,1,0,0), 'circular') calls of the reference's
+ * ResNet (src/models/resnet_modified.py:95-120, :159-177).
+ *   x    [rows][W] dense;  res (may be NULL) rows of width W at pitch res_pitch starting at element res_off
+ *   act  0 none, 1 tanh, 2 relu;  pad 0 or 1;  out [rows][W + 2*pad]
+ * Backward: grad_x[r][w] = (grad_out[r][pad+w] + folded wrap columns) * act'(y), y = the saved forward output;
+ * grad_res_padded (may be NULL) [rows][W+2] receives grad_x in its interior and zeros in its border columns.
+ */
+int dl_ring_act_pad_fwd(const float* x, const float* res, int64_t res_pitch, int64_t res_off, int64_t rows,
+                        int32_t W, int32_t pad, int32_t act, float* out, dl_stream stream);
+int dl_ring_act_pad_bwd(const float* grad_out, const float* y, int64_t rows, int32_t W, int32_t pad, int32_t act,
+                        float* grad_x, float* grad_res_padded, dl_stream stream);
+
 #ifdef __cplusplus
 }
 #endif
