@@ -12,9 +12,10 @@
 //     widened by the half-pixel rounding of the projection plus a safety margin, lies inside the scanned
 //     window, the neighbour is exact.  Otherwise the query goes to a compact "hard" list.
 //   pass B (one wave per hard query): the 64 lanes stride over the flattened (rows x columns) window that the
-//     spherical-cap bound of the best distance so far allows (columns wrap through the azimuth seam); when that
-//     bound is weak (holes, occlusions) a moderate window is probed first and the bound recomputed.  With no usable
-//     bound (d >= |q|) this degrades to an exhaustive scan, so the result is exact in every regime.
+//     spherical-cap bound of the best distance so far allows (columns wrap through the azimuth seam), restricted to a
+//     box around q's pixel that grows 4x16 -> 8x40 -> 16x96 -> image; the bound is recomputed after every scan and the
+//     search stops once it fits inside the covered box.  With no usable bound (d >= |q|) this ends in an exhaustive
+//     scan, so the result is exact in every regime.
 //
 // The target image is read in its packed form (one 16-byte load per candidate pixel).  Distances are accumulated
 // in fp64 from the fp32 coordinates, as the KD-tree does; ties resolve to the lower pixel index.  Bound: L2/LDS + VALU (candidates are re-read from cache), reported separately from the
@@ -25,10 +26,8 @@
 #define NN_RU 5
 #define NN_MARGIN 0.01f        // pixels: slack on the rounding of the stored points' (and our own) image coordinates
 #define NN_PI_F 3.14159265358979323846f
+#define NN_BATCH 16             // pass B: queries a wave draws at a time (one per lane for the per-query arithmetic)
 #define NN_UP (1.0f + 4e-6f)   // round-up factor for quantities that must not be under-estimated in fp32
-#define NN_CLIP_ROWS 8         // pass B, first probe when the bound from pass A is useless: +-8 rows x +-40 columns
-#define NN_CLIP_COLS 40
-#define NN_CLIP_LIMIT 2048     // candidates above which pass B probes before trusting a bound
 
 struct NNHard {                // one record per query that pass A could not certify
   double d2;                   // best squared distance found so far (1e300 = none)
@@ -238,16 +237,19 @@ __device__ __forceinline__ void wave_argmin(double& d2, int& idx) {
   }
 }
 
-// Scan a window with the 64 lanes striding over its flattened (row, column) candidates.
+// Scan a window with the 64 lanes striding over its flattened (row, column) candidates.  Every candidate is first
+// screened with an fp32 distance against the lane's best (relative slack 1e-5, far above the fp32 error of a sum of
+// three squares); only candidates that pass are evaluated in fp64, which is the value that decides.
 __device__ __forceinline__ void scan_window(const Window& w, const float4* __restrict__ tp, int HW, int W, float qx,
                                             float qy, float qz, int lane, double& best, int& bidx) {
   const int nrows = w.r1 - w.r0 + 1;
   if (nrows <= 0 || w.nc <= 0) return;
   const int total = nrows * w.nc;
   const float inv = 1.0f / (float)w.nc;
-  double lbest = 1e300;
+  double lbest = best;                        // seed with the running best: most candidates fail the fp32 screen
+  float thr = best < 1e30 ? (float)best * (1.0f + 1e-5f) : 3.0e38f;
   int lidx = -1;
-  constexpr int UN = 4;                       // candidates per lane per trip: 12 loads in flight
+  constexpr int UN = 4;                       // candidates per lane per trip: four 16-byte loads in flight
   for (int k0 = lane; k0 < total; k0 += DL_WAVE * UN) {
     float4 c4[UN];
     int p[UN];
@@ -265,15 +267,50 @@ __device__ __forceinline__ void scan_window(const Window& w, const float4* __res
     }
 #pragma unroll
     for (int i = 0; i < UN; ++i) {
-      if (p[i] < 0 || (c4[i].x == 0.f && c4[i].y == 0.f && c4[i].z == 0.f)) continue;
-      const double d2 = dist2(qx, qy, qz, c4[i].x, c4[i].y, c4[i].z);
-      if (d2 < lbest || (d2 == lbest && p[i] < lidx)) { lbest = d2; lidx = p[i]; }
+      const float dx = qx - c4[i].x, dy = qy - c4[i].y, dz = qz - c4[i].z;
+      const float d2f = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+      const bool empty = (c4[i].x == 0.f && c4[i].y == 0.f && c4[i].z == 0.f);
+      if (p[i] >= 0 && !empty && d2f <= thr) {
+        const double d2 = dist2(qx, qy, qz, c4[i].x, c4[i].y, c4[i].z);
+        if (d2 < lbest || (d2 == lbest && lidx >= 0 && p[i] < lidx)) {
+          lbest = d2; lidx = p[i];
+          thr = (float)lbest * (1.0f + 1e-5f);
+        }
+      }
     }
   }
+  if (lidx < 0) lbest = 1e300;               // this lane found nothing better than the running best
   wave_argmin(lbest, lidx);
   if (lidx >= 0 && (lbest < best || (lbest == best && (bidx < 0 || lidx < bidx)))) { best = lbest; bidx = lidx; }
 }
 
+// Signed column offset of column c from centre column u0 on the ring of W columns, in [-W/2, W/2).
+__device__ __forceinline__ int ring_offset(int c, int u0, int W) {
+  int d = (c - u0) % W;
+  if (d < -W / 2) d += W;
+  if (d >= W - W / 2) d -= W;
+  return d;
+}
+
+__device__ __forceinline__ float bcast_f(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+__device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ double bcast_d(double v, int src) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Pass B: a wave draws NN_BATCH of the queries that pass A could not certify, ONE PER LANE for everything that is per-query
+// arithmetic (projection, bound windows, containment tests, the final gather and store), and scans the windows
+// cooperatively, one query at a time, with all 64 lanes striding over the candidates.  The bound window of a query's
+// current best distance is intersected with a box around its pixel that grows (4x16 -> 8x40 -> 16x96 -> whole image
+// half-sizes); after each scan the bound is recomputed from the improved distance, and a query is finished as soon as
+// its bound fits inside the box already covered.  Pixels of an earlier box that lay outside the then-valid bound cannot
+// hold a closer point, so "covered" is simply the last box.  This keeps the examined candidates near the minimum any
+// exact search with this bound must look at (the window of the TRUE distance) even when pass A only saw far candidates.
 __global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float4* __restrict__ tgt, int64_t tgt_ss4,
                                                       const float4* __restrict__ tgtn, int64_t tgtn_ss4, SensorK sen,
                                                       int32_t* __restrict__ nn_pix, float* __restrict__ match,
@@ -283,36 +320,77 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float4* __restrict__
   const int nwaves = gridDim.x * DL_BLOCK / DL_WAVE;
   const int count = ws.counter[0];
   const int HW = sen.HW, H = sen.H, W = sen.W;
-  for (int h = wave; h < count; h += nwaves) {
-    const NNHard rec = ws.hard[h];
+  (void)wave; (void)nwaves;
+  for (;;) {
+    // dynamic distribution in batches of NN_BATCH queries (a few queries scan thousands of candidates: static
+    // partitioning leaves the wave that drew them running long after the others)
+    int h0 = 0;
+    if (lane == 0) h0 = atomicAdd(&ws.counter[1], NN_BATCH);
+    h0 = bcast_i(h0, 0);
+    if (h0 >= count) break;
+    const bool live = lane < NN_BATCH && h0 + lane < count;
+    NNHard rec;
+    rec.d2 = 1e300; rec.slot = 0; rec.idx = -1; rec.qx = 1.f; rec.qy = 0.f; rec.qz = 0.f; rec.pad = 0;
+    if (live) rec = ws.hard[h0 + lane];
     const int b = rec.slot / HW;
-    const float4* tp = tgt + (size_t)b * tgt_ss4;
     const QueryF q = make_query(rec.qx, rec.qy, rec.qz, sen);
     double best = rec.d2;
     int bidx = rec.idx;
-    Window w = bound_window(q, bidx >= 0 ? (float)sqrt(best) * NN_UP : 3.0e38f, sen);
-    if ((w.r1 - w.r0 + 1) * w.nc > NN_CLIP_LIMIT) {
-      // the bound from pass A is weak (hole / occlusion around the projected pixel): probe a moderate window first,
-      // then bound again with what was found
+    const int u0 = wrap_col((int)rintf(q.uq), W);
+    int v0 = (int)rintf(q.vq);
+    v0 = v0 < 0 ? 0 : (v0 > H - 1 ? H - 1 : v0);
+    int box_r = NN_RV, box_c = NN_RU;          // pass A covered this box (when its columns did not wrap; else rescanned)
+    bool covered_valid = (rintf(q.uq) - NN_RU >= 0.f) && (rintf(q.uq) + NN_RU <= (float)(W - 1));
+    bool done = !live;
+#pragma unroll 1
+    for (int round = 0; round < 4; ++round) {
       Window c;
-      int v0 = (int)rintf(q.vq);
-      v0 = v0 < 0 ? 0 : (v0 > H - 1 ? H - 1 : v0);
-      c.r0 = v0 - NN_CLIP_ROWS < 0 ? 0 : v0 - NN_CLIP_ROWS;
-      c.r1 = v0 + NN_CLIP_ROWS > H - 1 ? H - 1 : v0 + NN_CLIP_ROWS;
-      c.nc = 2 * NN_CLIP_COLS + 1 < W ? 2 * NN_CLIP_COLS + 1 : W;
-      c.c0 = wrap_col((int)rintf(q.uq) - NN_CLIP_COLS, W);
-      scan_window(c, tp, HW, W, rec.qx, rec.qy, rec.qz, lane, best, bidx);
-      w = bound_window(q, bidx >= 0 ? (float)sqrt(best) * NN_UP : 3.0e38f, sen);
+      c.r0 = 0; c.r1 = -1; c.c0 = 0; c.nc = 0;
+      if (!done) {
+        const Window w = bound_window(q, bidx >= 0 ? (float)sqrt(best) * NN_UP : 3.0e38f, sen);
+        int lo = -W / 2, hi = W - W / 2 - 1;
+        if (w.nc < W) { lo = ring_offset(w.c0, u0, W); hi = lo + w.nc - 1; }
+        const int cov_r0 = v0 - box_r < 0 ? 0 : v0 - box_r, cov_r1 = v0 + box_r > H - 1 ? H - 1 : v0 + box_r;
+        const bool rows_in = w.r0 >= cov_r0 && w.r1 <= cov_r1;
+        const bool cols_in = (w.nc < W) ? (lo >= -box_c && hi <= box_c) : (2 * box_c + 1 >= W);
+        if (covered_valid && rows_in && cols_in) {
+          done = true;
+        } else {
+          if (round == 0) { box_r = 4; box_c = 16; } else if (round == 1) { box_r = 8; box_c = 40; }
+          else if (round == 2) { box_r = 16; box_c = 96; } else { box_r = H; box_c = W; }
+          c.r0 = w.r0 > v0 - box_r ? w.r0 : v0 - box_r;
+          c.r1 = w.r1 < v0 + box_r ? w.r1 : v0 + box_r;
+          c.r0 = c.r0 < 0 ? 0 : c.r0;
+          c.r1 = c.r1 > H - 1 ? H - 1 : c.r1;
+          const int clo = lo > -box_c ? lo : -box_c, chi = hi < box_c ? hi : box_c;
+          if (w.nc >= W && 2 * box_c + 1 >= W) { c.c0 = 0; c.nc = W; }
+          else { c.c0 = wrap_col(u0 + clo, W); c.nc = chi - clo + 1; if (c.nc > W) { c.c0 = 0; c.nc = W; } }
+          covered_valid = true;
+        }
+      }
+      unsigned long long todo = __ballot(!done);
+      if (todo == 0ull) break;
+      while (todo) {                                  // cooperative scans, one query of this wave at a time
+        const int i = __builtin_ctzll(todo);
+        todo &= todo - 1;
+        Window wi;
+        wi.r0 = bcast_i(c.r0, i); wi.r1 = bcast_i(c.r1, i); wi.c0 = bcast_i(c.c0, i); wi.nc = bcast_i(c.nc, i);
+        const float qx = bcast_f(rec.qx, i), qy = bcast_f(rec.qy, i), qz = bcast_f(rec.qz, i);
+        const int bi = bcast_i(b, i);
+        double sbest = bcast_d(best, i);
+        int sidx = bcast_i(bidx, i);
+        scan_window(wi, tgt + (size_t)bi * tgt_ss4, HW, W, qx, qy, qz, lane, sbest, sidx);
+        if (lane == i) { best = sbest; bidx = sidx; }
+      }
     }
-    scan_window(w, tp, HW, W, rec.qx, rec.qy, rec.qz, lane, best, bidx);
-    if (lane == 0) {
+    if (live) {
       nn_pix[rec.slot] = bidx;
       if (match) {
         const int px = rec.slot - b * HW;
         float* mp = match + (size_t)b * 6 * HW + px;
         float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f), n4 = p4;
         if (bidx >= 0) {
-          p4 = tp[bidx];
+          p4 = (tgt + (size_t)b * tgt_ss4)[bidx];
           if (tgtn) n4 = (tgtn + (size_t)b * tgtn_ss4)[bidx];
         }
         mp[0] = p4.x; mp[HW] = p4.y; mp[2 * HW] = p4.z; mp[3 * HW] = n4.x; mp[4 * HW] = n4.y; mp[5 * HW] = n4.z;
