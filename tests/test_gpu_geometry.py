@@ -454,3 +454,28 @@ def test_loss_identity_on_same_image_is_zero_and_deterministic():
         r.append((nn2.clone(), t2.clone()))
     assert torch.equal(r[0][0], r[1][0]) and torch.equal(r[0][1], r[1][1])
     assert torch.allclose(r[0][1][0], r[0][1][7])
+
+
+def test_full_geometry_path_128_rings_2048_columns():
+    """BASELINE config 4 shape (Ouster-style 128x2048, vFoV +-22.5 deg): projection -> online normals -> correspondences ->
+    loss and dL/dT for one pair against the oracle (KD-tree on ~240k points)."""
+    G, dev = _geo(), _dev()
+    sensor, img, nrm, T_true = _pair_images(77128, 128, 2048, 128, 2250, vfov_deg=(-22.5, 22.5))
+    T0 = torch.from_numpy(T_true).clone()
+    T0[:3, 3] += torch.tensor([0.1, -0.05, 0.02])
+    T = T0.view(1, 4, 4).to(dev).requires_grad_(True)
+    tgt_pk, tgt_n_pk = G.pack_image(img[0:1]), G.pack_image(nrm[0:1])
+    nn, vis, match = G.nn_correspond(img[1:2], nrm[1:2], tgt_pk, tgt_n_pk, T, sensor)
+    terms, counts = G.icp_loss(T, img[1:2], nrm[1:2], match, nn, _flags("squared", False))
+    (terms[0, 1] + terms[0, 2]).backward()
+    tp, tn, tpix = util.lists_from_images(img[0].cpu(), nrm[0].cpu())
+    sp, sn, spix = util.lists_from_images(img[1].cpu(), nrm[1].cpu())
+    Tb = T0.view(1, 4, 4).clone().requires_grad_(True)
+    l, aux = orc.icp_losses(orc.transform_points(Tb, sp), orc.rotate_points(Tb, sn), tp, tn, return_aux=True)
+    (l["loss_po2pl"] + l["loss_pl2pl"]).sum().backward()
+    assert abs(int(counts[0, 0]) - aux["pairs"]) <= 2                      # fp32 ties of q only
+    _close(terms[0, 1:].detach().cpu().numpy(), [float(l["loss_po2pl"]), float(l["loss_pl2pl"])], what="128x2048 losses")
+    _close(T.grad[0, :3].cpu().numpy(), Tb.grad[0, :3].numpy(), rel=2e-4, what="128x2048 dL/dT")
+    got = nn[0].reshape(-1).cpu().long()[spix[aux["src_index_with_normals"]]]
+    exp = tpix[aux["nn_with_normals"]]
+    assert (got != exp).sum() <= 1e-4 * len(exp) + 2
