@@ -7,9 +7,9 @@ import sys
 
 _NAMES = ("deploy", "utility", "losses", "models", "preprocessing", "data")
 _SUBMODULES = {
-    "deploy": ("deployer", "trainer", "step_geometry"), "utility": ("projection",), "losses": ("icp_losses",),
+    "deploy": ("deployer", "trainer", "tester", "step_geometry"), "utility": ("projection", "poses"), "losses": ("icp_losses",),
     "models": ("model", "model_parts", "resnet_modified"), "preprocessing": ("normal_computation",),
-    "data": ("dataset", "synthetic"),
+    "data": ("dataset", "synthetic", "feed"),
 }
 
 for _name in _NAMES:

@@ -66,3 +66,36 @@ def training_config(training_run_name, experiment_name="", checkpoint="", config
         cfg["experiment"] = experiment_name
     cfg["mode"] = "training"
     return cfg
+
+
+def testing_config(testing_run_name, experiment_name="testing", checkpoint="", config_dir="config"):
+    """The dict ``bin/run_testing.py`` hands to ``Tester`` (reference bin/run_testing.py:20-88)."""
+    cfg = load_yaml_config(config_dir)
+    ckpt = torch.load(checkpoint, map_location="cpu", weights_only=False)
+    if "parameters" in ckpt:
+        print("Found parameters in checkpoint! Setting part of parameters to those ones.")
+        loaded = ckpt["parameters"]
+        loaded["device"] = resolve_device(cfg["device"])
+        loaded["datasets"] = cfg["datasets"]
+        for ds in loaded["datasets"]:
+            loaded[ds]["testing_identifiers"] = cfg[ds]["testing_identifiers"]
+            loaded[ds]["data_identifiers"] = loaded[ds]["testing_identifiers"]
+        loaded["inference_only"] = cfg["inference_only"]
+        loaded["store_dataset_in_RAM"] = cfg["store_dataset_in_RAM"]
+        cfg = loaded
+    else:
+        print("Checkpoint does not contain any parameters. Using those ones specified in the YAML files.")
+        cfg["device"] = resolve_device(cfg["device"])
+        for ds in cfg["datasets"]:
+            cfg[ds]["data_identifiers"] = cfg[ds]["testing_identifiers"]
+        degrees_to_radians(cfg)
+    if cfg["use_dropout"]:
+        cfg["use_dropout"] = False
+        print("Deactivating dropout for this mode.")
+    cfg["run_name"] = str(testing_run_name)
+    cfg["checkpoint"] = str(checkpoint)
+    if experiment_name:
+        cfg["experiment"] = experiment_name
+    cfg["mode"] = "testing"
+    cfg["unsupervised_at_start"] = True
+    return cfg

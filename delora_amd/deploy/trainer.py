@@ -14,6 +14,7 @@ import os
 import numpy as np
 import torch
 
+from ..data import feed
 from . import deployer
 
 try:                                  # optional third-party logging, absent in the build/bench image
@@ -65,13 +66,12 @@ class Trainer(deployer.Deployer):
 
     def train_epoch(self, epoch, dataloader):
         epoch_losses = self.new_epoch_losses()
-        iterator = dataloader
+        iterator = feed.DevicePrefetcher(dataloader, self.device)       # next batch is copied while this step runs
         show = self.rank == 0 and qqdm is not None
         if show:
-            iterator = qqdm.qqdm(dataloader, desc=qqdm.format_str("blue", "Epoch " + str(epoch)))
+            iterator = qqdm.qqdm(iterator, desc=qqdm.format_str("blue", "Epoch " + str(epoch)))
         every = max(1, int(self.config.get("progress_every", 50)))
         for counter, preprocessed_dicts in enumerate(iterator):
-            self.to_device(preprocessed_dicts)
             self.optimizer.zero_grad(set_to_none=True)
             epoch_losses, _ = self.step(preprocessed_dicts=preprocessed_dicts, epoch_losses=epoch_losses,
                                         log_images_bool=False)

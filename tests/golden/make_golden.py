@@ -346,11 +346,83 @@ def fx_model_and_step(out):
             print(f"  step {name}: loss={e['ep::loss_epoch']:.6f} po2pl={e['ep::loss_po2pl_epoch']:.6f} pl2pl={e['ep::loss_pl2pl_epoch']:.6f} vis={e['ep::visible_pixels_epoch']}")
 
 
+def fx_model_variants(out):
+    """OdometryModel with the optional architecture switches (src/models/model.py:31-48 feature tower, :59-72 single MLP)."""
+    import models.model as rmodel
+    rng = np.random.default_rng(77)
+    i1 = (rng.normal(size=(2, 4, 16, 128)) * 5).astype(np.float32)
+    i2 = (rng.normal(size=(2, 4, 16, 128)) * 5).astype(np.float32)
+    for name, over in {"tower_relu": dict(pre_feature_extraction=True, activation_fct="relu"),
+                       "single_mlp": dict(use_single_mlp_at_output=True, activation_fct="tanh")}.items():
+        cfg = reference_config(16, 128, factor_fewer_resnet_channels=8, resnet_outputs=64, **over)
+        torch.manual_seed(4321)
+        m = rmodel.OdometryModel(config=cfg)
+        with torch.no_grad():
+            t, q = m(image_1=torch.from_numpy(i1), image_2=torch.from_numpy(i2))
+        out["model_" + name] = dict(image_1=i1, image_2=i2, translation=t2n(t), quaternion=t2n(q),
+                                    **{"sd::" + k: t2n(v) for k, v in m.state_dict().items()},
+                                    **{"cfg::" + k: np.asarray(v) for k, v in dict(factor_fewer_resnet_channels=8, resnet_outputs=64, **over).items()})
+        print(f"  model {name}: {sum(p.numel() for p in m.parameters())} params, {len(m.state_dict())} tensors")
+
+
+def fx_step_normalized(out):
+    """Trainer.step with normalization_scaling (src/deploy/deployer.py:222-235, :344-346), B=1."""
+    import deploy.trainer as rtrainer
+    gm = dict(np.load(os.path.join(HERE, "model_small.npz")))
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg = reference_config(16, 128, factor_fewer_resnet_channels=8, resnet_outputs=64, unsupervised_at_start=True,
+                               inference_only=False, batch_size=1, normalization_scaling=True, lambda_po2pl=10.0)
+        cfg["kitti"]["preprocessed_path"] = tmp
+        cfg["kitti"]["data_identifiers"] = cfg["kitti"]["training_identifiers"] = [0]
+        os.makedirs(os.path.join(tmp, "00", "scans")); os.makedirs(os.path.join(tmp, "00", "normals"))
+        (l1, l2), _ = preprocessed_lists(41, 16, 160, 16, 200, cfg)
+        for i, (pts, nrm) in enumerate((l1, l2)):
+            np.save(os.path.join(tmp, "00", "scans", f"{i:06d}.npy"), pts)
+            np.save(os.path.join(tmp, "00", "normals", f"{i:06d}.npy"), nrm)
+        trn = rtrainer.Trainer(config=cfg)
+        trn.model.load_state_dict({k[4:]: torch.from_numpy(v) for k, v in gm.items() if k.startswith("sd::")})
+        d = trn.dataset[0]
+        raw = {k: (t2n(v).copy() if hasattr(v, "numpy") else v) for k, v in d.items()}
+        ep = {k: 0.0 for k in ("loss_epoch", "loss_point_cloud_epoch", "loss_po2po_epoch", "loss_po2pl_epoch", "loss_pl2pl_epoch", "visible_pixels_epoch")}
+        trn.optimizer.zero_grad()
+        ep, T = trn.step(preprocessed_dicts=[d], epoch_losses=ep, log_images_bool=False)
+        e = dict(H=16, W=128, T=t2n(T), lambda_po2pl=10.0, **{"ep::" + k: float(np.asarray(v).sum()) for k, v in ep.items()},
+                 **{"gradnorm::" + k: float(np.linalg.norm(t2n(p.grad).astype(np.float64))) for k, p in trn.model.named_parameters()})
+        for k in ("scan_1", "scan_2", "normal_list_1", "normal_list_2"):
+            e["s0::" + k] = raw[k]
+        out["step_b1_norm"] = e
+        print(f"  step normalized: loss={e['ep::loss_epoch']:.6f} T_t={t2n(T)[0, :3, 3]}")
+
+
+def fx_poses(out):
+    """utility.poses.compute_poses / write_poses_to_text_file (src/utility/poses.py:11-74) on a short trajectory."""
+    import utility.poses as rposes
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(3)
+    Ts = []
+    for _ in range(25):
+        T = np.eye(4)
+        T[:3, :3] = Rotation.from_euler("zyx", rng.normal(0, [0.03, 0.005, 0.005])).as_matrix()
+        T[:3, :3] += rng.normal(0, 1e-6, (3, 3))              # slightly non-orthonormal, as a network output is
+        T[:3, 3] = [rng.uniform(0.5, 1.2), rng.normal(0, 0.05), rng.normal(0, 0.02)]
+        Ts.append(T.astype(np.float32).reshape(1, 4, 4))
+    poses = rposes.compute_poses(computed_transformations=[t.copy() for t in Ts])
+    with tempfile.TemporaryDirectory() as tmp:
+        fn = os.path.join(tmp, "p.txt")
+        rposes.write_poses_to_text_file(file_name=fn, poses=poses)
+        text = open(fn).read()
+    out["poses"] = dict(transformations=np.concatenate(Ts, axis=0), poses=poses, text=np.frombuffer(text.encode(), dtype=np.uint8))
+    print(f"  poses: {poses.shape}, end position {poses[-1, :3, 3]}")
+
+
 def main():
     install_stubs()
     torch.set_num_threads(8)
     out = {}
-    for f in (fx_projection, fx_normals, fx_geometry, fx_loss, fx_model_and_step):
+    only = sys.argv[1:]
+    for f in (fx_projection, fx_normals, fx_geometry, fx_loss, fx_model_and_step, fx_model_variants, fx_step_normalized, fx_poses):
+        if only and f.__name__ not in only:
+            continue
         print(f.__name__)
         f(out)
     for name, d in out.items():

@@ -217,3 +217,66 @@ def test_icp_losses_module_on_lists(mode, p2p):
         ref_g = g[key + "_gradT"]
         assert np.allclose(T.grad.cpu().numpy(), ref_g, rtol=1e-3, atol=1e-4 * np.abs(ref_g).max()), key
         assert plotting["scan_2_transformed"].shape[2] == int(g[key + "_pairs"])
+
+
+def test_normalized_step_matches_reference_on_gpu():
+    from delora_amd.deploy.trainer import Trainer
+    dev = _dev()
+    g, gm = util.load_golden("step_b1_norm"), util.load_golden("model_small")
+    cfg = _small_model_cfg(gm, int(g["H"]), int(g["W"]), batch_size=1, normalization_scaling=True,
+                           lambda_po2pl=float(g["lambda_po2pl"]))
+    sample = {**{k: torch.from_numpy(g[f"s0::{k}"]).to(dev) for k in ("scan_1", "scan_2", "normal_list_1", "normal_list_2")},
+              "dataset": "kitti"}
+    tr = Trainer(cfg, dataset=util.ListDataset([sample]))
+    tr.raw_model.load_state_dict(_state_dict(gm, dev))
+    ep, T = tr.step(preprocessed_dicts=[dict(sample)], epoch_losses=tr.new_epoch_losses())
+    assert np.allclose(T.detach().cpu().numpy(), g["T"], rtol=REL, atol=REL * np.abs(g["T"]).max())
+    for key in ("loss_epoch", "loss_po2pl_epoch", "loss_pl2pl_epoch"):
+        assert np.isclose(float(ep[key]), g["ep::" + key], rtol=REL), key
+    for k, p in tr.raw_model.named_parameters():
+        assert np.isclose(float(p.grad.double().norm()), float(g["gradnorm::" + k]), rtol=2e-3, atol=1e-9), k
+
+
+@pytest.mark.parametrize("name", ["tower_relu", "single_mlp"])
+def test_model_architecture_switches_on_gpu(name):
+    from delora_amd.models.model import OdometryModel
+    dev = _dev()
+    g = util.load_golden("model_" + name)
+    over = {k[5:]: v for k, v in g.items() if k.startswith("cfg::")}
+    over = {k: (str(v) if k == "activation_fct" else (bool(v) if k in ("pre_feature_extraction", "use_single_mlp_at_output") else int(v)))
+            for k, v in over.items()}
+    cfg = util.repo_config(16, 128, device="cuda:0", **over)
+    m = OdometryModel(cfg).to(dev)
+    m.load_state_dict({k[4:]: torch.from_numpy(v).to(dev) for k, v in g.items() if k.startswith("sd::")})
+    with torch.no_grad():
+        t, q = m(torch.from_numpy(g["image_1"]).to(dev), torch.from_numpy(g["image_2"]).to(dev))
+    assert np.allclose(t.cpu().numpy(), g["translation"], rtol=REL, atol=1e-5)
+    assert np.allclose(q.cpu().numpy(), g["quaternion"], rtol=REL, atol=1e-5)
+
+
+def test_train_loop_with_prefetcher_and_checkpoints(tmp_path):
+    """Trainer.train(): DataLoader -> pinned async H2D prefetch -> steps -> per-epoch metrics -> checkpoint files with the
+    reference's layout; identity pre-training first (unsupervised_at_start False), as the reference's default."""
+    from delora_amd.data.dataset import SyntheticPairDataset
+    from delora_amd.deploy.trainer import Trainer
+    _dev()
+    cfg = util.repo_config(16, 128, device="cuda:0", factor_fewer_resnet_channels=8, resnet_outputs=64, batch_size=2,
+                           unsupervised_at_start=False, inference_only=False, checkpoint_dir=str(tmp_path), learning_rate=1e-3)
+    ds = SyntheticPairDataset(cfg, "kitti", 4, rings=16, azimuth_steps=160)
+    tr = Trainer(cfg, dataset=ds)
+    tr.train(max_epochs=2)
+    latest = tmp_path / "test_latest_checkpoint.pth"
+    assert latest.exists() and (tmp_path / "test_checkpoint_epoch_0.pth").exists()
+    ck = torch.load(str(latest), map_location="cpu", weights_only=False)
+    assert ck["epoch"] == 1 and set(ck) == {"epoch", "model_state_dict", "optimizer_state_dict", "loss", "parameters"}
+    assert np.isfinite(ck["loss"])
+
+
+def test_device_prefetcher_on_gpu():
+    from delora_amd.data.feed import DevicePrefetcher
+    dev = _dev()
+    batches = [[{"scan_1": torch.randn(1, 3, 1000) + i, "dataset": "kitti"}] for i in range(5)]
+    ref = [b[0]["scan_1"].clone() for b in batches]
+    got = list(DevicePrefetcher(batches, dev))
+    torch.cuda.synchronize()
+    assert all(g[0]["scan_1"].is_cuda and torch.equal(g[0]["scan_1"].cpu(), r) for g, r in zip(got, ref))

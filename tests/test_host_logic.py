@@ -186,3 +186,87 @@ def test_preprocessed_dataset_reads_reference_layout(tmp_path):
     assert s["scan_1"].shape == (1, 3, 51) and s["scan_2"].shape == (1, 3, 52) and s["dataset"] == "kitti"
     assert set(s) >= {"index", "index_dataset", "index_sequence", "index_scan", "dataset", "scan_1", "scan_2",
                       "normal_list_1", "normal_list_2"}
+
+
+@pytest.mark.parametrize("name", ["tower_relu", "single_mlp"])
+def test_model_architecture_switches_match_reference(name):
+    """pre_feature_extraction / use_single_mlp_at_output / relu: same parameter names, same outputs as the reference."""
+    from delora_amd.models.model import OdometryModel
+    g = util.load_golden("model_" + name)
+    over = {k[5:]: (v.item() if v.shape == () else v) for k, v in g.items() if k.startswith("cfg::")}
+    over = {k: (str(v) if k == "activation_fct" else (bool(v) if k in ("pre_feature_extraction", "use_single_mlp_at_output") else int(v)))
+            for k, v in over.items()}
+    cfg = util.repo_config(16, 128, device="cpu", **over)
+    m = OdometryModel(cfg)
+    sd = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("sd::")}
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        t, q = m(torch.from_numpy(g["image_1"]), torch.from_numpy(g["image_2"]))
+    assert np.allclose(t.numpy(), g["translation"], atol=2e-6) and np.allclose(q.numpy(), g["quaternion"], atol=2e-6)
+
+
+def test_normalized_step_matches_reference():
+    """normalization_scaling (deployer.py:222-235,344-346) with lambda_po2pl = 10: scans divided by the mean range,
+    translation rescaled afterwards."""
+    from delora_amd.deploy.trainer import Trainer
+    g = util.load_golden("step_b1_norm")
+    cfg, sd = _small_cfg(int(g["H"]), int(g["W"]), 1, normalization_scaling=True, lambda_po2pl=float(g["lambda_po2pl"]))
+    tr = Trainer(cfg, dataset=util.ListDataset([]), geometry_backend=util.OracleStepGeometry())
+    tr.raw_model.load_state_dict(sd)
+    ep = tr.new_epoch_losses()
+    tr.optimizer.zero_grad()
+    ep, T = tr.step(preprocessed_dicts=_samples(g, 1), epoch_losses=ep)
+    assert np.allclose(T.detach().numpy(), g["T"], rtol=1e-4, atol=1e-5)
+    for key in ("loss_epoch", "loss_po2pl_epoch", "loss_pl2pl_epoch"):
+        assert np.isclose(float(ep[key]), g["ep::" + key], rtol=5e-5), key
+
+
+def test_pose_integration_matches_reference():
+    """utility.poses.compute_poses / write_poses_to_text_file against the reference's trajectory (bit-exact, incl. the file)."""
+    from delora_amd.utility import poses
+    g = util.load_golden("poses")
+    P = poses.compute_poses([t.reshape(1, 4, 4) for t in g["transformations"]])
+    assert np.array_equal(P, g["poses"])
+    import tempfile
+    fn = tempfile.mktemp()
+    poses.write_poses_to_text_file(fn, P)
+    assert open(fn).read().encode() == g["text"].tobytes()
+    bad = np.eye(4); bad[:3, :3] *= 1.5
+    assert not poses.check_validity_so3(bad[:3, :3])
+
+
+def test_tester_writes_kitti_pose_files(tmp_path):
+    """Checkpoint -> Tester over a two-pair 'sequence' (oracle geometry backend on CPU) -> pose file = compute_poses(T)."""
+    from delora_amd.deploy.tester import Tester
+    from delora_amd.deploy.trainer import Trainer
+    from delora_amd.utility import poses
+    g = util.load_golden("step_b2")
+    cfg, sd = _small_cfg(int(g["H"]), int(g["W"]), 1)
+    tr = Trainer(cfg, dataset=util.ListDataset([]), geometry_backend=util.OracleStepGeometry())
+    tr.raw_model.load_state_dict(sd)
+    ck = str(tmp_path / "m.pth")
+    tr.save_checkpoint(ck, 0, 0.0)
+    cfg2, _ = _small_cfg(int(g["H"]), int(g["W"]), 1)
+    cfg2.update(checkpoint=ck, inference_only=True, output_dir=str(tmp_path), run_name="t", mode="testing")
+    cfg2["kitti"]["data_identifiers"] = [9]
+    samples = []
+    for j, s in enumerate(_samples(g, 2)):
+        s.update(index=j, index_dataset=0, index_sequence=0, index_scan=j)
+        samples.append(s)
+    te = Tester(cfg2, dataset=util.ListDataset(samples), geometry_backend=util.OracleStepGeometry())
+    te.test()
+    assert len(te.written) == 1 and te.written[0]["poses_text"].endswith("t_poses_text_file_kitti_09.txt")
+    T = np.load(te.written[0]["transformations"])
+    assert T.shape == (2, 1, 4, 4) and np.allclose(T[:, 0], g["T"], atol=1e-5)
+    P = np.load(te.written[0]["poses"])
+    assert np.allclose(P, poses.compute_poses(list(T)))
+    assert len(open(te.written[0]["poses_text"]).read().strip().splitlines()) == 3
+
+
+def test_prefetcher_passes_batches_through_on_cpu():
+    from delora_amd.data.feed import DevicePrefetcher
+    batches = [[{"a": torch.ones(3) * i, "name": "x"}] for i in range(4)]
+    got = list(DevicePrefetcher(batches, torch.device("cpu")))
+    assert len(got) == 4 and all(float(b[0]["a"][0]) == i for i, b in enumerate(got))
+    assert list(DevicePrefetcher([], torch.device("cpu"))) == []
