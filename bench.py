@@ -222,10 +222,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # test hooks (never set in production): run all ranks on one GPU over gloo to exercise the N>1 code path on a 1-GPU box
+    if os.environ.get("DELORA_BENCH_SHARE_GPU") == "1":
+        local = 0
+    backend = os.environ.get("DELORA_BENCH_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        torch.distributed.init_process_group(backend="nccl", device_id=device)
+        if backend == "nccl":
+            torch.distributed.init_process_group(backend="nccl", device_id=device)
+        else:
+            torch.distributed.init_process_group(backend=backend)
     from delora_amd.deploy.trainer import Trainer
     from delora_amd.data.dataset import ListDataset
     cfg = build_config(args, device)

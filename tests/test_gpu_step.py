@@ -1,6 +1,8 @@
 """The full training step (projection -> CNN -> T -> correspondences -> losses -> backward -> Adam) on the GPU against
 the vectors recorded from the reference's own ``Trainer.step`` (tests/golden/step_b{1,2}.npz), and the mirrors of
 the reference's module API against golden vectors / the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -280,3 +282,43 @@ def test_device_prefetcher_on_gpu():
     got = list(DevicePrefetcher(batches, dev))
     torch.cuda.synchronize()
     assert all(g[0]["scan_1"].is_cuda and torch.equal(g[0]["scan_1"].cpu(), r) for g, r in zip(got, ref))
+
+
+def _ddp_gpu_worker(rank, world, port, ret):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from delora_amd.deploy.trainer import Trainer
+        dev = torch.device("cuda:0")
+        g, gm = util.load_golden("step_b2"), util.load_golden("model_small")
+        cfg = _small_model_cfg(gm, int(g["H"]), int(g["W"]), batch_size=1)
+        sample = {**{k: torch.from_numpy(g[f"s{rank}::{k}"]).to(dev) for k in ("scan_1", "scan_2", "normal_list_1", "normal_list_2")},
+                  "dataset": "kitti"}
+        tr = Trainer(cfg, dataset=util.ListDataset([sample]))
+        tr.raw_model.load_state_dict(_state_dict(gm, dev))
+        assert tr.world_size == 2 and isinstance(tr.model, torch.nn.parallel.DistributedDataParallel)
+        ep = tr.new_epoch_losses()
+        tr.optimizer.zero_grad()
+        ep, T = tr.step(preprocessed_dicts=[dict(sample)], epoch_losses=ep)
+        torch.cuda.synchronize()
+        ret[rank] = {"T": T.detach().cpu(), "loss": float(ep["loss_epoch"]),
+                     "gn": {k: float(p.grad.double().norm()) for k, p in tr.raw_model.named_parameters()}}
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def test_data_parallel_step_on_gpu_matches_reference_batch():
+    """Two DDP ranks (one GPU, gloo transport; RCCL itself needs >1 GPU) x B=1 through the HIP path reproduce the
+    reference's single-process B=2 step: poses, loss, averaged gradient norms."""
+    import torch.multiprocessing as mp
+    _dev()
+    g = util.load_golden("step_b2")
+    ret = mp.Manager().dict()
+    mp.spawn(_ddp_gpu_worker, args=(2, 29650 + (os.getpid() % 300), ret), nprocs=2, join=True)
+    for r in (0, 1):
+        assert np.allclose(ret[r]["T"][0].numpy(), g["T"][r], rtol=REL, atol=REL * np.abs(g["T"]).max())
+        for k, v in ret[r]["gn"].items():
+            assert np.isclose(v, float(g["gradnorm::" + k]), rtol=3e-3, atol=1e-9), k
+    assert np.isclose(ret[0]["loss"] + ret[1]["loss"], g["ep::loss_epoch"], rtol=REL)
