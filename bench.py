@@ -38,6 +38,8 @@ def parse():
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--amp", default="", help="optional autocast dtype for the CNN (bfloat16/float16); default fp32 = parity mode")
     ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark = True (exhaustive MIOpen find)")
+    ap.add_argument("--graph", action="store_true", help="replay the whole step as one captured HIP graph (single GPU only)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs evaluated by the CPU baseline")
     ap.add_argument("--cpu-threads", type=int, default=16, help="torch CPU threads of the baseline (more is slower on a 256-thread host: "
@@ -235,6 +237,8 @@ def main():
             torch.distributed.init_process_group(backend=backend)
     from delora_amd.deploy.trainer import Trainer
     from delora_amd.data.dataset import ListDataset
+    if args.miopen_benchmark:
+        torch.backends.cudnn.benchmark = True
     cfg = build_config(args, device)
     torch.manual_seed(1234)
     batch = make_batch(args, rank, device)
@@ -249,11 +253,18 @@ def main():
 
     for _ in range(args.warmup):
         run_step(False)
+    graphed = None
+    if args.graph and world == 1:
+        from delora_amd.deploy.graph_step import GraphedStep
+        graphed = GraphedStep(trainer, batch)
+        if graphed.captured:
+            run_step = lambda timed: graphed()[0]            # noqa: E731
     # in-situ HIP events immediately before and after the launch of the streaming loss kernel (k_icp_loss) of every
     # timed step, recorded on the stream the kernel is launched on (geometry.PARTIAL_HOOK)
     from delora_amd import geometry as G
     marks = []
-    G.PARTIAL_HOOK = lambda: (marks.append(torch.cuda.Event(enable_timing=True)), marks[-1].record())
+    if graphed is None or not graphed.captured:            # events cannot be recorded inside a replayed graph
+        G.PARTIAL_HOOK = lambda: (marks.append(torch.cuda.Event(enable_timing=True)), marks[-1].record())
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -279,11 +290,18 @@ def main():
         "config": {"workload": f"KITTI-shaped {args.height}x{args.width}, batch={args.batch} pairs/GPU, raw scans of ~141k points, "
                                f"online normals, ResNet pose CNN (11.9M params, identity-pretrained state) on PyTorch-ROCm, Adam; BASELINE configs[1]",
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "cnn": "fp32" if not args.amp else "autocast " + args.amp,
-                   "channels_last": bool(args.channels_last)},
+                   "channels_last": bool(args.channels_last), "hip_graph": bool(graphed is not None and graphed.captured)},
         "final_loss": final_loss,
     }
     if rank == 0:
         rows, counts = kernel_table(trainer, batch, args.kernel_reps)
+        if not marks:                                          # graph mode: measure the same launch right after the timed region
+            G.PARTIAL_HOOK = lambda: (marks.append(torch.cuda.Event(enable_timing=True)), marks[-1].record())
+            for _ in range(5):
+                trainer.optimizer.zero_grad(set_to_none=True)
+                trainer.step(preprocessed_dicts=[dict(s) for s in batch], epoch_losses=trainer.new_epoch_losses())
+            torch.cuda.synchronize()
+            G.PARTIAL_HOOK = None
         loss_ms = float(np.mean([marks[i].elapsed_time(marks[i + 1]) for i in range(0, len(marks) - 1, 2)]))
         # in-situ measurement uses the poses the network actually predicted in the timed steps
         last = trainer.last_step

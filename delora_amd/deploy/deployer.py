@@ -124,8 +124,8 @@ class Deployer(object):
         # global batch bookkeeping: this rank holds samples [rank*B, (rank+1)*B) of a batch of world_size*B
         Bg = B * self.world_size
         j_global = torch.arange(B, device=terms.device, dtype=terms.dtype) + float(self.rank * B)
-        lam = torch.tensor([1.0, float(cfg["lambda_po2pl"]), 1.0], device=terms.device, dtype=terms.dtype)
-        weighted = terms * lam                                                   # deployer.py:309-311
+        # lambda_po2pl scales the point-to-plane column only (deployer.py:309-311); built from device-side ops (capturable)
+        weighted = torch.stack((terms[:, 0], terms[:, 1] * float(cfg["lambda_po2pl"]), terms[:, 2]), dim=1)
         sums = weighted.sum(dim=0)
         losses = {"loss_po2po": sums[0] / Bg, "loss_po2pl": sums[1] / Bg, "loss_pl2pl": sums[2] / Bg,
                   # running sums added inside the sample loop (:312) <=> weight (Bg - j) on sample j; then /Bg (:329)

@@ -48,5 +48,5 @@ class GeometryHandler:
         R = GeometryHandler.quaternion_to_rot_matrix(quaternion)
         B = R.shape[0]
         top = torch.cat((R, translation.reshape(B, 3, 1).to(R.dtype)), dim=2)
-        bottom = torch.tensor([0.0, 0.0, 0.0, 1.0], device=R.device, dtype=R.dtype).expand(B, 1, 4)
+        bottom = torch.cat((R.new_zeros((B, 1, 3)), R.new_ones((B, 1, 1))), dim=2)   # device-side fills: graph-capturable
         return torch.cat((top, bottom), dim=1)

@@ -322,3 +322,36 @@ def test_data_parallel_step_on_gpu_matches_reference_batch():
         for k, v in ret[r]["gn"].items():
             assert np.isclose(v, float(g["gradnorm::" + k]), rtol=3e-3, atol=1e-9), k
     assert np.isclose(ret[0]["loss"] + ret[1]["loss"], g["ep::loss_epoch"], rtol=REL)
+
+
+def test_graphed_step_equals_eager_step():
+    """The captured HIP graph of the whole training step replays to the same losses and weights as eager execution."""
+    from delora_amd.data.dataset import SyntheticPairDataset
+    from delora_amd.deploy.graph_step import GraphedStep
+    from delora_amd.deploy.trainer import Trainer
+    dev = _dev()
+
+    def make():
+        cfg = util.repo_config(32, 256, device="cuda:0", factor_fewer_resnet_channels=4, resnet_outputs=128,
+                               unsupervised_at_start=True, inference_only=False, batch_size=2, learning_rate=1e-4)
+        ds = SyntheticPairDataset(cfg, "kitti", 2, rings=32, azimuth_steps=300)
+        torch.manual_seed(7)
+        tr = Trainer(cfg, dataset=ds)
+        return tr, tr.to_device([ds[0], ds[1]])
+
+    tr_e, batch = make()
+    eager = []
+    for _ in range(6):
+        tr_e.optimizer.zero_grad(set_to_none=True)
+        ep, _ = tr_e.step(preprocessed_dicts=[dict(b) for b in batch], epoch_losses=tr_e.new_epoch_losses())
+        eager.append(float(ep["loss_epoch"]))
+    tr_g, batch_g = make()
+    gs = GraphedStep(tr_g, batch_g, warmup=3)               # 3 eager warm-up steps + 1 capture pass (which does not execute)
+    assert gs.captured
+    got = []
+    for _ in range(3):
+        ep, _ = gs()
+        got.append(float(ep["loss_epoch"]))
+    assert np.allclose(got, eager[3:6], rtol=1e-4), (got, eager)
+    for (k, a), (_, b) in zip(tr_g.raw_model.state_dict().items(), tr_e.raw_model.state_dict().items()):
+        assert torch.allclose(a, b, rtol=1e-3, atol=1e-6), k
