@@ -42,15 +42,18 @@ struct NNWorkspace {
   NNHard* hard;                // [B*HW]
 };
 
-static inline NNWorkspace carve_nn(void* ws) {
+#define NN_VIS0 64             // counter[0]: number of hard queries; counter[NN_VIS0 + 32 b + k]: visible-pixel sub-counters
+static inline size_t nn_header_bytes(int B) { return (((size_t)(NN_VIS0 + 32 * B) * sizeof(int32_t)) + 255) / 256 * 256; }
+
+static inline NNWorkspace carve_nn(void* ws, int B) {
   NNWorkspace w;
   w.counter = (int32_t*)ws;
-  w.hard = (NNHard*)((char*)ws + 256);
+  w.hard = (NNHard*)((char*)ws + nn_header_bytes(B));
   return w;
 }
 
 extern "C" size_t dl_nn_workspace_bytes(int32_t B, int32_t H, int32_t W) {
-  return 256 + (size_t)B * H * W * sizeof(NNHard);
+  return nn_header_bytes(B) + (size_t)B * H * W * sizeof(NNHard);
 }
 
 // Angular description of a query in fp32.  The image is only a spatial index here: these values pick WHICH pixels
@@ -163,8 +166,15 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
     }
   }
   if (visible) {
+    // one atomic per workgroup, spread over 32 sub-counters per sample (2048 same-address atomics per sample
+    // serialise for ~80 us at the end of the kernel); k_nn_hard folds the sub-counters into visible[b]
+    __shared__ int s_vis;
+    if (threadIdx.x == 0) s_vis = 0;
+    __syncthreads();
     const unsigned long long vm = __ballot(vis);
-    if ((threadIdx.x & (DL_WAVE - 1)) == 0 && vm) atomicAdd(&visible[b], (int)__popcll(vm));
+    if ((threadIdx.x & (DL_WAVE - 1)) == 0 && vm) atomicAdd(&s_vis, (int)__popcll(vm));
+    __syncthreads();
+    if (threadIdx.x == 0 && s_vis) atomicAdd(&ws.counter[NN_VIS0 + b * 32 + (blockIdx.x & 31)], s_vis);
   }
   if (px >= HW) return;
   float* mp = match ? match + (size_t)b * 6 * HW + px : nullptr;
@@ -314,12 +324,20 @@ __device__ __forceinline__ double bcast_d(double v, int src) {
 __global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float4* __restrict__ tgt, int64_t tgt_ss4,
                                                       const float4* __restrict__ tgtn, int64_t tgtn_ss4, SensorK sen,
                                                       int32_t* __restrict__ nn_pix, float* __restrict__ match,
-                                                      NNWorkspace ws) {
+                                                      int32_t* __restrict__ visible, int nb, NNWorkspace ws) {
   const int lane = threadIdx.x & (DL_WAVE - 1);
   const int wave = (blockIdx.x * DL_BLOCK + threadIdx.x) / DL_WAVE;
   const int nwaves = gridDim.x * DL_BLOCK / DL_WAVE;
   const int count = ws.counter[0];
   const int HW = sen.HW, H = sen.H, W = sen.W;
+  if (visible && blockIdx.x == 0 && (int)threadIdx.x < nb) {      // fold the visible-pixel sub-counters of pass A
+    int sum = 0;
+    for (int i = 0; i < 32; ++i) sum += ws.counter[NN_VIS0 + threadIdx.x * 32 + i];
+    visible[threadIdx.x] = sum;
+  }
+  // (Also measured and rejected: pinning each sample to one XCD so that its 2 MiB packed target stays in that XCD's L2 --
+  // pass A unchanged, pass B 2.0 -> 5.5 ms because a sample's expensive queries then share 1/8 of the chip; 16 instead of
+  // 4 candidate loads in flight per lane for big windows -- no change.)
   // static striding in batches of NN_BATCH queries per wave.  Measured at 64x2048, B=8 (382k hard queries): one query
   // per wave 1.85 ms, dynamic batches of 16 (atomic queue) 2.05 ms, 64 per wave 5.1 ms (a few queries scan thousands
   // of candidates and serialise behind each other): the scans, not the per-query arithmetic, are the cost.
@@ -408,15 +426,15 @@ extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const f
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_nn_correspond: bad sizes B=%d H=%d W=%d", B, sensor->H, sensor->W);
   hipStream_t st = (hipStream_t)stream;
   const SensorK sen = make_sensor(sensor);
-  NNWorkspace ws = carve_nn(workspace);
-  (void)hipMemsetAsync(ws.counter, 0, 256, st);
-  if (visible) (void)hipMemsetAsync(visible, 0, sizeof(int32_t) * B, st);
+  if (B > 256) return dl_fail(DL_ERR_UNSUPPORTED, "dl_nn_correspond: at most 256 samples per launch (got %d)", B);
+  NNWorkspace ws = carve_nn(workspace, B);
+  (void)hipMemsetAsync(ws.counter, 0, nn_header_bytes(B), st);
   hipLaunchKernelGGL(k_nn_window, dim3((sen.HW + DL_BLOCK - 1) / DL_BLOCK, B), dim3(DL_BLOCK), 0, st,
                      src_image4, src_ss, src_normals, srcn_ss, (const float4*)tgt_packed, tgt_ss / 4,
                      (const float4*)tgt_normals_packed, tgtn_ss / 4, T, sen, need_without_normals, nn_pix, match, visible,
                      ws);
   hipLaunchKernelGGL(k_nn_hard, dim3(2048), dim3(DL_BLOCK), 0, st, (const float4*)tgt_packed, tgt_ss / 4,
-                     (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, ws);
+                     (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, visible, B, ws);
   return dl_check_launch("dl_nn_correspond");
 }
 
