@@ -26,6 +26,9 @@
 #define NN_RU 5
 #define NN_MARGIN 0.01f        // pixels: slack on the rounding of the stored points' (and our own) image coordinates
 #define NN_PI_F 3.14159265358979323846f
+#ifndef NN_PIXEL_ROUNDS
+#define NN_PIXEL_ROUNDS 0       // pass B: pixel-scanned boxes (4x16[, 8x40]) before the tile-culled walk of the bound window
+#endif
 #define NN_BATCH 1              // pass B: queries per wave and trip (one per lane for the per-query arithmetic)
 #define NN_UP (1.0f + 4e-6f)   // round-up factor for quantities that must not be under-estimated in fp32
 
@@ -37,23 +40,30 @@ struct NNHard {                // one record per query that pass A could not cer
   int32_t pad;
 };
 
+#define NN_TR 4                 // target tile: 4 rows x 16 columns = 64 pixels = one wave-wide load
+#define NN_TC 16
+
 struct NNWorkspace {
   int32_t* counter;            // counter[0] = number of hard queries
   NNHard* hard;                // [B*HW]
+  float4* tiles;               // [B][ceil(H/4)][ceil(W/16)] bounding sphere (cx,cy,cz,radius) of every target tile; radius < 0: empty
 };
 
 #define NN_VIS0 64             // counter[0]: number of hard queries; counter[NN_VIS0 + 32 b + k]: visible-pixel sub-counters
 static inline size_t nn_header_bytes(int B) { return (((size_t)(NN_VIS0 + 32 * B) * sizeof(int32_t)) + 255) / 256 * 256; }
 
-static inline NNWorkspace carve_nn(void* ws, int B) {
+static inline size_t nn_tiles(int H, int W) { return (size_t)((H + NN_TR - 1) / NN_TR) * ((W + NN_TC - 1) / NN_TC); }
+
+static inline NNWorkspace carve_nn(void* ws, int B, int H, int W) {
   NNWorkspace w;
   w.counter = (int32_t*)ws;
   w.hard = (NNHard*)((char*)ws + nn_header_bytes(B));
+  w.tiles = (float4*)((char*)w.hard + (size_t)B * H * W * sizeof(NNHard));
   return w;
 }
 
 extern "C" size_t dl_nn_workspace_bytes(int32_t B, int32_t H, int32_t W) {
-  return nn_header_bytes(B) + (size_t)B * H * W * sizeof(NNHard);
+  return nn_header_bytes(B) + (size_t)B * H * W * sizeof(NNHard) + (size_t)B * nn_tiles(H, W) * sizeof(float4);
 }
 
 // Angular description of a query in fp32.  The image is only a spatial index here: these values pick WHICH pixels
@@ -302,6 +312,114 @@ __device__ __forceinline__ int ring_offset(int c, int u0, int W) {
   return d;
 }
 
+__device__ __forceinline__ int nn_tiles_dev(int H, int W) { return ((H + NN_TR - 1) / NN_TR) * ((W + NN_TC - 1) / NN_TC); }
+
+__device__ __forceinline__ float wave_min_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, DL_WAVE));
+  return v;
+}
+__device__ __forceinline__ float wave_max_f(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, DL_WAVE));
+  return v;
+}
+
+// One wave per 4x16 target tile: bounding sphere of its occupied pixels (centre = middle of the bounding box, radius
+// rounded up).  A second level of the image-as-index: a tile whose sphere is farther from q than the best distance
+// cannot hold the neighbour, which turns the large windows of pass B from pixel scans into tile tests.
+__global__ __launch_bounds__(DL_BLOCK) void k_nn_tiles(const float4* __restrict__ tgt, int64_t tgt_ss4, int H, int W,
+                                                       int nb, float4* __restrict__ tiles) {
+  const int lane = threadIdx.x & (DL_WAVE - 1);
+  const int ntr = (H + NN_TR - 1) / NN_TR, ntc = (W + NN_TC - 1) / NN_TC;
+  const int t = (blockIdx.x * DL_BLOCK + threadIdx.x) / DL_WAVE;
+  if (t >= nb * ntr * ntc) return;
+  const int b = t / (ntr * ntc), r = t - b * ntr * ntc;
+  const int tr = r / ntc, tc = r - tr * ntc;
+  const int row = tr * NN_TR + lane / NN_TC, col = tc * NN_TC + lane % NN_TC;
+  float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (row < H && col < W) p = (tgt + (size_t)b * tgt_ss4)[row * W + col];
+  const bool occ = !(p.x == 0.f && p.y == 0.f && p.z == 0.f);
+  const float big = 3.0e38f;
+  const float xmin = wave_min_f(occ ? p.x : big), xmax = wave_max_f(occ ? p.x : -big);
+  const float ymin = wave_min_f(occ ? p.y : big), ymax = wave_max_f(occ ? p.y : -big);
+  const float zmin = wave_min_f(occ ? p.z : big), zmax = wave_max_f(occ ? p.z : -big);
+  float4 out = make_float4(0.f, 0.f, 0.f, -1.f);
+  if (xmax >= xmin) {
+    const float cx = 0.5f * (xmin + xmax), cy = 0.5f * (ymin + ymax), cz = 0.5f * (zmin + zmax);
+    const float dx = p.x - cx, dy = p.y - cy, dz = p.z - cz;
+    const float r2 = wave_max_f(occ ? fmaf(dz, dz, fmaf(dy, dy, dx * dx)) : 0.f);
+    out = make_float4(cx, cy, cz, sqrtf(r2) * (1.0f + 2e-6f) + 1e-7f);
+  }
+  if (lane == 0) tiles[t] = out;
+}
+
+// Final, exact stage of pass B for one query (wave-uniform arguments): the bound window is walked tile by tile; 64
+// tiles are tested per trip (one per lane: sphere distance against the best distance so far) and surviving tiles are
+// scanned one pixel per lane; the cull distance is refreshed once per trip.
+__device__ __forceinline__ void scan_tiles(const Window& w, const float4* __restrict__ tiles_b,
+                                           const float4* __restrict__ tp, int H, int W, float qx, float qy, float qz,
+                                           int lane, double& best, int& bidx) {
+  const int ntr = (H + NN_TR - 1) / NN_TR, ntc_all = (W + NN_TC - 1) / NN_TC;
+  if (w.r1 < w.r0 || w.nc <= 0) return;
+  const int tr0 = w.r0 / NN_TR, tr1 = w.r1 / NN_TR;
+  int tc0 = w.c0 / NN_TC, ntc = (w.c0 % NN_TC + w.nc + NN_TC - 1) / NN_TC;
+  if (w.nc >= W || ntc >= ntc_all || ((W % NN_TC) != 0 && w.c0 + w.nc > W)) { tc0 = 0; ntc = ntc_all; }
+  const int ntiles = (tr1 - tr0 + 1) * ntc;
+  double lbest = best;
+  int lidx = -1;
+  float thr = best < 1e30 ? (float)best * (1.0f + 1e-5f) : 3.0e38f;       // fp32 screen of squared distances
+  float dcur = best < 1e30 ? sqrtf((float)best) * (1.0f + 1e-6f) : 3.0e38f;   // wave-uniform cull distance
+  const float inv = 1.0f / (float)ntc;
+  (void)ntr;
+  for (int t0 = 0; t0 < ntiles; t0 += DL_WAVE) {
+    const int t = t0 + lane;
+    int tr = 0, tc = 0;
+    bool survive = false;
+    if (t < ntiles) {
+      int r = (int)(((float)t + 0.5f) * inv);
+      int c = t - r * ntc;
+      if (c < 0) { --r; c += ntc; } else if (c >= ntc) { ++r; c -= ntc; }
+      tr = tr0 + r;
+      tc = tc0 + c;
+      tc = tc >= ntc_all ? tc - ntc_all : tc;
+      const float4 s4 = tiles_b[tr * ntc_all + tc];
+      const float dx = qx - s4.x, dy = qy - s4.y, dz = qz - s4.z;
+      const float dist = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+      survive = s4.w >= 0.f && (dist - s4.w) <= dcur + 2e-6f * dist;
+    }
+    unsigned long long mask = __ballot(survive);
+    while (mask) {
+      const int i = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const int row = __builtin_amdgcn_readlane(tr, i) * NN_TR + lane / NN_TC;
+      const int col = __builtin_amdgcn_readlane(tc, i) * NN_TC + lane % NN_TC;
+      if (row < H && col < W) {
+        const int p = row * W + col;
+        const float4 c4 = tp[p];
+        const float dx = qx - c4.x, dy = qy - c4.y, dz = qz - c4.z;
+        const float d2f = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        if (!(c4.x == 0.f && c4.y == 0.f && c4.z == 0.f) && d2f <= thr) {
+          const double d2 = dist2(qx, qy, qz, c4.x, c4.y, c4.z);
+          if (d2 < lbest || (d2 == lbest && lidx >= 0 && p < lidx)) {
+            lbest = d2; lidx = p;
+            thr = (float)lbest * (1.0f + 1e-5f);
+          }
+        }
+      }
+    }
+    // refresh the cull distance from the lanes' bests (each lane's thr bounds its own best from above).  (Scanning the
+    // survivors best-first with a refresh after every tile was measured slower: two wave reductions per tile cost more
+    // than the tiles they save.)
+    const float tmin = wave_min_f(thr);
+    thr = fminf(thr, tmin * (1.0f + 1e-5f));
+    dcur = tmin < 3.0e38f ? sqrtf(tmin) * (1.0f + 1e-6f) : dcur;
+  }
+  if (lidx < 0) lbest = 1e300;
+  wave_argmin(lbest, lidx);
+  if (lidx >= 0 && (lbest < best || (lbest == best && (bidx < 0 || lidx < bidx)))) { best = lbest; bidx = lidx; }
+}
+
 __device__ __forceinline__ float bcast_f(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
@@ -316,9 +434,10 @@ __device__ __forceinline__ double bcast_d(double v, int src) {
 // Pass B: a wave takes NN_BATCH of the queries that pass A could not certify, ONE PER LANE for everything that is per-query
 // arithmetic (projection, bound windows, containment tests, the final gather and store), and scans the windows
 // cooperatively, one query at a time, with all 64 lanes striding over the candidates.  The bound window of a query's
-// current best distance is intersected with a box around its pixel that grows (4x16 -> 8x40 -> 16x96 -> whole image
-// half-sizes); after each scan the bound is recomputed from the improved distance, and a query is finished as soon as
-// its bound fits inside the box already covered.  Pixels of an earlier box that lay outside the then-valid bound cannot
+// current best distance is intersected with a box around its pixel that grows (4x16 -> 8x40 half-sizes, pixel scans);
+// after each scan the bound is recomputed from the improved distance, and a query is finished as soon as its bound fits
+// inside the box already covered; what is left after two boxes walks its whole bound window through the tile spheres
+// (scan_tiles), where most 64-pixel tiles are rejected by one distance test.  Pixels of an earlier box that lay outside the then-valid bound cannot
 // hold a closer point, so "covered" is simply the last box.  This keeps the examined candidates near the minimum any
 // exact search with this bound must look at (the window of the TRUE distance) even when pass A only saw far candidates.
 __global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float4* __restrict__ tgt, int64_t tgt_ss4,
@@ -357,7 +476,7 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float4* __restrict__
     bool covered_valid = (rintf(q.uq) - NN_RU >= 0.f) && (rintf(q.uq) + NN_RU <= (float)(W - 1));
     bool done = !live;
 #pragma unroll 1
-    for (int round = 0; round < 4; ++round) {
+    for (int round = 0; round < NN_PIXEL_ROUNDS + 1; ++round) {
       Window c;
       c.r0 = 0; c.r1 = -1; c.c0 = 0; c.nc = 0;
       if (!done) {
@@ -370,8 +489,8 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float4* __restrict__
         if (covered_valid && rows_in && cols_in) {
           done = true;
         } else {
-          if (round == 0) { box_r = 4; box_c = 16; } else if (round == 1) { box_r = 8; box_c = 40; }
-          else if (round == 2) { box_r = 16; box_c = 96; } else { box_r = H; box_c = W; }
+          if (round == NN_PIXEL_ROUNDS) { box_r = H; box_c = W; }    // last round: the whole bound window, tile-culled
+          else if (round == 0) { box_r = 4; box_c = 16; } else { box_r = 8; box_c = 40; }
           c.r0 = w.r0 > v0 - box_r ? w.r0 : v0 - box_r;
           c.r1 = w.r1 < v0 + box_r ? w.r1 : v0 + box_r;
           c.r0 = c.r0 < 0 ? 0 : c.r0;
@@ -393,7 +512,9 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float4* __restrict__
         const int bi = bcast_i(b, i);
         double sbest = bcast_d(best, i);
         int sidx = bcast_i(bidx, i);
-        scan_window(wi, tgt + (size_t)bi * tgt_ss4, HW, W, qx, qy, qz, lane, sbest, sidx);
+        if (round < NN_PIXEL_ROUNDS) scan_window(wi, tgt + (size_t)bi * tgt_ss4, HW, W, qx, qy, qz, lane, sbest, sidx);
+        else scan_tiles(wi, ws.tiles + (size_t)bi * nn_tiles_dev(H, W), tgt + (size_t)bi * tgt_ss4, H, W, qx, qy, qz, lane,
+                        sbest, sidx);
         if (lane == i) { best = sbest; bidx = sidx; }
       }
     }
@@ -427,8 +548,13 @@ extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const f
   hipStream_t st = (hipStream_t)stream;
   const SensorK sen = make_sensor(sensor);
   if (B > 256) return dl_fail(DL_ERR_UNSUPPORTED, "dl_nn_correspond: at most 256 samples per launch (got %d)", B);
-  NNWorkspace ws = carve_nn(workspace, B);
+  NNWorkspace ws = carve_nn(workspace, B, sen.H, sen.W);
   (void)hipMemsetAsync(ws.counter, 0, nn_header_bytes(B), st);
+  {
+    const int waves = (int)(B * nn_tiles(sen.H, sen.W));
+    hipLaunchKernelGGL(k_nn_tiles, dim3((waves * DL_WAVE + DL_BLOCK - 1) / DL_BLOCK), dim3(DL_BLOCK), 0, st,
+                       (const float4*)tgt_packed, tgt_ss / 4, sen.H, sen.W, B, ws.tiles);
+  }
   hipLaunchKernelGGL(k_nn_window, dim3((sen.HW + DL_BLOCK - 1) / DL_BLOCK, B), dim3(DL_BLOCK), 0, st,
                      src_image4, src_ss, src_normals, srcn_ss, (const float4*)tgt_packed, tgt_ss / 4,
                      (const float4*)tgt_normals_packed, tgtn_ss / 4, T, sen, need_without_normals, nn_pix, match, visible,

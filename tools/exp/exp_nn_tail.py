@@ -14,7 +14,7 @@ src, srcn, tpk, tnpk = prep["images"][:, 1], prep["normals"][:, 1], prep["packed
 B, H, W = 8, 64, 2048
 vp = lambda t: ctypes.c_void_p(t.data_ptr())
 st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-for extra in ([],):
+for extra in (["-DNN_PIXEL_ROUNDS=1"], ["-DNN_PIXEL_ROUNDS=2"], ["-DNN_PIXEL_ROUNDS=0"]):
     so = f"/tmp/nnt{len(extra)}{extra[0][-1] if extra else 0}.so"
     subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-ffp-contract=off", "--offload-arch=gfx950", *extra, "-shared", "-fPIC",
                     os.path.join(csrc, "abi.hip"), os.path.join(csrc, "nn.hip"), "-o", so], check=True)
