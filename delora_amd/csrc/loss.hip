@@ -247,6 +247,30 @@ __global__ __launch_bounds__(DL_BLOCK) void k_icp_loss(
   }
 }
 
+// Measurement aid: the same thirteen 16-byte load streams as k_icp_loss with the arithmetic replaced by one add per
+// value -- what the memory system delivers for this access pattern and transfer size (bench.py reports it beside the
+// loss kernel: a 54 MB cold read is far from the asymptotic copy rate).
+__global__ __launch_bounds__(DL_BLOCK) void k_probe_read(const float* __restrict__ src, int64_t src_ss,
+                                                         const float* __restrict__ srcn, int64_t srcn_ss,
+                                                         const float* __restrict__ match, int64_t match_ss,
+                                                         const int32_t* __restrict__ nn_pix, int HW,
+                                                         float* __restrict__ sink) {
+  constexpr int CHUNK = DL_WAVE * LOSS_PX;
+  const int b = blockIdx.y;
+  const int lane = threadIdx.x & (DL_WAVE - 1), wv = threadIdx.x / DL_WAVE;
+  const int waves = gridDim.x * (DL_BLOCK / DL_WAVE), gw = blockIdx.x * (DL_BLOCK / DL_WAVE) + wv;
+  const int nchunks = HW / CHUNK, q4 = HW / 4;
+  float acc = 0.f;
+  for (int c = gw; c < nchunks; c += waves) {
+    const StreamRegs r = load_stream(nn_pix + (size_t)b * HW, src + (size_t)b * src_ss, srcn + (size_t)b * srcn_ss,
+                                     match + (size_t)b * match_ss, q4, c * DL_WAVE + lane);
+    acc += (float)(r.j.x + r.j.w) + r.x.x + r.x.w + r.y.x + r.y.w + r.z.x + r.z.w + r.a.x + r.a.w + r.b.x + r.b.w + r.c.x +
+           r.c.w + r.tx.x + r.tx.w + r.ty.x + r.ty.w + r.tz.x + r.tz.w + r.ta.x + r.ta.w + r.tb.x + r.tb.w + r.tc.x + r.tc.w;
+  }
+  acc = wave_sum(acc);
+  if (lane == 0) sink[((size_t)b * gridDim.x + blockIdx.x) * (DL_BLOCK / DL_WAVE) + wv] = acc;
+}
+
 // Second (tiny) launch: one workgroup per sample sums that sample's partial rows in fp64, in a fixed order.
 __global__ __launch_bounds__(DL_BLOCK) void k_icp_reduce(const float* __restrict__ partials, int nrows, LossOut out) {
   __shared__ double tot[FIN_SLICES * ACC_PITCH];
@@ -291,6 +315,16 @@ extern "C" int dl_icp_loss_partial(const float* src_image4, int64_t src_ss, cons
   else DL_LAUNCH_LOSS(false, false);
 #undef DL_LAUNCH_LOSS
   return dl_check_launch("dl_icp_loss_partial");
+}
+
+extern "C" int dl_probe_stream_read(const float* src_image4, int64_t src_ss, const float* src_normals, int64_t srcn_ss,
+                                    const float* match, int64_t match_ss, const int32_t* nn_pix, int32_t B, int32_t H,
+                                    int32_t W, void* workspace, dl_stream stream) {
+  if (!src_image4 || !src_normals || !match || !nn_pix || !workspace || B <= 0 || H <= 0 || W <= 0 || (H * W) % 256)
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_probe_stream_read: bad argument (H*W must be a multiple of 256)");
+  hipLaunchKernelGGL(k_probe_read, dim3(loss_blocks(H * W), B), dim3(DL_BLOCK), 0, (hipStream_t)stream, src_image4, src_ss,
+                     src_normals, srcn_ss, match, match_ss, nn_pix, H * W, (float*)workspace);
+  return dl_check_launch("dl_probe_stream_read");
 }
 
 extern "C" int dl_icp_loss_reduce(const void* workspace, int32_t B, int32_t H, int32_t W, uint32_t flags,

@@ -218,3 +218,15 @@ def nn_bruteforce(src, tgt):
     _lib.check(lib.dl_nn_bruteforce(_ptr(src), max(Ms, 1), Ms, _ptr(tgt), max(Mt, 1), Mt, _ptr(nn), _stream()),
                "dl_nn_bruteforce")
     return nn
+
+
+def probe_stream_read(src_image4, src_normals, match, nn_pix):
+    """Launch the read-only twin of the loss kernel on the same operands (measurement aid, see dl_probe_stream_read)."""
+    lib = _lib.load()
+    s, s_ss = _planar(src_image4, 3)
+    sn, sn_ss = _planar(src_normals, 3)
+    mt, mt_ss = _planar(match, 6)
+    B, _, H, W = s.shape
+    ws = torch.empty((lib.dl_icp_loss_workspace_bytes(B, H, W) // 4,), dtype=torch.float32, device=s.device)
+    _lib.check(lib.dl_probe_stream_read(_ptr(s), s_ss, _ptr(sn), sn_ss, _ptr(mt), mt_ss, _ptr(nn_pix), B, H, W, _ptr(ws),
+                                        _stream()), "dl_probe_stream_read")

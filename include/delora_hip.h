@@ -158,6 +158,12 @@ int dl_icp_loss_partial(const float* src_image4, int64_t src_ss, const float* sr
 int dl_icp_loss_reduce(const void* workspace, int32_t B, int32_t H, int32_t W, uint32_t flags, float* loss_terms,
                        int32_t* pair_counts, float* grad_terms, dl_stream stream);
 
+/* Measurement aid: reads exactly the operand streams of dl_icp_loss_partial (same grid, same 16-byte loads) and does
+ * no arithmetic -- the time the memory system needs for this transfer.  workspace as for dl_icp_loss_fwd. */
+int dl_probe_stream_read(const float* src_image4, int64_t src_ss, const float* src_normals, int64_t srcn_ss,
+                         const float* match, int64_t match_ss, const int32_t* nn_pix, int32_t B, int32_t H, int32_t W,
+                         void* workspace, dl_stream stream);
+
 /*
  * Backward of dl_icp_loss_fwd: grad_T[b][:3,:4] = sum_k grad_loss_terms[b][k] * grad_terms[b][k]
  * (row 3 of grad_T is zero).  grad_T is [B][4][4].
