@@ -8,8 +8,8 @@ import sys
 _NAMES = ("deploy", "utility", "losses", "models", "preprocessing", "data")
 _SUBMODULES = {
     "deploy": ("deployer", "trainer", "tester", "step_geometry"), "utility": ("projection", "poses"), "losses": ("icp_losses",),
-    "models": ("model", "model_parts", "resnet_modified"), "preprocessing": ("normal_computation",),
-    "data": ("dataset", "synthetic", "feed"),
+    "models": ("model", "model_parts", "resnet_modified"), "preprocessing": ("normal_computation", "preprocesser"),
+    "data": ("dataset", "synthetic", "feed", "kitti_scans"),
 }
 
 for _name in _NAMES:

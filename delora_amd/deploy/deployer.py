@@ -93,20 +93,40 @@ class Deployer(object):
             # the reference indexes batch_size transforms against the list and fails on a short last batch
             # (deployer.py:240,290-292); make that explicit
             raise ValueError(f"step() needs exactly batch_size={self.batch_size} samples, got {B} (use drop_last)")
-        dataset = preprocessed_dicts[0]["dataset"]
-        sensor = self.img_projection.sensor(dataset)
         for i, d in enumerate(preprocessed_dicts):
-            if d["dataset"] != dataset and geometry.Sensor.from_config(cfg, d["dataset"]).key() != sensor.key():
-                raise ValueError("all samples of a batch must share one image geometry (reference: hyperparameters.yaml:3)")
             if self.training_bool:
                 d = self.augment_input(preprocessed_data=d)
             if cfg["normalization_scaling"]:
                 d, _ = self.normalize_input(preprocessed_data=d)
             preprocessed_dicts[i] = d
-        prepared = self.geo.prepare(preprocessed_dicts, sensor, self._normal_params(dataset))
-        translations, rotation_representation = self._run_model(prepared["stacked"])
-        computed_transformations = self.geometry_handler.get_transformation_matrix_quaternion(
-            translation=translations, quaternion=rotation_representation, device=self.device)
+        # Samples are grouped by image geometry (sensor rings / columns / fields of view).  The reference requires ONE
+        # geometry per batch (hyperparameters.yaml:3, deployer.py:240-243) -- then there is exactly one group and one launch
+        # per kernel.  A mixed-sensor batch (BASELINE config 5; no reference semantics) runs one sub-batch per geometry
+        # through projection / CNN / correspondences / loss and is re-assembled in sample order, so that every sample sees
+        # exactly what it would see in a batch of its own kind and the loss weights still follow the sample index.
+        groups = {}
+        for i, d in enumerate(preprocessed_dicts):
+            groups.setdefault(self.img_projection.sensor(d["dataset"]).key(), []).append(i)
+        flags = geometry.loss_flags(cfg)
+        T_rows, term_rows, count_rows, vis_rows = [None] * B, [None] * B, [None] * B, [None] * B
+        for idx in groups.values():
+            dataset = preprocessed_dicts[idx[0]]["dataset"]
+            sensor = self.img_projection.sensor(dataset)
+            prepared = self.geo.prepare([preprocessed_dicts[i] for i in idx], sensor, self._normal_params(dataset))
+            translations, rotation_representation = self._run_model(prepared["stacked"])
+            T_g = self.geometry_handler.get_transformation_matrix_quaternion(
+                translation=translations, quaternion=rotation_representation, device=self.device)
+            if not cfg["inference_only"]:
+                terms_g, counts_g, vis_g = self.geo.losses(T_g, prepared, flags,
+                                                           need_without_normals=bool(cfg["point_to_point_loss"]))
+            for k, i in enumerate(idx):
+                T_rows[i] = T_g[k]
+                if not cfg["inference_only"]:
+                    term_rows[i] = terms_g[k]
+                    count_rows[i] = counts_g[k] if counts_g is not None else None
+                    vis_rows[i] = vis_g[k] if vis_g is not None else None
+        single = len(groups) == 1
+        computed_transformations = T_g if single else torch.stack(T_rows)
 
         def rescale(T):
             if cfg["normalization_scaling"]:
@@ -118,9 +138,9 @@ class Deployer(object):
         if cfg["inference_only"]:
             return rescale(computed_transformations)
 
-        flags = geometry.loss_flags(cfg)
-        terms, counts, visible = self.geo.losses(computed_transformations, prepared, flags,
-                                                 need_without_normals=bool(cfg["point_to_point_loss"]))
+        terms = terms_g if single else torch.stack(term_rows)
+        counts = counts_g if single else (torch.stack(count_rows) if count_rows[0] is not None else None)
+        visible = vis_g if single else (torch.stack(vis_rows) if vis_rows[0] is not None else None)
         # global batch bookkeeping: this rank holds samples [rank*B, (rank+1)*B) of a batch of world_size*B
         Bg = B * self.world_size
         j_global = torch.arange(B, device=terms.device, dtype=terms.dtype) + float(self.rank * B)

@@ -357,3 +357,49 @@ def test_graphed_step_equals_eager_step():
     assert np.allclose(got, eager[3:6], rtol=1e-3), (got, eager)
     for (k, a), (_, b) in zip(tr_g.raw_model.state_dict().items(), tr_e.raw_model.state_dict().items()):
         assert torch.allclose(a, b, rtol=1e-2, atol=2e-4), k
+
+
+def test_mixed_sensor_batch_on_gpu():
+    """Mixed kitti 16x128 / darpa 16x96 batch through the HIP path == the two samples run on their own."""
+    from tests.test_host_logic import _mixed_setup, _terms_of
+    _dev()
+    cfg, sd, samples = _mixed_setup("cuda:0")
+    terms, T, losses = _terms_of(cfg, sd, samples, None, device="cuda:0")
+    for j, smp in enumerate(samples):
+        t1, T1, _ = _terms_of(cfg, sd, [smp], None, device="cuda:0")
+        assert torch.allclose(terms[j], t1[0], rtol=1e-5, atol=1e-7) and torch.allclose(T[j], T1[0], atol=1e-6)
+    assert np.isfinite(float(losses["loss_pc"]))
+
+
+def test_offline_preprocessing_writes_the_training_format(tmp_path):
+    """Raw KITTI .bin scans -> Preprocesser (dl_project + dl_normals) -> scans/normals npy lists that (i) match the oracle's
+    projection + normals of the same scan and (ii) load through PreprocessedPointCloudDataset."""
+    from delora_amd.data import synthetic
+    from delora_amd.data.dataset import PreprocessedPointCloudDataset
+    from delora_amd.preprocessing.preprocesser import Preprocesser
+    _dev()
+    cfg = util.repo_config(16, 128, device="cuda:0")
+    cfg["kitti"].update(horizontal_cells_preprocessing=160, data_path=str(tmp_path / "raw"), preprocessed_path=str(tmp_path / "pre"),
+                        data_identifiers=[4])
+    os.makedirs(tmp_path / "raw" / "04" / "velodyne")
+    scans = [synthetic.make_pair(900 + i, rings=16, azimuth_steps=200)[0] for i in range(3)]
+    for i, sc in enumerate(scans):
+        np.concatenate([sc.T, np.ones((sc.shape[1], 1), np.float32)], axis=1).astype(np.float32).tofile(
+            str(tmp_path / "raw" / "04" / "velodyne" / f"{i:06d}.bin"))
+    Preprocesser(cfg).preprocess_data()
+    assert cfg["kitti"]["horizontal_cells"] == 160
+    o_sensor = util.oracle_sensor(16, 160, cfg["kitti"]["vertical_field_of_view"], cfg["horizontal_field_of_view"])
+    for i, sc in enumerate(scans):
+        pts = np.load(str(tmp_path / "pre" / "04" / "scans" / f"{i:06d}.npy"))
+        nrm = np.load(str(tmp_path / "pre" / "04" / "normals" / f"{i:06d}.npy"))
+        img, _, _, _, _ = orc.project_to_img(torch.from_numpy(sc).view(1, 3, -1), o_sensor)
+        on, oh, op = orc.compute_normal_vectors(img.clone(), o_sensor)
+        if util.ambiguity_mask(sc, o_sensor).sum() == 0 or pts.shape == tuple(op.shape):
+            assert pts.shape == tuple(op.shape) and np.array_equal(pts, op.numpy())
+            both = (np.abs(nrm).sum(1) > 0) & oh.numpy()
+            a, b = nrm[both].astype(np.float64), on.numpy()[both].astype(np.float64)
+            ang = np.arctan2(np.linalg.norm(np.cross(a, b), axis=1), np.sum(a * b, axis=1))
+            assert np.median(ang) < 1e-5 and np.mean(ang > 5e-3) < 5e-3
+    cfg["kitti"]["horizontal_cells"] = 128
+    ds = PreprocessedPointCloudDataset(cfg)
+    assert len(ds) == 2 and ds[0]["scan_1"].shape[1] == 3 and ds[0]["normal_list_2"].shape == ds[0]["scan_2"].shape

@@ -270,3 +270,44 @@ def test_prefetcher_passes_batches_through_on_cpu():
     got = list(DevicePrefetcher(batches, torch.device("cpu")))
     assert len(got) == 4 and all(float(b[0]["a"][0]) == i for i, b in enumerate(got))
     assert list(DevicePrefetcher([], torch.device("cpu"))) == []
+
+
+def _mixed_setup(device):
+    """Two samples from different sensor blocks: kitti 16x128 (vFoV -24.5..2) and darpa 16x96 (vFoV +-22.5)."""
+    from delora_amd.data import synthetic
+    g = util.load_golden("step_b2")
+    cfg, sd = _small_cfg(16, 128, 2)
+    cfg["device"] = torch.device(device)
+    cfg["datasets"] = ["kitti", "darpa"]
+    cfg["darpa"]["vertical_cells"], cfg["darpa"]["horizontal_cells"] = 16, 96
+    cfg["darpa"]["vertical_field_of_view"] = [-22.5 * np.pi / 180.0, 22.5 * np.pi / 180.0]
+    s_k = _samples(g, 1)[0]
+    d1, d2, _ = synthetic.make_pair(5150, rings=16, azimuth_steps=120, vfov_deg=(-22.5, 22.5))
+    s_d = {"scan_1": torch.from_numpy(d1).unsqueeze(0), "scan_2": torch.from_numpy(d2).unsqueeze(0),
+           "normal_list_1": None, "normal_list_2": None, "dataset": "darpa"}
+    return cfg, sd, [s_k, s_d]
+
+
+def _terms_of(cfg, sd, samples, backend, device="cpu"):
+    from delora_amd.deploy.deployer import Deployer
+    import copy
+    c = copy.deepcopy(cfg)
+    c["batch_size"] = len(samples)
+    dep = Deployer(c, dataset=util.ListDataset([]), geometry_backend=backend)
+    dep.model.load_state_dict({k: v.to(device) for k, v in sd.items()})
+    batch = [{k: (v.to(device) if torch.is_tensor(v) else v) for k, v in s.items()} for s in samples]
+    with torch.no_grad():
+        ep, T = dep.step(preprocessed_dicts=batch, epoch_losses=None)
+    return dep.last_step["loss_terms"].cpu(), T.cpu(), dep.last_step["losses"]
+
+
+def test_mixed_sensor_batch_equals_per_sample_results():
+    """BASELINE config 5 semantics: a batch mixing two image geometries gives every sample exactly the result it has in a
+    batch of its own (sub-batch per geometry), and loss_pc uses the (B-j)/B weights over the sample order."""
+    cfg, sd, samples = _mixed_setup("cpu")
+    terms, T, losses = _terms_of(cfg, sd, samples, util.OracleStepGeometry())
+    for j, smp in enumerate(samples):
+        t1, T1, _ = _terms_of(cfg, sd, [smp], util.OracleStepGeometry())
+        assert torch.allclose(terms[j], t1[0], rtol=1e-6, atol=1e-8) and torch.allclose(T[j], T1[0], atol=1e-7)
+    c = terms[:, 0] + cfg["lambda_po2pl"] * terms[:, 1] + terms[:, 2]
+    assert np.isclose(float(losses["loss_pc"]), float((2 * c[0] + 1 * c[1]) / 2), rtol=1e-6)
