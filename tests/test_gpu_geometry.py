@@ -479,3 +479,30 @@ def test_full_geometry_path_128_rings_2048_columns():
     got = nn[0].reshape(-1).cpu().long()[spix[aux["src_index_with_normals"]]]
     exp = tpix[aux["nn_with_normals"]]
     assert (got != exp).sum() <= 1e-4 * len(exp) + 2
+
+
+def test_projection_random_small_clouds_with_duplicates_and_border_points():
+    """20 random clouds (0..400 points, duplicated points = exact range+pixel ties, points just outside the vertical FoV)
+    projected in ONE ragged batch; every scan obeys the projection contract."""
+    from tests.test_oracle_properties import SENSOR, _cloud
+    sensor = gpu_sensor(SENSOR.H, SENSOR.W, SENSOR.vfov, SENSOR.hfov)
+    rng = np.random.default_rng(0)
+    scans = [_cloud(int(rng.integers(0, 400)), int(rng.integers(0, 10_000))) for _ in range(20)]
+    out = run_project(scans, sensor, want_uv=False)
+    for s, scan in enumerate(scans):
+        check_projection(scan, out, s, SENSOR)
+
+
+def test_normals_known_answer_plane():
+    """Wall x = 10 m: all normals are (-1,0,0), i.e. they face the sensor (viewpoint flip, normal_computation.py:78-81)."""
+    G, dev = _geo(), _dev()
+    vf, hf = util.kitti_fov()
+    vv, uu = np.meshgrid(np.arange(16), np.arange(64), indexing="ij")
+    el = vf[0] + vv / 15.0 * (vf[1] - vf[0])
+    az = -0.6 + uu / 63.0 * 1.2
+    d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)])
+    img = torch.zeros(1, 4, 16, 64, device=dev)
+    img[0, :3] = torch.from_numpy((d * (10.0 / d[0])).astype(np.float32)).to(dev)
+    n = G.normals(img)[0].cpu().numpy().reshape(3, -1).T
+    has = np.abs(n).sum(1) > 0
+    assert has.mean() > 0.9 and np.allclose(n[has], [-1.0, 0.0, 0.0], atol=2e-3)
