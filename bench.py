@@ -259,12 +259,12 @@ def main():
         graphed = GraphedStep(trainer, batch)
         if graphed.captured:
             run_step = lambda timed: graphed()[0]            # noqa: E731
-    # in-situ HIP events immediately before and after the launch of the streaming loss kernel (k_icp_loss) of every
-    # timed step, recorded on the stream the kernel is launched on (geometry.PARTIAL_HOOK)
+    # in-situ timing of the streaming loss kernel (k_icp_loss) in every timed step: the launch carries a pair of HIP
+    # events that receive the kernel's own begin/end timestamps (dl_icp_loss_partial_timed) on the launch stream
     from delora_amd import geometry as G
-    marks = []
-    if graphed is None or not graphed.captured:            # events cannot be recorded inside a replayed graph
-        G.PARTIAL_HOOK = lambda: (marks.append(torch.cuda.Event(enable_timing=True)), marks[-1].record())
+    timers = G.LossTimers()
+    if graphed is None or not graphed.captured:            # event-carrying launches cannot be captured into a graph
+        G.LOSS_TIMER_FACTORY = timers.new
     torch.cuda.synchronize()
     if world > 1:
         torch.distributed.barrier()
@@ -275,7 +275,7 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     elapsed = time.perf_counter() - t0
-    G.PARTIAL_HOOK = None
+    G.LOSS_TIMER_FACTORY = None
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -295,14 +295,15 @@ def main():
     }
     if rank == 0:
         rows, counts = kernel_table(trainer, batch, args.kernel_reps)
-        if not marks:                                          # graph mode: measure the same launch right after the timed region
-            G.PARTIAL_HOOK = lambda: (marks.append(torch.cuda.Event(enable_timing=True)), marks[-1].record())
+        if not timers.handles:                                 # graph mode: measure the same launch right after the timed region
+            G.LOSS_TIMER_FACTORY = timers.new
             for _ in range(5):
                 trainer.optimizer.zero_grad(set_to_none=True)
                 trainer.step(preprocessed_dicts=[dict(s) for s in batch], epoch_losses=trainer.new_epoch_losses())
             torch.cuda.synchronize()
-            G.PARTIAL_HOOK = None
-        loss_ms = float(np.mean([marks[i].elapsed_time(marks[i + 1]) for i in range(0, len(marks) - 1, 2)]))
+            G.LOSS_TIMER_FACTORY = None
+        loss_ms = float(np.mean(timers.elapsed_ms()))
+        timers.close()
         # in-situ measurement uses the poses the network actually predicted in the timed steps
         last = trainer.last_step
         K_live = int(last["pair_counts"][:, 0].sum())
@@ -313,7 +314,7 @@ def main():
                               "frac": round(live_bytes / loss_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("k_icp_loss"),
                               "ms_per_launch_in_step": round(loss_ms, 5), "ms_per_launch_back_to_back": alg["ms"],
                               "algorithmic_bytes": live_bytes,
-                              "note": "HIP events on the launch stream around the kernel launch in each of the K timed steps; 52 B x source points with a correspondence"}
+                              "note": "kernel begin/end timestamps on HIP events attached to the launch (hipExtLaunchKernelGGL) in each of the K timed steps; 52 B x source points with a correspondence"}
         result["kernels"] = rows
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, cfg)

@@ -140,9 +140,37 @@ def nn_correspond(src_image4, src_normals, tgt_packed, tgt_normals_packed, T, se
     return nn, vis, match
 
 
-# bench.py sets this to a callable that records a HIP event on the current stream: it is invoked immediately before
-# and after the launch of the streaming loss kernel, so that its duration can be measured inside real training steps
-PARTIAL_HOOK = None
+# bench.py sets this to a callable returning a fresh timer handle (LossTimers.new): the streaming loss kernel of every
+# training step is then launched with its own begin/end timestamps attached, so that its duration can be measured
+# inside real steps (dl_icp_loss_partial_timed)
+LOSS_TIMER_FACTORY = None
+
+
+class LossTimers:
+    """A pool of dl_timer handles; ``new()`` hands one to each launch, ``elapsed_ms()`` reads them all back."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self.handles = []
+
+    def new(self):
+        h = ctypes.c_void_p()
+        _lib.check(self.lib.dl_timer_create(ctypes.byref(h)), "dl_timer_create")
+        self.handles.append(h)
+        return h
+
+    def elapsed_ms(self):
+        out = []
+        for h in self.handles:
+            ms = ctypes.c_float()
+            _lib.check(self.lib.dl_timer_elapsed_ms(h, ctypes.byref(ms)), "dl_timer_elapsed_ms")
+            out.append(ms.value)
+        return out
+
+    def close(self):
+        for h in self.handles:
+            self.lib.dl_timer_destroy(h)
+        self.handles = []
 
 
 class _IcpLoss(torch.autograd.Function):
@@ -162,12 +190,9 @@ class _IcpLoss(torch.autograd.Function):
         counts = torch.empty((B, 2), dtype=torch.int32, device=dev)
         grad_terms = torch.empty((B, 3, 12), dtype=torch.float32, device=dev)
         ws = torch.empty((lib.dl_icp_loss_workspace_bytes(B, H, W) // 4,), dtype=torch.float32, device=dev)
-        if PARTIAL_HOOK is not None:
-            PARTIAL_HOOK()
-        _lib.check(lib.dl_icp_loss_partial(_ptr(s), s_ss, _ptr(sn), sn_ss, _ptr(mt), mt_ss, _ptr(nn_pix),
-                                           _ptr(Tc), B, H, W, int(flags), _ptr(ws), _stream()), "dl_icp_loss_partial")
-        if PARTIAL_HOOK is not None:
-            PARTIAL_HOOK()
+        timer = LOSS_TIMER_FACTORY() if LOSS_TIMER_FACTORY is not None else None
+        _lib.check(lib.dl_icp_loss_partial_timed(_ptr(s), s_ss, _ptr(sn), sn_ss, _ptr(mt), mt_ss, _ptr(nn_pix), _ptr(Tc),
+                                                 B, H, W, int(flags), _ptr(ws), timer, _stream()), "dl_icp_loss_partial")
         _lib.check(lib.dl_icp_loss_reduce(_ptr(ws), B, H, W, int(flags), _ptr(loss_terms), _ptr(counts),
                                           _ptr(grad_terms), _stream()), "dl_icp_loss_reduce")
         ctx.save_for_backward(grad_terms)

@@ -158,6 +158,16 @@ int dl_icp_loss_partial(const float* src_image4, int64_t src_ss, const float* sr
 int dl_icp_loss_reduce(const void* workspace, int32_t B, int32_t H, int32_t W, uint32_t flags, float* loss_terms,
                        int32_t* pair_counts, float* grad_terms, dl_stream stream);
 
+/* Measurement aid: dl_icp_loss_partial with the kernel's own begin/end timestamps attached to a timer (two HIP events
+ * filled by hipExtLaunchKernelGGL), so that its duration can be read inside real training steps; timer may be NULL.
+ * dl_timer_elapsed_ms waits for the kernel to finish.  Not graph-capturable when a timer is given. */
+int dl_timer_create(void** timer);
+int dl_timer_destroy(void* timer);
+int dl_timer_elapsed_ms(void* timer, float* ms);
+int dl_icp_loss_partial_timed(const float* src_image4, int64_t src_ss, const float* src_normals, int64_t srcn_ss,
+                              const float* match, int64_t match_ss, const int32_t* nn_pix, const float* T, int32_t B,
+                              int32_t H, int32_t W, uint32_t flags, void* workspace, void* timer, dl_stream stream);
+
 /* Measurement aid: reads exactly the operand streams of dl_icp_loss_partial (same grid, same 16-byte loads) and does
  * no arithmetic -- the time the memory system needs for this transfer.  workspace as for dl_icp_loss_fwd. */
 int dl_probe_stream_read(const float* src_image4, int64_t src_ss, const float* src_normals, int64_t srcn_ss,
