@@ -41,6 +41,8 @@ SIGNATURES = {
     "dl_icp_loss_partial": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp, _i32, _i32, _i32, _u32, _vp, _vp]),
     "dl_icp_loss_reduce": (_i32, [_vp, _i32, _i32, _i32, _u32, _vp, _vp, _vp, _vp]),
     "dl_icp_loss_bwd": (_i32, [_vp, _vp, _i32, _vp, _vp]),
+    "dl_ring_act_pool_pad_fwd": (_i32, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "dl_ring_act_pool_pad_bwd": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "dl_timer_create": (_i32, [ctypes.POINTER(ctypes.c_void_p)]),
     "dl_timer_destroy": (_i32, [_vp]),
     "dl_timer_elapsed_ms": (_i32, [_vp, ctypes.POINTER(ctypes.c_float)]),

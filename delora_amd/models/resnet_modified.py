@@ -5,11 +5,12 @@ Same topology and parameter names as the reference so that its checkpoints load 
 tanh (or relu) activations, every 3x3 convolution sees one wrapped column on each side of W and one zero row on
 each side of H, strides (1,2) in the stem/pool/layer2/layer3 and (2,2) in layer4.  Activations travel between
 convolutions in wrapped form: activation (+ residual add) and the wrap-around padding are ONE fused HIP elementwise
-op (``ring_ops.ring_act_pad``) instead of the reference's separate tanh, add and three-copy F.pad per layer.
+op (``ring_ops.ring_act_pad``) instead of the reference's separate tanh, add and three-copy F.pad per layer; the stem's
+activation + padding + max-pooling + padding is one more (``ring_ops.ring_act_pool_pad``).
 """
 import torch
 
-from .ring_ops import ring_act_pad
+from .ring_ops import ring_act_pad, ring_act_pool_pad
 
 
 class RingConv2d(torch.nn.Conv2d):
@@ -86,8 +87,7 @@ class ResNetModified(torch.nn.Module):
     def forward(self, x):
         act = "relu" if self.activation_fct == "relu" else "tanh"
         p = ring_act_pad(self.dropout_values(x), "none", pad=True)
-        p = ring_act_pad(self.conv1(p), act, pad=True)
-        p = ring_act_pad(self.maxpool(p), "none", pad=True)
+        p = ring_act_pool_pad(self.conv1(p), act)                    # act + wrap + self.maxpool + wrap, fused
         p1 = self.layer1(p)
         p2 = self.layer2(p1)
         p3 = self.dropout_channels(self.layer3(p2))

@@ -66,6 +66,44 @@ class _RingActPad(torch.autograd.Function):
         return grad_x, grad_res, None, None
 
 
+class _RingActPoolPad(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        lib = _lib.load()
+        x = x.contiguous()
+        N, C, H, W = x.shape
+        Wo = (W - 1) // 2 + 1
+        out = torch.empty((N, C, H, Wo + 2), dtype=x.dtype, device=x.device)
+        win = torch.empty((N, C, H, Wo), dtype=torch.int8, device=x.device)
+        _lib.check(lib.dl_ring_act_pool_pad_fwd(_ptr(x), N * C, H, W, act, _ptr(out), _ptr(win), _stream()),
+                   "dl_ring_act_pool_pad_fwd")
+        ctx.save_for_backward(out, win)
+        ctx.meta = (N, C, H, W, act)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        lib = _lib.load()
+        y, win = ctx.saved_tensors
+        N, C, H, W, act = ctx.meta
+        grad_out = grad_out.contiguous()
+        grad_x = torch.empty((N, C, H, W), dtype=y.dtype, device=y.device)
+        _lib.check(lib.dl_ring_act_pool_pad_bwd(_ptr(grad_out), _ptr(y), _ptr(win), N * C, H, W, act, _ptr(grad_x),
+                                                _stream()), "dl_ring_act_pool_pad_bwd")
+        return grad_x, None
+
+
+def ring_act_pool_pad(x, act="tanh"):
+    """Stem of the pose CNN: ``act``, wrap-around padding, ``MaxPool2d(3, stride=(1,2), padding=(1,0))`` and the
+    wrap-around padding of the pooled map (reference resnet_modified.py:100-102 + the F.pad of the next convolution) --
+    one HIP kernel each way on CUDA fp32 tensors, the separate torch ops otherwise."""
+    if x.is_cuda and x.dtype == torch.float32:
+        return _RingActPoolPad.apply(x, ACT[act])
+    v = torch.tanh(x) if act == "tanh" else (torch.relu(x) if act == "relu" else x)
+    v = F.max_pool2d(F.pad(v, (1, 1, 0, 0), mode="circular"), kernel_size=3, stride=(1, 2), padding=(1, 0))
+    return F.pad(v, (1, 1, 0, 0), mode="circular")
+
+
 def ring_act_pad(x, act="none", pad=True, residual=None):
     """``act(x + residual)`` with one wrapped column added on each side of W (``pad=False``: unpadded).  ``residual`` is
     either dense ``[N,C,H,W]`` or a padded ``[N,C,H,W+2]`` tensor whose interior is the residual."""

@@ -205,6 +205,17 @@ int dl_ring_act_pad_fwd(const float* x, const float* res, int64_t res_pitch, int
 int dl_ring_act_pad_bwd(const float* grad_out, const float* y, int64_t rows, int32_t W, int32_t pad, int32_t act,
                         float* grad_x, float* grad_res_padded, dl_stream stream);
 
+/* Stem of the pose CNN in one pass: activation, wrap-around padding, 3x3 max-pooling with stride (1,2) and H padding 1
+ * (torch.nn.MaxPool2d arg-max rule), wrap-around padding of the pooled map.  Replaces reference
+ * src/models/resnet_modified.py:100-102 (act, F.pad circular, self.maxpool) and the F.pad of the next convolution.
+ *   x [planes][H][W] dense, planes = N*C;  out [planes][H][Wo+2], Wo = (W-1)/2 + 1;  win [planes][H][Wo] int8: position
+ *   0..8 of each maximum inside its window (saved for the backward).  act as in dl_ring_act_pad_fwd. */
+int dl_ring_act_pool_pad_fwd(const float* x, int64_t planes, int32_t H, int32_t W, int32_t act, float* out, int8_t* win,
+                             dl_stream stream);
+/* grad_out, y [planes][H][Wo+2] (y = forward output); grad_x [planes][H][W] = dL/dx. */
+int dl_ring_act_pool_pad_bwd(const float* grad_out, const float* y, const int8_t* win, int64_t planes, int32_t H,
+                             int32_t W, int32_t act, float* grad_x, dl_stream stream);
+
 #ifdef __cplusplus
 }
 #endif
