@@ -55,57 +55,82 @@ struct LossOut {
   uint32_t flags;
 };
 
-// One matched pair, branch-free: `w` (0 or 1) masks pairs that do not count, so that the loads of several
-// pixels can be issued before any of them is consumed.
+// Packed fp32: the kernel is bound by VALU issue once its operands sit in the infinity cache (which they do right after
+// the correspondence search), so two pixels travel through every arithmetic instruction (v_pk_fma_f32 / v_pk_mul_f32 /
+// v_pk_add_f32 on the register pairs the 16-byte loads deliver) and the accumulators hold even/odd-pixel partial sums.
+typedef float f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 fma2(float a, f2 b, f2 c) { return __builtin_elementwise_fma((f2){a, a}, b, c); }
+__device__ __forceinline__ f2 mul2(float a, f2 b) { return (f2){a, a} * b; }
+
+// Two matched pairs, branch-free: `w` (0 or 1 per pixel) masks pairs that do not count, so that the loads of several
+// pixels can be issued before any of them is consumed.  Per pixel the arithmetic is the same sequence of fp32
+// operations as the scalar form of the formulas above.
 template <bool P2P, bool LINEAR, int NA>
-__device__ __forceinline__ void accumulate_pair(float (&acc)[NA], const float (&m)[12], bool valid, float x, float y,
-                                                float z, float nx, float ny, float nz, float tx, float ty, float tz,
-                                                float tnx, float tny, float tnz) {
-  const bool has_s = (nx != 0.f) || (ny != 0.f) || (nz != 0.f);               // icp_losses.py:48-50
-  const bool has_t = (tnx != 0.f) || (tny != 0.f) || (tnz != 0.f);            // :51-52
-  const float w = (valid && has_s && has_t) ? 1.f : 0.f;                       // :110-121
-  const float qx = (fmaf(m[2], z, fmaf(m[1], y, (m[0] * x))) + m[3]);
-  const float qy = (fmaf(m[6], z, fmaf(m[5], y, (m[4] * x))) + m[7]);
-  const float qz = (fmaf(m[10], z, fmaf(m[9], y, (m[8] * x))) + m[11]);
-  const float dx = qx - tx, dy = qy - ty, dz = qz - tz;
+__device__ __forceinline__ void accumulate_pair2(f2 (&acc)[NA], const float (&m)[12], bool valid0, bool valid1, f2 x,
+                                                 f2 y, f2 z, f2 nx, f2 ny, f2 nz, f2 tx, f2 ty, f2 tz, f2 tnx, f2 tny,
+                                                 f2 tnz) {
+  const bool hs0 = (nx.x != 0.f) || (ny.x != 0.f) || (nz.x != 0.f);           // icp_losses.py:48-50
+  const bool hs1 = (nx.y != 0.f) || (ny.y != 0.f) || (nz.y != 0.f);
+  const bool ht0 = (tnx.x != 0.f) || (tny.x != 0.f) || (tnz.x != 0.f);        // :51-52
+  const bool ht1 = (tnx.y != 0.f) || (tny.y != 0.f) || (tnz.y != 0.f);
+  const f2 w = {(valid0 && hs0 && ht0) ? 1.f : 0.f, (valid1 && hs1 && ht1) ? 1.f : 0.f};   // :110-121
+  const f2 qx = fma2(m[2], z, fma2(m[1], y, mul2(m[0], x))) + m[3];
+  const f2 qy = fma2(m[6], z, fma2(m[5], y, mul2(m[4], x))) + m[7];
+  const f2 qz = fma2(m[10], z, fma2(m[9], y, mul2(m[8], x))) + m[11];
+  const f2 dx = qx - tx, dy = qy - ty, dz = qz - tz;
   {
     // point-to-plane (:196-203)
-    const float r = w * fmaf(dz, tnz, fmaf(dy, tny, dx * tnx));
-    acc[0] = fmaf(r, r, acc[0]);
-    const float gx = r * tnx, gy = r * tny, gz = r * tnz;
+    const f2 r = w * fma2(dz, tnz, fma2(dy, tny, dx * tnx));
+    acc[0] = fma2(r, r, acc[0]);
+    const f2 gx = r * tnx, gy = r * tny, gz = r * tnz;
     acc[1] += gx; acc[2] += gy; acc[3] += gz;
-    acc[4] = fmaf(gx, x, acc[4]); acc[5] = fmaf(gx, y, acc[5]); acc[6] = fmaf(gx, z, acc[6]);
-    acc[7] = fmaf(gy, x, acc[7]); acc[8] = fmaf(gy, y, acc[8]); acc[9] = fmaf(gy, z, acc[9]);
-    acc[10] = fmaf(gz, x, acc[10]); acc[11] = fmaf(gz, y, acc[11]); acc[12] = fmaf(gz, z, acc[12]);
+    acc[4] = fma2(gx, x, acc[4]); acc[5] = fma2(gx, y, acc[5]); acc[6] = fma2(gx, z, acc[6]);
+    acc[7] = fma2(gy, x, acc[7]); acc[8] = fma2(gy, y, acc[8]); acc[9] = fma2(gy, z, acc[9]);
+    acc[10] = fma2(gz, x, acc[10]); acc[11] = fma2(gz, y, acc[11]); acc[12] = fma2(gz, z, acc[12]);
     // plane-to-plane (:224-238) on the rotated source normal (deployer.py:297-299)
-    const float rx = fmaf(m[2], nz, fmaf(m[1], ny, m[0] * nx));
-    const float ry = fmaf(m[6], nz, fmaf(m[5], ny, m[4] * nx));
-    const float rz = fmaf(m[10], nz, fmaf(m[9], ny, m[8] * nx));
-    float ex, ey, ez;
+    const f2 rx = fma2(m[2], nz, fma2(m[1], ny, mul2(m[0], nx)));
+    const f2 ry = fma2(m[6], nz, fma2(m[5], ny, mul2(m[4], nx)));
+    const f2 rz = fma2(m[10], nz, fma2(m[9], ny, mul2(m[8], nx)));
+    f2 ex, ey, ez;
     if (LINEAR) {
-      const float c1 = w * (1.f - fmaf(rz, tnz, fmaf(ry, tny, rx * tnx)));
-      acc[13] = fmaf(c1, c1, acc[13]);
+      const f2 c1 = w * (1.f - fma2(rz, tnz, fma2(ry, tny, rx * tnx)));
+      acc[13] = fma2(c1, c1, acc[13]);
       ex = -c1 * tnx; ey = -c1 * tny; ez = -c1 * tnz;
     } else {
       ex = w * (rx - tnx); ey = w * (ry - tny); ez = w * (rz - tnz);
-      acc[13] += fmaf(ez, ez, fmaf(ey, ey, ex * ex));
+      acc[13] += fma2(ez, ez, fma2(ey, ey, ex * ex));
     }
-    acc[14] = fmaf(ex, nx, acc[14]); acc[15] = fmaf(ex, ny, acc[15]); acc[16] = fmaf(ex, nz, acc[16]);
-    acc[17] = fmaf(ey, nx, acc[17]); acc[18] = fmaf(ey, ny, acc[18]); acc[19] = fmaf(ey, nz, acc[19]);
-    acc[20] = fmaf(ez, nx, acc[20]); acc[21] = fmaf(ez, ny, acc[21]); acc[22] = fmaf(ez, nz, acc[22]);
+    acc[14] = fma2(ex, nx, acc[14]); acc[15] = fma2(ex, ny, acc[15]); acc[16] = fma2(ex, nz, acc[16]);
+    acc[17] = fma2(ey, nx, acc[17]); acc[18] = fma2(ey, ny, acc[18]); acc[19] = fma2(ey, nz, acc[19]);
+    acc[20] = fma2(ez, nx, acc[20]); acc[21] = fma2(ez, ny, acc[21]); acc[22] = fma2(ez, nz, acc[22]);
     acc[23] += w;
   }
   if (P2P) {
     // point-to-point on pairs without normals on either side (:85-100, :168-172)
-    const float w2 = (valid && !has_s && !has_t) ? 1.f : 0.f;
-    const float ux = w2 * dx, uy = w2 * dy, uz = w2 * dz;
-    acc[ACC_N + 0] += fmaf(uz, uz, fmaf(uy, uy, ux * ux));
+    const f2 w2 = {(valid0 && !hs0 && !ht0) ? 1.f : 0.f, (valid1 && !hs1 && !ht1) ? 1.f : 0.f};
+    const f2 ux = w2 * dx, uy = w2 * dy, uz = w2 * dz;
+    acc[ACC_N + 0] += fma2(uz, uz, fma2(uy, uy, ux * ux));
     acc[ACC_N + 1] += ux; acc[ACC_N + 2] += uy; acc[ACC_N + 3] += uz;
-    acc[ACC_N + 4] = fmaf(ux, x, acc[ACC_N + 4]); acc[ACC_N + 5] = fmaf(ux, y, acc[ACC_N + 5]); acc[ACC_N + 6] = fmaf(ux, z, acc[ACC_N + 6]);
-    acc[ACC_N + 7] = fmaf(uy, x, acc[ACC_N + 7]); acc[ACC_N + 8] = fmaf(uy, y, acc[ACC_N + 8]); acc[ACC_N + 9] = fmaf(uy, z, acc[ACC_N + 9]);
-    acc[ACC_N + 10] = fmaf(uz, x, acc[ACC_N + 10]); acc[ACC_N + 11] = fmaf(uz, y, acc[ACC_N + 11]); acc[ACC_N + 12] = fmaf(uz, z, acc[ACC_N + 12]);
+    acc[ACC_N + 4] = fma2(ux, x, acc[ACC_N + 4]); acc[ACC_N + 5] = fma2(ux, y, acc[ACC_N + 5]); acc[ACC_N + 6] = fma2(ux, z, acc[ACC_N + 6]);
+    acc[ACC_N + 7] = fma2(uy, x, acc[ACC_N + 7]); acc[ACC_N + 8] = fma2(uy, y, acc[ACC_N + 8]); acc[ACC_N + 9] = fma2(uy, z, acc[ACC_N + 9]);
+    acc[ACC_N + 10] = fma2(uz, x, acc[ACC_N + 10]); acc[ACC_N + 11] = fma2(uz, y, acc[ACC_N + 11]); acc[ACC_N + 12] = fma2(uz, z, acc[ACC_N + 12]);
     acc[ACC_N + 13] += w2;
   }
+}
+
+// Sum over the 16 lanes of a DPP row, result in every lane of the row: four v_add_f32 with a DPP operand (quad
+// butterflies, then the half-row and row mirrors) -- no LDS traffic, unlike the ds_bpermute behind __shfl_xor.
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row_sum(float v) {
+  v += dpp_get<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_get<0x141>(v);     // row_half_mirror
+  v += dpp_get<0x140>(v);     // row_mirror
+  return v;
 }
 
 // Sum of the partial rows of one sample in fp64 (fixed order) and the final means / gradient moments.  Runs in the
@@ -206,9 +231,9 @@ __global__ __launch_bounds__(DL_BLOCK) void k_icp_loss(
   float m[12];
 #pragma unroll
   for (int i = 0; i < 12; ++i) m[i] = T[b * 16 + i];
-  float acc[NA];
+  f2 acc[NA];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) acc[i] = 0.f;
+  for (int i = 0; i < NA; ++i) acc[i] = (f2){0.f, 0.f};
   const float* sp = src + (size_t)b * src_ss;
   const float* sn = srcn + (size_t)b * srcn_ss;
   const float* mt = match + (size_t)b * match_ss;
@@ -222,32 +247,48 @@ __global__ __launch_bounds__(DL_BLOCK) void k_icp_loss(
   for (int c = gw; c < nchunks; c += waves) {
     if (vec && c * CHUNK + CHUNK <= HW) {
       const StreamRegs cur = load_stream(nn, sp, sn, mt, q4, c * DL_WAVE + lane);
-#define DL_PAIR(C) accumulate_pair<P2P, LINEAR, NA>(acc, m, cur.j.C >= 0, cur.x.C, cur.y.C, cur.z.C, cur.a.C, cur.b.C, \
-                                                    cur.c.C, cur.tx.C, cur.ty.C, cur.tz.C, cur.ta.C, cur.tb.C, cur.tc.C)
-      DL_PAIR(x); DL_PAIR(y); DL_PAIR(z); DL_PAIR(w);
-#undef DL_PAIR
+#define DL_LO(V) ((f2){cur.V.x, cur.V.y})
+#define DL_HI(V) ((f2){cur.V.z, cur.V.w})
+      accumulate_pair2<P2P, LINEAR, NA>(acc, m, cur.j.x >= 0, cur.j.y >= 0, DL_LO(x), DL_LO(y), DL_LO(z), DL_LO(a), DL_LO(b),
+                                        DL_LO(c), DL_LO(tx), DL_LO(ty), DL_LO(tz), DL_LO(ta), DL_LO(tb), DL_LO(tc));
+      accumulate_pair2<P2P, LINEAR, NA>(acc, m, cur.j.z >= 0, cur.j.w >= 0, DL_HI(x), DL_HI(y), DL_HI(z), DL_HI(a), DL_HI(b),
+                                        DL_HI(c), DL_HI(tx), DL_HI(ty), DL_HI(tz), DL_HI(ta), DL_HI(tb), DL_HI(tc));
+#undef DL_LO
+#undef DL_HI
     } else {                                                     // ragged tail / unaligned image: scalar loads
-      for (int k = 0; k < LOSS_PX; ++k) {
-        const int px = c * CHUNK + lane * LOSS_PX + k;
-        if (px < HW)
-          accumulate_pair<P2P, LINEAR, NA>(acc, m, nn[px] >= 0, sp[px], sp[HW + px], sp[2 * HW + px], sn[px], sn[HW + px],
-                                           sn[2 * HW + px], mt[px], mt[HW + px], mt[2 * HW + px], mt[3 * HW + px],
-                                           mt[4 * HW + px], mt[5 * HW + px]);
+      for (int k = 0; k < LOSS_PX; k += 2) {
+        const int p0 = c * CHUNK + lane * LOSS_PX + k, p1 = p0 + 1;
+        const bool i0 = p0 < HW, i1 = p1 < HW;
+        const int a0 = i0 ? p0 : 0, a1 = i1 ? p1 : 0;            // out-of-range pixels read pixel 0 and are masked
+#define DL_PL(P, O) ((f2){P[(size_t)(O) * HW + a0], P[(size_t)(O) * HW + a1]})
+        accumulate_pair2<P2P, LINEAR, NA>(acc, m, i0 && nn[a0] >= 0, i1 && nn[a1] >= 0, DL_PL(sp, 0), DL_PL(sp, 1),
+                                          DL_PL(sp, 2), DL_PL(sn, 0), DL_PL(sn, 1), DL_PL(sn, 2), DL_PL(mt, 0), DL_PL(mt, 1),
+                                          DL_PL(mt, 2), DL_PL(mt, 3), DL_PL(mt, 4), DL_PL(mt, 5));
+#undef DL_PL
       }
     }
   }
-  // wave shuffle tree, then the four waves of the workgroup through LDS: one partial row per workgroup
-  __shared__ float red[(DL_BLOCK / DL_WAVE) * ACC_PITCH];
+  // even/odd pixels, then the 16 lanes of each DPP row; the 16 row sums of the workgroup meet in LDS and are added in a
+  // fixed order: one partial row per workgroup
+  constexpr int ROWS = DL_BLOCK / 16;
+  __shared__ float red[ROWS * ACC_PITCH];
+  float rs[NA];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const float v = wave_sum(acc[i]);
-    if (lane == 0) red[wv * ACC_PITCH + i] = v;
+  for (int i = 0; i < NA; ++i) rs[i] = row_sum(acc[i].x + acc[i].y);
+  if ((lane & 15) == 0) {
+    float* dst = red + (threadIdx.x >> 4) * ACC_PITCH;
+#pragma unroll
+    for (int i = 0; i < NA; ++i) dst[i] = rs[i];
   }
   __syncthreads();
   if (threadIdx.x < ACC_PITCH) {
     const int t = threadIdx.x;
-    partials[((size_t)b * gridDim.x + blockIdx.x) * ACC_PITCH + t] =
-        t < NA ? (red[t] + red[ACC_PITCH + t]) + (red[2 * ACC_PITCH + t] + red[3 * ACC_PITCH + t]) : 0.f;
+    float v = 0.f;
+    if (t < NA) {
+#pragma unroll
+      for (int r = 0; r < ROWS; ++r) v += red[r * ACC_PITCH + t];
+    }
+    partials[((size_t)b * gridDim.x + blockIdx.x) * ACC_PITCH + t] = v;
   }
 }
 
