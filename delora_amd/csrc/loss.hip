@@ -38,11 +38,9 @@ extern "C" int dl_icp_loss_partial_timed(const float*, int64_t, const float*, in
 #define LOSS_WG_PER_SAMPLE 128  // workgroups (4 waves each) per sample: 512 waves, 1 chunk per wave at 64x2048
 #endif
 static inline int loss_blocks(int HW) {
-  static int cap = 0;
-  if (!cap) { const char* e = getenv("DL_LOSS_WG"); cap = e ? atoi(e) : LOSS_WG_PER_SAMPLE; }   // EXPERIMENT
   const int chunks = (HW + DL_WAVE * LOSS_PX - 1) / (DL_WAVE * LOSS_PX);
   int wg = (chunks + 3) / 4;
-  return wg < cap ? wg : cap;
+  return wg < LOSS_WG_PER_SAMPLE ? wg : LOSS_WG_PER_SAMPLE;
 }
 static inline int loss_rows(int HW) { return loss_blocks(HW); }
 
@@ -215,25 +213,14 @@ __device__ __forceinline__ StreamRegs load_stream(const int32_t* __restrict__ nn
   return r;
 }
 
-template <bool P2P, bool LINEAR, int NA>
-__device__ __forceinline__ void consume_chunk(f2 (&acc)[NA], const float (&m)[12], const StreamRegs& cur) {
-#define DL_LO(V) ((f2){cur.V.x, cur.V.y})
-#define DL_HI(V) ((f2){cur.V.z, cur.V.w})
-  accumulate_pair2<P2P, LINEAR, NA>(acc, m, cur.j.x >= 0, cur.j.y >= 0, DL_LO(x), DL_LO(y), DL_LO(z), DL_LO(a), DL_LO(b),
-                                    DL_LO(c), DL_LO(tx), DL_LO(ty), DL_LO(tz), DL_LO(ta), DL_LO(tb), DL_LO(tc));
-  accumulate_pair2<P2P, LINEAR, NA>(acc, m, cur.j.z >= 0, cur.j.w >= 0, DL_HI(x), DL_HI(y), DL_HI(z), DL_HI(a), DL_HI(b),
-                                    DL_HI(c), DL_HI(tx), DL_HI(ty), DL_HI(tz), DL_HI(ta), DL_HI(tb), DL_HI(tc));
-#undef DL_LO
-#undef DL_HI
-}
-
 // A pure streaming pass: thirteen fp32 planes per sample -- the correspondence map (validity), the source point and
 // normal, and the matched target point and normal that the correspondence kernel wrote in SOURCE pixel order -- are
 // read once with 16-byte loads, 52 bytes per source pixel, no dependent gather.  Every wave is an independent worker
 // that walks 256-pixel chunks of one sample with a stride of `waves per sample` (one chunk per wave at 64x2048: the
 // thirteen loads of a chunk are all in flight before the first use, and 16 waves per CU overlap each other).  One
-// reduction and one partial row per workgroup at the end.  (A software-pipelined two-chunks-per-wave variant was measured
-// slower: 200+ VGPRs halve the occupancy.)
+// reduction and one partial row per workgroup at the end.  (Two chunks per wave with all 26 loads in flight and half /
+// a quarter as many waves -- i.e. half the reduction work per pixel -- measured 12.9 / 12.6 us against 12.1: with the
+// operands cached the kernel is short enough that the parallelism of 16 waves per CU matters more than instruction count.)
 template <bool P2P, bool LINEAR>
 __global__ __launch_bounds__(DL_BLOCK) void k_icp_loss(
     const float* __restrict__ src, int64_t src_ss, const float* __restrict__ srcn, int64_t srcn_ss,
@@ -258,18 +245,17 @@ __global__ __launch_bounds__(DL_BLOCK) void k_icp_loss(
   const int nchunks = (HW + CHUNK - 1) / CHUNK;
   const int q4 = HW / 4;
   const bool vec = (HW & 3) == 0;
-  int c = gw;
-  // two chunks per trip while both are whole: all 26 loads are in flight before the first use
-  for (; vec && (c + waves) * CHUNK + CHUNK <= HW; c += 2 * waves) {
-    const StreamRegs s0 = load_stream(nn, sp, sn, mt, q4, c * DL_WAVE + lane);
-    const StreamRegs s1 = load_stream(nn, sp, sn, mt, q4, (c + waves) * DL_WAVE + lane);
-    consume_chunk<P2P, LINEAR, NA>(acc, m, s0);
-    consume_chunk<P2P, LINEAR, NA>(acc, m, s1);
-  }
-  for (; c < nchunks; c += waves) {
+  for (int c = gw; c < nchunks; c += waves) {
     if (vec && c * CHUNK + CHUNK <= HW) {
       const StreamRegs cur = load_stream(nn, sp, sn, mt, q4, c * DL_WAVE + lane);
-      consume_chunk<P2P, LINEAR, NA>(acc, m, cur);
+#define DL_LO(V) ((f2){cur.V.x, cur.V.y})
+#define DL_HI(V) ((f2){cur.V.z, cur.V.w})
+      accumulate_pair2<P2P, LINEAR, NA>(acc, m, cur.j.x >= 0, cur.j.y >= 0, DL_LO(x), DL_LO(y), DL_LO(z), DL_LO(a), DL_LO(b),
+                                        DL_LO(c), DL_LO(tx), DL_LO(ty), DL_LO(tz), DL_LO(ta), DL_LO(tb), DL_LO(tc));
+      accumulate_pair2<P2P, LINEAR, NA>(acc, m, cur.j.z >= 0, cur.j.w >= 0, DL_HI(x), DL_HI(y), DL_HI(z), DL_HI(a), DL_HI(b),
+                                        DL_HI(c), DL_HI(tx), DL_HI(ty), DL_HI(tz), DL_HI(ta), DL_HI(tb), DL_HI(tc));
+#undef DL_LO
+#undef DL_HI
     } else {                                                     // ragged tail / unaligned image: scalar loads
       for (int k = 0; k < LOSS_PX; k += 2) {
         const int p0 = c * CHUNK + lane * LOSS_PX + k, p1 = p0 + 1;
