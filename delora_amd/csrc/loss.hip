@@ -119,18 +119,11 @@ __device__ __forceinline__ void accumulate_pair2(f2 (&acc)[NA], const float (&m)
   }
 }
 
-// Sum over the 16 lanes of a DPP row, result in every lane of the row: four v_add_f32 with a DPP operand (quad
-// butterflies, then the half-row and row mirrors) -- no LDS traffic, unlike the ds_bpermute behind __shfl_xor.
+// A value of another lane of the same 16-lane DPP row (CTRL: quad_perm 0x00-0xFF, row_ror:n 0x120+n, ...): a VALU
+// operand modifier -- no LDS traffic, unlike the ds_bpermute behind __shfl_xor.
 template <int CTRL>
 __device__ __forceinline__ float dpp_get(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-__device__ __forceinline__ float row_sum(float v) {
-  v += dpp_get<0xB1>(v);      // quad_perm [1,0,3,2]
-  v += dpp_get<0x4E>(v);      // quad_perm [2,3,0,1]
-  v += dpp_get<0x141>(v);     // row_half_mirror
-  v += dpp_get<0x140>(v);     // row_mirror
-  return v;
 }
 
 // Sum of the partial rows of one sample in fp64 (fixed order) and the final means / gradient moments.  Runs in the
@@ -269,17 +262,36 @@ __global__ __launch_bounds__(DL_BLOCK) void k_icp_loss(
       }
     }
   }
-  // even/odd pixels, then the 16 lanes of each DPP row; the 16 row sums of the workgroup meet in LDS and are added in a
-  // fixed order: one partial row per workgroup
+  // Reduction over the workgroup.  Even/odd pixels first; then the four lanes of every quad TRANSPOSE-reduce the NA values
+  // (each butterfly step halves the number of values a lane carries: lane l of a quad ends up with the quad sums of
+  // accumulators 4k + l), two row rotations add the four quads of a 16-lane DPP row, and the 16 row sums of the workgroup
+  // meet in LDS where they are added in a fixed order: one partial row per workgroup.  ~70 VALU instructions for 24
+  // values instead of the 144 adds + 144 ds_bpermute of a shuffle tree per value, and no LDS traffic in the wave part.
   constexpr int ROWS = DL_BLOCK / 16;
+  constexpr int NP = (NA + 3) / 4 * 4;
   __shared__ float red[ROWS * ACC_PITCH];
-  float rs[NA];
+  float v[NP];
 #pragma unroll
-  for (int i = 0; i < NA; ++i) rs[i] = row_sum(acc[i].x + acc[i].y);
-  if ((lane & 15) == 0) {
-    float* dst = red + (threadIdx.x >> 4) * ACC_PITCH;
+  for (int i = 0; i < NP; ++i) v[i] = i < NA ? acc[i].x + acc[i].y : 0.f;
+  const bool b0 = lane & 1, b1 = lane & 2;
+  float u[NP / 2];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) dst[i] = rs[i];
+  for (int k = 0; k < NP / 2; ++k) {
+    const float keep = b0 ? v[2 * k + 1] : v[2 * k], send = b0 ? v[2 * k] : v[2 * k + 1];
+    u[k] = keep + dpp_get<0xB1>(send);                  // quad_perm [1,0,3,2]: lane ^ 1
+  }
+  float q[NP / 4];
+#pragma unroll
+  for (int k = 0; k < NP / 4; ++k) {
+    const float keep = b1 ? u[2 * k + 1] : u[2 * k], send = b1 ? u[2 * k] : u[2 * k + 1];
+    q[k] = keep + dpp_get<0x4E>(send);                  // quad_perm [2,3,0,1]: lane ^ 2
+    q[k] += dpp_get<0x124>(q[k]);                       // row_ror:4
+    q[k] += dpp_get<0x128>(q[k]);                       // row_ror:8
+  }
+  if ((lane & 12) == 0) {                               // the first quad of every row holds the row's NA sums
+    float* dst = red + (threadIdx.x >> 4) * ACC_PITCH + (lane & 3);
+#pragma unroll
+    for (int k = 0; k < NP / 4; ++k) dst[4 * k] = q[k];
   }
   __syncthreads();
   if (threadIdx.x < ACC_PITCH) {

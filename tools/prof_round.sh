@@ -10,6 +10,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_trace -o benc
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/geo_trace -o geo -- python tools/geo_bench.py 30 0.4 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/geo_fetch -o geo -- python tools/geo_bench.py 5 0.4 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/geo_write -o geo -- python tools/geo_bench.py 5 0.4 > /dev/null 2>&1
+python tools/loss_warm.py 50 > $out/loss_warm.txt 2>/dev/null
+PYTHONPATH=. python tools/ring_bench.py 20 > $out/ring_bench.txt 2>/dev/null
 find $out -name "*.csv" | head -30
 # keep only summaries (the raw traces are large)
 find $out -name "*kernel_trace.csv" -size +20M -delete
