@@ -324,6 +324,41 @@ def test_data_parallel_step_on_gpu_matches_reference_batch():
     assert np.isclose(ret[0]["loss"] + ret[1]["loss"], g["ep::loss_epoch"], rtol=REL)
 
 
+def _rccl_worker(rank, world, port, ret):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0",
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    torch.distributed.init_process_group(backend="nccl", device_id=dev)      # exactly bench.py's call
+    try:
+        from delora_amd.models import model as model_module
+        gm = util.load_golden("model_small")
+        cfg = _small_model_cfg(gm, 16, 128)
+        net = model_module.OdometryModel(config=cfg).to(dev)
+        ddp = torch.nn.parallel.DistributedDataParallel(net, device_ids=[0], gradient_as_bucket_view=True, bucket_cap_mb=25)
+        x = torch.randn(2, 8, 16, 128, device=dev)
+        t, q = ddp(x)
+        (t.square().sum() + q.square().sum()).backward()
+        v = torch.ones(4, device=dev)
+        torch.distributed.all_reduce(v)
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+        ret[rank] = {"sum": float(v.sum()), "grads": all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())}
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def test_rccl_backend_initialises_and_reduces_on_one_rank():
+    """backend="nccl" (RCCL) with the init call and the DDP arguments bench.py / Trainer use, on the one GPU a test box
+    has: communicator creation, DDP's bucketed all-reduce hooks in backward, an explicit all_reduce and a barrier."""
+    import torch.multiprocessing as mp
+    _dev()
+    ret = mp.Manager().dict()
+    mp.spawn(_rccl_worker, args=(1, 29350 + (os.getpid() % 300), ret), nprocs=1, join=True)
+    assert ret[0]["sum"] == 4.0 and ret[0]["grads"]
+
+
 def test_graphed_step_equals_eager_step():
     """The captured HIP graph of the whole training step replays to the same losses and weights as eager execution."""
     from delora_amd.data.dataset import SyntheticPairDataset
