@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Copy the summaries of a tools/prof_round.sh bundle (gpurun_out/profiles_<round>/) into profiles/ (tracked):
+   python tools/collect_profiles.py r01"""
+import csv, json, os, shutil, statistics, subprocess, sys
+
+R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(ROOT, "gpurun_out", f"profiles_{R}"), os.path.join(ROOT, "profiles")
+OWN = ["k_project_scatter", "k_project_resolve", "k_normals", "k_nn_tiles", "k_nn_window", "k_nn_hard", "k_icp_loss", "k_icp_reduce",
+       "k_probe_read"]
+
+
+def last_json(path):
+    return json.loads(open(path).read().strip().splitlines()[-1])
+
+
+for a, b in [("bench.json", f"{R}_bench.json"), ("bench_profiled.json", f"{R}_bench_profiled.json")]:
+    json.dump(last_json(os.path.join(src, a)), open(os.path.join(dst, b), "w"), indent=1)
+shutil.copy(os.path.join(src, "bench_trace", "bench_kernel_stats.csv"), os.path.join(dst, f"{R}_bench_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "geo_trace", "geo_kernel_stats.csv"), os.path.join(dst, f"{R}_geometry_kernel_stats.csv"))
+for name in ("loss_warm.txt", "ring_bench.txt"):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, f"{R}_{name}"))
+
+
+def counter(path, name):
+    vals = {}
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != name:
+            continue
+        for k in OWN:
+            if k in r["Kernel_Name"]:
+                vals.setdefault(k, []).append(float(r["Counter_Value"]))
+    return {k: statistics.mean(v) for k, v in vals.items()}
+
+
+fetch = counter(os.path.join(src, "geo_fetch", "geo_counter_collection.csv"), "FETCH_SIZE")
+write = counter(os.path.join(src, "geo_write", "geo_counter_collection.csv"), "WRITE_SIZE")
+pmc = {"workload": "tools/geo_bench.py 5 0.4: bench batch B=8, 64x2048, residual motion 0.4 m; rocprofv3 --kernel-trace --pmc FETCH_SIZE / "
+                   "--pmc WRITE_SIZE in separate passes",
+       "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read (MI355X_MICROARCH.md, HBM section) -> read "
+                     "bytes = FETCH_SIZE*1024*2; WRITE_SIZE*1024 uncorrected; exact for streaming kernels (k_icp_loss), an upper bound for "
+                     "gather-heavy kernels",
+       "kernels": {}}
+for k in OWN:
+    if k in fetch and k in write:
+        rd, wr = fetch[k] * 1024 * 2, write[k] * 1024
+        pmc["kernels"][k] = {"FETCH_SIZE_KB_raw": fetch[k], "WRITE_SIZE_KB_raw": write[k], "read_bytes_corrected_x2": rd, "write_bytes": wr,
+                             "hbm_bytes_per_launch": rd + wr}
+json.dump(pmc, open(os.path.join(dst, f"{R}_geometry_pmc.json"), "w"), indent=1)
+trace = os.path.join(src, "bench_trace", "bench_kernel_trace.csv")
+if os.path.exists(trace):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_breakdown.py"), trace, "20", "40"], capture_output=True, text=True)
+    open(os.path.join(dst, f"{R}_step_breakdown.txt"), "w").write(out.stdout)
+geo = os.path.join(src, "geo_trace", "geo_kernel_trace.csv")
+if os.path.exists(geo):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "loss_calibration.py"), geo, "30"], capture_output=True, text=True)
+    open(os.path.join(dst, f"{R}_loss_calibration.txt"), "w").write(out.stdout)
+print("k_icp_loss PMC bytes/launch:", pmc["kernels"].get("k_icp_loss", {}).get("hbm_bytes_per_launch"))
