@@ -29,7 +29,9 @@
 #ifndef NN_PIXEL_ROUNDS
 #define NN_PIXEL_ROUNDS 0       // pass B: pixel-scanned boxes (4x16[, 8x40]) before the tile-culled walk of the bound window
 #endif
+#ifndef NN_BATCH
 #define NN_BATCH 1              // pass B: queries per wave and trip (one per lane for the per-query arithmetic)
+#endif
 #define NN_UP (1.0f + 4e-6f)   // round-up factor for quantities that must not be under-estimated in fp32
 
 struct NNHard {                // one record per query that pass A could not certify
@@ -459,7 +461,9 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float4* __restrict__
   // 4 candidate loads in flight per lane for big windows -- no change.)
   // static striding in batches of NN_BATCH queries per wave.  Measured at 64x2048, B=8 (382k hard queries): one query
   // per wave 1.85 ms, dynamic batches of 16 (atomic queue) 2.05 ms, 64 per wave 5.1 ms (a few queries scan thousands
-  // of candidates and serialise behind each other): the scans, not the per-query arithmetic, are the cost.
+  // of candidates and serialise behind each other): the scans, not the per-query arithmetic, are the cost.  Re-measured
+  // with the tile-culled walk (tools/nn_time.py, whole dl_nn_correspond): 1 per wave 1.29 ms, 4 per wave 1.38 ms, 16 per
+  // wave 1.96 ms.
   for (int h0 = wave * NN_BATCH; h0 < count; h0 += nwaves * NN_BATCH) {
     const bool live = lane < NN_BATCH && h0 + lane < count;
     NNHard rec;
