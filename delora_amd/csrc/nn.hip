@@ -11,11 +11,11 @@
 //     (2*RV+1)x(2*RU+1) window, then CERTIFY the result: if the angular bound of the best distance found,
 //     widened by the half-pixel rounding of the projection plus a safety margin, lies inside the scanned
 //     window, the neighbour is exact.  Otherwise the query goes to a compact "hard" list.
-//   pass B (one wave per hard query): the 64 lanes stride over the flattened (rows x columns) window that the
-//     spherical-cap bound of the best distance so far allows (columns wrap through the azimuth seam), restricted to a
-//     box around q's pixel that grows 4x16 -> 8x40 -> 16x96 -> image; the bound is recomputed after every scan and the
-//     search stops once it fits inside the covered box.  With no usable bound (d >= |q|) this ends in an exhaustive
-//     scan, so the result is exact in every regime.
+//   pass B (one wave per hard query): the window that the spherical-cap bound of pass A's best distance allows (pass A
+//     stores it with the query; columns wrap through the azimuth seam) is walked tile by tile through a pyramid of
+//     bounding spheres of 4x16-pixel target tiles: 64 tiles are tested per trip and only tiles whose sphere can hold a
+//     closer point are scanned, one pixel per lane.  With no usable bound (d >= |q|, or nothing found in pass A) the
+//     window is the whole image, so the result is exact in every regime.
 //
 // The target image is read in its packed form (one 16-byte load per candidate pixel).  Distances are accumulated
 // in fp64 from the fp32 coordinates, as the KD-tree does; ties resolve to the lower pixel index.  Bound: L2/LDS + VALU (candidates are re-read from cache), reported separately from the
@@ -26,20 +26,16 @@
 #define NN_RU 5
 #define NN_MARGIN 0.01f        // pixels: slack on the rounding of the stored points' (and our own) image coordinates
 #define NN_PI_F 3.14159265358979323846f
-#ifndef NN_PIXEL_ROUNDS
-#define NN_PIXEL_ROUNDS 0       // pass B: pixel-scanned boxes (4x16[, 8x40]) before the tile-culled walk of the bound window
-#endif
-#ifndef NN_BATCH
-#define NN_BATCH 1              // pass B: queries per wave and trip (one per lane for the per-query arithmetic)
-#endif
 #define NN_UP (1.0f + 4e-6f)   // round-up factor for quantities that must not be under-estimated in fp32
 
-struct NNHard {                // one record per query that pass A could not certify
+struct NNHard {                // one record per query that pass A could not certify (40 bytes)
   double d2;                   // best squared distance found so far (1e300 = none)
   int32_t slot;                // b*HW + source pixel
   int32_t idx;                 // target pixel of that best (-1 = none)
   float qx, qy, qz;            // transformed source point
-  int32_t pad;
+  uint32_t rows;               // bound window of that best distance: r0 | r1 << 16 ...
+  uint32_t cols;               // ... and c0 | (nc - 1) << 16 (circular column range)
+  int32_t b;                   // sample
 };
 
 #define NN_TR 4                 // target tile: 4 rows x 16 columns = 64 pixels = one wave-wide load
@@ -227,9 +223,11 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
   // certificate: every pixel that can hold a closer target lies inside the scanned window (and the needed columns do
   // not run through the azimuth seam, where the scanned columns were wrapped)
   bool exact = false;
+  Window w;
+  w.r0 = 0; w.r1 = H - 1; w.c0 = 0; w.nc = W;              // nothing found: the whole image
   if (bidx >= 0) {
     const float d = (float)sqrt(best) * NN_UP;
-    const Window w = bound_window(q, d, sen);
+    w = bound_window(q, d, sen);
     const bool rows_ok = (w.r0 >= v0 - NN_RV) && (w.r1 <= v0 + NN_RV);
     const bool cols_ok = (w.nc <= 2 * NN_RU + 1) && (w.c0 >= u0 - NN_RU) && (w.c0 + w.nc - 1 <= u0 + NN_RU) &&
                          (w.c0 + w.nc - 1 <= W - 1);
@@ -245,7 +243,9 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
   } else {
     const int pos = atomicAdd(ws.counter, 1);
     NNHard h;
-    h.d2 = best; h.slot = b * HW + px; h.idx = bidx; h.qx = fx; h.qy = fy; h.qz = fz; h.pad = 0;
+    h.d2 = best; h.slot = b * HW + px; h.idx = bidx; h.qx = fx; h.qy = fy; h.qz = fz; h.b = b;
+    h.rows = (uint32_t)w.r0 | ((uint32_t)w.r1 << 16);
+    h.cols = (uint32_t)w.c0 | ((uint32_t)(w.nc - 1) << 16);
     ws.hard[pos] = h;
   }
 }
@@ -257,61 +257,6 @@ __device__ __forceinline__ void wave_argmin(double& d2, int& idx) {
     const int oi = __shfl_xor(idx, o, DL_WAVE);
     if (od < d2 || (od == d2 && oi >= 0 && (idx < 0 || oi < idx))) { d2 = od; idx = oi; }
   }
-}
-
-// Scan a window with the 64 lanes striding over its flattened (row, column) candidates.  Every candidate is first
-// screened with an fp32 distance against the lane's best (relative slack 1e-5, far above the fp32 error of a sum of
-// three squares); only candidates that pass are evaluated in fp64, which is the value that decides.
-__device__ __forceinline__ void scan_window(const Window& w, const float4* __restrict__ tp, int HW, int W, float qx,
-                                            float qy, float qz, int lane, double& best, int& bidx) {
-  const int nrows = w.r1 - w.r0 + 1;
-  if (nrows <= 0 || w.nc <= 0) return;
-  const int total = nrows * w.nc;
-  const float inv = 1.0f / (float)w.nc;
-  double lbest = best;                        // seed with the running best: most candidates fail the fp32 screen
-  float thr = best < 1e30 ? (float)best * (1.0f + 1e-5f) : 3.0e38f;
-  int lidx = -1;
-  constexpr int UN = 4;                       // candidates per lane per trip: four 16-byte loads in flight
-  for (int k0 = lane; k0 < total; k0 += DL_WAVE * UN) {
-    float4 c4[UN];
-    int p[UN];
-#pragma unroll
-    for (int i = 0; i < UN; ++i) {
-      const int k = k0 + i * DL_WAVE;
-      const int kk = k < total ? k : 0;
-      int r = (int)(((float)kk + 0.5f) * inv);
-      int c = kk - r * w.nc;
-      if (c < 0) { --r; c += w.nc; } else if (c >= w.nc) { ++r; c -= w.nc; }
-      c += w.c0;
-      c = c >= W ? c - W : c;
-      p[i] = k < total ? (w.r0 + r) * W + c : -1;
-      c4[i] = tp[p[i] < 0 ? 0 : p[i]];
-    }
-#pragma unroll
-    for (int i = 0; i < UN; ++i) {
-      const float dx = qx - c4[i].x, dy = qy - c4[i].y, dz = qz - c4[i].z;
-      const float d2f = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-      const bool empty = (c4[i].x == 0.f && c4[i].y == 0.f && c4[i].z == 0.f);
-      if (p[i] >= 0 && !empty && d2f <= thr) {
-        const double d2 = dist2(qx, qy, qz, c4[i].x, c4[i].y, c4[i].z);
-        if (d2 < lbest || (d2 == lbest && lidx >= 0 && p[i] < lidx)) {
-          lbest = d2; lidx = p[i];
-          thr = (float)lbest * (1.0f + 1e-5f);
-        }
-      }
-    }
-  }
-  if (lidx < 0) lbest = 1e300;               // this lane found nothing better than the running best
-  wave_argmin(lbest, lidx);
-  if (lidx >= 0 && (lbest < best || (lbest == best && (bidx < 0 || lidx < bidx)))) { best = lbest; bidx = lidx; }
-}
-
-// Signed column offset of column c from centre column u0 on the ring of W columns, in [-W/2, W/2).
-__device__ __forceinline__ int ring_offset(int c, int u0, int W) {
-  int d = (c - u0) % W;
-  if (d < -W / 2) d += W;
-  if (d >= W - W / 2) d -= W;
-  return d;
 }
 
 __device__ __forceinline__ int nn_tiles_dev(int H, int W) { return ((H + NN_TR - 1) / NN_TR) * ((W + NN_TC - 1) / NN_TC); }
@@ -422,32 +367,18 @@ __device__ __forceinline__ void scan_tiles(const Window& w, const float4* __rest
   if (lidx >= 0 && (lbest < best || (lbest == best && (bidx < 0 || lidx < bidx)))) { best = lbest; bidx = lidx; }
 }
 
-__device__ __forceinline__ float bcast_f(float v, int src) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
-}
-__device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
-__device__ __forceinline__ double bcast_d(double v, int src) {
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src);
-  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-
-// Pass B: a wave takes NN_BATCH of the queries that pass A could not certify, ONE PER LANE for everything that is per-query
-// arithmetic (projection, bound windows, containment tests, the final gather and store), and scans the windows
-// cooperatively, one query at a time, with all 64 lanes striding over the candidates.  The bound window of a query's
-// current best distance is intersected with a box around its pixel that grows (4x16 -> 8x40 half-sizes, pixel scans);
-// after each scan the bound is recomputed from the improved distance, and a query is finished as soon as its bound fits
-// inside the box already covered; what is left after two boxes walks its whole bound window through the tile spheres
-// (scan_tiles), where most 64-pixel tiles are rejected by one distance test.  Pixels of an earlier box that lay outside the then-valid bound cannot
-// hold a closer point, so "covered" is simply the last box.  This keeps the examined candidates near the minimum any
-// exact search with this bound must look at (the window of the TRUE distance) even when pass A only saw far candidates.
+// Pass B: one wave per query that pass A could not certify.  Everything per-query is wave-uniform (the record is read
+// through the scalar path): pass A already evaluated the projection of q and the bound window of its best distance at
+// full lane efficiency and stored the window with the query, so this kernel is the tile walk plus the final gather.
+// (Measured and rejected, see the history in DESIGN.md: several queries per wave with per-lane arithmetic -- 4 per wave
+// 1.38 ms, 16 per wave 1.96 ms against 1.29 ms for the whole search; pixel-scanned boxes growing around q's pixel before
+// the tile walk; pinning each sample to one XCD, 2.0 -> 5.5 ms; 16 instead of 4 candidate loads in flight.)
 __global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float4* __restrict__ tgt, int64_t tgt_ss4,
                                                       const float4* __restrict__ tgtn, int64_t tgtn_ss4, SensorK sen,
                                                       int32_t* __restrict__ nn_pix, float* __restrict__ match,
                                                       int32_t* __restrict__ visible, int nb, NNWorkspace ws) {
   const int lane = threadIdx.x & (DL_WAVE - 1);
-  const int wave = (blockIdx.x * DL_BLOCK + threadIdx.x) / DL_WAVE;
+  const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * DL_BLOCK + threadIdx.x) / DL_WAVE);
   const int nwaves = gridDim.x * DL_BLOCK / DL_WAVE;
   const int count = ws.counter[0];
   const int HW = sen.HW, H = sen.H, W = sen.W;
@@ -456,84 +387,27 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float4* __restrict__
     for (int i = 0; i < 32; ++i) sum += ws.counter[NN_VIS0 + threadIdx.x * 32 + i];
     visible[threadIdx.x] = sum;
   }
-  // (Also measured and rejected: pinning each sample to one XCD so that its 2 MiB packed target stays in that XCD's L2 --
-  // pass A unchanged, pass B 2.0 -> 5.5 ms because a sample's expensive queries then share 1/8 of the chip; 16 instead of
-  // 4 candidate loads in flight per lane for big windows -- no change.)
-  // static striding in batches of NN_BATCH queries per wave.  Measured at 64x2048, B=8 (382k hard queries): one query
-  // per wave 1.85 ms, dynamic batches of 16 (atomic queue) 2.05 ms, 64 per wave 5.1 ms (a few queries scan thousands
-  // of candidates and serialise behind each other): the scans, not the per-query arithmetic, are the cost.  Re-measured
-  // with the tile-culled walk (tools/nn_time.py, whole dl_nn_correspond): 1 per wave 1.29 ms, 4 per wave 1.38 ms, 16 per
-  // wave 1.96 ms.
-  for (int h0 = wave * NN_BATCH; h0 < count; h0 += nwaves * NN_BATCH) {
-    const bool live = lane < NN_BATCH && h0 + lane < count;
-    NNHard rec;
-    rec.d2 = 1e300; rec.slot = 0; rec.idx = -1; rec.qx = 1.f; rec.qy = 0.f; rec.qz = 0.f; rec.pad = 0;
-    if (live) rec = ws.hard[h0 + lane];
-    const int b = rec.slot / HW;
-    const QueryF q = make_query(rec.qx, rec.qy, rec.qz, sen);
+  const int ntiles_img = nn_tiles_dev(H, W);
+  for (int h = wave; h < count; h += nwaves) {
+    const NNHard rec = ws.hard[h];
+    const int b = rec.b;
+    Window w;
+    w.r0 = (int)(rec.rows & 0xffffu); w.r1 = (int)(rec.rows >> 16);
+    w.c0 = (int)(rec.cols & 0xffffu); w.nc = (int)(rec.cols >> 16) + 1;
     double best = rec.d2;
     int bidx = rec.idx;
-    const int u0 = wrap_col((int)rintf(q.uq), W);
-    int v0 = (int)rintf(q.vq);
-    v0 = v0 < 0 ? 0 : (v0 > H - 1 ? H - 1 : v0);
-    int box_r = NN_RV, box_c = NN_RU;          // pass A covered this box (when its columns did not wrap; else rescanned)
-    bool covered_valid = (rintf(q.uq) - NN_RU >= 0.f) && (rintf(q.uq) + NN_RU <= (float)(W - 1));
-    bool done = !live;
-#pragma unroll 1
-    for (int round = 0; round < NN_PIXEL_ROUNDS + 1; ++round) {
-      Window c;
-      c.r0 = 0; c.r1 = -1; c.c0 = 0; c.nc = 0;
-      if (!done) {
-        const Window w = bound_window(q, bidx >= 0 ? (float)sqrt(best) * NN_UP : 3.0e38f, sen);
-        int lo = -W / 2, hi = W - W / 2 - 1;
-        if (w.nc < W) { lo = ring_offset(w.c0, u0, W); hi = lo + w.nc - 1; }
-        const int cov_r0 = v0 - box_r < 0 ? 0 : v0 - box_r, cov_r1 = v0 + box_r > H - 1 ? H - 1 : v0 + box_r;
-        const bool rows_in = w.r0 >= cov_r0 && w.r1 <= cov_r1;
-        const bool cols_in = (w.nc < W) ? (lo >= -box_c && hi <= box_c) : (2 * box_c + 1 >= W);
-        if (covered_valid && rows_in && cols_in) {
-          done = true;
-        } else {
-          if (round == NN_PIXEL_ROUNDS) { box_r = H; box_c = W; }    // last round: the whole bound window, tile-culled
-          else if (round == 0) { box_r = 4; box_c = 16; } else { box_r = 8; box_c = 40; }
-          c.r0 = w.r0 > v0 - box_r ? w.r0 : v0 - box_r;
-          c.r1 = w.r1 < v0 + box_r ? w.r1 : v0 + box_r;
-          c.r0 = c.r0 < 0 ? 0 : c.r0;
-          c.r1 = c.r1 > H - 1 ? H - 1 : c.r1;
-          const int clo = lo > -box_c ? lo : -box_c, chi = hi < box_c ? hi : box_c;
-          if (w.nc >= W && 2 * box_c + 1 >= W) { c.c0 = 0; c.nc = W; }
-          else { c.c0 = wrap_col(u0 + clo, W); c.nc = chi - clo + 1; if (c.nc > W) { c.c0 = 0; c.nc = W; } }
-          covered_valid = true;
-        }
+    const float4* tp = tgt + (size_t)b * tgt_ss4;
+    scan_tiles(w, ws.tiles + (size_t)b * ntiles_img, tp, H, W, rec.qx, rec.qy, rec.qz, lane, best, bidx);
+    // the result: lanes 0-2 fetch and store the matched point's coordinates, lanes 3-5 the normal's
+    if (lane == 0) nn_pix[rec.slot] = bidx;
+    if (match && lane < 6) {
+      const int px = rec.slot - b * HW;
+      float v = 0.f;
+      if (bidx >= 0) {
+        if (lane < 3) v = reinterpret_cast<const float*>(tp)[(size_t)bidx * 4 + lane];
+        else if (tgtn) v = reinterpret_cast<const float*>(tgtn + (size_t)b * tgtn_ss4)[(size_t)bidx * 4 + (lane - 3)];
       }
-      unsigned long long todo = __ballot(!done);
-      if (todo == 0ull) break;
-      while (todo) {                                  // cooperative scans, one query of this wave at a time
-        const int i = __builtin_ctzll(todo);
-        todo &= todo - 1;
-        Window wi;
-        wi.r0 = bcast_i(c.r0, i); wi.r1 = bcast_i(c.r1, i); wi.c0 = bcast_i(c.c0, i); wi.nc = bcast_i(c.nc, i);
-        const float qx = bcast_f(rec.qx, i), qy = bcast_f(rec.qy, i), qz = bcast_f(rec.qz, i);
-        const int bi = bcast_i(b, i);
-        double sbest = bcast_d(best, i);
-        int sidx = bcast_i(bidx, i);
-        if (round < NN_PIXEL_ROUNDS) scan_window(wi, tgt + (size_t)bi * tgt_ss4, HW, W, qx, qy, qz, lane, sbest, sidx);
-        else scan_tiles(wi, ws.tiles + (size_t)bi * nn_tiles_dev(H, W), tgt + (size_t)bi * tgt_ss4, H, W, qx, qy, qz, lane,
-                        sbest, sidx);
-        if (lane == i) { best = sbest; bidx = sidx; }
-      }
-    }
-    if (live) {
-      nn_pix[rec.slot] = bidx;
-      if (match) {
-        const int px = rec.slot - b * HW;
-        float* mp = match + (size_t)b * 6 * HW + px;
-        float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f), n4 = p4;
-        if (bidx >= 0) {
-          p4 = (tgt + (size_t)b * tgt_ss4)[bidx];
-          if (tgtn) n4 = (tgtn + (size_t)b * tgtn_ss4)[bidx];
-        }
-        mp[0] = p4.x; mp[HW] = p4.y; mp[2 * HW] = p4.z; mp[3 * HW] = n4.x; mp[4 * HW] = n4.y; mp[5 * HW] = n4.z;
-      }
+      match[(size_t)b * 6 * HW + (size_t)lane * HW + px] = v;
     }
   }
 }
@@ -552,6 +426,8 @@ extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const f
   hipStream_t st = (hipStream_t)stream;
   const SensorK sen = make_sensor(sensor);
   if (B > 256) return dl_fail(DL_ERR_UNSUPPORTED, "dl_nn_correspond: at most 256 samples per launch (got %d)", B);
+  if (sensor->H > 65535 || sensor->W > 65535)
+    return dl_fail(DL_ERR_UNSUPPORTED, "dl_nn_correspond: images beyond 65535 rows or columns are not supported");
   NNWorkspace ws = carve_nn(workspace, B, sen.H, sen.W);
   (void)hipMemsetAsync(ws.counter, 0, nn_header_bytes(B), st);
   {
