@@ -15,7 +15,7 @@
 // same pass:  d po2pl = 2/K sum r n_t [p^T | 1],  d pl2pl = 2/K sum (R n - n_t) n^T  (resp. -(1-c) n_t n^T),
 // d po2po = 2/3K' sum (q - p_t) [p^T | 1].  The backward is then O(B) work (dl_icp_loss_bwd).
 //
-// Reduction: per-lane fp32 partial sums -> wave shuffle tree -> LDS -> one partial row per workgroup (no float atomics:
+// Reduction: per-lane fp32 partial sums -> DPP transpose-reduction per 16-lane row -> LDS -> one partial row per workgroup (no float atomics:
 // deterministic) -> a second, tiny launch sums each sample's rows in fp64 in a fixed order and writes the outputs.
 // (An in-kernel hand-off to the last-arriving workgroup was measured slower: the write-through drain + ticket round
 // trip sit on every workgroup's critical path, +8 us on a 17 us kernel; a kernel boundary costs ~1.5 us.)
