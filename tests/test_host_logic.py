@@ -311,3 +311,68 @@ def test_mixed_sensor_batch_equals_per_sample_results():
         assert torch.allclose(terms[j], t1[0], rtol=1e-6, atol=1e-8) and torch.allclose(T[j], T1[0], atol=1e-7)
     c = terms[:, 0] + cfg["lambda_po2pl"] * terms[:, 1] + terms[:, 2]
     assert np.isclose(float(losses["loss_pc"]), float((2 * c[0] + 1 * c[1]) / 2), rtol=1e-6)
+
+
+def _python_sources(*roots):
+    out = []
+    for root in roots:
+        p = os.path.join(ROOT, root)
+        if os.path.isfile(p):
+            out.append(p)
+            continue
+        for d, _, files in os.walk(p):
+            out += [os.path.join(d, f) for f in files if f.endswith(".py")]
+    return out
+
+
+def test_product_code_never_touches_the_oracle_or_the_reference_tree():
+    """The oracle is test infrastructure: nothing under delora_amd/ or bin/ may import it, bench.py may do so only inside its
+    cpu_baseline leg, and nothing that runs on the GPU box may read /root/reference (only tests/golden/make_golden.py,
+    which generated the committed fixtures, does)."""
+    import ast
+    for path in _python_sources("delora_amd", "bin"):
+        tree = ast.parse(open(path).read(), filename=path)
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            assert not any(n == "oracle" or n.startswith("oracle.") for n in names), f"{path} imports the oracle"
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    for node in tree.body:                                            # module level and every function except cpu_baseline
+        if isinstance(node, ast.FunctionDef) and node.name == "cpu_baseline":
+            continue
+        for sub in ast.walk(node):
+            if isinstance(sub, (ast.Import, ast.ImportFrom)):
+                names = [a.name for a in sub.names] if isinstance(sub, ast.Import) else [sub.module or ""]
+                assert not any(n == "oracle" or n.startswith("oracle.") for n in names), "bench.py imports the oracle outside cpu_baseline"
+    runtime = _python_sources("delora_amd", "bin", "bench.py", "__graft_entry__.py", "tests", "oracle")
+    for path in runtime:
+        if path.endswith(os.path.join("golden", "make_golden.py")) or path.endswith("test_host_logic.py"):
+            continue
+        code = open(path).read()
+        tree = ast.parse(code, filename=path)
+        strings = [n.value for n in ast.walk(tree) if isinstance(n, ast.Constant) and isinstance(n.value, str)]
+        docstrings = {ast.get_docstring(n) for n in ast.walk(tree)
+                      if isinstance(n, (ast.Module, ast.FunctionDef, ast.ClassDef)) and ast.get_docstring(n)}
+        for s in strings:
+            if "/root/reference" in s:
+                assert any(s.strip() == (d or "").strip() or s.strip() in (d or "") for d in docstrings), \
+                    f"{path} uses /root/reference outside a docstring"
+
+
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+def test_ring_ops_on_cpu_are_the_reference_op_sequence(act):
+    """On CPU tensors the fused ring ops evaluate the reference's separate ops (resnet_modified.py:97-102,159-177)."""
+    import torch.nn.functional as F
+    from delora_amd.models.ring_ops import ring_act_pad, ring_act_pool_pad
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn((2, 3, 5, 16), generator=gen)
+    res = torch.randn((2, 3, 5, 18), generator=gen)
+    f = torch.tanh if act == "tanh" else torch.relu
+    wrap = lambda v: F.pad(v, (1, 1, 0, 0), mode="circular")          # noqa: E731
+    assert torch.equal(ring_act_pad(x, act, pad=True, residual=res), wrap(f(x + res[..., 1:-1])))
+    assert torch.equal(ring_act_pad(x, act, pad=False), f(x))
+    want = wrap(F.max_pool2d(wrap(f(x)), kernel_size=3, stride=(1, 2), padding=(1, 0)))
+    assert torch.equal(ring_act_pool_pad(x, act), want)
