@@ -1,15 +1,16 @@
 """Import-name compatibility with the reference, whose packages are top-level (``import deploy.trainer``,
 ``utility.projection``, ``losses.icp_losses``, ``models.model``, ``preprocessing.normal_computation``,
-``data.dataset``; reference setup.py installs ``src/`` as the package root).  Importing this module registers
+``data.dataset``, ``ros_utils``; reference setup.py installs ``src/`` as the package root).  Importing this module registers
 the delora_amd sub-packages under those names."""
 import importlib
 import sys
 
-_NAMES = ("deploy", "utility", "losses", "models", "preprocessing", "data")
+_NAMES = ("deploy", "utility", "losses", "models", "preprocessing", "data", "ros_utils")
 _SUBMODULES = {
     "deploy": ("deployer", "trainer", "tester", "step_geometry"), "utility": ("projection", "poses"), "losses": ("icp_losses",),
     "models": ("model", "model_parts", "resnet_modified"), "preprocessing": ("normal_computation", "preprocesser"),
     "data": ("dataset", "synthetic", "feed", "kitti_scans"),
+    "ros_utils": ("odometry",),            # odometry_publisher needs ROS and is imported on demand
 }
 
 for _name in _NAMES:

@@ -99,3 +99,20 @@ def testing_config(testing_run_name, experiment_name="testing", checkpoint="", c
     cfg["mode"] = "testing"
     cfg["unsupervised_at_start"] = True
     return cfg
+
+
+def rosnode_config(checkpoint, dataset, lidar_topic, lidar_frame, integrate_odometry=True, config_dir="config"):
+    """The dict ``bin/run_rosnode.py`` hands to ``OdometryPublisher`` (reference bin/run_rosnode.py:27-71)."""
+    cfg = load_yaml_config(config_dir)
+    cfg["mode"] = "training"
+    if cfg["use_dropout"]:
+        cfg["use_dropout"] = False
+        print("Deactivating dropout for this mode.")
+    cfg["checkpoint"] = str(checkpoint)
+    cfg["datasets"] = [str(dataset)]
+    cfg["lidar_topic"] = str(lidar_topic)
+    cfg["lidar_frame"] = str(lidar_frame)
+    cfg["integrate_odometry"] = integrate_odometry
+    cfg["device"] = resolve_device(cfg["device"])
+    degrees_to_radians(cfg)
+    return cfg

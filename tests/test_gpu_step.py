@@ -438,3 +438,34 @@ def test_offline_preprocessing_writes_the_training_format(tmp_path):
     cfg["kitti"]["horizontal_cells"] = 128
     ds = PreprocessedPointCloudDataset(cfg)
     assert len(ds) == 2 and ds[0]["scan_1"].shape[1] == 3 and ds[0]["normal_list_2"].shape == ds[0]["scan_2"].shape
+
+
+def test_scan_to_scan_odometry_on_gpu_matches_the_cpu_core():
+    """The inference core (delora_amd/ros_utils/odometry.py) with the HIP projection on the GPU against the same core on
+    the CPU with the oracle's projection injected: same weights, same three scans, same poses."""
+    from delora_amd.data import synthetic
+    from delora_amd.models import model as model_module
+    from delora_amd.ros_utils import odometry
+    dev = _dev()
+    gm = util.load_golden("model_small")
+    cfg_gpu = _small_model_cfg(gm, 16, 128)
+    cfg_cpu = dict(cfg_gpu, device=torch.device("cpu"))
+    for c in (cfg_gpu, cfg_cpu):
+        c["integrate_odometry"] = True
+    net_gpu = model_module.OdometryModel(config=cfg_gpu).to(dev)
+    net_gpu.load_state_dict(_state_dict(gm, dev))
+    net_cpu = model_module.OdometryModel(config=cfg_cpu)
+    net_cpu.load_state_dict(_state_dict(gm, torch.device("cpu")))
+    o_sensor = util.oracle_sensor(16, 128, cfg_cpu["kitti"]["vertical_field_of_view"], cfg_cpu["horizontal_field_of_view"])
+
+    def oracle_pair(previous, current, sensor):
+        return torch.cat([orc.project_to_img(c.cpu(), o_sensor)[0][:, :4] for c in (previous, current)], dim=0)
+
+    gpu = odometry.ScanToScanOdometry(cfg_gpu, model=net_gpu)
+    cpu = odometry.ScanToScanOdometry(cfg_cpu, model=net_cpu, project_pair=oracle_pair)
+    scans = [synthetic.make_pair(300 + i, rings=16, azimuth_steps=140)[i % 2][None] for i in range(3)]
+    assert gpu.push(scans[0]) is None and cpu.push(scans[0]) is None
+    for k in (1, 2):
+        a, b = gpu.push(scans[k]), cpu.push(scans[k])
+        assert np.allclose(a["transformation"], b["transformation"], rtol=REL, atol=REL)
+        assert np.allclose(a["T_0_t"], b["T_0_t"], rtol=REL, atol=REL)

@@ -376,3 +376,86 @@ def test_ring_ops_on_cpu_are_the_reference_op_sequence(act):
     assert torch.equal(ring_act_pad(x, act, pad=False), f(x))
     want = wrap(F.max_pool2d(wrap(f(x)), kernel_size=3, stride=(1, 2), padding=(1, 0)))
     assert torch.equal(ring_act_pool_pad(x, act), want)
+
+
+def test_tf_quaternion_restatements_agree_with_scipy():
+    """quaternion_from_matrix / quaternion_matrix (restated tf.transformations, (x,y,z,w)) against scipy's Rotation on
+    random rotations, the three trace <= 0 branches and the identity; the two functions invert each other."""
+    from scipy.spatial.transform import Rotation
+    from delora_amd.ros_utils import odometry
+    rng = np.random.default_rng(5)
+    mats = list(Rotation.random(50, random_state=7).as_matrix())
+    mats += [np.diag([1.0, -1.0, -1.0]), np.diag([-1.0, 1.0, -1.0]), np.diag([-1.0, -1.0, 1.0]), np.eye(3)]
+    mats += list(Rotation.from_rotvec(rng.normal(size=(20, 3)) * 1e-4).as_matrix())       # near identity
+    mats += list(Rotation.from_rotvec([[np.pi - 1e-3, 0, 0], [0, np.pi - 1e-3, 0], [0, 0, np.pi - 1e-3]]).as_matrix())
+    for R in mats:
+        M = np.eye(4)
+        M[:3, :3] = R
+        q = odometry.quaternion_from_matrix(M)
+        assert np.isclose(np.linalg.norm(q), 1.0, atol=1e-12)
+        ref = Rotation.from_matrix(R).as_quat()
+        assert min(np.abs(q - ref).max(), np.abs(q + ref).max()) < 1e-9
+        assert np.allclose(odometry.quaternion_matrix(q)[:3, :3], R, atol=1e-9)
+    assert np.array_equal(odometry.quaternion_matrix([0.0, 0.0, 0.0, 0.0]), np.identity(4))
+
+
+def test_scan_filter_of_the_inference_node():
+    from delora_amd.ros_utils import odometry
+    scan = np.array([[[1.0, 0.0, 2.0, 0.1, 5.0], [1.0, 3.0, 0.0, 0.1, 0.0], [1.0, 3.0, 2.0, 0.1, 1.0]]], dtype=np.float32)
+    kept = odometry.filter_scans(scan)                 # exact-zero coordinate in points 1, 2, 4; point 3 closer than 0.3 m
+    assert kept.shape == (1, 3, 1) and np.array_equal(kept[0, :, 0], [1.0, 1.0, 1.0])
+
+
+@pytest.mark.parametrize("normalize", [False, True])
+def test_scan_to_scan_odometry_core_on_cpu(normalize):
+    """The ROS-free core of the inference node with the oracle's projection injected: nothing for the first scan, then the
+    network's pose for (previous, current) in metres, and an integrated pose that is the product of the steps."""
+    from delora_amd.data import synthetic
+    from delora_amd.models import model as model_module, model_parts
+    from delora_amd.ros_utils import odometry
+    gm = util.load_golden("model_small")
+    cfg = util.repo_config(16, 128, device="cpu", factor_fewer_resnet_channels=int(gm["cfg::factor_fewer_resnet_channels"]),
+                           resnet_outputs=int(gm["cfg::resnet_outputs"]), normalization_scaling=normalize)
+    cfg["integrate_odometry"] = True
+    torch.manual_seed(11)
+    net = model_module.OdometryModel(config=cfg)
+    o_sensor = util.oracle_sensor(16, 128, cfg["kitti"]["vertical_field_of_view"], cfg["horizontal_field_of_view"])
+
+    def project_pair(previous, current, sensor):
+        return torch.cat([util.orc.project_to_img(c.cpu(), o_sensor)[0][:, [0, 1, 2, 3]] for c in (previous, current)], dim=0)
+
+    odo = odometry.ScanToScanOdometry(cfg, model=net, project_pair=project_pair)
+    scans = []
+    for i in range(3):
+        s1, s2, _ = synthetic.make_pair(300 + i, rings=16, azimuth_steps=140)
+        scans.append(s1[None] if i % 2 == 0 else s2[None])
+    assert odo.push(scans[0]) is None
+    handler = model_parts.GeometryHandler(config=cfg)
+    chain = np.eye(4)
+    for k in (1, 2):
+        out = odo.push(scans[k])
+        prev = torch.from_numpy(odometry.filter_scans(scans[k - 1]))[:, :3]
+        cur = torch.from_numpy(odometry.filter_scans(scans[k]))[:, :3]
+        scale = 1.0
+        if normalize:
+            scale = float(torch.mean(torch.cat((torch.norm(cur, dim=1), torch.norm(prev, dim=1)), dim=1)))
+            prev, cur = prev / scale, cur / scale
+        imgs = project_pair(prev, cur, None)
+        with torch.no_grad():
+            t, q = net.eval()(imgs[0:1], imgs[1:2])
+            T = handler.get_transformation_matrix_quaternion(translation=t, quaternion=q, device="cpu")[0].double().numpy()
+        assert np.allclose(out["translation"], t[0].double().numpy() * scale, rtol=1e-5, atol=1e-7)
+        assert np.allclose(odometry.quaternion_matrix(out["quaternion"])[:3, :3], T[:3, :3], atol=1e-6)
+        step = odometry.quaternion_matrix(out["quaternion"])
+        step[:3, 3] = out["translation"]
+        chain = chain @ step
+        assert np.allclose(out["T_0_t"], chain, atol=1e-9)
+        assert np.allclose(out["global_translation"], chain[:3, 3], atol=1e-9)
+
+
+def test_rosnode_config_has_the_reference_cli_fields(tmp_path):
+    from delora_amd import config as config_module
+    cfg = config_module.rosnode_config("ckpt.pth", "kitti", "/velodyne_points", "velodyne", True, config_dir=os.path.join(ROOT, "config"))
+    assert cfg["datasets"] == ["kitti"] and cfg["lidar_topic"] == "/velodyne_points" and cfg["lidar_frame"] == "velodyne"
+    assert cfg["integrate_odometry"] is True and cfg["checkpoint"] == "ckpt.pth" and cfg["use_dropout"] is False
+    assert abs(cfg["horizontal_field_of_view"][1] - np.deg2rad(179.9)) < 1e-6          # radians, as the node expects
