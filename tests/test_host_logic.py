@@ -13,9 +13,10 @@ from tests.conftest import ROOT
 
 def _small_cfg(H, W, B, **over):
     gm = util.load_golden("model_small")
-    cfg = util.repo_config(H, W, device="cpu", factor_fewer_resnet_channels=int(gm["cfg::factor_fewer_resnet_channels"]),
-                           resnet_outputs=int(gm["cfg::resnet_outputs"]), unsupervised_at_start=True, inference_only=False,
-                           batch_size=B, **over)
+    opts = dict(factor_fewer_resnet_channels=int(gm["cfg::factor_fewer_resnet_channels"]), resnet_outputs=int(gm["cfg::resnet_outputs"]),
+                unsupervised_at_start=True, inference_only=False, batch_size=B)
+    opts.update(over)
+    cfg = util.repo_config(H, W, device="cpu", **opts)
     sd = {k[4:]: torch.from_numpy(v) for k, v in gm.items() if k.startswith("sd::")}
     return cfg, sd
 
@@ -459,3 +460,57 @@ def test_rosnode_config_has_the_reference_cli_fields(tmp_path):
     assert cfg["datasets"] == ["kitti"] and cfg["lidar_topic"] == "/velodyne_points" and cfg["lidar_frame"] == "velodyne"
     assert cfg["integrate_odometry"] is True and cfg["checkpoint"] == "ckpt.pth" and cfg["use_dropout"] is False
     assert abs(cfg["horizontal_field_of_view"][1] - np.deg2rad(179.9)) < 1e-6          # radians, as the node expects
+
+
+def _synthetic_samples(n, H=16, az=140):
+    from delora_amd.data import synthetic
+    out = []
+    for j in range(n):
+        s1, s2, _ = synthetic.make_pair(700 + j, rings=H, azimuth_steps=az)
+        out.append({"dataset": "kitti", "scan_1": torch.from_numpy(s1).unsqueeze(0), "scan_2": torch.from_numpy(s2).unsqueeze(0),
+                    "normal_list_1": None, "normal_list_2": None})
+    return out
+
+
+def _ddp_worker_n(rank, world, per_rank, port, identity_phase, return_dict):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from delora_amd.deploy.trainer import Trainer
+        torch.set_num_threads(2)
+        cfg, sd = _small_cfg(16, 128, per_rank, unsupervised_at_start=not identity_phase)
+        tr = Trainer(cfg, dataset=util.ListDataset([]), geometry_backend=util.OracleStepGeometry())
+        tr.raw_model.load_state_dict(sd)
+        ep = tr.new_epoch_losses()
+        tr.optimizer.zero_grad()
+        mine = _synthetic_samples(world * per_rank)[rank * per_rank:(rank + 1) * per_rank]
+        ep, T = tr.step(preprocessed_dicts=mine, epoch_losses=ep)
+        return_dict[rank] = {"T": T.detach().clone(), "grads": {k: p.grad.clone() for k, p in tr.raw_model.named_parameters()},
+                             "loss": float(ep["loss_epoch"]), "loss_pc": float(ep["loss_point_cloud_epoch"])}
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("identity_phase", [False, True])
+def test_three_ranks_times_two_samples_equal_one_batch_of_six(identity_phase):
+    """Odd world size, more than one sample per rank, online normals, both training phases: 3 ranks x B=2 (gloo) give the
+    poses, the summed loss and the averaged gradients of ONE process with B=6 (the (Bg - j)/Bg weights follow the global
+    sample index; the identity phase fits the last sample of the GLOBAL batch only)."""
+    from delora_amd.deploy.trainer import Trainer
+    world, per_rank = 3, 2
+    cfg, sd = _small_cfg(16, 128, world * per_rank, unsupervised_at_start=not identity_phase)
+    tr = Trainer(cfg, dataset=util.ListDataset([]), geometry_backend=util.OracleStepGeometry())
+    tr.raw_model.load_state_dict(sd)
+    ep = tr.new_epoch_losses()
+    tr.optimizer.zero_grad()
+    ep, T = tr.step(preprocessed_dicts=_synthetic_samples(world * per_rank), epoch_losses=ep)
+    single = {k: p.grad.clone() for k, p in tr.raw_model.named_parameters()}
+    ret = mp.Manager().dict()
+    mp.spawn(_ddp_worker_n, args=(world, per_rank, 31500 + (os.getpid() % 2000), identity_phase, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert torch.allclose(ret[r]["T"], T[r * per_rank:(r + 1) * per_rank].detach(), atol=2e-6)
+        for k, b in single.items():
+            a = ret[r]["grads"][k]
+            assert torch.allclose(a, b, rtol=2e-3, atol=3e-4 * float(b.abs().max()) + 1e-12), k
+    assert np.isclose(sum(ret[r]["loss"] for r in range(world)), float(ep["loss_epoch"]), rtol=1e-5)
+    assert np.isclose(sum(ret[r]["loss_pc"] for r in range(world)), float(ep["loss_point_cloud_epoch"]), rtol=1e-5)
