@@ -506,3 +506,62 @@ def test_normals_known_answer_plane():
     n = G.normals(img)[0].cpu().numpy().reshape(3, -1).T
     has = np.abs(n).sum(1) > 0
     assert has.mean() > 0.9 and np.allclose(n[has], [-1.0, 0.0, 0.0], atol=2e-3)
+
+
+def _torch_loss_terms(T, src, src_n, tgt, tgt_n, nn, mode, p2p):
+    """The three loss modules as plain fp32 torch ops on the device (icp_losses.py:102-121,168-240 with the gathers the
+    reference performs), differentiable with respect to T -- the full-size counterpart of the CPU oracle."""
+    rows = []
+    for b in range(src.shape[0]):
+        idx = nn[b].reshape(-1).long()
+        valid = idx >= 0
+        idx = idx.clamp(min=0)
+        p, n = src[b, :3].reshape(3, -1), src_n[b].reshape(3, -1)
+        pt, nt = tgt[b, :3].reshape(3, -1)[:, idx], tgt_n[b].reshape(3, -1)[:, idx]
+        R, t = T[b, :3, :3], T[b, :3, 3:4]
+        q, rn = R @ p + t, R @ n
+        has_s, has_t = (n != 0).any(dim=0), (nt != 0).any(dim=0)
+        m = valid & has_s & has_t
+        K = m.sum()
+        r = ((q - pt) * nt).sum(dim=0)
+        po2pl = (r[m] ** 2).sum() / K
+        if mode == "linear":
+            pl2pl = ((1.0 - (rn * nt).sum(dim=0))[m] ** 2).sum() / K
+        else:
+            pl2pl = ((rn - nt)[:, m] ** 2).sum() / K
+        po2po = torch.zeros((), device=src.device)
+        K2 = torch.zeros((), device=src.device)
+        if p2p:
+            m2 = valid & ~has_s & ~has_t
+            K2 = m2.sum()
+            po2po = ((q - pt)[:, m2] ** 2).sum() / (3 * K2)
+        rows.append((torch.stack((po2po, po2pl, pl2pl)), int(K), int(K2)))
+    return torch.stack([r[0] for r in rows]), [r[1] for r in rows], [r[2] for r in rows]
+
+
+@pytest.mark.parametrize("mode,p2p", [("squared", False), ("linear", True)])
+def test_loss_full_size_against_torch_ops(mode, p2p):
+    """BASELINE size (64x2048, ~128k pairs per sample): loss terms, pair counts and dL/dT of the fused kernel against
+    the same formulas written as plain fp32 torch ops (gather + transform + residuals + mean, autograd) on the device."""
+    G, dev = _geo(), _dev()
+    sensor, img, nrm, T_true = _pair_images(4243, 64, 2048, 64, 2250)
+    src, src_n = torch.stack((img[1], img[0])), torch.stack((nrm[1], nrm[0]))
+    tgt, tgt_n = torch.stack((img[0], img[1])), torch.stack((nrm[0], nrm[1]))
+    T0 = torch.from_numpy(T_true).float()
+    T0[:3, 3] += torch.tensor([0.05, -0.03, 0.02])
+    T = torch.stack((T0, torch.linalg.inv(T0))).to(dev).requires_grad_(True)
+    nn, _, match = G.nn_correspond(src, src_n, G.pack_image(tgt), G.pack_image(tgt_n), T, sensor, need_without_normals=p2p)
+    terms, counts = G.icp_loss(T, src, src_n, match, nn, _flags(mode, p2p))
+    w = torch.tensor([[1.0, 2.0, 0.5], [3.0, 1.5, 2.5]], device=dev)
+    if not p2p:
+        w[:, 0] = 0.0
+    (terms * w).sum().backward()
+    Tr = T.detach().clone().requires_grad_(True)
+    exp, K, K2 = _torch_loss_terms(Tr, src, src_n, tgt, tgt_n, nn, mode, p2p)
+    (exp * w).sum().backward()
+    assert [int(c) for c in counts[:, 0]] == K and min(K) > 100000
+    if p2p:
+        assert [int(c) for c in counts[:, 1]] == K2 and min(K2) > 0
+    for b in range(2):
+        _close(terms[b].detach().cpu().numpy(), exp[b].detach().cpu().numpy(), what=f"sample {b} terms")
+        _close(T.grad[b, :3].cpu().numpy(), Tr.grad[b, :3].cpu().numpy(), what=f"sample {b} dL/dT")
