@@ -565,3 +565,33 @@ def test_loss_full_size_against_torch_ops(mode, p2p):
     for b in range(2):
         _close(terms[b].detach().cpu().numpy(), exp[b].detach().cpu().numpy(), what=f"sample {b} terms")
         _close(T.grad[b, :3].cpu().numpy(), Tr.grad[b, :3].cpu().numpy(), what=f"sample {b} dL/dT")
+
+
+@pytest.mark.parametrize("shape", [(16, 130), (15, 131)])
+def test_loss_ragged_image_sizes_against_torch_ops(shape):
+    """Image sizes that are not a multiple of the 256-pixel chunk (16x130: whole chunks + a ragged tail) or not even a
+    multiple of 4 pixels (15x131: no 16-byte loads at all) take the scalar path of the loss kernel; same check as at
+    full size, with point-to-point enabled so that all 38 accumulators are exercised."""
+    G, dev = _geo(), _dev()
+    H, W = shape
+    sensor, img, nrm, T_true = _pair_images(4300 + H, H, W, 16, 150)
+    src, src_n = torch.stack((img[1], img[0])), torch.stack((nrm[1], nrm[0]))
+    tgt, tgt_n = torch.stack((img[0], img[1])), torch.stack((nrm[0], nrm[1]))
+    T0 = torch.from_numpy(T_true).float()
+    T0[:3, 3] += torch.tensor([0.05, -0.03, 0.02])
+    T = torch.stack((T0, torch.linalg.inv(T0))).to(dev).requires_grad_(True)
+    nn, _, match = G.nn_correspond(src, src_n, G.pack_image(tgt), G.pack_image(tgt_n), T, sensor, need_without_normals=True)
+    for mode in ("squared", "linear"):
+        T.grad = None
+        terms, counts = G.icp_loss(T, src, src_n, match, nn, _flags(mode, True))
+        w = torch.tensor([[1.0, 2.0, 0.5], [3.0, 1.5, 2.5]], device=dev)
+        Tr = T.detach().clone().requires_grad_(True)
+        exp, K, K2 = _torch_loss_terms(Tr, src, src_n, tgt, tgt_n, nn, mode, True)
+        use = torch.isfinite(exp)                       # an empty point-to-point set is 0/0 on both sides
+        assert torch.equal(torch.isfinite(terms), use)
+        (torch.where(use, terms, torch.zeros_like(terms)) * w).sum().backward()
+        (torch.where(use, exp, torch.zeros_like(exp)) * w).sum().backward()
+        assert [int(c) for c in counts[:, 0]] == K and [int(c) for c in counts[:, 1]] == K2 and min(K) > 500
+        for b in range(2):
+            _close(terms[b][use[b]].detach().cpu().numpy(), exp[b][use[b]].detach().cpu().numpy(), what=f"{mode} sample {b} terms")
+            _close(T.grad[b, :3].cpu().numpy(), Tr.grad[b, :3].cpu().numpy(), what=f"{mode} sample {b} dL/dT")
