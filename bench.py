@@ -8,7 +8,8 @@ fp32): spherical projection of the 2B raw scans, per-pixel normals from the proj
 quaternion -> T, exact nearest-neighbour correspondences, the fused point-to-plane/plane-to-plane loss, backward
 through loss and CNN, gradient all-reduce (N>1) and the Adam update.  Inputs (raw scan point lists) are resident in
 HBM when the timed region starts.  Rank 0 prints ONE JSON line (contract in the task statement) that also carries
-  "roofline":     the fused ICP loss launch, algorithmic bytes / HIP-event time inside the timed steps, vs 8 TB/s HBM
+  "roofline":     the fused ICP loss kernel, algorithmic bytes / its duration inside the timed steps (begin/end timestamps
+                  on HIP events attached to the launch), vs 8 TB/s HBM
   "cpu_baseline": the same step evaluated by the CPU oracle (oracle/delora_oracle.py + torch CPU ops) on a bounded
                   sample, on this box's host cores (kind "port")
   "kernels":      per-launch HIP-event times and achieved bandwidth of every geometry kernel (back-to-back launches).
