@@ -7,11 +7,16 @@ A "step" is one full training step over a batch of B scan pairs per GPU (BASELIN
 fp32): spherical projection of the 2B raw scans, per-pixel normals from the projected images, the pose CNN forward,
 quaternion -> T, exact nearest-neighbour correspondences, the fused point-to-plane/plane-to-plane loss, backward
 through loss and CNN, gradient all-reduce (N>1) and the Adam update.  Inputs (raw scan point lists) are resident in
-HBM when the timed region starts.  Rank 0 prints ONE JSON line (contract in the task statement) that also carries
-  "roofline":     the fused ICP loss kernel, algorithmic bytes / its duration inside the timed steps (begin/end timestamps
-                  on HIP events attached to the launch), vs 8 TB/s HBM
-  "cpu_baseline": the same step evaluated by the CPU oracle (oracle/delora_oracle.py + torch CPU ops) on a bounded
-                  sample, on this box's host cores (kind "port")
+HBM when the timed region starts; the timed steps ROTATE over `--rotate` distinct batches (ragged scan lengths) so
+that no step finds the previous step's intermediates of the same data in a cache.  Rank 0 prints ONE JSON line
+(contract in the task statement) that also carries
+  "roofline":     the fused ICP loss kernel: algorithmic bytes / its duration, measured in the timed steps themselves
+                  (begin/end timestamps on HIP events attached to the launch) = the infinity-cache-warm regime the step
+                  runs in, AND behind a cache flush (cold, HBM), vs 8 TB/s
+  "long_run":     the same loop for `--long-steps` (default 200) steps
+  "feed":         the same steps fed from pinned host memory through DataLoader + DevicePrefetcher (H2D in the loop)
+  "cpu_baseline": the reference-like step (stored normal lists, B=1) evaluated by the CPU oracle on a bounded sample;
+  "cpu_baseline_online_normals": the GPU workload itself (normals computed in the step) on the CPU
   "kernels":      per-launch HIP-event times and achieved bandwidth of every geometry kernel (back-to-back launches).
 """
 import argparse
@@ -24,12 +29,13 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s measured copy rate)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -37,16 +43,20 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="scan pairs per GPU per step")
     ap.add_argument("--height", type=int, default=64)
     ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--rotate", type=int, default=8, help="distinct batches the steps rotate over (HBM resident)")
+    ap.add_argument("--long-steps", type=int, default=200, help="extra timed run of this many steps (0 = skip); N=1 only")
+    ap.add_argument("--feed-steps", type=int, default=64, help="steps of the host-fed leg (0 = skip); N=1 only")
     ap.add_argument("--amp", default="", help="optional autocast dtype for the CNN (bfloat16/float16); default fp32 = parity mode")
     ap.add_argument("--channels-last", action="store_true")
+    ap.add_argument("--cnn", default="", help="CNN implementation override (config key cnn_impl)")
     ap.add_argument("--miopen-benchmark", action="store_true", help="torch.backends.cudnn.benchmark = True (exhaustive MIOpen find)")
-    ap.add_argument("--graph", action="store_true", help="replay the whole step as one captured HIP graph (single GPU only)")
+    ap.add_argument("--graph", action="store_true", help="replay the whole step as one captured HIP graph (single GPU, one batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs evaluated by the CPU baseline")
+    ap.add_argument("--cpu-pairs", type=int, default=2, help="pairs evaluated by the CPU baseline (stored-normals leg)")
     ap.add_argument("--cpu-threads", type=int, default=16, help="torch CPU threads of the baseline (more is slower on a 256-thread host: "
                     "the step is a chain of small ops; 128 threads measured 190 s/pair vs ~10 s/pair)")
     ap.add_argument("--kernel-reps", type=int, default=50)
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def build_config(args, device):
@@ -62,6 +72,8 @@ def build_config(args, device):
         cfg["amp_dtype"] = args.amp
     if args.channels_last:
         cfg["channels_last"] = True
+    if getattr(args, "cnn", ""):
+        cfg["cnn_impl"] = args.cnn
     return cfg
 
 
@@ -79,6 +91,43 @@ def make_batch(args, rank, device=None):
     return samples
 
 
+def derived_batches(base, count, rank):
+    """`count` distinct host batches from one ray-cast batch (ray casting costs ~0.4 s per pair): batch 0 is `base`, batch k
+    is the same scenes seen under a different heading -- both scans of a pair rotated about the vertical axis by the same
+    angle, which moves every point to another pixel column and keeps the pair's relative motion small -- with a different
+    random 0-3 % of the points dropped (ragged scan lengths) and the points shuffled."""
+    out = [[{k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()} for d in base]]
+    for k in range(1, count):
+        rng = np.random.default_rng(77000 + 100 * rank + k)
+        batch = []
+        for d in base:
+            yaw = 2.0 * np.pi * k / count + rng.uniform(-0.2, 0.2)
+            c, s = np.cos(yaw), np.sin(yaw)
+            R = torch.tensor([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]], dtype=torch.float32)
+            e = dict(d)
+            for name in ("scan_1", "scan_2"):
+                pts = d[name][0]
+                n = pts.shape[1]
+                keep = torch.from_numpy(rng.permutation(n)[: n - int(rng.integers(0, max(1, int(0.03 * n))))])
+                e[name] = (R @ pts[:, keep]).unsqueeze(0).contiguous()
+            batch.append(e)
+        out.append(batch)
+    return out
+
+
+def pin_batches(batches):
+    for b in batches:
+        for d in b:
+            for k, v in d.items():
+                if torch.is_tensor(v) and not v.is_cuda:
+                    d[k] = v.pin_memory()
+    return batches
+
+
+def to_device(batch, device):
+    return [{k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in d.items()} for d in batch]
+
+
 def identity_pretrained_state(model):
     """Put the randomly initialised network into the state the reference's own first training phase leaves it in
     (identity fitting until its loss < 1e-2, src/deploy/trainer.py:184-186): it predicts T = I.  Done by zeroing the last
@@ -89,25 +138,6 @@ def identity_pretrained_state(model):
         rot, tra = model.fully_connected_rotation[-1], model.fully_connected_translation[-1]
         rot.weight.zero_(); rot.bias.copy_(torch.tensor([0.0, 0.0, 0.0, 1.0]))
         tra.weight.zero_(); tra.bias.zero_()
-
-
-class _Events:
-    """HIP events on torch's current stream -- the stream every delora kernel is launched on."""
-
-    def __init__(self):
-        self.pairs = []
-
-    def __enter__(self):
-        self.a, self.b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.a.record()
-        return self
-
-    def __exit__(self, *exc):
-        self.b.record()
-        self.pairs.append((self.a, self.b))
-
-    def mean_ms(self):
-        return float(np.mean([a.elapsed_time(b) for a, b in self.pairs])) if self.pairs else float("nan")
 
 
 def pmc_traffic(kernel):
@@ -125,7 +155,8 @@ def pmc_traffic(kernel):
 
 def kernel_table(trainer, batch, reps):
     """Per-launch time of each geometry entry point on the bench batch: `reps` back-to-back launches between two HIP
-    events (launch gaps included), with the algorithmic bytes of DESIGN.md."""
+    events (launch gaps included), with the algorithmic bytes of DESIGN.md; and the loss kernel alone behind a flush of
+    the infinity cache (cold)."""
     from delora_amd import geometry as G
     cfg = trainer.config
     sensor = trainer.img_projection.sensor("kitti")
@@ -133,9 +164,6 @@ def kernel_table(trainer, batch, reps):
     prepared = trainer.geo.prepare(batch, sensor, trainer._normal_params("kitti"))
     img, nrm = prepared["images"], prepared["normals"]
     tgt_pk, tgt_n_pk = prepared["packed"][:, 0], prepared["normals_packed"][:, 0]
-    with torch.no_grad():
-        t, q = trainer._run_model(prepared["stacked"])
-        T = trainer.geometry_handler.get_transformation_matrix_quaternion(t, q, trainer.device)
     # a realistic pose (small residual motion) for the correspondence / loss kernels
     T_small = torch.eye(4, device=trainer.device).repeat(B, 1, 1)
     T_small[:, 0, 3] = 0.4
@@ -171,52 +199,100 @@ def kernel_table(trainer, batch, reps):
     row("dl_project", timed(lambda: G.project(pts, offs, max(lengths), sensor, want_kept=False)), 12 * n_pts + 36 * 2 * B * HW, "hbm",
         f"{2 * B} scans, {n_pts} points -> {2 * B}x{sensor.H}x{sensor.W}; 12 B/point + 36 B/pixel (planar + packed image, map)")
     row("dl_normals", timed(lambda: G.normals(prepared["stacked"].view(2 * B, 4, sensor.H, sensor.W), want_packed=True)), 40 * 2 * B * HW, "valu",
-        "7x11 stencil + fp64 3x3 eigen; 40 B/pixel (read xyz, write planar + packed normals)")
+        "7x11 stencil + 3x3 eigen solve; 40 B/pixel (read xyz, write planar + packed normals)")
     row("dl_nn_correspond", timed(lambda: G.nn_correspond(img[:, 1], nrm[:, 1], tgt_pk, tgt_n_pk, T_small, sensor)), 28 * B * HW + 12 * B * HW, "l2+valu",
         f"{M} queries, residual motion 0.4 m")
+    # the random-pose regime (an untrained network): every query falls back to the tile walk over the whole image
+    g = torch.Generator().manual_seed(5)
+    q = torch.randn((B, 4), generator=g)
+    from delora_amd.models.model_parts import GeometryHandler
+    T_rand = GeometryHandler.get_transformation_matrix_quaternion(torch.randn((B, 3), generator=g), q, torch.device("cpu")).to(trainer.device)
+    row("dl_nn_correspond/random-pose", timed(lambda: G.nn_correspond(img[:, 1], nrm[:, 1], tgt_pk, tgt_n_pk, T_rand, sensor)),
+        28 * B * HW + 12 * B * HW, "l2+valu", "random rotations + 1 m translations (worst case of the exact search)")
     row("dl_icp_loss_fwd", timed(lambda: G.icp_loss(T_small, img[:, 1], nrm[:, 1], match, nn, flags)), 52 * M, "hbm",
         f"both launches (stream + reduce); {M} source points with a correspondence, {K} pairs; 52 B/point")
-    return rows, {"M": M, "K": K, "kept": kept}
+    # cold: the loss kernel alone right after 1 GiB of unrelated writes has gone through the 256 MiB infinity cache
+    timers = G.LossTimers()
+    flush = torch.empty((256 * 1024 * 1024,), dtype=torch.float32, device=trainer.device)
+    G.LOSS_TIMER_FACTORY = timers.new
+    try:
+        for i in range(12):
+            flush.fill_(float(i))
+            G.icp_loss(T_small, img[:, 1], nrm[:, 1], match, nn, flags)
+        torch.cuda.synchronize()
+    finally:
+        G.LOSS_TIMER_FACTORY = None
+    cold = timers.elapsed_ms()[2:]
+    timers.close()
+    del flush
+    return rows, {"M": M, "K": K, "kept": kept, "loss_cold_ms": float(np.mean(cold)), "loss_cold_min_ms": float(np.min(cold))}
+
+
+def _cpu_step(orc, model, opt, cfg, lists, images):
+    from delora_amd.models.model_parts import GeometryHandler
+    opt.zero_grad()
+    t, q = model(images[0], images[1])
+    T = GeometryHandler.get_transformation_matrix_quaternion(t, q, torch.device("cpu"))
+    out, _ = orc.step_losses([lists], T, lambda_po2pl=cfg["lambda_po2pl"], normal_loss=cfg["normal_loss"])
+    out["loss_pc"].sum().backward()
+    opt.step()
 
 
 def cpu_baseline(args, cfg):
-    """The same training step on the host: oracle geometry (torch CPU ops + scipy cKDTree) + the CNN on CPU threads.
-    Bounded sample: `cpu_pairs` pairs at B=1 (the reference's own batch size), same 64x2048 synthetic generator."""
+    """The training step on the host with the CPU oracle (torch CPU ops + scipy cKDTree) + the CNN on CPU threads, B=1 (the
+    reference's own batch size), same 64x2048 synthetic generator, bounded sample.
+      cpu_baseline                 the reference's step (src/deploy/trainer.py:43-91, deployer.py:237-375): point and normal
+                                   lists come from disk (computed offline, untimed here), the step re-projects them, runs the
+                                   network, KD-tree correspondences, losses, backward, Adam
+      cpu_baseline_online_normals  the GPU workload itself: normals computed inside the step from the projected images."""
     from oracle import delora_oracle as orc
     from delora_amd.models.model import OdometryModel
-    from delora_amd.models.model_parts import GeometryHandler
+    from delora_amd.data import synthetic
     torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
     cores = torch.get_num_threads()
     ccfg = dict(cfg)
     ccfg["device"] = torch.device("cpu")
+    ccfg.pop("cnn_impl", None)
     torch.manual_seed(0)
     model = OdometryModel(ccfg)
     opt = torch.optim.Adam(model.parameters(), lr=cfg["learning_rate"])
     sensor = orc.Sensor(args.height, args.width, cfg["kitti"]["vertical_field_of_view"], cfg["horizontal_field_of_view"])
+    pre = orc.Sensor(args.height, 2250, cfg["kitti"]["vertical_field_of_view"], cfg["horizontal_field_of_view"])
     side = cfg["kitti"]["neighborhood_side_length"]
-    from delora_amd.data import synthetic
-    t_total = 0.0
+    kw = dict(side=side, epsilon_range=cfg["epsilon_range"], min_neighbors=cfg["min_num_points_in_neighborhood_to_determine_point_class"])
+    t_stored, t_online = 0.0, 0.0
+    online_pairs = 1
     for k in range(args.cpu_pairs):
         s1, s2, _ = synthetic.make_pair(2000 + k, rings=args.height, azimuth_steps=2250)
-        t0 = time.perf_counter()
-        lists, images = {}, []
+        # offline preprocessing of the reference (bin/preprocess_data.py -> scans/normals lists on disk), untimed
+        stored = {}
         for name, s in (("1", s1), ("2", s2)):
-            img, _, _, _, _ = orc.project_to_img(torch.from_numpy(s).view(1, 3, -1), sensor)
-            nrm, has, pts = orc.compute_normal_vectors(img.clone(), sensor, side=side, epsilon_range=cfg["epsilon_range"],
-                                                       min_neighbors=cfg["min_num_points_in_neighborhood_to_determine_point_class"])
-            lists["scan_" + name] = pts.t().contiguous().view(1, 3, -1)
-            lists["normal_list_" + name] = nrm.t().contiguous().view(1, 3, -1)
-            images.append(img)
-        opt.zero_grad()
-        t, q = model(images[0], images[1])
-        T = GeometryHandler.get_transformation_matrix_quaternion(t, q, torch.device("cpu"))
-        out, _ = orc.step_losses([lists], T, lambda_po2pl=cfg["lambda_po2pl"], normal_loss=cfg["normal_loss"])
-        out["loss_pc"].sum().backward()
-        opt.step()
-        t_total += time.perf_counter() - t0
-    return {"value": round(args.cpu_pairs / t_total, 4), "unit": "scan-pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{args.cpu_pairs} pairs, B=1, {args.height}x{args.width}, oracle geometry (torch CPU + scipy cKDTree) + CNN fwd/bwd + Adam on {cores} threads",
-            "s_per_pair": round(t_total / args.cpu_pairs, 3)}
+            img, _, _, _, _ = orc.project_to_img(torch.from_numpy(s).view(1, 3, -1), pre)
+            nrm, has, pts = orc.compute_normal_vectors(img.clone(), pre, **kw)
+            stored["scan_" + name] = pts.t().contiguous().view(1, 3, -1)
+            stored["normal_list_" + name] = nrm.t().contiguous().view(1, 3, -1)
+        t0 = time.perf_counter()
+        img1, img2, lists = orc.filter_to_projected(stored, sensor)                 # deployer.py:252-267
+        _cpu_step(orc, model, opt, cfg, lists, [img1.unsqueeze(0), img2.unsqueeze(0)])
+        t_stored += time.perf_counter() - t0
+        if k < online_pairs:
+            t0 = time.perf_counter()
+            lists, images = {}, []
+            for name, s in (("1", s1), ("2", s2)):
+                img, _, _, _, _ = orc.project_to_img(torch.from_numpy(s).view(1, 3, -1), sensor)
+                nrm, has, pts = orc.compute_normal_vectors(img.clone(), sensor, **kw)
+                lists["scan_" + name] = pts.t().contiguous().view(1, 3, -1)
+                lists["normal_list_" + name] = nrm.t().contiguous().view(1, 3, -1)
+                images.append(img)
+            _cpu_step(orc, model, opt, cfg, lists, images)
+            t_online += time.perf_counter() - t0
+    base = {"unit": "scan-pairs/s", "cores": cores, "kind": "port"}
+    stored_leg = dict(base, value=round(args.cpu_pairs / t_stored, 4), s_per_pair=round(t_stored / args.cpu_pairs, 3),
+                      sample=f"{args.cpu_pairs} pairs, B=1, {args.height}x{args.width}, stored point+normal lists (offline preprocessing untimed, as the reference), "
+                             f"oracle re-projection + CNN fwd/bwd + cKDTree + losses + Adam on {cores} threads")
+    online_leg = dict(base, value=round(online_pairs / t_online, 4), s_per_pair=round(t_online / online_pairs, 3),
+                      sample=f"{online_pairs} pair, B=1, {args.height}x{args.width}, normals computed inside the step (the GPU workload) on {cores} threads")
+    return stored_leg, online_leg
 
 
 def main():
@@ -238,87 +314,139 @@ def main():
             torch.distributed.init_process_group(backend=backend)
     from delora_amd.deploy.trainer import Trainer
     from delora_amd.data.dataset import ListDataset
+    from delora_amd.data.feed import DevicePrefetcher
     if args.miopen_benchmark:
         torch.backends.cudnn.benchmark = True
     cfg = build_config(args, device)
     torch.manual_seed(1234)
-    batch = make_batch(args, rank, device)
-    trainer = Trainer(cfg, dataset=ListDataset(batch))
+    host_batches = pin_batches(derived_batches(make_batch(args, rank), max(1, args.rotate), rank))
+    batches = [to_device(b, device) for b in host_batches]
+    trainer = Trainer(cfg, dataset=ListDataset([d for b in host_batches for d in b]))
     identity_pretrained_state(trainer.raw_model)
+    counter = {"i": 0}
 
-    def run_step(timed):
+    def run_step(batch=None):
+        if batch is None:
+            batch = batches[counter["i"] % len(batches)]
+            counter["i"] += 1
         trainer.optimizer.zero_grad(set_to_none=True)
         ep = trainer.new_epoch_losses()
         ep, T = trainer.step(preprocessed_dicts=[dict(s) for s in batch], epoch_losses=ep)
         return ep
 
     for _ in range(args.warmup):
-        run_step(False)
+        run_step()
     graphed = None
     if args.graph and world == 1:
         from delora_amd.deploy.graph_step import GraphedStep
-        graphed = GraphedStep(trainer, batch)
+        graphed = GraphedStep(trainer, batches[0])
         if graphed.captured:
-            run_step = lambda timed: graphed()[0]            # noqa: E731
+            run_step = lambda batch=None: graphed()[0]            # noqa: E731  (static shapes: one batch replayed)
     # in-situ timing of the streaming loss kernel (k_icp_loss) in every timed step: the launch carries a pair of HIP
     # events that receive the kernel's own begin/end timestamps (dl_icp_loss_partial_timed) on the launch stream
     from delora_amd import geometry as G
     timers = G.LossTimers()
     if graphed is None or not graphed.captured:            # event-carrying launches cannot be captured into a graph
         G.LOSS_TIMER_FACTORY = timers.new
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        ep = run_step(True)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    elapsed = time.perf_counter() - t0
+
+    def timed_region(steps, step_fn):
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        t0 = time.perf_counter()
+        ep = None
+        for _ in range(steps):
+            ep = step_fn()
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([el], device=device, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            el = float(tt.item())
+        return el, ep
+
+    counter["i"] = 0
+    elapsed, ep = timed_region(args.steps, run_step)
     G.LOSS_TIMER_FACTORY = None
-    if world > 1:
-        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(tt.item())
     final_loss = float(ep["loss_epoch"])
     pairs = world * args.batch * args.steps
+    ranks_seen = torch.distributed.get_world_size() if world > 1 else 1
     result = {
         "metric": "training scan-pairs/sec, KITTI 64x2048 range images", "value": round(pairs / elapsed, 3), "unit": "scan-pairs/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if not args.amp else args.amp,
         "data": "synthetic",
-        "config": {"workload": f"KITTI-shaped {args.height}x{args.width}, batch={args.batch} pairs/GPU, raw scans of ~141k points, "
-                               f"online normals, ResNet pose CNN (11.9M params, identity-pretrained state) on PyTorch-ROCm, Adam; BASELINE configs[1]",
+        "config": {"workload": f"KITTI-shaped {args.height}x{args.width}, batch={args.batch} pairs/GPU, raw scans of ~141k points (ragged), "
+                               f"steps rotate over {len(batches)} distinct HBM-resident batches, online normals, ResNet pose CNN (11.9M params, "
+                               f"identity-pretrained state), Adam; BASELINE configs[1]",
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "cnn": "fp32" if not args.amp else "autocast " + args.amp,
-                   "channels_last": bool(args.channels_last), "hip_graph": bool(graphed is not None and graphed.captured)},
+                   "cnn_impl": str(getattr(trainer.raw_model.resnet, "impl", "modules")),
+                   "channels_last": bool(args.channels_last), "hip_graph": bool(graphed is not None and graphed.captured),
+                   "distinct_batches": len(batches)},
         "final_loss": final_loss,
+        "rccl_ranks": ranks_seen, "collective_backend": (backend if world > 1 else None),
     }
     if rank == 0:
-        rows, counts = kernel_table(trainer, batch, args.kernel_reps)
+        rows, counts = kernel_table(trainer, batches[0], args.kernel_reps)
         if not timers.handles:                                 # graph mode: measure the same launch right after the timed region
             G.LOSS_TIMER_FACTORY = timers.new
             for _ in range(5):
                 trainer.optimizer.zero_grad(set_to_none=True)
-                trainer.step(preprocessed_dicts=[dict(s) for s in batch], epoch_losses=trainer.new_epoch_losses())
+                trainer.step(preprocessed_dicts=[dict(s) for s in batches[0]], epoch_losses=trainer.new_epoch_losses())
             torch.cuda.synchronize()
             G.LOSS_TIMER_FACTORY = None
         loss_ms = float(np.mean(timers.elapsed_ms()))
         timers.close()
-        # in-situ measurement uses the poses the network actually predicted in the timed steps
-        last = trainer.last_step
-        K_live = int(last["pair_counts"][:, 0].sum())
         alg = next(r for r in rows if r["kernel"] == "dl_icp_loss_fwd")
         live_bytes = 52 * counts["M"]
-        result["roofline"] = {"kernel": "k_icp_loss (dl_icp_loss_partial: fused transform + residuals + reduction, 13 planes streamed)", "bound": "hbm",
-                              "achieved": round(live_bytes / loss_ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                              "frac": round(live_bytes / loss_ms / 1e6 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("k_icp_loss"),
-                              "ms_per_launch_in_step": round(loss_ms, 5), "ms_per_launch_back_to_back": alg["ms"],
-                              "algorithmic_bytes": live_bytes,
-                              "note": "kernel begin/end timestamps on HIP events attached to the launch (hipExtLaunchKernelGGL) in each of the K timed steps; 52 B x source points with a correspondence"}
+        warm = live_bytes / loss_ms / 1e6
+        cold = live_bytes / counts["loss_cold_ms"] / 1e6
+        result["roofline"] = {
+            "kernel": "k_icp_loss (dl_icp_loss_partial: fused transform + residuals + reduction, 13 planes streamed)",
+            "bound": "hbm", "regime_in_step": "infinity-cache (the search kernel has just written/read the 54 MB of operands)",
+            "achieved": round(warm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(warm / HBM_PEAK_GBS, 4),
+            "frac_warm": round(warm / HBM_PEAK_GBS, 4), "frac_cold": round(cold / HBM_PEAK_GBS, 4),
+            "achieved_cold": round(cold, 1), "traffic": pmc_traffic("k_icp_loss"),
+            "ms_per_launch_in_step": round(loss_ms, 5), "ms_per_launch_cold": round(counts["loss_cold_ms"], 5),
+            "ms_per_launch_cold_min": round(counts["loss_cold_min_ms"], 5), "ms_per_launch_back_to_back": alg["ms"],
+            "algorithmic_bytes": live_bytes,
+            "note": "frac = frac_warm: kernel begin/end timestamps on HIP events attached to the launch (hipExtLaunchKernelGGL) in each of "
+                    "the K timed steps, where the operands sit in the 256 MiB infinity cache; frac_cold: the same launch right after 1 GiB "
+                    "of unrelated writes (operands come from HBM); 52 B x source points with a correspondence, vs the 8 TB/s HBM peak"}
         result["kernels"] = rows
-        if world == 1 and not args.no_cpu_baseline:
-            result["cpu_baseline"] = cpu_baseline(args, cfg)
+        if world == 1:
+            if args.long_steps > 0:
+                el, _ = timed_region(args.long_steps, run_step)
+                result["long_run"] = {"steps": args.long_steps, "ms_per_step": round(1e3 * el / args.long_steps, 3),
+                                      "value": round(args.batch * args.long_steps / el, 3)}
+            if args.feed_steps > 0 and (graphed is None or not graphed.captured):
+                loader = torch.utils.data.DataLoader(dataset=trainer.dataset, batch_size=args.batch, shuffle=False,
+                                                     collate_fn=Trainer.list_collate, drop_last=True, num_workers=0)
+                moved = {"bytes": 0}
+
+                def epochs():
+                    while True:
+                        for b in DevicePrefetcher(loader, device):
+                            yield b
+                it = epochs()
+
+                def fed_step():
+                    b = next(it)
+                    moved["bytes"] += sum(v.numel() * v.element_size() for d in b for v in d.values() if torch.is_tensor(v))
+                    return run_step(b)
+                for _ in range(3):
+                    fed_step()
+                moved["bytes"] = 0
+                el, _ = timed_region(args.feed_steps, fed_step)
+                result["feed"] = {"steps": args.feed_steps, "value": round(args.batch * args.feed_steps / el, 3), "unit": "scan-pairs/s",
+                                  "ms_per_step": round(1e3 * el / args.feed_steps, 3), "feed_GB_s": round(moved["bytes"] / el / 1e9, 3),
+                                  "MB_per_pair": round(moved["bytes"] / (args.batch * args.feed_steps) / 1e6, 3),
+                                  "note": "same steps with every batch read from pinned host memory through DataLoader + DevicePrefetcher "
+                                          "(async H2D one batch ahead on a side stream)"}
+            if not args.no_cpu_baseline:
+                result["cpu_baseline"], result["cpu_baseline_online_normals"] = cpu_baseline(args, cfg)
         print(json.dumps(result))
     if world > 1:
         torch.distributed.barrier()

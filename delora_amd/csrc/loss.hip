@@ -67,14 +67,15 @@ __device__ __forceinline__ f2 mul2(float a, f2 b) { return (f2){a, a} * b; }
 // pixels can be issued before any of them is consumed.  Per pixel the arithmetic is the same sequence of fp32
 // operations as the scalar form of the formulas above.
 template <bool P2P, bool LINEAR, int NA>
-__device__ __forceinline__ void accumulate_pair2(f2 (&acc)[NA], const float (&m)[12], bool valid0, bool valid1, f2 x,
+__device__ __forceinline__ void accumulate_pair2(f2 (&acc)[NA], const float (&m)[12], bool alone, bool valid0, bool valid1, f2 x,
                                                  f2 y, f2 z, f2 nx, f2 ny, f2 nz, f2 tx, f2 ty, f2 tz, f2 tnx, f2 tny,
                                                  f2 tnz) {
   const bool hs0 = (nx.x != 0.f) || (ny.x != 0.f) || (nz.x != 0.f);           // icp_losses.py:48-50
   const bool hs1 = (nx.y != 0.f) || (ny.y != 0.f) || (nz.y != 0.f);
   const bool ht0 = (tnx.x != 0.f) || (tny.x != 0.f) || (tnz.x != 0.f);        // :51-52
   const bool ht1 = (tnx.y != 0.f) || (tny.y != 0.f) || (tnz.y != 0.f);
-  const f2 w = {(valid0 && hs0 && ht0) ? 1.f : 0.f, (valid1 && hs1 && ht1) ? 1.f : 0.f};   // :110-121
+  // po2po_alone (:36-45): no pair takes part in the normal-based terms, every matched source point in point-to-point
+  const f2 w = {(valid0 && hs0 && ht0 && !alone) ? 1.f : 0.f, (valid1 && hs1 && ht1 && !alone) ? 1.f : 0.f};   // :110-121
   const f2 qx = fma2(m[2], z, fma2(m[1], y, mul2(m[0], x))) + m[3];
   const f2 qy = fma2(m[6], z, fma2(m[5], y, mul2(m[4], x))) + m[7];
   const f2 qz = fma2(m[10], z, fma2(m[9], y, mul2(m[8], x))) + m[11];
@@ -108,7 +109,7 @@ __device__ __forceinline__ void accumulate_pair2(f2 (&acc)[NA], const float (&m)
   }
   if (P2P) {
     // point-to-point on pairs without normals on either side (:85-100, :168-172)
-    const f2 w2 = {(valid0 && !hs0 && !ht0) ? 1.f : 0.f, (valid1 && !hs1 && !ht1) ? 1.f : 0.f};
+    const f2 w2 = {(valid0 && (alone || (!hs0 && !ht0))) ? 1.f : 0.f, (valid1 && (alone || (!hs1 && !ht1))) ? 1.f : 0.f};
     const f2 ux = w2 * dx, uy = w2 * dy, uz = w2 * dz;
     acc[ACC_N + 0] += fma2(uz, uz, fma2(uy, uy, ux * ux));
     acc[ACC_N + 1] += ux; acc[ACC_N + 2] += uy; acc[ACC_N + 3] += uz;
@@ -218,7 +219,8 @@ template <bool P2P, bool LINEAR>
 __global__ __launch_bounds__(DL_BLOCK) void k_icp_loss(
     const float* __restrict__ src, int64_t src_ss, const float* __restrict__ srcn, int64_t srcn_ss,
     const float* __restrict__ match, int64_t match_ss, const int32_t* __restrict__ nn_pix,
-    const float* __restrict__ T, int HW, float* __restrict__ partials) {
+    const float* __restrict__ T, int HW, int alone_i, float* __restrict__ partials) {
+  const bool alone = alone_i != 0;
   constexpr int NA = P2P ? ACC_MAX : ACC_N;
   constexpr int CHUNK = DL_WAVE * LOSS_PX;                       // 256 pixels
   const int b = blockIdx.y;
@@ -243,9 +245,9 @@ __global__ __launch_bounds__(DL_BLOCK) void k_icp_loss(
       const StreamRegs cur = load_stream(nn, sp, sn, mt, q4, c * DL_WAVE + lane);
 #define DL_LO(V) ((f2){cur.V.x, cur.V.y})
 #define DL_HI(V) ((f2){cur.V.z, cur.V.w})
-      accumulate_pair2<P2P, LINEAR, NA>(acc, m, cur.j.x >= 0, cur.j.y >= 0, DL_LO(x), DL_LO(y), DL_LO(z), DL_LO(a), DL_LO(b),
+      accumulate_pair2<P2P, LINEAR, NA>(acc, m, alone, cur.j.x >= 0, cur.j.y >= 0, DL_LO(x), DL_LO(y), DL_LO(z), DL_LO(a), DL_LO(b),
                                         DL_LO(c), DL_LO(tx), DL_LO(ty), DL_LO(tz), DL_LO(ta), DL_LO(tb), DL_LO(tc));
-      accumulate_pair2<P2P, LINEAR, NA>(acc, m, cur.j.z >= 0, cur.j.w >= 0, DL_HI(x), DL_HI(y), DL_HI(z), DL_HI(a), DL_HI(b),
+      accumulate_pair2<P2P, LINEAR, NA>(acc, m, alone, cur.j.z >= 0, cur.j.w >= 0, DL_HI(x), DL_HI(y), DL_HI(z), DL_HI(a), DL_HI(b),
                                         DL_HI(c), DL_HI(tx), DL_HI(ty), DL_HI(tz), DL_HI(ta), DL_HI(tb), DL_HI(tc));
 #undef DL_LO
 #undef DL_HI
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(DL_BLOCK) void k_icp_loss(
         const bool i0 = p0 < HW, i1 = p1 < HW;
         const int a0 = i0 ? p0 : 0, a1 = i1 ? p1 : 0;            // out-of-range pixels read pixel 0 and are masked
 #define DL_PL(P, O) ((f2){P[(size_t)(O) * HW + a0], P[(size_t)(O) * HW + a1]})
-        accumulate_pair2<P2P, LINEAR, NA>(acc, m, i0 && nn[a0] >= 0, i1 && nn[a1] >= 0, DL_PL(sp, 0), DL_PL(sp, 1),
+        accumulate_pair2<P2P, LINEAR, NA>(acc, m, alone, i0 && nn[a0] >= 0, i1 && nn[a1] >= 0, DL_PL(sp, 0), DL_PL(sp, 1),
                                           DL_PL(sp, 2), DL_PL(sn, 0), DL_PL(sn, 1), DL_PL(sn, 2), DL_PL(mt, 0), DL_PL(mt, 1),
                                           DL_PL(mt, 2), DL_PL(mt, 3), DL_PL(mt, 4), DL_PL(mt, 5));
 #undef DL_PL
@@ -401,17 +403,21 @@ extern "C" int dl_icp_loss_partial_timed(const float* src_image4, int64_t src_ss
   if ((H * W) % 4 == 0 && ((src_ss | srcn_ss | match_ss) % 4 ||
                            (((uintptr_t)src_image4 | (uintptr_t)src_normals | (uintptr_t)match | (uintptr_t)nn_pix) & 15)))
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_icp_loss_partial: planes and nn_pix must be 16-byte aligned");
+  if ((flags & DL_LOSS_PO2PO_ALONE) && (flags & (DL_LOSS_POINT_TO_PLANE | DL_LOSS_PLANE_TO_PLANE)))
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_icp_loss_partial: po2po_alone excludes the point-to-plane / plane-to-plane terms "
+                                            "(the reference has no pair lists for them in this mode, icp_losses.py:36-45,135-146)");
   hipStream_t st = (hipStream_t)stream;
   float* partials = (float*)workspace;
   const dim3 grid(loss_blocks(H * W), B), block(DL_BLOCK);
   const bool p2p = flags & DL_LOSS_POINT_TO_POINT, lin = flags & DL_LOSS_NORMAL_LINEAR;
+  const int alone = (flags & DL_LOSS_PO2PO_ALONE) ? 1 : 0;
   // with a timer the kernel's own begin/end timestamps are attached to the two events (hipExtLaunchKernelGGL), i.e. the
   // same quantity a profiler reports, without the dispatch latency that two separately recorded events would add
   DlTimer* tm = (DlTimer*)timer;
 #define DL_LAUNCH_LOSS(P, L)                                                                               \
   hipExtLaunchKernelGGL((k_icp_loss<P, L>), grid, block, 0, st, tm ? tm->start : nullptr,                  \
                         tm ? tm->stop : nullptr, 0, src_image4, src_ss, src_normals, srcn_ss, match,       \
-                        match_ss, nn_pix, T, H * W, partials)
+                        match_ss, nn_pix, T, H * W, alone, partials)
   if (p2p && lin) DL_LAUNCH_LOSS(true, true);
   else if (p2p) DL_LAUNCH_LOSS(true, false);
   else if (lin) DL_LAUNCH_LOSS(false, true);

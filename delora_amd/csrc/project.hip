@@ -99,8 +99,12 @@ extern "C" int dl_project(const float* pts, int64_t pts_cs, const int32_t* offs,
   if (packed_aux && C < 6) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_project: packed_aux needs C >= 6 (got %d)", C);
   hipStream_t st = (hipStream_t)stream;
   const SensorK sen = make_sensor(sensor);
-  (void)hipMemsetAsync(keys_ws, 0xff, dl_project_workspace_bytes(S, sen.H, sen.W), st);
-  if (kept) (void)hipMemsetAsync(kept, 0, sizeof(int32_t) * S, st);
+  // the key plane and the counters MUST be initialised before the kernels run: a failed memset (stream in an error state,
+  // unsupported capture mode) would let stale keys be resolved as points
+  if (hipMemsetAsync(keys_ws, 0xff, dl_project_workspace_bytes(S, sen.H, sen.W), st) != hipSuccess)
+    return dl_fail(DL_ERR_LAUNCH, "dl_project: hipMemsetAsync(key plane) failed: %s", hipGetErrorString(hipGetLastError()));
+  if (kept && hipMemsetAsync(kept, 0, sizeof(int32_t) * S, st) != hipSuccess)
+    return dl_fail(DL_ERR_LAUNCH, "dl_project: hipMemsetAsync(kept) failed: %s", hipGetErrorString(hipGetLastError()));
   if (max_n > 0) {
     int gx = (max_n + DL_BLOCK - 1) / DL_BLOCK;
     if (gx > 4096) gx = 4096;

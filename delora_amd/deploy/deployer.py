@@ -118,7 +118,7 @@ class Deployer(object):
                 translation=translations, quaternion=rotation_representation, device=self.device)
             if not cfg["inference_only"]:
                 terms_g, counts_g, vis_g = self.geo.losses(T_g, prepared, flags,
-                                                           need_without_normals=bool(cfg["point_to_point_loss"]))
+                                                           need_without_normals=geometry.need_without_normals(cfg))
             for k, i in enumerate(idx):
                 T_rows[i] = T_g[k]
                 if not cfg["inference_only"]:

@@ -35,13 +35,7 @@ class Trainer(deployer.Deployer):
         self.training_bool = True
         self.raw_model = self.model
         if self.world_size > 1:
-            ids = [self.device.index] if getattr(self.device, "type", "cpu") == "cuda" else None
-            # Buckets fill in backward order: heads, fc and the four 9.4 MB convolutions of layer4 -- 80 % of the 47.5 MB --
-            # are ready in the first fraction of backward; layer3..conv1 (11 MB) only at its very end.  With 10 MB buckets the
-            # last, exposed all-reduce carries ~6 MB instead of the ~21 MB a 25 MB cap leaves for it.
-            self.model = torch.nn.parallel.DistributedDataParallel(
-                self.model, device_ids=ids, gradient_as_bucket_view=True,
-                bucket_cap_mb=config.get("ddp_bucket_cap_mb", 10))
+            self.model = self._wrap_ddp(self.raw_model)
         self.optimizer = torch.optim.Adam(params=self.raw_model.parameters(), lr=config["learning_rate"])
         if config["checkpoint"]:
             checkpoint = torch.load(config["checkpoint"], map_location=self.device, weights_only=False)
@@ -53,6 +47,15 @@ class Trainer(deployer.Deployer):
         if config["inference_only"]:
             print("Config error: Inference only does not make sense during training. Changing to inference_only=False.")
             config["inference_only"] = False
+
+    def _wrap_ddp(self, model):
+        """DistributedDataParallel over the process group (backend "nccl" = RCCL over xGMI).  Buckets fill in backward order:
+        heads, fc and the four 9.4 MB convolutions of layer4 -- 80 % of the 47.5 MB -- are ready in the first fraction of
+        backward; layer3..conv1 (11 MB) only at its very end.  With 10 MB buckets the last, exposed all-reduce carries ~6 MB
+        instead of the ~21 MB a 25 MB cap leaves for it."""
+        ids = [self.device.index] if getattr(self.device, "type", "cpu") == "cuda" else None
+        return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, gradient_as_bucket_view=True,
+                                                         bucket_cap_mb=self.config.get("ddp_bucket_cap_mb", 10))
 
     @staticmethod
     def new_epoch_losses():
@@ -89,7 +92,11 @@ class Trainer(deployer.Deployer):
                 "visible_pixels_epoch")
         vec = torch.stack([torch.as_tensor(epoch_losses[k], dtype=torch.float32, device=self.device).reshape(()) for k in keys])
         if self.world_size > 1:
-            # loss terms are already normalised by the global batch on every rank: the global value is the SUM
+            # loss terms are already normalised by the global batch on every rank: the global value is the SUM.
+            # visible_pixels is a COUNT of the last sample of the (global) batch (deployer.py:349-367): only the last
+            # rank holds that sample, so the others contribute zero to the sum.
+            if self.rank != self.world_size - 1:
+                vec[-1] = 0.0
             torch.distributed.all_reduce(vec, op=torch.distributed.ReduceOp.SUM)
         vals = (vec / max(self.steps_per_epoch_effective, 1)).tolist()
         return dict(zip(keys, vals))

@@ -12,7 +12,7 @@ import torch
 
 from . import _lib
 
-LOSS_POINT_TO_POINT, LOSS_POINT_TO_PLANE, LOSS_PLANE_TO_PLANE, LOSS_NORMAL_LINEAR = 1, 2, 4, 8
+LOSS_POINT_TO_POINT, LOSS_POINT_TO_PLANE, LOSS_PLANE_TO_PLANE, LOSS_NORMAL_LINEAR, LOSS_PO2PO_ALONE = 1, 2, 4, 8, 16
 
 
 class Sensor:
@@ -222,8 +222,17 @@ def icp_loss(T, src_image4, src_normals, match, nn_pix, flags):
 
 
 def loss_flags(config):
-    """Flag word of dl_icp_loss_fwd from the reference's hyper-parameters (config/hyperparameters.yaml:14-19)."""
+    """Flag word of dl_icp_loss_fwd from the reference's hyper-parameters (config/hyperparameters.yaml:14-19).
+
+    ``po2po_alone`` (src/losses/icp_losses.py:36-45) pairs EVERY source point with its nearest target and keeps the
+    point-to-point term only; the reference defines no pair lists for the normal-based terms in that branch and dies
+    with an UnboundLocalError when one of them is enabled as well (:135-146) -- made explicit here."""
     f = 0
+    if config.get("po2po_alone", False):
+        if config["point_to_plane_loss"] or config["plane_to_plane_loss"]:
+            raise Exception("po2po_alone needs point_to_plane_loss and plane_to_plane_loss switched off "
+                            "(the reference fails for this combination, icp_losses.py:36-45,135-146).")
+        f |= LOSS_PO2PO_ALONE
     if config["point_to_point_loss"]:
         f |= LOSS_POINT_TO_POINT
     if config["point_to_plane_loss"]:
@@ -235,6 +244,12 @@ def loss_flags(config):
     elif config["normal_loss"] != "squared":
         raise Exception("The normal loss which is defined here is not admissible.")
     return f
+
+
+def need_without_normals(config):
+    """Whether the search must also answer source points WITHOUT a normal: the point-to-point term uses them
+    (icp_losses.py:85-100), and po2po_alone uses every source point (:36-45)."""
+    return bool(config["point_to_point_loss"]) or bool(config.get("po2po_alone", False))
 
 
 def nn_bruteforce(src, tgt):

@@ -29,6 +29,8 @@ class ICPLosses(torch.nn.Module):
         zero = torch.zeros(1, device=dev)
         losses = {"loss_po2po": zero, "loss_po2pl": zero, "loss_po2pl_pointwise": zero, "loss_pl2pl": zero}
         if cfg["po2po_alone"]:                                             # icp_losses.py:36-45
+            if cfg["point_to_plane_loss"] or cfg["plane_to_plane_loss"]:       # the reference dies here (:135-146)
+                raise Exception("po2po_alone needs point_to_plane_loss and plane_to_plane_loss switched off.")
             nn = self.find_target_correspondences(target_point_cloud, source_point_cloud_transformed)
             if cfg["point_to_point_loss"]:
                 d = source_point_cloud_transformed - target_point_cloud[:, :, nn]

@@ -98,6 +98,11 @@ def ring_act_pool_pad(x, act="tanh"):
     wrap-around padding of the pooled map (reference resnet_modified.py:100-102 + the F.pad of the next convolution) --
     one HIP kernel each way on CUDA fp32 tensors, the separate torch ops otherwise."""
     if x.is_cuda and x.dtype == torch.float32:
+        N, C, H, W = x.shape
+        per_sample = C * H * (W + 2)
+        if N * per_sample >= 2 ** 31 and N > 1:          # the stem kernels index with 32 bits: split the batch
+            n = max(1, (2 ** 31 - 1) // per_sample)
+            return torch.cat([_RingActPoolPad.apply(x[i:i + n], ACT[act]) for i in range(0, N, n)], dim=0)
         return _RingActPoolPad.apply(x, ACT[act])
     v = torch.tanh(x) if act == "tanh" else (torch.relu(x) if act == "relu" else x)
     v = F.max_pool2d(F.pad(v, (1, 1, 0, 0), mode="circular"), kernel_size=3, stride=(1, 2), padding=(1, 0))

@@ -58,6 +58,9 @@ typedef struct {
 #define DL_LOSS_POINT_TO_PLANE 2u   /* point_to_plane_loss */
 #define DL_LOSS_PLANE_TO_PLANE 4u   /* plane_to_plane_loss */
 #define DL_LOSS_NORMAL_LINEAR  8u   /* normal_loss == "linear" (default "squared") */
+#define DL_LOSS_PO2PO_ALONE   16u   /* po2po_alone (hyperparameters.yaml:19, src/losses/icp_losses.py:36-45): EVERY matched
+                                       source point takes part in point-to-point, no normal masks; excludes flags 2 and 4
+                                       (the reference fails for that combination) */
 
 int dl_abi_version(void);
 const char* dl_last_error(void);

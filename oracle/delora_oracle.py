@@ -229,9 +229,15 @@ def nearest_target_indices(target, source):
 
 
 def icp_losses(src_t, src_n_t, tgt, tgt_n, normal_loss="squared", point_to_point=False,
-               point_to_plane=True, plane_to_plane=True, return_aux=False):
-    """ICP loss terms of one pair (src/losses/icp_losses.py:28-158 with po2po_alone False;
-    :196-206 point-to-plane, :224-240 plane-to-plane, :168-179 point-to-point).
+               point_to_plane=True, plane_to_plane=True, return_aux=False, po2po_alone=False):
+    """ICP loss terms of one pair (src/losses/icp_losses.py:28-158; :196-206 point-to-plane,
+    :224-240 plane-to-plane, :168-179 point-to-point).
+
+    ``po2po_alone`` (:36-45): EVERY source point is paired with its nearest target point and the
+    only term is the point-to-point MSE over all of them (no normal masks).  The reference defines
+    the pair lists of the two normal-based terms only in the other branch, so enabling
+    point_to_plane / plane_to_plane together with po2po_alone raises UnboundLocalError there
+    (:135-146); this restatement raises too.
 
     src_t, src_n_t: transformed source points / rotated normals ``[1,3,Ms]`` (may carry
     autograd history); tgt, tgt_n: ``[1,3,Mt]``.  A point "has a normal" iff any component
@@ -240,6 +246,17 @@ def icp_losses(src_t, src_n_t, tgt, tgt_n, normal_loss="squared", point_to_point
     MSE, as the reference), linear = mean (1-n_s.n_t)^2, po2po = MSE over the 3K'
     components of source-without-normal -> target-without-normal pairs.
     """
+    if po2po_alone:
+        if point_to_plane or plane_to_plane:
+            raise UnboundLocalError("po2po_alone with point_to_plane/plane_to_plane: the reference has no pair lists "
+                                    "for the normal-based terms in this mode (icp_losses.py:135-146)")
+        zero = torch.zeros(1)
+        nn_all = nearest_target_indices(tgt, src_t)
+        loss_po2po = torch.nn.MSELoss()(src_t, tgt[:, :, nn_all]) if point_to_point else zero
+        losses = {"loss_po2po": loss_po2po, "loss_po2pl": zero, "loss_pl2pl": zero}
+        if return_aux:
+            return losses, {"nn_all": nn_all, "pairs": int(src_t.shape[2])}
+        return losses
     src_has = (src_n_t[:, 0, :] != 0) | (src_n_t[:, 1, :] != 0) | (src_n_t[:, 2, :] != 0)
     tgt_has = (tgt_n[:, 0, :] != 0) | (tgt_n[:, 1, :] != 0) | (tgt_n[:, 2, :] != 0)
     s_w = src_t[:, :, src_has[0]]
@@ -298,7 +315,7 @@ def filter_to_projected(sample, sensor):
 
 
 def step_losses(lists_batch, T, lambda_po2pl=1.0, normal_loss="squared", point_to_point=False,
-                point_to_plane=True, plane_to_plane=True, batch_offset=0, global_batch=None):
+                point_to_plane=True, plane_to_plane=True, batch_offset=0, global_batch=None, po2po_alone=False):
     """Batch loss accumulation of ``Deployer.step`` (src/deploy/deployer.py:290-332).
 
     Reproduces the accumulation order of the reference: the running sums of the three terms are
@@ -317,7 +334,7 @@ def step_losses(lists_batch, T, lambda_po2pl=1.0, normal_loss="squared", point_t
         n_t = rotate_points(Tj, L["normal_list_2"])
         l = icp_losses(s_t, n_t, L["scan_1"], L["normal_list_1"], normal_loss=normal_loss,
                        point_to_point=point_to_point, point_to_plane=point_to_plane,
-                       plane_to_plane=plane_to_plane)
+                       plane_to_plane=plane_to_plane, po2po_alone=po2po_alone)
         per_sample.append(l)
         out["loss_po2po"] = out["loss_po2po"] + l["loss_po2po"]
         out["loss_po2pl"] = out["loss_po2pl"] + lambda_po2pl * l["loss_po2pl"]

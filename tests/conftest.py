@@ -15,3 +15,25 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Table of the deviations the parity tests measured (tests/util.py: measured()); also kept as JSON for profiles/."""
+    try:
+        from tests import util
+    except Exception:          # pragma: no cover
+        return
+    if not util.MEASURED:
+        return
+    import json
+    print("\n==== measured parity deviations (value / bound) ====")
+    for k in sorted(util.MEASURED):
+        v = util.MEASURED[k]
+        print(f"  {k:78s} {v['value']:.6g}" + (f" / {v['bound']:.6g}" if v["bound"] is not None else ""))
+    out = os.path.join(ROOT, "gpurun_out")
+    try:
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_measured.json"), "w") as f:
+            json.dump(util.MEASURED, f, indent=1, sort_keys=True)
+    except OSError:            # pragma: no cover
+        pass

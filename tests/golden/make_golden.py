@@ -278,6 +278,67 @@ def fx_loss(out):
     out["loss_pair"] = entry
 
 
+def fx_loss_alone(out):
+    """po2po_alone (icp_losses.py:36-45): every source point against its nearest target, point-to-point only.  Also records
+    that the reference itself raises when a normal-based term is enabled in this mode."""
+    import losses.icp_losses as rloss
+    import models.model_parts as rparts
+    import utility.projection as rproj
+    cfg0 = reference_config(16, 128)
+    (l1, l2), T_true = preprocessed_lists(31, 16, 160, 16, 200, cfg0)
+    layer = rproj.ImageProjectionLayer(config=cfg0)
+    filt = []
+    for pts, nrm in (l1, l2):
+        x = torch.from_numpy(pts).permute(1, 0).view(1, 3, -1)
+        n = torch.from_numpy(nrm).permute(1, 0).view(1, 3, -1)
+        _, _, _, idx, _ = layer(input=x, dataset="kitti")
+        filt.append((x[:, :, idx].contiguous(), n[:, :, idx].contiguous()))
+    (tgt, tgt_n), (src, src_n) = filt
+    rng = np.random.default_rng(6)
+    entry = dict(raw_tgt=l1[0], raw_tgt_n=l1[1], raw_src=l2[0], raw_src_n=l2[1], T_true=T_true, H=16, W=128,
+                 tgt=t2n(tgt[0]), tgt_n=t2n(tgt_n[0]), src=t2n(src[0]), src_n=t2n(src_n[0]))
+    cfg = reference_config(16, 128, po2po_alone=True, point_to_point_loss=True, point_to_plane_loss=False,
+                           plane_to_plane_loss=False)
+    ref = rloss.ICPLosses(config=cfg)
+    from scipy.spatial.transform import Rotation
+    poses = {"identity": (np.array([0, 0, 0, 1.0]), np.zeros(3)),
+             "true": (Rotation.from_matrix(T_true[:3, :3].astype(np.float64)).as_quat() + rng.normal(0, 1e-3, 4),
+                      T_true[:3, 3] + rng.normal(0, 0.02, 3)),
+             "random": (rng.normal(size=4), rng.normal(0, 1.0, 3))}
+    for qname, (qv, tv) in poses.items():
+        t = torch.tensor(tv, dtype=torch.float32).view(1, 3).requires_grad_(True)
+        q = torch.tensor(qv, dtype=torch.float32).view(1, 4).requires_grad_(True)
+        T = rparts.GeometryHandler.get_transformation_matrix_quaternion(translation=t, quaternion=q, device=torch.device("cpu"))
+        T.retain_grad()
+        s_t = T[:, :3, :3].matmul(src) + T[:, :3, 3].view(-1, 3, 1)
+        n_t = T[:, :3, :3].matmul(src_n)
+        losses, plotting = ref(source_point_cloud_transformed=s_t, source_normal_list_transformed=n_t,
+                               target_point_cloud=tgt, target_normal_list=tgt_n, compute_pointwise_loss_bool=False)
+        assert plotting is None
+        losses["loss_po2po"].backward()
+        o, aux = orc.icp_losses(orc.transform_points(T.detach(), src), orc.rotate_points(T.detach(), src_n), tgt, tgt_n,
+                                point_to_point=True, point_to_plane=False, plane_to_plane=False, po2po_alone=True, return_aux=True)
+        assert_same(t2n(losses["loss_po2po"]), t2n(o["loss_po2po"]), f"loss_alone/{qname}")
+        assert float(losses["loss_po2pl"]) == 0.0 and float(losses["loss_pl2pl"]) == 0.0
+        entry[qname + "_T"] = t2n(T)
+        entry[qname + "_loss_po2po"] = np.float64(t2n(losses["loss_po2po"]).item())
+        entry[qname + "_gradT"] = t2n(T.grad)
+        entry[qname + "_nn"] = t2n(aux["nn_all"]).astype(np.int32)
+        entry[qname + "_pairs"] = aux["pairs"]
+        print(f"  loss_alone {qname}: pairs={aux['pairs']} po2po={entry[qname + '_loss_po2po']}")
+    # the default terms together with po2po_alone: the reference has no pair lists for them and fails
+    bad = rloss.ICPLosses(config=reference_config(16, 128, po2po_alone=True))
+    raised = False
+    try:
+        bad(source_point_cloud_transformed=src, source_normal_list_transformed=src_n, target_point_cloud=tgt,
+            target_normal_list=tgt_n, compute_pointwise_loss_bool=False)
+    except UnboundLocalError:
+        raised = True
+    entry["reference_raises_with_normal_terms"] = raised
+    assert raised
+    out["loss_pair_alone"] = entry
+
+
 def fx_geometry(out):
     import models.model_parts as rparts
     rng = np.random.default_rng(9)
@@ -420,7 +481,7 @@ def main():
     torch.set_num_threads(8)
     out = {}
     only = sys.argv[1:]
-    for f in (fx_projection, fx_normals, fx_geometry, fx_loss, fx_model_and_step, fx_model_variants, fx_step_normalized, fx_poses):
+    for f in (fx_projection, fx_normals, fx_geometry, fx_loss, fx_loss_alone, fx_model_and_step, fx_model_variants, fx_step_normalized, fx_poses):
         if only and f.__name__ not in only:
             continue
         print(f.__name__)

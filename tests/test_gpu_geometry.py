@@ -61,6 +61,9 @@ def check_projection(scan, out, s, o_sensor, expect_pix2pt=None, expect_image=No
         differ = gpu_pix != ref_pix
         amb = util.ambiguity_mask(scan, o_sensor)
         assert not np.any(differ & ~amb), "pixel index differs outside the ambiguity mask"
+        # how many points actually moved (SURVEY.md's probe: ~5e-5 of the points; the mask itself covers ~4e-3)
+        util.measured(f"projection: points in another pixel than the torch-CPU reference (N={N}, H={H}, W={W})",
+                      int(differ.sum()), bound=max(2, int(np.ceil(2e-4 * N))))
     else:
         differ = np.zeros(N, dtype=bool)
         gpu_pix = ref_pix
@@ -182,7 +185,8 @@ def check_normals(image, got, ref_normals, ref_has, ref_v, ref_u, eigenvalues, p
     g = got[:, ref_v, ref_u].T                                  # [M,3]
     got_has = np.any(g != 0, axis=1)
     mism = got_has != ref_has
-    assert mism.mean() <= 2e-3, f"has-normal mask differs on {mism.sum()} of {len(mism)} pixels"
+    util.measured(f"normals: has-normal mask differs from the reference (pixels of {len(mism)})", int(mism.sum()),
+                  bound=max(2, int(np.ceil(5e-4 * len(mism)))))
     both = got_has & ref_has
     lam = eigenvalues[both].astype(np.float64)
     gap = (lam[:, 1] - lam[:, 0]) / np.maximum(lam[:, 2], 1e-30)
@@ -197,8 +201,8 @@ def check_normals(image, got, ref_normals, ref_has, ref_v, ref_u, eigenvalues, p
     # fp32 LAPACK error of the reference scales like eps32 * lambda_max / gap
     bound = 2e-4 + 50 * 6e-8 / np.maximum(gap, 1e-12)
     frac_bad = np.mean(ang[well] > bound[well])
-    assert frac_bad <= 1e-3, f"{frac_bad:.2e} of well-conditioned normals off (max {ang[well].max():.3e} rad)"
-    assert np.median(ang) < 1e-5
+    util.measured(f"normals: fraction of well-conditioned normals outside the conditioning bound (M={len(mism)})", frac_bad, bound=1e-3)
+    util.measured(f"normals: median angle to the reference [rad] (M={len(mism)})", float(np.median(ang)), bound=1e-5)
     # pixels that are not valid in the reference carry no normal
     mask = np.ones(got.shape[1:], dtype=bool)
     mask[ref_v, ref_u] = False
@@ -391,6 +395,49 @@ def test_loss_golden_from_reference(mode, p2p):
         _close(terms[0].detach().cpu().numpy(), g[key + "_losses"], what=key + " losses")
         _close(T.grad[0, :3].cpu().numpy(), g[key + "_gradT"][0, :3], what=key + " dL/dT")
         assert torch.all(T.grad[0, 3] == 0)
+
+
+def test_loss_po2po_alone_golden_from_reference():
+    """po2po_alone (src/losses/icp_losses.py:36-45): every source point against its nearest target, point-to-point
+    only -- loss, pair count, correspondences and dL/dT against the reference's ICPLosses + autograd; the combination with a
+    normal-based term (which the reference cannot evaluate) is rejected by the C ABI."""
+    g = util.load_golden("loss_pair_alone")
+    G, dev = _geo(), _dev()
+    vf, hf = util.kitti_fov()
+    sensor = gpu_sensor(g["H"], g["W"], vf, hf)
+    scans = [np.ascontiguousarray(np.concatenate([g["raw_tgt"].T, g["raw_tgt_n"].T], axis=0), dtype=np.float32),
+             np.ascontiguousarray(np.concatenate([g["raw_src"].T, g["raw_src_n"].T], axis=0), dtype=np.float32)]
+    out = run_project(scans, sensor, want_uv=False)
+    img, nrm = out["image4"], out["aux"]
+    flags = G.LOSS_POINT_TO_POINT | G.LOSS_PO2PO_ALONE
+    assert G.loss_flags({"point_to_point_loss": True, "point_to_plane_loss": False, "plane_to_plane_loss": False,
+                         "normal_loss": "squared", "po2po_alone": True}) == flags
+    for qname in ("identity", "true", "random"):
+        T = torch.from_numpy(g[qname + "_T"]).to(dev).requires_grad_(True)
+        nn, _, match = G.nn_correspond(img[1:2], nrm[1:2], out["packed"][0:1], out["packed_aux"][0:1], T, sensor,
+                                       need_without_normals=True)
+        terms, counts = G.icp_loss(T, img[1:2], nrm[1:2], match, nn, flags)
+        terms[0, 0].backward()
+        assert int(counts[0, 1]) == int(g[qname + "_pairs"]) and int(counts[0, 0]) == 0
+        _close([float(terms[0, 0])], [float(g[qname + "_loss_po2po"])], what=qname + " po2po")
+        assert float(terms[0, 1]) == 0.0 and float(terms[0, 2]) == 0.0
+        _close(T.grad[0, :3].cpu().numpy(), g[qname + "_gradT"][0, :3], what=qname + " dL/dT")
+        # correspondences of ALL source points: source point (bit pattern) -> matched target point, compared as maps
+        occ = (nn[0].reshape(-1) >= 0).cpu().numpy()
+        sp = img[1, :3].reshape(3, -1).cpu().numpy()[:, occ]
+        mp = match[0, :3].reshape(3, -1).cpu().numpy()[:, occ]
+        got = {sp[:, i].tobytes(): mp[:, i].tobytes() for i in range(sp.shape[1])}
+        exp_t = g["tgt"][:, g[qname + "_nn"]]
+        exp = {np.ascontiguousarray(g["src"][:, i]).tobytes(): np.ascontiguousarray(exp_t[:, i]).tobytes() for i in range(exp_t.shape[1])}
+        assert got.keys() == exp.keys()
+        differ = sum(1 for k in exp if got[k] != exp[k])
+        print(f"po2po_alone {qname}: {differ} of {len(exp)} correspondences differ from the reference's KD-tree")
+        assert differ <= 1e-3 * len(exp)
+    with pytest.raises(Exception):
+        G.icp_loss(T, img[1:2], nrm[1:2], match, nn, flags | G.LOSS_POINT_TO_PLANE)
+    with pytest.raises(Exception):
+        G.loss_flags({"point_to_point_loss": True, "point_to_plane_loss": True, "plane_to_plane_loss": False,
+                      "normal_loss": "squared", "po2po_alone": True})
 
 
 @pytest.mark.parametrize("mode,p2p", [("squared", False), ("linear", True)])

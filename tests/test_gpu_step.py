@@ -81,9 +81,11 @@ def test_training_step_matches_reference(name):
     for key in ("loss_epoch", "loss_point_cloud_epoch", "loss_po2pl_epoch", "loss_pl2pl_epoch", "loss_po2po_epoch"):
         assert np.isclose(float(ep[key]), g["ep::" + key], rtol=REL, atol=1e-7), key
     assert int(ep["visible_pixels_epoch"]) == int(g["ep::visible_pixels_epoch"])
+    worst = 0.0
     for k, p in trainer.raw_model.named_parameters():
         ref = float(g["gradnorm::" + k])
-        assert np.isclose(float(p.grad.double().norm()), ref, rtol=2e-3, atol=1e-9), f"grad norm {k}"
+        worst = max(worst, abs(float(p.grad.double().norm()) - ref) / max(ref, 1e-9))
+    util.measured(f"step_{name}: worst relative error of the per-parameter gradient norms vs the reference", worst, bound=5e-4)
     after = trainer.raw_model.state_dict()
     for k in before:                                        # Adam's first step moves every weight by ~lr*sign(grad)
         got = float((after[k].double() - before[k].double()).sum())
@@ -469,3 +471,47 @@ def test_scan_to_scan_odometry_on_gpu_matches_the_cpu_core():
         a, b = gpu.push(scans[k]), cpu.push(scans[k])
         assert np.allclose(a["transformation"], b["transformation"], rtol=REL, atol=REL)
         assert np.allclose(a["T_0_t"], b["T_0_t"], rtol=REL, atol=REL)
+
+
+def test_tester_on_gpu_path_matches_oracle_backend_and_pose_integration(tmp_path):
+    """Reference src/deploy/tester.py:38-109 + src/utility/poses.py:11-74 on the HIP path: checkpoint -> Tester.test() over a
+    3-scan synthetic sequence on the GPU (projection / normals / search / loss kernels, batch size 1, losses evaluated) ->
+    transformations equal to the same Tester run on the CPU with the oracle geometry backend; pose files = compute_poses."""
+    from delora_amd.data import synthetic
+    from delora_amd.deploy.tester import Tester
+    from delora_amd.deploy.trainer import Trainer
+    from delora_amd.utility import poses
+    dev = _dev()
+    gm = util.load_golden("model_small")
+    H, W = 16, 128
+    cfg = _small_model_cfg(gm, H, W, batch_size=1)
+    tr = Trainer(cfg, dataset=util.ListDataset([]))
+    tr.raw_model.load_state_dict(_state_dict(gm, dev))
+    ck = str(tmp_path / "m.pth")
+    tr.save_checkpoint(ck, 0, 0.0)
+    scans = [synthetic.make_pair(700 + i, rings=16, azimuth_steps=160)[0] for i in range(3)]
+    samples = []
+    for j in range(2):                                          # pairs (scan j, scan j+1) of one sequence
+        samples.append({"index": j, "index_dataset": 0, "index_sequence": 0, "index_scan": j, "dataset": "kitti",
+                        "scan_1": torch.from_numpy(scans[j]).unsqueeze(0), "scan_2": torch.from_numpy(scans[j + 1]).unsqueeze(0),
+                        "normal_list_1": None, "normal_list_2": None})
+    results = {}
+    for name, device, backend in (("gpu", "cuda:0", None), ("cpu", "cpu", util.OracleStepGeometry())):
+        c = _small_model_cfg(gm, H, W, batch_size=1)
+        c.update(device=torch.device(device), checkpoint=ck, inference_only=False, output_dir=str(tmp_path / name), run_name="t",
+                 mode="testing")
+        os.makedirs(str(tmp_path / name), exist_ok=True)
+        c["kitti"]["data_identifiers"] = [9]
+        te = Tester(c, dataset=util.ListDataset([dict(s) for s in samples]), geometry_backend=backend)
+        summary = te.test()
+        assert len(te.written) == 1
+        results[name] = (np.load(te.written[0]["transformations"]), np.load(te.written[0]["poses"]),
+                         open(te.written[0]["poses_text"]).read(), summary)
+    Tg, Pg, txt, sg = results["gpu"]
+    Tc, Pc, _, sc = results["cpu"]
+    assert Tg.shape == (2, 1, 4, 4)
+    util.measured("Tester: max |T_gpu - T_cpu(oracle backend)|", float(np.abs(Tg - Tc).max()), bound=REL)
+    assert np.array_equal(Pg, poses.compute_poses(list(Tg)))
+    assert len(txt.strip().splitlines()) == 3
+    for k in ("loss_point_cloud_epoch", "loss_po2pl_epoch", "loss_pl2pl_epoch"):
+        assert np.isclose(sg[k], sc[k], rtol=5e-3), (k, sg[k], sc[k])    # images differ by the atan2-ambiguous pixels only

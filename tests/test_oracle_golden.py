@@ -120,3 +120,20 @@ def test_step_loss_accumulation_quirk(name):
     assert np.isclose(float(sum(halves)), float(out["loss_pc"]), rtol=1e-6)
     sp = orc.transform_points(_t(g["T"])[B - 1:B], lists[B - 1]["scan_2"])
     assert orc.visible_pixels(sp, sensor) == int(g["ep::visible_pixels_epoch"])
+
+
+def test_losses_po2po_alone():
+    """po2po_alone branch (src/losses/icp_losses.py:36-45) of the oracle against the reference's numbers."""
+    g = util.load_golden("loss_pair_alone")
+    assert bool(g["reference_raises_with_normal_terms"])
+    src, src_n, tgt, tgt_n = (_t(g[k]).view(1, 3, -1) for k in ("src", "src_n", "tgt", "tgt_n"))
+    for qname in ("identity", "true", "random"):
+        T = _t(g[qname + "_T"]).clone().requires_grad_(True)
+        l, aux = orc.icp_losses(orc.transform_points(T, src), orc.rotate_points(T, src_n), tgt, tgt_n, point_to_point=True,
+                                point_to_plane=False, plane_to_plane=False, po2po_alone=True, return_aux=True)
+        l["loss_po2po"].backward()
+        assert np.isclose(float(l["loss_po2po"]), float(g[qname + "_loss_po2po"]), rtol=1e-6)
+        assert np.array_equal(aux["nn_all"].numpy(), g[qname + "_nn"]) and aux["pairs"] == int(g[qname + "_pairs"])
+        assert np.allclose(T.grad.numpy(), g[qname + "_gradT"], rtol=1e-5, atol=1e-7)
+    with pytest.raises(UnboundLocalError):
+        orc.icp_losses(src, src_n, tgt, tgt_n, po2po_alone=True)

@@ -9,6 +9,19 @@ from oracle import delora_oracle as orc
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
+# Measured deviations (mismatch counts, worst relative errors) recorded by the parity tests: printed as a table at the end
+# of the session and written to gpurun_out/parity_measured.json (tests/conftest.py), so that a regression inside a
+# tolerance is still visible as a number.
+MEASURED = {}
+
+
+def measured(name, value, bound=None):
+    """Record (and print) a measured deviation; with ``bound`` also assert value <= bound."""
+    MEASURED[name] = {"value": float(value), "bound": None if bound is None else float(bound)}
+    print(f"[measured] {name} = {float(value):.6g}" + (f"  (bound {float(bound):.6g})" if bound is not None else ""))
+    if bound is not None:
+        assert float(value) <= float(bound), f"{name}: measured {float(value):.6g} exceeds the bound {float(bound):.6g}"
+
 
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
@@ -134,7 +147,7 @@ class OracleStepGeometry:
             s_t = orc.transform_points(Tj, L["scan_2"])
             l = orc.icp_losses(s_t, orc.rotate_points(Tj, L["normal_list_2"]), L["scan_1"], L["normal_list_1"],
                                normal_loss="linear" if flags & 8 else "squared", point_to_point=bool(flags & 1),
-                               point_to_plane=bool(flags & 2), plane_to_plane=bool(flags & 4))
+                               point_to_plane=bool(flags & 2), plane_to_plane=bool(flags & 4), po2po_alone=bool(flags & 16))
             rows.append(torch.stack([l["loss_po2po"].reshape(()), l["loss_po2pl"].reshape(()), l["loss_pl2pl"].reshape(())]))
             vis.append(orc.visible_pixels(s_t, prepared["sensor"]))
         return torch.stack(rows), None, torch.tensor(vis)
