@@ -1,0 +1,594 @@
+// Convolutions of the pose CNN for 360-degree range images as implicit GEMMs on the fp32 matrix cores of gfx950
+// (v_mfma_f32_32x32x2_f32: exact fp32, one rounding per product -- the parity mode of the network), channels-last.
+//
+// Replaces, for every 3x3 / 1x1 convolution of the reference's ResNet (src/models/resnet_modified.py:97-98, :101-102,
+// :159-177; torch Conv2d = cuDNN there), the sequence  F.pad(x, (1,1,0,0), 'circular') -> Conv2d(padding=(1,0)) ->
+// [+ residual] -> tanh/relu  and its autograd.  The wrap-around of the width axis and the zero rows above/below the image
+// are ADDRESSING in the tile loader (column -1 reads column W-1, row -1 reads zeros): no padded copy of an activation ever
+// exists.  The elementwise tail of each layer runs in the epilogue on the accumulators:
+//     forward          y  = act(conv(x, w) [+ shortcut])
+//     backward-data    g' = (conv(g, flip(w)^T) [+ g_shortcut]) * act'(x)        (x = the saved forward activation)
+//     backward-weight  dw[k][tap][c] = sum_pixels g[pixel][k] * x[pixel + tap][c]
+// so a residual block is 2 (+1) launches forward and 4 (+2) backward with no separate activation / padding / add kernels.
+//
+// Layouts (fp32): activations [N][H][W][C]; weights [K][KS][KS][C] (= the torch parameter [K,C,KS,KS] in channels_last
+// memory format, so forward and weight gradient use the parameter / its .grad in place, no repacking).
+//
+// GEMM view of the forward pass: M = output pixels, N = output channels, reduction = (tap, input channel).  A workgroup
+// (4 waves) owns BM = TH x TW output pixels of one image and BN output channels.  Per chunk of CK input channels it
+// stages the (TH-1)*SH+KS rows x (TW-1)*SW+KS columns x CK halo tile of the input and the [BN][taps][CK] weight slab in
+// LDS once; all KS*KS taps then read the same halo tile at shifted pixel offsets.  Fragments: lane (i = lane & 31,
+// half = lane >> 5) fetches FOUR consecutive channels 4*half .. 4*half+3 of pixel i with one ds_read_b128 and uses
+// element j as the A operand of MFMA j -- the reduction index is only permuted (MFMA j covers channels {j, 4+j}), so one
+// 16-byte LDS read feeds four MFMAs; the pixel stride CK+4 floats makes those reads bank-conflict free.  fp32 MFMA
+// issues one instruction per 64 cycles per SIMD, so the loop is matrix-core bound with a wide margin on LDS and HBM:
+// the next chunk is fetched into registers while the current one is multiplied (single LDS buffer, 2-3 workgroups/CU).
+//
+// Bound: MFMA (157 TFLOP/s fp32).  2*9*C*K flop per output pixel.
+#include <type_traits>
+
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define CV_THREADS 256
+#define CV_EPI_ADD 1u    // v += add[pixel][k]
+#define CV_EPI_ACT 2u    // v = act(v)
+#define CV_EPI_DACT 4u   // v *= act'(dsrc[pixel][k]), dsrc = saved forward OUTPUT of the activation
+#define CV_ACT_NONE 0
+#define CV_ACT_TANH 1
+#define CV_ACT_RELU 2
+
+struct ConvArgs {
+  const float* x;      // [N][H][W][C]
+  const float* w;      // BT=0: [K][taps][C]   BT=1: [C][taps][K] read with flipped taps (forward weight of the layer)
+  float* y;            // [N][Ho][Wo][K]
+  const float* add;    // [N][Ho][Wo][K] or null
+  const float* dsrc;   // [N][Ho][Wo][K] or null
+  int N, H, W, C, K, Ho, Wo;
+  int act;
+  unsigned epi;
+};
+
+__device__ __forceinline__ float cv_act(float v, int act) {
+  if (act == CV_ACT_TANH) return tanhf(v);
+  if (act == CV_ACT_RELU) return v < 0.f ? 0.f : v;
+  return v;
+}
+__device__ __forceinline__ float cv_dact(float y, int act) {
+  if (act == CV_ACT_TANH) return 1.f - y * y;
+  if (act == CV_ACT_RELU) return y <= 0.f ? 0.f : 1.f;
+  return 1.f;
+}
+
+// XCD-aware tile order: consecutive workgroup ids go to different XCDs (id % 8); give every XCD a contiguous range of
+// tiles instead, so that neighbouring tiles (which share input rows and the weight slab) meet in one L2.  Bijective for
+// any tile count (cdna_hip_programming.md T1).
+__device__ __forceinline__ int cv_xcd_swizzle(int id, int n) {
+  const int q = n / 8, r = n % 8, xcd = id % 8, k = id / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+template <int BM, int BN, int CK, int TW, int SH, int SW, int KS, bool BT, int WGN>
+#ifndef CV_MINWAVES
+#define CV_MINWAVES 2
+#endif
+__global__ __launch_bounds__(CV_THREADS, CV_MINWAVES) void k_conv_f32(ConvArgs a) {
+  constexpr int TH = BM / TW;
+  constexpr int PAD = (KS - 1) / 2;
+  constexpr int RH = (TH - 1) * SH + KS, RW = (TW - 1) * SW + KS;
+  constexpr int S = CK + 4;                       // floats per staged pixel: 4*odd for CK = 8, 16, 32
+  constexpr int TAPS = KS * KS;
+  constexpr int C4 = CK / 4;
+  constexpr int IN_FLOATS = RH * RW * S;
+  constexpr int W_FLOATS = BT ? TAPS * CK * BN : TAPS * BN * S;
+  constexpr int NI = RH * RW * C4;                // float4 items of the input tile
+  constexpr int NW = BT ? CK * TAPS * (BN / 4) : BN * TAPS * C4;
+  constexpr int NI_IT = (NI + CV_THREADS - 1) / CV_THREADS, NW_IT = (NW + CV_THREADS - 1) / CV_THREADS;
+  constexpr int WGM = 4 / WGN;
+  constexpr int WM = BM / 32 / WGM, WN = BN / 32 / WGN;
+  static_assert(BM % TW == 0 && BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0 && CK % 8 == 0, "tile shape");
+  static_assert(!BT || (SH == 1 && SW == 1), "transposed weights: stride 1 only");
+  static_assert((S / 4) % 2 == 1, "pixel stride must be 4*odd floats");
+  __shared__ __attribute__((aligned(16))) float lds[IN_FLOATS + W_FLOATS];
+  float* in_lds = lds;
+  float* w_lds = lds + IN_FLOATS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, half = lane >> 5;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int KT = a.K / BN;
+  const int tiles_w = a.Wo / TW, tiles_h = a.Ho / TH;
+  const int ntiles = a.N * tiles_h * tiles_w * KT;
+  const int t = cv_xcd_swizzle(blockIdx.x, ntiles);
+  const int kt = t % KT;
+  int pt = t / KT;
+  const int tw_i = pt % tiles_w; pt /= tiles_w;
+  const int th_i = pt % tiles_h;
+  const int n = pt / tiles_h;
+  const int ho0 = th_i * TH, wo0 = tw_i * TW, k0 = kt * BN;
+  const int h_base = ho0 * SH - PAD, w_base = wo0 * SW - PAD;
+  const float* xn = a.x + (size_t)n * a.H * a.W * a.C;
+
+  // chunk-invariant staging offsets (element offsets relative to xn / a.w, without the channel chunk).  Item ids beyond
+  // the tile are clamped to the last item: those threads load and store the same 16 bytes as its owner, which keeps the
+  // staging code free of branches (hipcc otherwise sinks each load into its conditional store and serialises them).
+  int in_g[NI_IT], in_l[NI_IT];
+#pragma unroll
+  for (int it = 0; it < NI_IT; ++it) {
+    const int q = min(tid + it * CV_THREADS, NI - 1);
+    const int c4 = q % C4, pc = q / C4;
+    const int col = pc % RW, row = pc / RW;
+    const int h = h_base + row;
+    int w = w_base + col;
+    w = w < 0 ? w + a.W : (w >= a.W ? w - a.W : w);
+    in_l[it] = pc * S + c4 * 4;
+    in_g[it] = (h >= 0 && h < a.H) ? (h * a.W + w) * a.C + c4 * 4 : -1;     // -1: a zero row above / below the image
+  }
+  int w_g[NW_IT], w_l[NW_IT];
+#pragma unroll
+  for (int it = 0; it < NW_IT; ++it) {
+    const int q = min(tid + it * CV_THREADS, NW - 1);
+    if (!BT) {
+      const int c4 = q % C4, t2 = q / C4;
+      const int tap = t2 % TAPS, kk = t2 / TAPS;
+      w_g[it] = ((k0 + kk) * TAPS + tap) * a.C + c4 * 4;
+      w_l[it] = (tap * BN + kk) * S + c4 * 4;
+    } else {
+      const int co4 = q % (BN / 4), t2 = q / (BN / 4);
+      const int tap = t2 % TAPS, kr = t2 / TAPS;
+      w_g[it] = (kr * TAPS + (TAPS - 1 - tap)) * a.K + k0 + co4 * 4;      // + c0 * TAPS * K per chunk
+      w_l[it] = (tap * CK + kr) * BN + co4 * 4;
+    }
+  }
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // LDS read offsets of this lane's A fragments (pixel of M-subtile mi, tap (0,0)); B fragment bases
+  int a_off[WM];
+#pragma unroll
+  for (int mi = 0; mi < WM; ++mi) {
+    const int p = (wm * WM + mi) * 32 + li;
+    const int th = p / TW, tw = p % TW;
+    a_off[mi] = ((th * SH) * RW + tw * SW) * S + half * 4;
+  }
+
+#ifdef CV_OLD_STAGE
+#define CV_LOADV(C0) f32x4 v = {0.f, 0.f, 0.f, 0.f}; if (in) v = *reinterpret_cast<const f32x4*>(xn + in_g[it] + (C0));
+#else
+#define CV_LOADV(C0) const f32x4 v = *reinterpret_cast<const f32x4*>(xn + (in ? in_g[it] + (C0) : 0));
+#endif
+  f32x4 in_r[NI_IT], w_r[NW_IT];     // native vectors (HIP's float4 struct arrays end up in scratch here)
+  // (macros, not lambdas: arrays captured by reference keep hipcc from promoting them to registers)
+#define CV_FETCH(C0)                                                                                                      \
+  {                                                                                                                       \
+    _Pragma("unroll") for (int it = 0; it < NI_IT; ++it) {                                                                \
+      const bool in = in_g[it] >= 0;                                                                                      \
+      CV_LOADV(C0)                                                                                                        \
+      /* select, not multiply: a NaN at element 0 must not leak into the zero rows */                                     \
+      in_r[it] = in ? v : (f32x4){0.f, 0.f, 0.f, 0.f};                                                                    \
+    }                                                                                                                     \
+    _Pragma("unroll") for (int it = 0; it < NW_IT; ++it) w_r[it] = *reinterpret_cast<const f32x4*>(                       \
+        a.w + (BT ? (size_t)w_g[it] + (size_t)(C0) * TAPS * a.K : (size_t)w_g[it] + (C0)));                               \
+  }
+#define CV_STAGE()                                                                                                        \
+  {                                                                                                                       \
+    _Pragma("unroll") for (int it = 0; it < NI_IT; ++it) *reinterpret_cast<f32x4*>(in_lds + in_l[it]) = in_r[it];         \
+    _Pragma("unroll") for (int it = 0; it < NW_IT; ++it) *reinterpret_cast<f32x4*>(w_lds + w_l[it]) = w_r[it];            \
+  }
+
+  CV_FETCH(0)
+  CV_STAGE()
+  __syncthreads();
+  for (int c0 = 0; c0 < a.C; c0 += CK) {
+    const bool more = c0 + CK < a.C;
+    if (more) CV_FETCH(c0 + CK)
+#ifdef CV_OLD_LOOP
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap) {
+      const int r = tap / KS, s = tap % KS;
+#pragma unroll
+      for (int kq = 0; kq < CK / 8; ++kq) {
+        float4 af[WM];
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi)
+          af[mi] = *reinterpret_cast<const float4*>(in_lds + a_off[mi] + (r * RW + s) * S + kq * 8);
+        float bf[WN][4];
+#pragma unroll
+        for (int ni = 0; ni < WN; ++ni) {
+          const int col = (wn * WN + ni) * 32 + li;
+          if (!BT) {
+            const float4 v = *reinterpret_cast<const float4*>(w_lds + (tap * BN + col) * S + kq * 8 + half * 4);
+            bf[ni][0] = v.x; bf[ni][1] = v.y; bf[ni][2] = v.z; bf[ni][3] = v.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bf[ni][j] = w_lds[(tap * CK + kq * 8 + half * 4 + j) * BN + col];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int mi = 0; mi < WM; ++mi) {
+            const float av = j == 0 ? af[mi].x : (j == 1 ? af[mi].y : (j == 2 ? af[mi].z : af[mi].w));
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni)
+              acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[ni][j], acc[mi][ni], 0, 0, 0);
+          }
+      }
+    }
+#else
+    // (tap, 8-channel group) steps, software-pipelined: the fragments of step i+1 are read while step i multiplies
+    constexpr int KQ = CK / 8, NSTEP = TAPS * KQ;
+    float4 af[2][WM];
+    float bf[2][WN][4];
+    auto load_frags = [&](int step, int buf) {
+      const int tap = step / KQ, kq = step % KQ;
+      const int r = tap / KS, s = tap % KS;
+#pragma unroll
+      for (int mi = 0; mi < WM; ++mi)
+        af[buf][mi] = *reinterpret_cast<const float4*>(in_lds + a_off[mi] + (r * RW + s) * S + kq * 8);
+#pragma unroll
+      for (int ni = 0; ni < WN; ++ni) {
+        const int col = (wn * WN + ni) * 32 + li;
+        if (!BT) {
+          const float4 v = *reinterpret_cast<const float4*>(w_lds + (tap * BN + col) * S + kq * 8 + half * 4);
+          bf[buf][ni][0] = v.x; bf[buf][ni][1] = v.y; bf[buf][ni][2] = v.z; bf[buf][ni][3] = v.w;
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) bf[buf][ni][j] = w_lds[(tap * CK + kq * 8 + half * 4 + j) * BN + col];
+        }
+      }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int step = 0; step < NSTEP; ++step) {
+      const int cur = step & 1;
+      if (step + 1 < NSTEP) load_frags(step + 1, cur ^ 1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int mi = 0; mi < WM; ++mi) {
+          const float av = j == 0 ? af[cur][mi].x : (j == 1 ? af[cur][mi].y : (j == 2 ? af[cur][mi].z : af[cur][mi].w));
+#pragma unroll
+          for (int ni = 0; ni < WN; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bf[cur][ni][j], acc[mi][ni], 0, 0, 0);
+        }
+      // issue order: the next step's LDS reads first, then this step's MFMAs (hipcc otherwise sinks the reads to their use)
+#ifndef CV_NO_SGB
+      if (step + 1 < NSTEP) __builtin_amdgcn_sched_group_barrier(0x100, WM + (BT ? 4 * WN : WN), 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4 * WM * WN, 0);
+#endif
+    }
+#endif
+    __syncthreads();
+    if (more) {
+      CV_STAGE()
+      __syncthreads();
+    }
+  }
+
+  // Epilogue.  Accumulator (mi, ni), register r holds pixel (r & 3) + 8 * (r >> 2) + 4 * half, channel li of its 32x32
+  // tile -- a dword-per-lane layout.  Each wave transposes its 32-pixel slabs through its own LDS region (the staging
+  // buffers are free now) so that a lane owns FOUR consecutive channels of one pixel: the elementwise tail then runs on
+  // float4s in a rolled loop (compact code: the tanh expansion exists once) with 16-byte loads of the shortcut / saved
+  // activation and 16-byte stores of whole 128/256-byte channel rows.
+  constexpr int EW = WN * 32, ES = EW + 4;              // floats per staged pixel row (+4: the two halves hit different banks)
+  static_assert(4 * 32 * ES <= IN_FLOATS + W_FLOATS, "epilogue staging must fit the main-loop LDS");
+  __syncthreads();                                       // every wave is done with the last chunk's fragments
+  float* ep = lds + wave * (32 * ES);
+  const size_t out_n = (size_t)n * a.Ho * a.Wo;
+  const bool f_add = a.epi & CV_EPI_ADD, f_act = a.epi & CV_EPI_ACT, f_dact = a.epi & CV_EPI_DACT;
+#pragma unroll
+  for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * half) * ES + ni * 32 + li] = acc[mi][ni][r];
+    // same-wave LDS traffic is ordered; the compiler inserts the lgkmcnt wait before the reads below
+#pragma unroll 2
+    for (int q = lane; q < 32 * (EW / 4); q += 64) {
+      const int row = q / (EW / 4), c4 = q % (EW / 4);
+      const int p = (wm * WM + mi) * 32 + row;
+      const int th = p / TW, tw = p % TW;
+      const size_t o = (out_n + (size_t)(ho0 + th) * a.Wo + (wo0 + tw)) * a.K + k0 + wn * EW + c4 * 4;
+      float4 v = *reinterpret_cast<const float4*>(ep + row * ES + c4 * 4);
+      if (f_add) {
+        const float4 t = *reinterpret_cast<const float4*>(a.add + o);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
+      if (f_act) { v.x = cv_act(v.x, a.act); v.y = cv_act(v.y, a.act); v.z = cv_act(v.z, a.act); v.w = cv_act(v.w, a.act); }
+      if (f_dact) {
+        const float4 t = *reinterpret_cast<const float4*>(a.dsrc + o);
+        v.x *= cv_dact(t.x, a.act); v.y *= cv_dact(t.y, a.act); v.z *= cv_dact(t.z, a.act); v.w *= cv_dact(t.w, a.act);
+      }
+      *reinterpret_cast<float4*>(a.y + o) = v;
+    }
+  }
+}
+
+#undef CV_FETCH
+#undef CV_STAGE
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient: dw[k][tap][c] = sum over pixels of g[pixel][k] * x[pixel shifted by tap][c].
+// GEMM view: M = output channels k (BMK per workgroup), N = input channels c (BNC), reduction = output pixels; nine
+// accumulator sets, one per tap, share the A fragment (g) -- the B fragment of tap (r,s) is the same staged halo tile of
+// x read at a shifted pixel.  A workgroup reduces a SLAB of pixels (whole rows); slabs are summed by k_wgrad_reduce in a
+// fixed order (deterministic, no float atomics).  g[p][k] and x[p][c] both have the reduction index as the slow axis, so
+// fragments are ds_read_b32 with lanes along k / c (consecutive addresses, conflict-free) -- one read per MFMA operand,
+// which the 64-cycle fp32 MFMA hides easily.
+template <int BMK, int BNC, int PK, int SH, int SW, int KS>
+__global__ __launch_bounds__(CV_THREADS) void k_wgrad_f32(const float* __restrict__ x, const float* __restrict__ g,
+                                                          float* __restrict__ part, int N, int H, int W, int C, int K,
+                                                          int Ho, int Wo, int rows_per_slab, int nslabs) {
+  // pixel chunk: PK consecutive output columns of one output row
+  constexpr int PAD = (KS - 1) / 2;
+  constexpr int TAPS = KS * KS;
+  constexpr int RW = (PK - 1) * SW + KS;
+  constexpr int XS = BNC + 0;                       // floats per staged x pixel (lanes run along c: conflict-free)
+  constexpr int GS = BMK + 0;
+  constexpr int X_FLOATS = KS * RW * XS, G_FLOATS = PK * GS;
+  constexpr int NX = KS * RW * (BNC / 4), NG = PK * (BMK / 4);
+  constexpr int NX_IT = (NX + CV_THREADS - 1) / CV_THREADS, NG_IT = (NG + CV_THREADS - 1) / CV_THREADS;
+  constexpr int TM = BMK / 32, TN = BNC / 32;       // 32x32 tiles per tap
+  constexpr int TILES = TM * TN;                    // distributed over the 4 waves
+  static_assert(TILES % 4 == 0 || TILES == 1 || TILES == 2, "tile count");
+  constexpr int TPW = TILES >= 4 ? TILES / 4 : 1;   // tiles per wave (per tap)
+  __shared__ __attribute__((aligned(16))) float lds[X_FLOATS + G_FLOATS];
+  float* x_lds = lds;
+  float* g_lds = lds + X_FLOATS;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, half = lane >> 5;
+  const int KT = K / BMK, CT = C / BNC;
+  int t = blockIdx.x;
+  const int ct = t % CT; t /= CT;
+  const int kt = t % KT; t /= KT;
+  const int slab = t;
+  const int k0 = kt * BMK, c0 = ct * BNC;
+  const bool active = wave * TPW < TILES;
+
+  f32x16 acc[TAPS][TPW];
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+    for (int j = 0; j < TPW; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tp][j][r] = 0.f;
+
+  const int total_rows = N * Ho;
+  const int row_begin = slab * rows_per_slab;
+  const int row_end = min(row_begin + rows_per_slab, total_rows);
+  const int chunks_per_row = Wo / PK;
+  for (int row = row_begin; row < row_end; ++row) {
+    const int n = row / Ho, ho = row % Ho;
+    for (int ch = 0; ch < chunks_per_row; ++ch) {
+      const int wo0 = ch * PK;
+      __syncthreads();
+      // stage x halo: KS input rows x RW columns x BNC channels; g: PK pixels x BMK channels
+#pragma unroll
+      for (int it = 0; it < NX_IT; ++it) {
+        const int q = tid + it * CV_THREADS;
+        if (q < NX) {
+          const int c4 = q % (BNC / 4), pc = q / (BNC / 4);
+          const int col = pc % RW, r = pc / RW;
+          const int h = ho * SH - PAD + r;
+          int w = wo0 * SW - PAD + col;
+          w = w < 0 ? w + W : (w >= W ? w - W : w);
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (h >= 0 && h < H) v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + h) * W + w) * C + c0 + c4 * 4);
+          *reinterpret_cast<float4*>(x_lds + pc * XS + c4 * 4) = v;
+        }
+      }
+#pragma unroll
+      for (int it = 0; it < NG_IT; ++it) {
+        const int q = tid + it * CV_THREADS;
+        if (q < NG) {
+          const int k4 = q % (BMK / 4), p = q / (BMK / 4);
+          *reinterpret_cast<float4*>(g_lds + p * GS + k4 * 4) =
+              *reinterpret_cast<const float4*>(g + (((size_t)n * Ho + ho) * Wo + wo0 + p) * K + k0 + k4 * 4);
+        }
+      }
+      __syncthreads();
+      if (active) {
+#pragma unroll 4
+        for (int p = 0; p < PK; p += 2) {
+          // A: g[p + half][k = tile row*32 + li]; B: x[(p + half) * SW + s][r][c = tile col*32 + li]
+          float af[TPW], bf[TAPS][TPW];
+#pragma unroll
+          for (int j = 0; j < TPW; ++j) {
+            const int tile = wave * TPW + j, tm = tile / TN, tn = tile % TN;
+            af[j] = g_lds[(p + half) * GS + tm * 32 + li];
+#pragma unroll
+            for (int tp = 0; tp < TAPS; ++tp) {
+              const int r = tp / KS, s = tp % KS;
+              bf[tp][j] = x_lds[(r * RW + (p + half) * SW + s) * XS + tn * 32 + li];
+            }
+          }
+#pragma unroll
+          for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+            for (int j = 0; j < TPW; ++j)
+              acc[tp][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf[tp][j], acc[tp][j], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // partial result of this slab: part[slab][k][tap][c]
+  if (active) {
+    float* dst = part + (size_t)slab * K * TAPS * C;
+#pragma unroll
+    for (int j = 0; j < TPW; ++j) {
+      const int tile = wave * TPW + j, tm = tile / TN, tn = tile % TN;
+#pragma unroll
+      for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = k0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+          dst[((size_t)k * TAPS + tp) * C + c0 + tn * 32 + li] = acc[tp][j][r];
+        }
+    }
+  }
+}
+
+__global__ __launch_bounds__(CV_THREADS) void k_wgrad_reduce(const float* __restrict__ part, int nslabs, size_t count,
+                                                             float* __restrict__ dw) {
+  const size_t i = ((size_t)blockIdx.x * CV_THREADS + threadIdx.x) * 4;
+  if (i >= count) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < nslabs; ++k) {
+    const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * count + i);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  *reinterpret_cast<float4*>(dw + i) = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+
+template <int BM, int BN, int CK, int TW, int SH, int SW, int KS, bool BT, int WGN>
+static int launch_conv(const ConvArgs& a, hipStream_t st) {
+  constexpr int TH = BM / TW;
+  if (a.Wo % TW || a.Ho % TH || a.K % BN || a.C % CK) return 1;
+  const int ntiles = a.N * (a.Ho / TH) * (a.Wo / TW) * (a.K / BN);
+  hipLaunchKernelGGL((k_conv_f32<BM, BN, CK, TW, SH, SW, KS, BT, WGN>), dim3(ntiles), dim3(CV_THREADS), 0, st, a);
+  return 0;
+}
+
+#ifndef CV_BN
+#define CV_BN 64
+#endif
+#ifndef CV_CK
+#define CV_CK 16
+#endif
+#ifndef CV_WGN
+#define CV_WGN 2
+#endif
+
+#ifdef CV_TUNE
+// tuning build (tools/conv_harness): the tile variant of the stride-1 3x3 kernels is chosen at run time
+int g_cv_variant = 0;
+template <int SH, int SW, int KS, bool BT, int BM, int BN, int CKK, int WGNN>
+static int variant_conv(const ConvArgs& a, hipStream_t st) {
+  constexpr int ROWS128 = BM / 128, ROWS64 = BM / 64, ROWS32 = BM / 32;
+  (void)ROWS128; (void)ROWS64; (void)ROWS32;
+  if (a.Wo % 128 == 0 && !launch_conv<BM, BN, CKK, 128, SH, SW, KS, BT, WGNN>(a, st)) return 0;
+  if (a.Wo % 64 == 0 && !launch_conv<BM, BN, CKK, 64, SH, SW, KS, BT, WGNN>(a, st)) return 0;
+  return 1;
+}
+#endif
+
+template <int SH, int SW, int KS, bool BT>
+static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
+#ifdef CV_TUNE
+  if (SH == 1 && SW == 1 && KS == 3) {
+    switch (g_cv_variant) {
+      case 1: return variant_conv<1, 1, 3, BT, 128, 64, 8, 2>(a, st);
+      case 2: return variant_conv<1, 1, 3, BT, 128, 64, 32, 2>(a, st);
+      case 3: return variant_conv<1, 1, 3, BT, 128, 128, 8, 2>(a, st);
+      case 4: return variant_conv<1, 1, 3, BT, 128, 128, 16, 2>(a, st);
+      case 5: return variant_conv<1, 1, 3, BT, 256, 64, 8, 1>(a, st);
+      case 6: return variant_conv<1, 1, 3, BT, 256, 64, 16, 1>(a, st);
+      case 7: return variant_conv<1, 1, 3, BT, 256, 128, 8, 2>(a, st);
+      case 8: return variant_conv<1, 1, 3, BT, 128, 64, 16, 1>(a, st);
+      case 9: return variant_conv<1, 1, 3, BT, 256, 128, 16, 2>(a, st);
+      default: break;
+    }
+  }
+#endif
+  // tile width: the widest of 128 / 64 / 32 that divides the output row; narrow images take several rows per tile
+  if (a.Wo % 128 == 0 && !launch_conv<128, CV_BN, CV_CK, 128, SH, SW, KS, BT, CV_WGN>(a, st)) return 0;
+  if (a.Wo % 64 == 0 && !launch_conv<128, CV_BN, CV_CK, 64, SH, SW, KS, BT, CV_WGN>(a, st)) return 0;
+  if (a.Wo % 32 == 0 && !launch_conv<128, CV_BN, CV_CK, 32, SH, SW, KS, BT, CV_WGN>(a, st)) return 0;
+  return 1;
+}
+
+/* see include/delora_hip.h */
+extern "C" int dl_conv2d_nhwc_f32(const float* x, const float* w, float* y, const float* add, const float* dsrc, int32_t N,
+                                  int32_t H, int32_t W, int32_t C, int32_t K, int32_t ksize, int32_t stride_h,
+                                  int32_t stride_w, int32_t transposed, int32_t act, uint32_t epilogue, dl_stream stream) {
+  if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0)
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_nhwc_f32: bad argument");
+  if (((epilogue & CV_EPI_ADD) && !add) || ((epilogue & CV_EPI_DACT) && !dsrc) || act < 0 || act > 2)
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_nhwc_f32: epilogue operand missing / bad activation");
+  if (H % stride_h || W % stride_w)
+    return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_f32: image size must be a multiple of the stride");
+  if ((size_t)N * H * W * C >= ((size_t)1 << 31) || (size_t)N * H * W * K >= ((size_t)1 << 31))
+    return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_f32: tensors beyond 2^31 elements are not supported (split the batch)");
+  ConvArgs a{x, w, y, add, dsrc, N, H, W, C, K, H / stride_h, W / stride_w, act, epilogue};
+  hipStream_t st = (hipStream_t)stream;
+  int rc = 1;
+  if (ksize == 3 && stride_h == 1 && stride_w == 1) rc = transposed ? dispatch_conv<1, 1, 3, true>(a, st) : dispatch_conv<1, 1, 3, false>(a, st);
+  else if (transposed) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_f32: transposed weights need stride 1, 3x3");
+  else if (ksize == 3 && stride_h == 1 && stride_w == 2) rc = dispatch_conv<1, 2, 3, false>(a, st);
+  else if (ksize == 3 && stride_h == 2 && stride_w == 2) rc = dispatch_conv<2, 2, 3, false>(a, st);
+  else if (ksize == 1 && stride_h == 1 && stride_w == 2) rc = dispatch_conv<1, 2, 1, false>(a, st);
+  else if (ksize == 1 && stride_h == 2 && stride_w == 2) rc = dispatch_conv<2, 2, 1, false>(a, st);
+  else return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_f32: kernel %d stride (%d,%d) is not built", ksize, stride_h, stride_w);
+  if (rc) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_f32: shape N=%d H=%d W=%d C=%d K=%d does not tile (Wo %% 32, K %% %d, C %% %d)",
+                         N, H, W, C, K, CV_BN, CV_CK);
+  return dl_check_launch("dl_conv2d_nhwc_f32");
+}
+
+#ifndef WG_PK
+#define WG_PK 32
+#endif
+
+static int wgrad_slabs(int total_rows, int tiles) {
+  // enough workgroups to fill 256 CUs a few times over; at least one output row per slab
+  int want = (512 + tiles - 1) / tiles;
+  if (want > total_rows) want = total_rows;
+  if (want < 1) want = 1;
+  const int rows = (total_rows + want - 1) / want;
+  return (total_rows + rows - 1) / rows;
+}
+
+extern "C" size_t dl_conv2d_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, int32_t ksize,
+                                                  int32_t stride_h, int32_t stride_w) {
+  const int Ho = H / stride_h;
+  const int tiles = (K / 64 > 0 ? K / 64 : 1) * (C / 64 > 0 ? C / 64 : 1);
+  return (size_t)wgrad_slabs(N * Ho, tiles) * K * ksize * ksize * C * sizeof(float);
+}
+
+template <int SH, int SW, int KS>
+static int launch_wgrad(const float* x, const float* g, float* dw, float* ws, int N, int H, int W, int C, int K, hipStream_t st) {
+  constexpr int BMK = 64, BNC = 64;
+  const int Ho = H / SH, Wo = W / SW;
+  if (K % BMK || C % BNC || Wo % WG_PK) return 1;
+  const int tiles = (K / BMK) * (C / BNC);
+  const int total_rows = N * Ho;
+  const int nslabs = wgrad_slabs(total_rows, tiles);
+  const int rows_per_slab = (total_rows + nslabs - 1) / nslabs;
+  hipLaunchKernelGGL((k_wgrad_f32<BMK, BNC, WG_PK, SH, SW, KS>), dim3(tiles * nslabs), dim3(CV_THREADS), 0, st, x, g, ws, N,
+                     H, W, C, K, Ho, Wo, rows_per_slab, nslabs);
+  const size_t count = (size_t)K * KS * KS * C;
+  hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((count / 4 + CV_THREADS - 1) / CV_THREADS)), dim3(CV_THREADS), 0, st,
+                     (const float*)ws, nslabs, count, dw);
+  return 0;
+}
+
+extern "C" int dl_conv2d_wgrad_nhwc_f32(const float* x, const float* g, float* dw, void* workspace, int32_t N, int32_t H,
+                                        int32_t W, int32_t C, int32_t K, int32_t ksize, int32_t stride_h, int32_t stride_w,
+                                        dl_stream stream) {
+  if (!x || !g || !dw || !workspace || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0)
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_wgrad_nhwc_f32: bad argument");
+  if (H % stride_h || W % stride_w)
+    return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_wgrad_nhwc_f32: image size must be a multiple of the stride");
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  int rc = 1;
+  if (ksize == 3 && stride_h == 1 && stride_w == 1) rc = launch_wgrad<1, 1, 3>(x, g, dw, ws, N, H, W, C, K, st);
+  else if (ksize == 3 && stride_h == 1 && stride_w == 2) rc = launch_wgrad<1, 2, 3>(x, g, dw, ws, N, H, W, C, K, st);
+  else if (ksize == 3 && stride_h == 2 && stride_w == 2) rc = launch_wgrad<2, 2, 3>(x, g, dw, ws, N, H, W, C, K, st);
+  else if (ksize == 1 && stride_h == 1 && stride_w == 2) rc = launch_wgrad<1, 2, 1>(x, g, dw, ws, N, H, W, C, K, st);
+  else if (ksize == 1 && stride_h == 2 && stride_w == 2) rc = launch_wgrad<2, 2, 1>(x, g, dw, ws, N, H, W, C, K, st);
+  else return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_wgrad_nhwc_f32: kernel %d stride (%d,%d) is not built", ksize, stride_h, stride_w);
+  if (rc) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_wgrad_nhwc_f32: shape N=%d H=%d W=%d C=%d K=%d does not tile", N, H, W, C, K);
+  return dl_check_launch("dl_conv2d_wgrad_nhwc_f32");
+}

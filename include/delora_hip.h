@@ -219,6 +219,40 @@ int dl_ring_act_pool_pad_fwd(const float* x, int64_t planes, int32_t H, int32_t 
 int dl_ring_act_pool_pad_bwd(const float* grad_out, const float* y, const int8_t* win, int64_t planes, int32_t H,
                              int32_t W, int32_t act, float* grad_x, dl_stream stream);
 
+/*
+ * Convolutions of the pose CNN on 360-degree range images, channels-last fp32 on the fp32 matrix cores (exact fp32
+ * products, v_mfma_f32_32x32x2_f32), with the wrap-around width padding as addressing and the elementwise tail fused.
+ * Replaces F.pad(x, (1,1,0,0), 'circular') + Conv2d(kernel 3, padding (1,0)) [+ residual add] + tanh/relu and the
+ * 1x1 strided down-sampling convolution of the reference's ResNet (src/models/resnet_modified.py:97-98, :101-102,
+ * :150-177; torch Conv2d there) and their autograd.
+ *   x    [N][H][W][C]  input (channels-last);  y [N][H/stride_h][W/stride_w][K] output
+ *   w    transposed == 0: [K][ksize][ksize][C] (the torch parameter [K,C,k,k] in channels_last memory format)
+ *        transposed == 1: [C][ksize][ksize][K] -- the FORWARD weight of the layer whose input gradient is wanted: the
+ *                         kernel reads it with flipped taps and swapped channel roles (stride 1, 3x3 only)
+ *   3x3: rows -1 and H read zeros, columns -1 and W read columns W-1 and 0; 1x1: no padding.
+ *   epilogue (flags, applied in this order on the fp32 accumulator v of output element (pixel, k)):
+ *     1 DL_CONV_ADD   v += add[pixel][k]
+ *     2 DL_CONV_ACT   v  = act(v)                      act: 0 none, 1 tanh, 2 relu
+ *     4 DL_CONV_DACT  v *= act'(dsrc[pixel][k])        dsrc = saved OUTPUT of the activation (tanh' = 1 - y^2)
+ *   add, dsrc: [N][Ho][Wo][K] or NULL.  Shapes must tile: Wo % 32 == 0, K % 64 == 0, C % 16 == 0 (DL_ERR_UNSUPPORTED
+ *   otherwise; the caller then uses its library convolution).
+ */
+#define DL_CONV_ADD  1u
+#define DL_CONV_ACT  2u
+#define DL_CONV_DACT 4u
+int dl_conv2d_nhwc_f32(const float* x, const float* w, float* y, const float* add, const float* dsrc, int32_t N,
+                       int32_t H, int32_t W, int32_t C, int32_t K, int32_t ksize, int32_t stride_h, int32_t stride_w,
+                       int32_t transposed, int32_t act, uint32_t epilogue, dl_stream stream);
+
+/* Weight gradient of the same convolutions: dw[k][tap][c] = sum over output pixels of g[pixel][k] * x[pixel + tap][c]
+ * (wrap-around / zero-row addressing as above), slab-wise partial sums added in a fixed order (deterministic).
+ *   x [N][H][W][C], g [N][Ho][Wo][K], dw [K][ksize][ksize][C];  workspace: dl_conv2d_wgrad_workspace_bytes(...) bytes.
+ *   Shapes must tile: K % 64 == 0, C % 64 == 0, Wo % 32 == 0. */
+size_t dl_conv2d_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, int32_t ksize,
+                                       int32_t stride_h, int32_t stride_w);
+int dl_conv2d_wgrad_nhwc_f32(const float* x, const float* g, float* dw, void* workspace, int32_t N, int32_t H, int32_t W,
+                             int32_t C, int32_t K, int32_t ksize, int32_t stride_h, int32_t stride_w, dl_stream stream);
+
 #ifdef __cplusplus
 }
 #endif
