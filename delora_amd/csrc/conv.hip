@@ -325,22 +325,20 @@ __global__ __launch_bounds__(CV_THREADS, CV_MINWAVES) void k_conv_f32(ConvArgs a
 // fragments are ds_read_b32 with lanes along k / c (consecutive addresses, conflict-free) -- one read per MFMA operand,
 // which the 64-cycle fp32 MFMA hides easily.
 template <int BMK, int BNC, int PK, int SH, int SW, int KS>
-__global__ __launch_bounds__(CV_THREADS) void k_wgrad_f32(const float* __restrict__ x, const float* __restrict__ g,
-                                                          float* __restrict__ part, int N, int H, int W, int C, int K,
-                                                          int Ho, int Wo, int rows_per_slab, int nslabs) {
-  // pixel chunk: PK consecutive output columns of one output row
+__global__ __launch_bounds__(CV_THREADS, (SW == 2 && KS == 3) ? 1 : 2) void k_wgrad_f32(const float* __restrict__ x, const float* __restrict__ g,
+                                                             float* __restrict__ part, int N, int H, int W, int C, int K,
+                                                             int Ho, int Wo, int chunks_per_slab, int nslabs) {
+  // pixel chunk: PK consecutive output columns of one output row; a slab is a run of consecutive chunks
   constexpr int PAD = (KS - 1) / 2;
   constexpr int TAPS = KS * KS;
   constexpr int RW = (PK - 1) * SW + KS;
-  constexpr int XS = BNC + 0;                       // floats per staged x pixel (lanes run along c: conflict-free)
-  constexpr int GS = BMK + 0;
-  constexpr int X_FLOATS = KS * RW * XS, G_FLOATS = PK * GS;
+  constexpr int X_FLOATS = KS * RW * BNC, G_FLOATS = PK * BMK;
   constexpr int NX = KS * RW * (BNC / 4), NG = PK * (BMK / 4);
   constexpr int NX_IT = (NX + CV_THREADS - 1) / CV_THREADS, NG_IT = (NG + CV_THREADS - 1) / CV_THREADS;
   constexpr int TM = BMK / 32, TN = BNC / 32;       // 32x32 tiles per tap
   constexpr int TILES = TM * TN;                    // distributed over the 4 waves
-  static_assert(TILES % 4 == 0 || TILES == 1 || TILES == 2, "tile count");
-  constexpr int TPW = TILES >= 4 ? TILES / 4 : 1;   // tiles per wave (per tap)
+  static_assert(TILES % 4 == 0, "tile count");
+  constexpr int TPW = TILES / 4;                    // tiles per wave (per tap)
   __shared__ __attribute__((aligned(16))) float lds[X_FLOATS + G_FLOATS];
   float* x_lds = lds;
   float* g_lds = lds + X_FLOATS;
@@ -352,7 +350,6 @@ __global__ __launch_bounds__(CV_THREADS) void k_wgrad_f32(const float* __restric
   const int kt = t % KT; t /= KT;
   const int slab = t;
   const int k0 = kt * BMK, c0 = ct * BNC;
-  const bool active = wave * TPW < TILES;
 
   f32x16 acc[TAPS][TPW];
 #pragma unroll
@@ -362,91 +359,117 @@ __global__ __launch_bounds__(CV_THREADS) void k_wgrad_f32(const float* __restric
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tp][j][r] = 0.f;
 
-  const int total_rows = N * Ho;
-  const int row_begin = slab * rows_per_slab;
-  const int row_end = min(row_begin + rows_per_slab, total_rows);
-  const int chunks_per_row = Wo / PK;
-  for (int row = row_begin; row < row_end; ++row) {
-    const int n = row / Ho, ho = row % Ho;
-    for (int ch = 0; ch < chunks_per_row; ++ch) {
-      const int wo0 = ch * PK;
-      __syncthreads();
-      // stage x halo: KS input rows x RW columns x BNC channels; g: PK pixels x BMK channels
+  // chunk-invariant parts of the staging items (ids beyond the tile are clamped: duplicates of the last item)
+  int x_row[NX_IT], x_col[NX_IT], x_c4[NX_IT], x_l[NX_IT];
 #pragma unroll
-      for (int it = 0; it < NX_IT; ++it) {
-        const int q = tid + it * CV_THREADS;
-        if (q < NX) {
-          const int c4 = q % (BNC / 4), pc = q / (BNC / 4);
-          const int col = pc % RW, r = pc / RW;
-          const int h = ho * SH - PAD + r;
-          int w = wo0 * SW - PAD + col;
-          w = w < 0 ? w + W : (w >= W ? w - W : w);
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (h >= 0 && h < H) v = *reinterpret_cast<const float4*>(x + (((size_t)n * H + h) * W + w) * C + c0 + c4 * 4);
-          *reinterpret_cast<float4*>(x_lds + pc * XS + c4 * 4) = v;
-        }
-      }
-#pragma unroll
-      for (int it = 0; it < NG_IT; ++it) {
-        const int q = tid + it * CV_THREADS;
-        if (q < NG) {
-          const int k4 = q % (BMK / 4), p = q / (BMK / 4);
-          *reinterpret_cast<float4*>(g_lds + p * GS + k4 * 4) =
-              *reinterpret_cast<const float4*>(g + (((size_t)n * Ho + ho) * Wo + wo0 + p) * K + k0 + k4 * 4);
-        }
-      }
-      __syncthreads();
-      if (active) {
-#pragma unroll 4
-        for (int p = 0; p < PK; p += 2) {
-          // A: g[p + half][k = tile row*32 + li]; B: x[(p + half) * SW + s][r][c = tile col*32 + li]
-          float af[TPW], bf[TAPS][TPW];
-#pragma unroll
-          for (int j = 0; j < TPW; ++j) {
-            const int tile = wave * TPW + j, tm = tile / TN, tn = tile % TN;
-            af[j] = g_lds[(p + half) * GS + tm * 32 + li];
-#pragma unroll
-            for (int tp = 0; tp < TAPS; ++tp) {
-              const int r = tp / KS, s = tp % KS;
-              bf[tp][j] = x_lds[(r * RW + (p + half) * SW + s) * XS + tn * 32 + li];
-            }
-          }
-#pragma unroll
-          for (int tp = 0; tp < TAPS; ++tp)
-#pragma unroll
-            for (int j = 0; j < TPW; ++j)
-              acc[tp][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf[tp][j], acc[tp][j], 0, 0, 0);
-        }
-      }
-    }
+  for (int it = 0; it < NX_IT; ++it) {
+    const int q = min(tid + it * CV_THREADS, NX - 1);
+    x_c4[it] = (q % (BNC / 4)) * 4;
+    const int pc = q / (BNC / 4);
+    x_col[it] = pc % RW; x_row[it] = pc / RW;
+    x_l[it] = pc * BNC + x_c4[it];
   }
-  // partial result of this slab: part[slab][k][tap][c]
-  if (active) {
-    float* dst = part + (size_t)slab * K * TAPS * C;
+  int g_p[NG_IT], g_k4[NG_IT];
 #pragma unroll
-    for (int j = 0; j < TPW; ++j) {
-      const int tile = wave * TPW + j, tm = tile / TN, tn = tile % TN;
+  for (int it = 0; it < NG_IT; ++it) {
+    const int q = min(tid + it * CV_THREADS, NG - 1);
+    g_k4[it] = (q % (BMK / 4)) * 4;
+    g_p[it] = q / (BMK / 4);
+  }
+  const int chunks_per_row = Wo / PK;
+  const int total_chunks = N * Ho * chunks_per_row;
+  const int ch_begin = slab * chunks_per_slab;
+  const int ch_end = min(ch_begin + chunks_per_slab, total_chunks);
+
+  f32x4 x_r[NX_IT], g_r[NG_IT];
+#define WG_FETCH(CH)                                                                                                      \
+  {                                                                                                                       \
+    const int row_ = (CH) / chunks_per_row, wo0_ = ((CH) % chunks_per_row) * PK;                                          \
+    const int n_ = row_ / Ho, ho_ = row_ % Ho;                                                                            \
+    _Pragma("unroll") for (int it = 0; it < NX_IT; ++it) {                                                                \
+      const int h = ho_ * SH - PAD + x_row[it];                                                                           \
+      int w = wo0_ * SW - PAD + x_col[it];                                                                                \
+      w = w < 0 ? w + W : (w >= W ? w - W : w);                                                                           \
+      const bool in = h >= 0 && h < H;                                                                                    \
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (in ? (((size_t)n_ * H + h) * W + w) * C + c0 + x_c4[it] : 0)); \
+      x_r[it] = in ? v : (f32x4){0.f, 0.f, 0.f, 0.f};                                                                     \
+    }                                                                                                                     \
+    _Pragma("unroll") for (int it = 0; it < NG_IT; ++it) g_r[it] = *reinterpret_cast<const f32x4*>(                       \
+        g + (((size_t)n_ * Ho + ho_) * Wo + wo0_ + g_p[it]) * K + k0 + g_k4[it]);                                         \
+  }
+#define WG_STAGE()                                                                                                        \
+  {                                                                                                                       \
+    _Pragma("unroll") for (int it = 0; it < NX_IT; ++it) *reinterpret_cast<f32x4*>(x_lds + x_l[it]) = x_r[it];            \
+    _Pragma("unroll") for (int it = 0; it < NG_IT; ++it) *reinterpret_cast<f32x4*>(g_lds + g_p[it] * BMK + g_k4[it]) = g_r[it]; \
+  }
+  if (ch_begin < ch_end) {
+    WG_FETCH(ch_begin)
+    WG_STAGE()
+  }
+  __syncthreads();
+  for (int ch = ch_begin; ch < ch_end; ++ch) {
+    const bool more = ch + 1 < ch_end;
+    if (more) WG_FETCH(ch + 1)
+#pragma unroll 2
+    for (int p = 0; p < PK; p += 2) {
+      // A: g[p + half][k = tile row * 32 + li]; B: x[(p + half) * SW + s][r][c = tile col * 32 + li]
+      float af[TPW], bf[TAPS][TPW];
+#pragma unroll
+      for (int j = 0; j < TPW; ++j) {
+        const int tile = wave * TPW + j, tm = tile / TN, tn = tile % TN;
+        af[j] = g_lds[(p + half) * BMK + tm * 32 + li];
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) {
+          const int r = tp / KS, s = tp % KS;
+          bf[tp][j] = x_lds[(r * RW + (p + half) * SW + s) * BNC + tn * 32 + li];
+        }
+      }
 #pragma unroll
       for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int k = k0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-          dst[((size_t)k * TAPS + tp) * C + c0 + tn * 32 + li] = acc[tp][j][r];
-        }
+        for (int j = 0; j < TPW; ++j)
+          acc[tp][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf[tp][j], acc[tp][j], 0, 0, 0);
     }
+    __syncthreads();
+    if (more) {
+      WG_STAGE()
+      __syncthreads();
+    }
+  }
+#undef WG_FETCH
+#undef WG_STAGE
+  // partial result of this slab: part[slab][k][tap][c]
+  float* dst = part + (size_t)slab * K * TAPS * C;
+#pragma unroll
+  for (int j = 0; j < TPW; ++j) {
+    const int tile = wave * TPW + j, tm = tile / TN, tn = tile % TN;
+#pragma unroll
+    for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int k = k0 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        dst[((size_t)k * TAPS + tp) * C + c0 + tn * 32 + li] = acc[tp][j][r];
+      }
   }
 }
 
+// Sum of the slab partials in a fixed order (slab 0, 1, 2, ... per element: deterministic).  Eight slabs are loaded per
+// trip so that eight independent 16-byte loads are in flight per lane -- the one-load-per-trip form ran at 1.7 TB/s.
 __global__ __launch_bounds__(CV_THREADS) void k_wgrad_reduce(const float* __restrict__ part, int nslabs, size_t count,
                                                              float* __restrict__ dw) {
   const size_t i = ((size_t)blockIdx.x * CV_THREADS + threadIdx.x) * 4;
   if (i >= count) return;
-  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k = 0; k < nslabs; ++k) {
-    const float4 v = *reinterpret_cast<const float4*>(part + (size_t)k * count + i);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= nslabs; k += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(part + (size_t)(k + u) * count + i));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
   }
-  *reinterpret_cast<float4*>(dw + i) = s;
+  for (; k < nslabs; ++k) s += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(part + (size_t)k * count + i));
+  *reinterpret_cast<f32x4*>(dw + i) = s;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -502,7 +525,20 @@ static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
     }
   }
 #endif
-  // tile width: the widest of 128 / 64 / 32 that divides the output row; narrow images take several rows per tile
+  // Tile choice (measured on the layer shapes of the network, tools/conv_harness tune; profiles/): stride-1 3x3 layers take
+  // 256 pixels x 64 channels per workgroup (each wave a 64x64 block: one LDS read feeds four MFMAs on both operands), with
+  // 8-channel chunks (3 workgroups per CU) for the shallow layers and 16-channel chunks for C >= 256; strided and 1x1
+  // layers and images that do not tile by 256 pixels take 128-pixel tiles.  Tile width = the widest of 128 / 64 / 32 that
+  // divides the output row; narrow images take several rows per tile.
+  if constexpr (SH == 1 && SW == 1 && KS == 3) {
+    if (a.C >= 256) {
+      if (a.Wo % 128 == 0 && !launch_conv<256, 64, 16, 128, SH, SW, KS, BT, 1>(a, st)) return 0;
+      if (a.Wo % 64 == 0 && !launch_conv<256, 64, 16, 64, SH, SW, KS, BT, 1>(a, st)) return 0;
+    } else {
+      if (a.Wo % 128 == 0 && !launch_conv<256, 64, 8, 128, SH, SW, KS, BT, 1>(a, st)) return 0;
+      if (a.Wo % 64 == 0 && !launch_conv<256, 64, 8, 64, SH, SW, KS, BT, 1>(a, st)) return 0;
+    }
+  }
   if (a.Wo % 128 == 0 && !launch_conv<128, CV_BN, CV_CK, 128, SH, SW, KS, BT, CV_WGN>(a, st)) return 0;
   if (a.Wo % 64 == 0 && !launch_conv<128, CV_BN, CV_CK, 64, SH, SW, KS, BT, CV_WGN>(a, st)) return 0;
   if (a.Wo % 32 == 0 && !launch_conv<128, CV_BN, CV_CK, 32, SH, SW, KS, BT, CV_WGN>(a, st)) return 0;
@@ -540,20 +576,20 @@ extern "C" int dl_conv2d_nhwc_f32(const float* x, const float* w, float* y, cons
 #define WG_PK 32
 #endif
 
-static int wgrad_slabs(int total_rows, int tiles) {
-  // enough workgroups to fill 256 CUs a few times over; at least one output row per slab
+static int wgrad_slabs(int total_chunks, int tiles) {
+  // enough workgroups to fill 256 CUs twice over (2 resident per CU); a slab is a run of pixel chunks
   int want = (512 + tiles - 1) / tiles;
-  if (want > total_rows) want = total_rows;
+  if (want > total_chunks) want = total_chunks;
   if (want < 1) want = 1;
-  const int rows = (total_rows + want - 1) / want;
-  return (total_rows + rows - 1) / rows;
+  const int per = (total_chunks + want - 1) / want;
+  return (total_chunks + per - 1) / per;
 }
 
 extern "C" size_t dl_conv2d_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, int32_t ksize,
                                                   int32_t stride_h, int32_t stride_w) {
-  const int Ho = H / stride_h;
+  const int Ho = H / stride_h, Wo = W / stride_w;
   const int tiles = (K / 64 > 0 ? K / 64 : 1) * (C / 64 > 0 ? C / 64 : 1);
-  return (size_t)wgrad_slabs(N * Ho, tiles) * K * ksize * ksize * C * sizeof(float);
+  return (size_t)wgrad_slabs(N * Ho * (Wo / WG_PK > 0 ? Wo / WG_PK : 1), tiles) * K * ksize * ksize * C * sizeof(float);
 }
 
 template <int SH, int SW, int KS>
@@ -562,11 +598,11 @@ static int launch_wgrad(const float* x, const float* g, float* dw, float* ws, in
   const int Ho = H / SH, Wo = W / SW;
   if (K % BMK || C % BNC || Wo % WG_PK) return 1;
   const int tiles = (K / BMK) * (C / BNC);
-  const int total_rows = N * Ho;
-  const int nslabs = wgrad_slabs(total_rows, tiles);
-  const int rows_per_slab = (total_rows + nslabs - 1) / nslabs;
+  const int total_chunks = N * Ho * (Wo / WG_PK);
+  const int nslabs = wgrad_slabs(total_chunks, tiles);
+  const int chunks_per_slab = (total_chunks + nslabs - 1) / nslabs;
   hipLaunchKernelGGL((k_wgrad_f32<BMK, BNC, WG_PK, SH, SW, KS>), dim3(tiles * nslabs), dim3(CV_THREADS), 0, st, x, g, ws, N,
-                     H, W, C, K, Ho, Wo, rows_per_slab, nslabs);
+                     H, W, C, K, Ho, Wo, chunks_per_slab, nslabs);
   const size_t count = (size_t)K * KS * KS * C;
   hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((count / 4 + CV_THREADS - 1) / CV_THREADS)), dim3(CV_THREADS), 0, st,
                      (const float*)ws, nslabs, count, dw);

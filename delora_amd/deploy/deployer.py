@@ -29,6 +29,8 @@ class Deployer(object):
         self.model = model_module.OdometryModel(config=config).to(self.device)
         if config.get("channels_last", False):
             self.model = self.model.to(memory_format=torch.channels_last)
+        elif getattr(self.device, "type", "cpu") == "cuda" and config.get("cnn_impl", "auto") != "modules":
+            self.model.resnet.trunk_weights_channels_last()
         if config["use_jit"]:
             first = config["datasets"][0]
             example = torch.zeros((1, 4, config[first]["vertical_cells"], config[first]["horizontal_cells"]), device=self.device)

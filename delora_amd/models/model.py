@@ -37,7 +37,8 @@ class OdometryModel(torch.nn.Module):
         self.resnet = resnet_modified.ResNetModified(
             in_channels=in_channels if not self.pre_feature_extraction else 2 * n_pre * in_channels,
             num_outputs=config["resnet_outputs"], use_dropout=config["use_dropout"], layers=config["layers"],
-            factor_fewer_resnet_channels=config["factor_fewer_resnet_channels"], activation_fct=act)
+            factor_fewer_resnet_channels=config["factor_fewer_resnet_channels"], activation_fct=act,
+            impl=config.get("cnn_impl", "auto"))
         n_feat = config["resnet_outputs"]
         if config["use_single_mlp_at_output"]:           # model.py:59-72
             self.fully_connected_rot_trans = _mlp(act, [n_feat, 512, 512, 256, 64, 3 + 4])

@@ -10,6 +10,7 @@ activation + padding + max-pooling + padding is one more (``ring_ops.ring_act_po
 """
 import torch
 
+from . import ring_conv
 from .ring_ops import ring_act_pad, ring_act_pool_pad
 
 
@@ -52,9 +53,14 @@ class BasicBlock(torch.nn.Module):
 
 class ResNetModified(torch.nn.Module):
     def __init__(self, in_channels, num_outputs, use_dropout=False, layers=(2, 2, 2, 2),
-                 factor_fewer_resnet_channels=1, activation_fct="relu"):
+                 factor_fewer_resnet_channels=1, activation_fct="relu", impl="auto"):
         super().__init__()
         self.activation_fct = activation_fct
+        # "auto": the channels-last HIP trunk (ring_conv.RingTrunk: fp32 MFMA convolutions with fused epilogues) whenever
+        # the tensors are fp32 on the GPU and the shapes tile, the module path (library convolutions + fused ring ops)
+        # otherwise; "modules" forces the latter, "hip" makes unsupported shapes an error.
+        self.impl = impl
+        self.use_dropout = bool(use_dropout)
         widths = [int(c / factor_fewer_resnet_channels) for c in (64, 128, 256, 512)]
         self.inplanes = widths[0]
         self.dropout_values = torch.nn.Dropout(p=0.2) if use_dropout else torch.nn.Identity()
@@ -84,10 +90,46 @@ class ResNetModified(torch.nn.Module):
         stack += [BasicBlock(self.inplanes, planes, activation_fct=self.activation_fct) for _ in range(1, blocks)]
         return torch.nn.Sequential(*stack)
 
+    def _trunk_blocks(self):
+        blocks, weights = [], []
+        for layer in (self.layer1, self.layer2, self.layer3, self.layer4):
+            for blk in layer:
+                stride = blk.stride if isinstance(blk.stride, tuple) else (blk.stride, blk.stride)
+                has_ds = blk.downsample is not None
+                blocks.append((blk.conv1.in_channels, blk.conv1.out_channels, tuple(stride), has_ds))
+                weights += [blk.conv1.weight, blk.conv2.weight] + ([blk.downsample[0].weight] if has_ds else [])
+        return tuple(blocks), weights
+
+    def trunk_weights_channels_last(self):
+        """Store the trunk's convolution weights as ``[K][k][k][C]`` (torch channels_last): the HIP trunk then reads the
+        parameters and writes their gradients in place.  Shapes, names and values of the state_dict do not change; the stem
+        convolution (library, NCHW input) keeps the default layout."""
+        for w in self._trunk_blocks()[1]:
+            w.data = w.data.contiguous(memory_format=torch.channels_last)
+        return self
+
+    def hip_trunk_applicable(self, x_pooled_shape_nhwc, x):
+        """The HIP trunk runs fp32 CUDA tensors, no dropout, outside autocast, on shapes that tile."""
+        if self.impl == "modules" or not x.is_cuda or x.dtype != torch.float32 or torch.is_autocast_enabled():
+            return False
+        if self.use_dropout and self.training:
+            return False
+        return ring_conv.supported(x_pooled_shape_nhwc, self._trunk_blocks()[0])
+
     def forward(self, x):
         act = "relu" if self.activation_fct == "relu" else "tanh"
         p = ring_act_pad(self.dropout_values(x), "none", pad=True)
         p = ring_act_pool_pad(self.conv1(p), act)                    # act + wrap + self.maxpool + wrap, fused
+        N, C0, H0, Wp = p.shape
+        if self.hip_trunk_applicable((N, H0, Wp - 2, C0), p):
+            # channels-last trunk: layer1..layer4 as one autograd Function on the fp32 matrix cores
+            blocks, weights = self._trunk_blocks()
+            x0 = p[..., 1:-1].permute(0, 2, 3, 1).contiguous()
+            x4 = ring_conv.RingTrunk.apply(x0, ring_conv.ACT[act], blocks, *weights)          # [N,H',W',C']
+            out = self.dropout_values(self.fc(x4.mean(dim=(1, 2))))
+            return [None, None, None, x4.permute(0, 3, 1, 2), out]
+        if self.impl == "hip":
+            raise RuntimeError(f"cnn_impl 'hip': the HIP trunk does not support input {tuple(x.shape)} / dtype {x.dtype}")
         p1 = self.layer1(p)
         p2 = self.layer2(p1)
         p3 = self.dropout_channels(self.layer3(p2))

@@ -1,0 +1,170 @@
+"""Channels-last convolutions of the pose CNN on the fp32 matrix cores: thin torch wrappers over ``dl_conv2d_nhwc_f32`` /
+``dl_conv2d_wgrad_nhwc_f32`` (include/delora_hip.h) and the autograd Function of the whole residual trunk.
+
+Reference: ``ResNetModified._forward_impl`` / ``BasicBlock.forward`` (src/models/resnet_modified.py:95-120, :159-177) --
+17 x (F.pad circular + Conv2d) + tanh + residual adds under torch autograd.  Here the trunk (layer1..layer4) is ONE
+autograd Function on channels-last activations ``[N,H,W,C]``:
+
+  forward   per block   y1 = act(conv(x, w1));  y2 = act(conv(y1, w2) + shortcut)       2 (+1) launches, nothing else
+  backward  per block   dW2 = wgrad(y1, g2);  g1 = dgrad(g2, w2) * act'(y1);  dW1 = wgrad(x, g1);
+                        g2_prev = (dgrad(g1, w1) + g2) * act'(x)                         4 (+2) launches, nothing else
+
+where g denotes a gradient with respect to a PRE-activation: the activation derivative of the previous block and the
+shortcut gradient are folded into the epilogue of the input-gradient convolution, so no elementwise kernel runs between
+two convolutions.  The wrap-around of the image width and the zero rows above / below are addressing inside the kernels:
+no padded copy of an activation exists.  Weights are the torch parameters themselves in channels_last memory format
+(``[K][3][3][C]`` storage); weight gradients are written in the same layout.
+
+The three strided 3x3 convolutions and the three 1x1 down-sampling convolutions take their INPUT gradient from the library
+convolution (MIOpen, channels-last) -- the only library calls left in the trunk.
+"""
+import ctypes
+
+import torch
+
+from .. import _lib
+
+ACT = {"none": 0, "tanh": 1, "relu": 2}
+EPI_ADD, EPI_ACT, EPI_DACT = 1, 2, 4
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def weight_storage(w):
+    """The parameter ``[K,C,k,k]`` viewed as its channels_last storage ``[K,k,k,C]`` (no copy when it already has that
+    memory format -- ``OdometryModel`` converts its convolution weights once)."""
+    v = w.permute(0, 2, 3, 1)
+    return v if v.is_contiguous() else v.contiguous()
+
+
+def conv_nhwc(x, w_krsc, stride=(1, 1), act=0, epilogue=0, add=None, dsrc=None, transposed=False):
+    """``y = epilogue(conv(x, w))`` on channels-last fp32 tensors.  x ``[N,H,W,C]``; w ``[K,k,k,C]`` (``transposed``: the
+    forward weight ``[C,k,k,K]`` of the layer whose input gradient is computed, x then being the output gradient)."""
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    ks = w_krsc.shape[1]
+    K = w_krsc.shape[3] if transposed else w_krsc.shape[0]
+    y = torch.empty((N, H // stride[0], W // stride[1], K), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dl_conv2d_nhwc_f32(_ptr(x), _ptr(w_krsc), _ptr(y), _ptr(add), _ptr(dsrc), N, H, W, C, K, ks, stride[0],
+                                      stride[1], int(transposed), int(act), int(epilogue), _stream()), "dl_conv2d_nhwc_f32")
+    return y
+
+
+def wgrad_nhwc(x, g, ks, stride=(1, 1)):
+    """``dW [K,k,k,C]`` (channels_last storage of the parameter gradient) from input x ``[N,H,W,C]`` and output gradient g."""
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    K = g.shape[3]
+    dw = torch.empty((K, ks, ks, C), dtype=torch.float32, device=x.device)
+    ws = torch.empty((lib.dl_conv2d_wgrad_workspace_bytes(N, H, W, C, K, ks, stride[0], stride[1]) // 4,), dtype=torch.float32,
+                     device=x.device)
+    _lib.check(lib.dl_conv2d_wgrad_nhwc_f32(_ptr(x), _ptr(g), _ptr(dw), _ptr(ws), N, H, W, C, K, ks, stride[0], stride[1],
+                                            _stream()), "dl_conv2d_wgrad_nhwc_f32")
+    return dw
+
+
+def supported(x_shape, blocks):
+    """Whether the HIP trunk can run these shapes: channel counts multiples of 64, every feature-map width a multiple of
+    32 (and the rows a tile takes must divide the height) -- true for the reference's full-size network on 64/128-ring
+    images; narrower test networks use the module path."""
+    N, H, W, C = x_shape
+    if C % 64:
+        return False
+    for (cin, cout, stride, _) in blocks:
+        if cin % 64 or cout % 64 or H % stride[0] or W % stride[1]:
+            return False
+        H, W = H // stride[0], W // stride[1]
+        tw = 128 if W % 128 == 0 else (64 if W % 64 == 0 else (32 if W % 32 == 0 else 0))
+        if not tw or H % max(1, 128 // tw):                 # 128-pixel tiles are the fallback of every layer
+            return False
+    return True
+
+
+def _library_dgrad(g_nhwc, w_param, in_shape_nhwc, stride, ks):
+    """Input gradient of a STRIDED convolution from the library (MIOpen), channels-last in and out.  For the 3x3 case the
+    library sees the width padded by one wrapped column on each side; the two wrap columns are folded back here."""
+    N, H, W, C = in_shape_nhwc
+    g = g_nhwc.permute(0, 3, 1, 2)                       # NCHW-shaped view with channels_last strides
+    if ks == 3:
+        shape = (N, C, H, W + 2)
+        dummy = torch.empty((N, H, W + 2, C), dtype=g_nhwc.dtype, device=g_nhwc.device).permute(0, 3, 1, 2)
+        dxp, _, _ = torch.ops.aten.convolution_backward(g, dummy, w_param, None, list(stride), [1, 0], [1, 1], False, [0, 0], 1,
+                                                        [True, False, False])
+        dxp = dxp.permute(0, 2, 3, 1)                    # [N,H,W+2,C]
+        dx = dxp[:, :, 1:W + 1].clone()
+        dx[:, :, W - 1] += dxp[:, :, 0]
+        dx[:, :, 0] += dxp[:, :, W + 1]
+        return dx
+    dummy = torch.empty((N, H, W, C), dtype=g_nhwc.dtype, device=g_nhwc.device).permute(0, 3, 1, 2)
+    dx, _, _ = torch.ops.aten.convolution_backward(g, dummy, w_param, None, list(stride), [0, 0], [1, 1], False, [0, 0], 1,
+                                                   [True, False, False])
+    return dx.permute(0, 2, 3, 1).contiguous()
+
+
+class RingTrunk(torch.autograd.Function):
+    """layer1..layer4 of the pose CNN.  ``forward(x0, act, blocks, *weights)``: x0 ``[N,H,W,C0]`` channels-last, already
+    activated (the pooled stem output); blocks = tuple of (cin, cout, stride, has_downsample); weights in block order
+    (conv1, conv2[, downsample]).  Returns the last feature map ``[N,H',W',C']``."""
+
+    @staticmethod
+    def forward(ctx, x0, act, blocks, *weights):
+        saved, x, wi = [x0], x0, 0
+        for (cin, cout, stride, has_ds) in blocks:
+            w1, w2 = weight_storage(weights[wi]), weight_storage(weights[wi + 1])
+            wd = weight_storage(weights[wi + 2]) if has_ds else None
+            wi += 3 if has_ds else 2
+            y1 = conv_nhwc(x, w1, stride=stride, act=act, epilogue=EPI_ACT)
+            shortcut = conv_nhwc(x, wd, stride=stride) if has_ds else x
+            y2 = conv_nhwc(y1, w2, act=act, epilogue=EPI_ADD | EPI_ACT, add=shortcut)
+            saved += [y1, y2]
+            x = y2
+        ctx.act, ctx.blocks = act, blocks
+        ctx.save_for_backward(*saved, *weights)
+        return x
+
+    @staticmethod
+    def backward(ctx, dy):
+        act, blocks = ctx.act, ctx.blocks
+        nb = len(blocks)
+        saved = ctx.saved_tensors
+        acts, weights = saved[:1 + 2 * nb], saved[1 + 2 * nb:]
+        grads = [None] * len(weights)
+        # gradient with respect to the pre-activation of the last block's output
+        y_last = acts[-1]
+        dy = dy.contiguous()
+        if act == ACT["tanh"]:
+            g2 = dy * (1.0 - y_last * y_last)
+        elif act == ACT["relu"]:
+            g2 = dy * (y_last > 0).to(dy.dtype)
+        else:
+            g2 = dy
+        wi = len(weights)
+        for b in range(nb - 1, -1, -1):
+            cin, cout, stride, has_ds = blocks[b]
+            wi -= 3 if has_ds else 2
+            w1p, w2p = weights[wi], weights[wi + 1]
+            x, y1 = acts[2 * b], acts[2 * b + 1]
+            first = b == 0                                 # x0 is the pooled stem output: its act' belongs to the stem
+            grads[wi + 1] = wgrad_nhwc(y1, g2, 3).permute(0, 3, 1, 2)
+            g1 = conv_nhwc(g2, weight_storage(w2p), act=act, epilogue=EPI_DACT, dsrc=y1, transposed=True)
+            grads[wi] = wgrad_nhwc(x, g1, 3, stride=stride).permute(0, 3, 1, 2)
+            if not has_ds:
+                epi = EPI_ADD if first else (EPI_ADD | EPI_DACT)
+                g2 = conv_nhwc(g1, weight_storage(w1p), act=act, epilogue=epi, add=g2, dsrc=None if first else x, transposed=True)
+            else:
+                wdp = weights[wi + 2]
+                grads[wi + 2] = wgrad_nhwc(x, g2, 1, stride=stride).permute(0, 3, 1, 2)
+                dx = _library_dgrad(g1, w1p, x.shape, stride, 3) + _library_dgrad(g2, wdp, x.shape, stride, 1)
+                if first or act == ACT["none"]:
+                    g2 = dx
+                elif act == ACT["tanh"]:
+                    g2 = dx * (1.0 - x * x)
+                else:
+                    g2 = dx * (x > 0).to(dx.dtype)
+        return (g2, None, None, *grads)

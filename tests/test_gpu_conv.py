@@ -1,0 +1,125 @@
+"""The channels-last fp32 MFMA convolutions of the pose CNN (delora_amd/csrc/conv.hip through the C ABI) against plain torch
+fp32 ops: ``F.conv2d(F.pad(x, (1,1,0,0), 'circular'), w, padding=(1,0))`` -- the reference's layer (src/models/
+resnet_modified.py:97-98, :162-168) -- forward, both backward passes and the fused epilogues; and the whole residual trunk
+(ring_conv.RingTrunk) against the module path on the same weights.  Tolerance 1e-4 relative (fp32 summation order)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests import util
+
+pytestmark = pytest.mark.gpu
+REL = 1e-4
+
+
+def _dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda:0")
+
+
+def _ref_conv(x_nchw, w, stride, ks):
+    if ks == 3:
+        return F.conv2d(F.pad(x_nchw, (1, 1, 0, 0), mode="circular"), w, stride=stride, padding=(1, 0))
+    return F.conv2d(x_nchw, w, stride=stride)
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+SHAPES = [  # N, H, W, C, K, ks, stride
+    (2, 8, 128, 64, 64, 3, (1, 1)), (1, 4, 64, 128, 128, 3, (1, 1)), (2, 8, 32, 64, 128, 3, (1, 1)),
+    (1, 8, 256, 256, 64, 3, (1, 1)), (2, 8, 256, 64, 128, 3, (1, 2)), (1, 8, 128, 64, 64, 3, (2, 2)),
+    (2, 8, 128, 64, 128, 1, (1, 2)), (1, 8, 128, 64, 64, 1, (2, 2)),
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_conv_forward_and_both_gradients_against_torch(shape):
+    from delora_amd.models import ring_conv as rc
+    dev = _dev()
+    N, H, W, C, K, ks, stride = shape
+    g = torch.Generator(device="cpu").manual_seed(sum(shape[:5]))
+    x = torch.randn((N, C, H, W), generator=g).to(dev)
+    w = (torch.randn((K, C, ks, ks), generator=g) * 0.1).to(dev)
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    w_krsc = w.permute(0, 2, 3, 1).contiguous()
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    y_ref = _ref_conv(xr, wr, stride, ks)
+    gy = torch.randn(y_ref.shape, generator=g).to(dev)
+    y_ref.backward(gy)
+    tag = f"conv {ks}x{ks} s{stride} {N}x{H}x{W} {C}->{K}"
+    # forward, plain and with the fused tail  act(conv + shortcut)
+    y = rc.conv_nhwc(x_nhwc, w_krsc, stride=stride)
+    util.measured(f"{tag}: forward vs torch (relative)", _rel(y.permute(0, 3, 1, 2), y_ref.detach()), bound=REL)
+    sc = torch.randn(y.shape, generator=g).to(dev)
+    y2 = rc.conv_nhwc(x_nhwc, w_krsc, stride=stride, act=rc.ACT["tanh"], epilogue=rc.EPI_ADD | rc.EPI_ACT, add=sc)
+    ref2 = torch.tanh(y_ref.detach() + sc.permute(0, 3, 1, 2))
+    util.measured(f"{tag}: forward + shortcut + tanh vs torch (absolute)", float((y2.permute(0, 3, 1, 2) - ref2).abs().max()), bound=2e-5)
+    # weight gradient
+    gy_nhwc = gy.permute(0, 2, 3, 1).contiguous()
+    dw = rc.wgrad_nhwc(x_nhwc, gy_nhwc, ks, stride=stride)
+    util.measured(f"{tag}: weight gradient vs torch autograd (relative)", _rel(dw.permute(0, 3, 1, 2), wr.grad), bound=REL)
+    # input gradient (stride-1 3x3: the transposed kernel, with the activation derivative and shortcut gradient fused)
+    if ks == 3 and stride == (1, 1) and C % 64 == 0:
+        dx = rc.conv_nhwc(gy_nhwc, w_krsc, transposed=True)
+        util.measured(f"{tag}: input gradient vs torch autograd (relative)", _rel(dx.permute(0, 3, 1, 2), xr.grad), bound=REL)
+        ysave = torch.tanh(torch.randn(x_nhwc.shape, generator=g)).to(dev)
+        extra = torch.randn(x_nhwc.shape, generator=g).to(dev)
+        dx2 = rc.conv_nhwc(gy_nhwc, w_krsc, act=rc.ACT["tanh"], epilogue=rc.EPI_ADD | rc.EPI_DACT, add=extra, dsrc=ysave, transposed=True)
+        ref = (xr.grad.permute(0, 2, 3, 1) + extra) * (1 - ysave * ysave)
+        util.measured(f"{tag}: fused (dgrad + g) * tanh' vs torch (relative)", _rel(dx2, ref), bound=REL)
+
+
+def test_conv_rejects_shapes_that_do_not_tile():
+    from delora_amd import _lib
+    from delora_amd.models import ring_conv as rc
+    dev = _dev()
+    x = torch.zeros((1, 4, 24, 64), device=dev)          # width 24: no 32-pixel tile
+    w = torch.zeros((64, 3, 3, 64), device=dev)
+    with pytest.raises(_lib.DeloraHipError):
+        rc.conv_nhwc(x, w)
+    assert not rc.supported((1, 4, 24, 64), ((64, 64, (1, 1), False),))
+
+
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+def test_hip_trunk_matches_module_path(act):
+    """The full-width network (64..512 channels) on a 16x1024 pair: the channels-last HIP trunk against the module path
+    (library convolutions + ring ops) with the same weights -- poses, and the gradient of EVERY parameter."""
+    from delora_amd.models.model import OdometryModel
+    dev = _dev()
+    cfg = util.repo_config(16, 1024, device="cuda:0", activation_fct=act)
+    torch.manual_seed(5)
+    m_hip = OdometryModel(dict(cfg, cnn_impl="hip")).to(dev)
+    m_hip.resnet.trunk_weights_channels_last()
+    m_mod = OdometryModel(dict(cfg, cnn_impl="modules")).to(dev)
+    m_mod.load_state_dict(m_hip.state_dict())
+    x = torch.randn((2, 8, 16, 1024), device=dev)
+    out = []
+    for m in (m_hip, m_mod):
+        t, q = m(x)
+        (t.square().sum() + (q * torch.arange(1, 5, device=dev)).sum()).backward()
+        out.append((t.detach(), q.detach()))
+    util.measured(f"trunk[{act}]: translation hip vs modules (relative)", _rel(out[0][0], out[1][0]), bound=REL)
+    util.measured(f"trunk[{act}]: quaternion hip vs modules (relative)", _rel(out[0][1], out[1][1]), bound=REL)
+    worst, name = 0.0, ""
+    for (k, p), (_, p2) in zip(m_hip.named_parameters(), m_mod.named_parameters()):
+        assert p.grad is not None and p.grad.shape == p.shape, k
+        e = float((p.grad - p2.grad).norm() / p2.grad.norm().clamp_min(1e-30))
+        if e > worst:
+            worst, name = e, k
+    util.measured(f"trunk[{act}]: worst relative parameter-gradient difference hip vs modules ({name})", worst, bound=(5 * REL if act == "tanh" else 1e-2))   # relu: masks of pre-activations within rounding of 0 flip
+    assert m_hip.resnet.layer1[0].conv1.weight.grad.stride() == m_hip.resnet.layer1[0].conv1.weight.stride()
+
+
+def test_hip_trunk_is_used_by_the_full_size_step_and_falls_back_for_small_networks():
+    from delora_amd.models.model import OdometryModel
+    dev = _dev()
+    big = OdometryModel(util.repo_config(64, 2048, device="cuda:0")).to(dev)
+    assert big.resnet.hip_trunk_applicable((8, 64, 512, 64), torch.zeros(1, device=dev))
+    small = OdometryModel(util.repo_config(16, 128, device="cuda:0", factor_fewer_resnet_channels=8, resnet_outputs=64)).to(dev)
+    assert not small.resnet.hip_trunk_applicable((2, 16, 32, 8), torch.zeros(1, device=dev))
+    with torch.autocast("cuda", dtype=torch.bfloat16):
+        assert not big.resnet.hip_trunk_applicable((8, 64, 512, 64), torch.zeros(1, device=dev))
