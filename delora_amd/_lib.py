@@ -54,6 +54,9 @@ SIGNATURES = {
     "dl_conv2d_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _u32, _vp]),
     "dl_conv2d_wgrad_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "dl_conv2d_wgrad_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dl_wino_weights_floats": (_sz, [_i32, _i32]),
+    "dl_wino_weights_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "dl_wino_conv3x3_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _u32, _vp]),
 }
 
 _lib = None

@@ -1,0 +1,331 @@
+// Stride-1 3x3 convolutions of the pose CNN as fused Winograd F(2x2, 3x3) on the fp32 matrix cores of gfx950.
+//
+// The 13 stride-1 3x3 layers (reference src/models/resnet_modified.py:159-177, 85 % of the network's multiplications) run
+// forward and backward-data through this kernel: 2.25x fewer multiplications than the direct form, the same algorithm
+// class the library's fp32 path (MIOpen's Winograd f2x3 assembly) uses, here on the matrix cores and with the layer's
+// elementwise tail fused.  Everything happens in ONE launch per layer -- input transform, 16 batched GEMMs, output
+// transform, epilogue -- so the transformed tensors (4x the activation's size) never touch HBM:
+//
+//   per workgroup (8 waves): 64 Winograd tiles (2x2 output pixels each) x 64 output channels
+//   per chunk of 8 input channels:
+//     raw   (2TR+2) x (2TC+2) x 8 input patch, wrap-around columns / zero rows by addressing      global -> regs -> LDS
+//     V     = B^T d B  per (tile, channel):  16 planes [xi][tile][8]                              LDS -> regs -> LDS
+//     U     transformed weights [xi][k][8] of this chunk (k_wino_weights, once per step)         global -> regs -> LDS
+//     M[xi] += V[xi] (tiles x 8) * U[xi]^T (8 x k)        v_mfma_f32_32x32x2_f32, 16 independent GEMMs
+//   wave (mb, nb, xh) owns tiles mb*32.., channels nb*32.., and the 8 planes xi = 8*xh..8*xh+7 (rows a = 2xh, 2xh+1 of the
+//   4x4 Winograd domain): 8 accumulators = 128 VGPRs.  Output transform Y = A^T M A: the column pass is lane-local, the
+//   row pass needs both halves -- the two waves of a block exchange 2x16 registers through LDS, after which wave xh holds
+//   output row xh of every tile.  Epilogue (shortcut add, activation, activation derivative) as in conv.hip.
+//
+// Fragments use the same reduction-index permutation as conv.hip (one ds_read_b128 = four MFMAs); the [tile][8] rows are
+// XOR-swizzled in 16-byte granules (bit 3 of the row index) so that those reads are bank-conflict free without padding.
+//
+// Numerics: fp32 throughout; Winograd F(2x2,3x3) adds/subtracts before and after the products, error ~1e-6 relative to the
+// layer's output scale (tests/test_gpu_conv.py bounds it against torch's direct convolution at 1e-4).
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define WN_THREADS 512
+#define WN_CK 8
+#define WN_KB 64
+#define WN_TILES 64
+#define WN_PLANE (WN_TILES * WN_CK + 16)      // floats per xi plane (+16: the four b-planes a lane group writes hit different banks)
+#define WN_EPI_ADD 1u
+#define WN_EPI_ACT 2u
+#define WN_EPI_DACT 4u
+
+struct WinoArgs {
+  const float* x;      // [N][H][W][C]
+  const float* u;      // [C/8][16][K][8] transformed weights (k_wino_weights)
+  float* y;            // [N][H][W][K]
+  const float* add;
+  const float* dsrc;
+  int N, H, W, C, K;
+  int act;
+  unsigned epi;
+};
+
+__device__ __forceinline__ float wn_act(float v, int act) {
+  if (act == 1) return tanhf(v);
+  if (act == 2) return v < 0.f ? 0.f : v;
+  return v;
+}
+__device__ __forceinline__ float wn_dact(float y, int act) {
+  if (act == 1) return 1.f - y * y;
+  if (act == 2) return y <= 0.f ? 0.f : 1.f;
+  return 1.f;
+}
+
+__device__ __forceinline__ int wn_xcd_swizzle(int id, int n) {
+  const int q = n / 8, r = n % 8, xcd = id % 8, k = id / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+// U = G g G^T for one (k, c): g 3x3 -> 4x4.  G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].
+__device__ __forceinline__ void wn_weight_transform(const float (&g)[3][3], float (&u)[4][4]) {
+  float t[4][3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    t[0][j] = g[0][j];
+    t[1][j] = 0.5f * (g[0][j] + g[1][j] + g[2][j]);
+    t[2][j] = 0.5f * (g[0][j] - g[1][j] + g[2][j]);
+    t[3][j] = g[2][j];
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    u[i][0] = t[i][0];
+    u[i][1] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+    u[i][2] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+    u[i][3] = t[i][2];
+  }
+}
+
+// w [K][3][3][C] -> u_fwd [C/8][16][K][8] (reduction over c) and u_bwd [K/8][16][C][8] (the transposed convolution of the
+// input gradient: taps flipped, channel roles swapped, reduction over k).  One thread per (k, c).
+__global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ w, float* __restrict__ u_fwd,
+                                                      float* __restrict__ u_bwd, int K, int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= K * C) return;
+  const int c = i % C, k = i / C;
+  float g[3][3], gf[3][3], u[4][4];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      g[r][s] = w[((size_t)(k * 3 + r) * 3 + s) * C + c];
+      gf[2 - r][2 - s] = g[r][s];
+    }
+  if (u_fwd) {
+    wn_weight_transform(g, u);
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) u_fwd[(((size_t)(c / 8) * 16 + xi) * K + k) * 8 + (c % 8)] = u[xi / 4][xi % 4];
+  }
+  if (u_bwd) {
+    wn_weight_transform(gf, u);
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) u_bwd[(((size_t)(k / 8) * 16 + xi) * C + c) * 8 + (k % 8)] = u[xi / 4][xi % 4];
+  }
+}
+
+// TC tile columns x TR tile rows = 64 tiles per workgroup.
+template <int TC>
+__global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
+  constexpr int TR = WN_TILES / TC;
+  constexpr int RH = 2 * TR + 2, RW = 2 * TC + 2;
+  constexpr int RAW_FLOATS = RH * RW * WN_CK;
+  constexpr int V_FLOATS = 16 * WN_PLANE, U_FLOATS = 16 * WN_PLANE;
+  constexpr int NRAW = RH * RW * 2;                  // float4 items of the raw patch
+  constexpr int NRAW_IT = (NRAW + WN_THREADS - 1) / WN_THREADS;
+  constexpr int NU_IT = 16 * WN_KB * 2 / WN_THREADS;  // 4
+  __shared__ __attribute__((aligned(16))) float lds[RAW_FLOATS + V_FLOATS + U_FLOATS];
+  float* raw_lds = lds;
+  float* v_lds = lds + RAW_FLOATS;
+  float* u_lds = v_lds + V_FLOATS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, half = lane >> 5;
+  const int mb = wave & 1, nb = (wave >> 1) & 1, xh = wave >> 2;
+  const int KT = a.K / WN_KB;
+  const int tiles_w = (a.W / 2) / TC, tiles_h = (a.H / 2) / TR;
+  const int ngroups = a.N * tiles_h * tiles_w * KT;
+  int t = wn_xcd_swizzle(blockIdx.x, ngroups);
+  const int kt = t % KT; t /= KT;
+  const int gw = t % tiles_w; t /= tiles_w;
+  const int gh = t % tiles_h;
+  const int n = t / tiles_h;
+  const int k0 = kt * WN_KB;
+  const int h_base = gh * TR * 2 - 1, w_base = gw * TC * 2 - 1;     // image position of raw(0,0)
+  const float* xn = a.x + (size_t)n * a.H * a.W * a.C;
+
+  // staging items (ids beyond the patch are clamped: duplicates of the last item, branch-free)
+  int raw_g[NRAW_IT], raw_l[NRAW_IT];
+#pragma unroll
+  for (int it = 0; it < NRAW_IT; ++it) {
+    const int q = min(tid + it * WN_THREADS, NRAW - 1);
+    const int c4 = q & 1, pc = q >> 1;
+    const int col = pc % RW, row = pc / RW;
+    const int h = h_base + row;
+    int w = w_base + col;
+    w = w < 0 ? w + a.W : (w >= a.W ? w - a.W : w);
+    raw_l[it] = pc * WN_CK + c4 * 4;
+    raw_g[it] = (h >= 0 && h < a.H) ? (h * a.W + w) * a.C + c4 * 4 : -1;
+  }
+  int u_g[NU_IT], u_l[NU_IT];
+#pragma unroll
+  for (int it = 0; it < NU_IT; ++it) {
+    const int q = tid + it * WN_THREADS;             // (xi, kk, c4): 16 x 64 x 2
+    const int c4 = q & 1, kk = (q >> 1) & 63, xi = q >> 7;
+    u_g[it] = (xi * a.K + k0 + kk) * 8 + c4 * 4;     // + chunk * 16 * K * 8
+    u_l[it] = xi * WN_PLANE + kk * 8 + ((c4 ^ ((kk >> 3) & 1)) * 4);
+  }
+  // transform role of this thread: tile, channel quad, column b of the 4x4 domain
+  const int tb = tid & 3, tc4 = (tid >> 2) & 1, ttile = tid >> 3;
+  const int ttr = ttile / TC, ttc = ttile % TC;
+  const int j0 = tb == 0 ? 0 : 1, j1 = tb == 3 ? 3 : 2;             // the two raw columns column b combines
+  const float sg0 = tb == 2 ? -1.f : 1.f, sg1 = (tb == 0 || tb == 3) ? -1.f : 1.f;   // T[.][b] = sg0*d[.][j0] + sg1*d[.][j1]
+  const int t_rd = ((2 * ttr) * RW + 2 * ttc) * WN_CK + tc4 * 4;
+  const int t_wr = tb * WN_PLANE + ttile * 8 + ((tc4 ^ ((ttile >> 3) & 1)) * 4);
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const int arow = mb * 32 + li, brow = nb * 32 + li;
+  const int a_off = arow * 8 + ((half ^ ((arow >> 3) & 1)) * 4);
+  const int b_off = brow * 8 + ((half ^ ((brow >> 3) & 1)) * 4);
+
+  f32x4 raw_r[NRAW_IT], u_r[NU_IT];
+#define WN_FETCH(CH)                                                                                                      \
+  {                                                                                                                       \
+    _Pragma("unroll") for (int it = 0; it < NRAW_IT; ++it) {                                                              \
+      const bool in = raw_g[it] >= 0;                                                                                     \
+      const f32x4 v = *reinterpret_cast<const f32x4*>(xn + (in ? raw_g[it] + (CH) * WN_CK : 0));                          \
+      raw_r[it] = in ? v : (f32x4){0.f, 0.f, 0.f, 0.f};                                                                   \
+    }                                                                                                                     \
+    _Pragma("unroll") for (int it = 0; it < NU_IT; ++it) u_r[it] =                                                        \
+        *reinterpret_cast<const f32x4*>(a.u + (size_t)(CH) * 16 * a.K * 8 + u_g[it]);                                     \
+  }
+#define WN_STAGE()                                                                                                        \
+  {                                                                                                                       \
+    _Pragma("unroll") for (int it = 0; it < NRAW_IT; ++it) *reinterpret_cast<f32x4*>(raw_lds + raw_l[it]) = raw_r[it];    \
+    _Pragma("unroll") for (int it = 0; it < NU_IT; ++it) *reinterpret_cast<f32x4*>(u_lds + u_l[it]) = u_r[it];            \
+  }
+#define WN_TRANSFORM()                                                                                                    \
+  {                                                                                                                       \
+    f32x4 tt[4];                                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                       \
+      const f32x4 d0 = *reinterpret_cast<const f32x4*>(raw_lds + t_rd + (i * RW + j0) * WN_CK);                           \
+      const f32x4 d1 = *reinterpret_cast<const f32x4*>(raw_lds + t_rd + (i * RW + j1) * WN_CK);                           \
+      tt[i] = sg0 * d0 + sg1 * d1;                                                                                        \
+    }                                                                                                                     \
+    *reinterpret_cast<f32x4*>(v_lds + t_wr + 0 * 4 * WN_PLANE) = tt[0] - tt[2];                                           \
+    *reinterpret_cast<f32x4*>(v_lds + t_wr + 1 * 4 * WN_PLANE) = tt[1] + tt[2];                                           \
+    *reinterpret_cast<f32x4*>(v_lds + t_wr + 2 * 4 * WN_PLANE) = tt[2] - tt[1];                                           \
+    *reinterpret_cast<f32x4*>(v_lds + t_wr + 3 * 4 * WN_PLANE) = tt[1] - tt[3];                                           \
+  }
+
+  const int nchunks = a.C / WN_CK;
+  WN_FETCH(0)
+  WN_STAGE()
+  __syncthreads();
+  WN_TRANSFORM()
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const bool more = ch + 1 < nchunks;
+    if (more) WN_FETCH(ch + 1)
+#pragma unroll
+    for (int xl = 0; xl < 8; ++xl) {
+      const int xi = xh * 8 + xl;
+      const f32x4 av = *reinterpret_cast<const f32x4*>(v_lds + xi * WN_PLANE + a_off);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(u_lds + xi * WN_PLANE + b_off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[xl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[xl], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) {
+      WN_STAGE()
+      __syncthreads();
+      WN_TRANSFORM()
+      __syncthreads();
+    }
+  }
+#undef WN_FETCH
+#undef WN_STAGE
+#undef WN_TRANSFORM
+
+  // Output transform.  This wave holds M[a][b] for a = 2xh, 2xh+1 (acc[(a - 2xh) * 4 + b]).  Column pass (over b):
+  //   P[a][0] = M[a][0] + M[a][1] + M[a][2],  P[a][1] = M[a][1] - M[a][2] - M[a][3]
+  // Row pass: Y[0][q] = P[0][q] + P[1][q] + P[2][q],  Y[1][q] = P[1][q] - P[2][q] - P[3][q].  Wave xh finalises output row xh
+  // of its tiles: it keeps its own contribution to that row and sends its contribution to the other row to its partner.
+  f32x16 keep[2], send[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    f32x16 p0, p1;                                  // P[2xh][q], P[2xh+1][q]
+    if (q == 0) { p0 = acc[0] + acc[1] + acc[2]; p1 = acc[4] + acc[5] + acc[6]; }
+    else        { p0 = acc[1] - acc[2] - acc[3]; p1 = acc[5] - acc[6] - acc[7]; }
+    if (xh == 0) { keep[q] = p0 + p1; send[q] = p1; }          // rows 0,1: Y0 += P0 + P1, Y1 += P1
+    else         { keep[q] = -p0 - p1; send[q] = p0; }         // rows 2,3: Y0 += P2,      Y1 += -P2 - P3
+  }
+  // exchange through LDS (the staging buffers are free): region per (block, direction): 2 x 16 x 64 floats
+  float* xch = lds;
+  const int blk = wave & 3;                          // (mb, nb) block; partner = wave ^ 4
+  {
+    float* dst = xch + ((blk * 2 + xh) * 32) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) dst[(q * 16 + r) * 64] = send[q][r];
+  }
+  __syncthreads();
+  {
+    const float* src = xch + ((blk * 2 + (xh ^ 1)) * 32) * 64 + lane;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) keep[q][r] += src[(q * 16 + r) * 64];
+  }
+  __syncthreads();
+  // Epilogue: keep[q][r] = output pixel (row 2*tr + xh, col 2*tc + q) of tile (r & 3) + 8 * (r >> 2) + 4 * half of this
+  // block, channel li.  Transposed through LDS per wave (32 tiles x 2 pixels x 32 channels) so that a lane owns four
+  // consecutive channels: float4 epilogue arithmetic and 16-byte stores of 128-byte channel rows.
+  constexpr int ES = 32 + 4;
+  float* ep = lds + wave * (64 * ES);
+  const bool f_add = a.epi & WN_EPI_ADD, f_act = a.epi & WN_EPI_ACT, f_dact = a.epi & WN_EPI_DACT;
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ep[(((r & 3) + 8 * (r >> 2) + 4 * half) * 2 + q) * ES + li] = keep[q][r];
+#pragma unroll 2
+  for (int i = lane; i < 64 * 8; i += 64) {
+    const int row = i >> 3, c4 = i & 7;               // row = tile_in_block * 2 + q
+    const int tile = mb * 32 + (row >> 1), q = row & 1;
+    const int tr = tile / TC, tc = tile % TC;
+    const int oh = (gh * TR + tr) * 2 + xh, ow = (gw * TC + tc) * 2 + q;
+    const size_t o = (((size_t)n * a.H + oh) * a.W + ow) * a.K + k0 + nb * 32 + c4 * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * ES + c4 * 4);
+    if (f_add) v += *reinterpret_cast<const f32x4*>(a.add + o);
+    if (f_act) { v[0] = wn_act(v[0], a.act); v[1] = wn_act(v[1], a.act); v[2] = wn_act(v[2], a.act); v[3] = wn_act(v[3], a.act); }
+    if (f_dact) {
+      const f32x4 s = *reinterpret_cast<const f32x4*>(a.dsrc + o);
+      v[0] *= wn_dact(s[0], a.act); v[1] *= wn_dact(s[1], a.act); v[2] *= wn_dact(s[2], a.act); v[3] *= wn_dact(s[3], a.act);
+    }
+    *reinterpret_cast<f32x4*>(a.y + o) = v;
+  }
+}
+
+extern "C" size_t dl_wino_weights_floats(int32_t K, int32_t C) { return (size_t)16 * K * C; }
+
+extern "C" int dl_wino_weights_f32(const float* w, float* u_fwd, float* u_bwd, int32_t K, int32_t C, dl_stream stream) {
+  if (!w || (!u_fwd && !u_bwd) || K <= 0 || C <= 0 || K % 8 || C % 8)
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wino_weights_f32: bad argument (K, C multiples of 8)");
+  hipLaunchKernelGGL(k_wino_weights, dim3((K * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, w, u_fwd, u_bwd, K, C);
+  return dl_check_launch("dl_wino_weights_f32");
+}
+
+extern "C" int dl_wino_conv3x3_nhwc_f32(const float* x, const float* u, float* y, const float* add, const float* dsrc,
+                                        int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, int32_t act,
+                                        uint32_t epilogue, dl_stream stream) {
+  if (!x || !u || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0)
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wino_conv3x3_nhwc_f32: bad argument");
+  if (((epilogue & WN_EPI_ADD) && !add) || ((epilogue & WN_EPI_DACT) && !dsrc) || act < 0 || act > 2)
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wino_conv3x3_nhwc_f32: epilogue operand missing / bad activation");
+  if (C % WN_CK || K % WN_KB || (H & 1) || (W & 1) || (size_t)N * H * W * (C > K ? C : K) >= ((size_t)1 << 31))
+    return dl_fail(DL_ERR_UNSUPPORTED, "dl_wino_conv3x3_nhwc_f32: shape N=%d H=%d W=%d C=%d K=%d not supported", N, H, W, C, K);
+  WinoArgs a{x, u, y, add, dsrc, N, H, W, C, K, act, epilogue};
+  hipStream_t st = (hipStream_t)stream;
+  const int tw = W / 2, th = H / 2;
+  if (tw % 64 == 0) {
+    hipLaunchKernelGGL(k_wino_conv<64>, dim3(N * th * (tw / 64) * (K / WN_KB)), dim3(WN_THREADS), 0, st, a);
+  } else if (tw % 32 == 0 && th % 2 == 0) {
+    hipLaunchKernelGGL(k_wino_conv<32>, dim3(N * (th / 2) * (tw / 32) * (K / WN_KB)), dim3(WN_THREADS), 0, st, a);
+  } else if (tw % 16 == 0 && th % 4 == 0) {
+    hipLaunchKernelGGL(k_wino_conv<16>, dim3(N * (th / 4) * (tw / 16) * (K / WN_KB)), dim3(WN_THREADS), 0, st, a);
+  } else {
+    return dl_fail(DL_ERR_UNSUPPORTED, "dl_wino_conv3x3_nhwc_f32: image %dx%d does not tile (W/2 %% 16, rows)", H, W);
+  }
+  return dl_check_launch("dl_wino_conv3x3_nhwc_f32");
+}

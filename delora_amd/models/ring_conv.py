@@ -25,6 +25,7 @@ import torch
 from .. import _lib
 
 ACT = {"none": 0, "tanh": 1, "relu": 2}
+USE_WINOGRAD = True          # stride-1 3x3 layers as fused Winograd F(2x2,3x3) (csrc/wino.hip); False: the direct kernel
 EPI_ADD, EPI_ACT, EPI_DACT = 1, 2, 4
 
 
@@ -67,6 +68,37 @@ def wgrad_nhwc(x, g, ks, stride=(1, 1)):
     _lib.check(lib.dl_conv2d_wgrad_nhwc_f32(_ptr(x), _ptr(g), _ptr(dw), _ptr(ws), N, H, W, C, K, ks, stride[0], stride[1],
                                             _stream()), "dl_conv2d_wgrad_nhwc_f32")
     return dw
+
+
+def wino_ok(H, W, C, K):
+    """Whether the fused Winograd F(2x2,3x3) kernel (csrc/wino.hip) takes a stride-1 3x3 layer of this shape."""
+    if H % 2 or W % 2 or C % 8 or K % 64:
+        return False
+    th, tw = H // 2, W // 2
+    return tw % 64 == 0 or (tw % 32 == 0 and th % 2 == 0) or (tw % 16 == 0 and th % 4 == 0)
+
+
+def wino_weights(w_param, want_fwd=True, want_bwd=True):
+    """Winograd-domain weights of a 3x3 layer: (u_fwd [C/8,16,K,8], u_bwd [K/8,16,C,8]) from the parameter ``[K,C,3,3]``."""
+    lib = _lib.load()
+    w = weight_storage(w_param)
+    K, C = w.shape[0], w.shape[3]
+    n = lib.dl_wino_weights_floats(K, C)
+    uf = torch.empty((n,), dtype=torch.float32, device=w.device) if want_fwd else None
+    ub = torch.empty((n,), dtype=torch.float32, device=w.device) if want_bwd else None
+    _lib.check(lib.dl_wino_weights_f32(_ptr(w), _ptr(uf), _ptr(ub), K, C, _stream()), "dl_wino_weights_f32")
+    return uf, ub
+
+
+def wino_conv(x, u, K, act=0, epilogue=0, add=None, dsrc=None):
+    """Stride-1 3x3 convolution of x ``[N,H,W,C]`` with Winograd-domain weights ``u`` (u_fwd: forward; u_bwd with the
+    output gradient as x: input gradient) -> ``[N,H,W,K]``, epilogue as conv_nhwc."""
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    y = torch.empty((N, H, W, K), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dl_wino_conv3x3_nhwc_f32(_ptr(x), _ptr(u), _ptr(y), _ptr(add), _ptr(dsrc), N, H, W, C, K, int(act),
+                                            int(epilogue), _stream()), "dl_wino_conv3x3_nhwc_f32")
+    return y
 
 
 def supported(x_shape, blocks):
@@ -114,17 +146,36 @@ class RingTrunk(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x0, act, blocks, *weights):
+        """Stride-1 3x3 layers run as fused Winograd F(2x2,3x3) when ``USE_WINOGRAD`` and the shape tiles (their
+        Winograd-domain weights for the backward pass are produced by the same launch and kept for it); the strided and 1x1
+        layers run the direct kernel."""
         saved, x, wi = [x0], x0, 0
+        ubwd = []
+        need_bwd = any(ctx.needs_input_grad)
         for (cin, cout, stride, has_ds) in blocks:
-            w1, w2 = weight_storage(weights[wi]), weight_storage(weights[wi + 1])
+            w1p, w2p = weights[wi], weights[wi + 1]
             wd = weight_storage(weights[wi + 2]) if has_ds else None
             wi += 3 if has_ds else 2
-            y1 = conv_nhwc(x, w1, stride=stride, act=act, epilogue=EPI_ACT)
+            N, H, W, _ = x.shape
+            if USE_WINOGRAD and stride == (1, 1) and wino_ok(H, W, cin, cout):
+                uf, ub1 = wino_weights(w1p, want_bwd=need_bwd)
+                y1 = wino_conv(x, uf, cout, act=act, epilogue=EPI_ACT)
+            else:
+                ub1 = None
+                y1 = conv_nhwc(x, weight_storage(w1p), stride=stride, act=act, epilogue=EPI_ACT)
             shortcut = conv_nhwc(x, wd, stride=stride) if has_ds else x
-            y2 = conv_nhwc(y1, w2, act=act, epilogue=EPI_ADD | EPI_ACT, add=shortcut)
+            Ho, Wo = y1.shape[1], y1.shape[2]
+            if USE_WINOGRAD and wino_ok(Ho, Wo, cout, cout):
+                uf, ub2 = wino_weights(w2p, want_bwd=need_bwd)
+                y2 = wino_conv(y1, uf, cout, act=act, epilogue=EPI_ADD | EPI_ACT, add=shortcut)
+            else:
+                ub2 = None
+                y2 = conv_nhwc(y1, weight_storage(w2p), act=act, epilogue=EPI_ADD | EPI_ACT, add=shortcut)
+            ubwd += [ub1, ub2]
             saved += [y1, y2]
             x = y2
         ctx.act, ctx.blocks = act, blocks
+        ctx.ubwd = ubwd
         ctx.save_for_backward(*saved, *weights)
         return x
 
@@ -152,11 +203,18 @@ class RingTrunk(torch.autograd.Function):
             x, y1 = acts[2 * b], acts[2 * b + 1]
             first = b == 0                                 # x0 is the pooled stem output: its act' belongs to the stem
             grads[wi + 1] = wgrad_nhwc(y1, g2, 3).permute(0, 3, 1, 2)
-            g1 = conv_nhwc(g2, weight_storage(w2p), act=act, epilogue=EPI_DACT, dsrc=y1, transposed=True)
+            ub1, ub2 = ctx.ubwd[2 * b], ctx.ubwd[2 * b + 1]
+            if ub2 is not None:
+                g1 = wino_conv(g2, ub2, cout, act=act, epilogue=EPI_DACT, dsrc=y1)
+            else:
+                g1 = conv_nhwc(g2, weight_storage(w2p), act=act, epilogue=EPI_DACT, dsrc=y1, transposed=True)
             grads[wi] = wgrad_nhwc(x, g1, 3, stride=stride).permute(0, 3, 1, 2)
             if not has_ds:
                 epi = EPI_ADD if first else (EPI_ADD | EPI_DACT)
-                g2 = conv_nhwc(g1, weight_storage(w1p), act=act, epilogue=epi, add=g2, dsrc=None if first else x, transposed=True)
+                if ub1 is not None:
+                    g2 = wino_conv(g1, ub1, cin, act=act, epilogue=epi, add=g2, dsrc=None if first else x)
+                else:
+                    g2 = conv_nhwc(g1, weight_storage(w1p), act=act, epilogue=epi, add=g2, dsrc=None if first else x, transposed=True)
             else:
                 wdp = weights[wi + 2]
                 grads[wi + 2] = wgrad_nhwc(x, g2, 1, stride=stride).permute(0, 3, 1, 2)

@@ -253,6 +253,21 @@ size_t dl_conv2d_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t 
 int dl_conv2d_wgrad_nhwc_f32(const float* x, const float* g, float* dw, void* workspace, int32_t N, int32_t H, int32_t W,
                              int32_t C, int32_t K, int32_t ksize, int32_t stride_h, int32_t stride_w, dl_stream stream);
 
+/*
+ * The same stride-1 3x3 convolution (forward and, with the backward weight set, input gradient) as fused Winograd
+ * F(2x2,3x3) on the fp32 matrix cores: 2.25x fewer multiplications; input transform, 16 batched GEMMs, output transform and
+ * the epilogue of dl_conv2d_nhwc_f32 in one launch (the transformed tensors never reach HBM).
+ *   dl_wino_weights_f32: w [K][3][3][C] -> u_fwd [C/8][16][K][8] and/or u_bwd [K/8][16][C][8] (each 16*K*C floats =
+ *                        dl_wino_weights_floats; either may be NULL).  Run once per optimiser step.
+ *   dl_wino_conv3x3_nhwc_f32: x [N][H][W][C], u = u_fwd of the layer -> y [N][H][W][K]; for the input gradient pass the
+ *                        output gradient as x, u = u_bwd and swap C and K.  epilogue / act / add / dsrc as above.
+ *   Shapes: H, W even; C % 8 == 0; K % 64 == 0; W/2 a multiple of 64, or of 32 with H/2 even, or of 16 with H/2 % 4 == 0.
+ */
+size_t dl_wino_weights_floats(int32_t K, int32_t C);
+int dl_wino_weights_f32(const float* w, float* u_fwd, float* u_bwd, int32_t K, int32_t C, dl_stream stream);
+int dl_wino_conv3x3_nhwc_f32(const float* x, const float* u, float* y, const float* add, const float* dsrc, int32_t N,
+                             int32_t H, int32_t W, int32_t C, int32_t K, int32_t act, uint32_t epilogue, dl_stream stream);
+
 #ifdef __cplusplus
 }
 #endif

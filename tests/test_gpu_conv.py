@@ -73,6 +73,40 @@ def test_conv_forward_and_both_gradients_against_torch(shape):
         util.measured(f"{tag}: fused (dgrad + g) * tanh' vs torch (relative)", _rel(dx2, ref), bound=REL)
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 128, 64, 64), (1, 4, 64, 128, 128), (2, 8, 32, 64, 128), (1, 6, 256, 64, 64), (1, 32, 64, 512, 512)])
+def test_winograd_forward_and_input_gradient_against_torch(shape):
+    """Fused Winograd F(2x2,3x3) (csrc/wino.hip) against torch's direct convolution of the wrapped image: forward with the
+    fused shortcut + tanh, input gradient with the fused activation derivative; all three tile layouts."""
+    from delora_amd.models import ring_conv as rc
+    dev = _dev()
+    N, H, W, C, K = shape
+    g = torch.Generator(device="cpu").manual_seed(sum(shape))
+    x = torch.randn((N, C, H, W), generator=g).to(dev)
+    w = (torch.randn((K, C, 3, 3), generator=g) * (0.5 / np.sqrt(9 * C))).to(dev).contiguous(memory_format=torch.channels_last)
+    assert rc.wino_ok(H, W, C, K)
+    xr = x.clone().requires_grad_(True)
+    y_ref = _ref_conv(xr, w, (1, 1), 3)
+    gy = torch.randn(y_ref.shape, generator=g).to(dev)
+    y_ref.backward(gy)
+    uf, ub = rc.wino_weights(w)
+    x_nhwc, gy_nhwc = x.permute(0, 2, 3, 1).contiguous(), gy.permute(0, 2, 3, 1).contiguous()
+    tag = f"winograd {N}x{H}x{W} {C}->{K}"
+    y = rc.wino_conv(x_nhwc, uf, K)
+    util.measured(f"{tag}: forward vs torch direct convolution (relative)", _rel(y.permute(0, 3, 1, 2), y_ref.detach()), bound=REL)
+    sc = torch.randn(y.shape, generator=g).to(dev)
+    y2 = rc.wino_conv(x_nhwc, uf, K, act=rc.ACT["tanh"], epilogue=rc.EPI_ADD | rc.EPI_ACT, add=sc)
+    util.measured(f"{tag}: forward + shortcut + tanh vs torch (absolute)",
+                  float((y2.permute(0, 3, 1, 2) - torch.tanh(y_ref.detach() + sc.permute(0, 3, 1, 2))).abs().max()), bound=2e-5)
+    dx = rc.wino_conv(gy_nhwc, ub, C)
+    util.measured(f"{tag}: input gradient vs torch autograd (relative)", _rel(dx.permute(0, 3, 1, 2), xr.grad), bound=REL)
+    ysave = torch.tanh(torch.randn(x_nhwc.shape, generator=g)).to(dev)
+    dx2 = rc.wino_conv(gy_nhwc, ub, C, act=rc.ACT["tanh"], epilogue=rc.EPI_DACT, dsrc=ysave)
+    util.measured(f"{tag}: fused dgrad * tanh' vs torch (relative)", _rel(dx2, xr.grad.permute(0, 2, 3, 1) * (1 - ysave * ysave)), bound=REL)
+    # and against this library's own direct kernel (same layout, same epilogue)
+    y_direct = rc.conv_nhwc(x_nhwc, rc.weight_storage(w))
+    util.measured(f"{tag}: Winograd vs the direct MFMA kernel (relative)", _rel(y, y_direct), bound=REL)
+
+
 def test_conv_rejects_shapes_that_do_not_tile():
     from delora_amd import _lib
     from delora_amd.models import ring_conv as rc
@@ -84,12 +118,14 @@ def test_conv_rejects_shapes_that_do_not_tile():
     assert not rc.supported((1, 4, 24, 64), ((64, 64, (1, 1), False),))
 
 
-@pytest.mark.parametrize("act", ["tanh", "relu"])
-def test_hip_trunk_matches_module_path(act):
+@pytest.mark.parametrize("act,wino", [("tanh", True), ("tanh", False), ("relu", True)])
+def test_hip_trunk_matches_module_path(act, wino, monkeypatch):
     """The full-width network (64..512 channels) on a 16x1024 pair: the channels-last HIP trunk against the module path
     (library convolutions + ring ops) with the same weights -- poses, and the gradient of EVERY parameter."""
+    from delora_amd.models import ring_conv
     from delora_amd.models.model import OdometryModel
     dev = _dev()
+    monkeypatch.setattr(ring_conv, "USE_WINOGRAD", wino)
     cfg = util.repo_config(16, 1024, device="cuda:0", activation_fct=act)
     torch.manual_seed(5)
     m_hip = OdometryModel(dict(cfg, cnn_impl="hip")).to(dev)
@@ -102,15 +138,15 @@ def test_hip_trunk_matches_module_path(act):
         t, q = m(x)
         (t.square().sum() + (q * torch.arange(1, 5, device=dev)).sum()).backward()
         out.append((t.detach(), q.detach()))
-    util.measured(f"trunk[{act}]: translation hip vs modules (relative)", _rel(out[0][0], out[1][0]), bound=REL)
-    util.measured(f"trunk[{act}]: quaternion hip vs modules (relative)", _rel(out[0][1], out[1][1]), bound=REL)
+    util.measured(f"trunk[{act}{',winograd' if wino else ',direct'}]: translation hip vs modules (relative)", _rel(out[0][0], out[1][0]), bound=REL)
+    util.measured(f"trunk[{act}{',winograd' if wino else ',direct'}]: quaternion hip vs modules (relative)", _rel(out[0][1], out[1][1]), bound=REL)
     worst, name = 0.0, ""
     for (k, p), (_, p2) in zip(m_hip.named_parameters(), m_mod.named_parameters()):
         assert p.grad is not None and p.grad.shape == p.shape, k
         e = float((p.grad - p2.grad).norm() / p2.grad.norm().clamp_min(1e-30))
         if e > worst:
             worst, name = e, k
-    util.measured(f"trunk[{act}]: worst relative parameter-gradient difference hip vs modules ({name})", worst, bound=(5 * REL if act == "tanh" else 1e-2))   # relu: masks of pre-activations within rounding of 0 flip
+    util.measured(f"trunk[{act}{',winograd' if wino else ',direct'}]: worst relative parameter-gradient difference hip vs modules ({name})", worst, bound=(5 * REL if act == "tanh" else 1e-2))   # relu: masks of pre-activations within rounding of 0 flip
     assert m_hip.resnet.layer1[0].conv1.weight.grad.stride() == m_hip.resnet.layer1[0].conv1.weight.stride()
 
 

@@ -16,6 +16,11 @@
 #define CV_TUNE 1
 #include "../delora_amd/csrc/abi.hip"
 #include "../delora_amd/csrc/conv.hip"
+#define f32x16 f32x16_w
+#define f32x4 f32x4_w
+#include "../delora_amd/csrc/wino.hip"
+#undef f32x16
+#undef f32x4
 
 #define CK(x)                                                                  \
   do {                                                                         \
@@ -200,6 +205,78 @@ static int check_shape(const Shape& s, std::mt19937& gen) {
   return bad;
 }
 
+// Winograd forward / input gradient against the host evaluation of the direct convolution
+static int check_wino(const Shape& s, std::mt19937& gen) {
+  const size_t nx = (size_t)s.N * s.H * s.W * s.C, ny = (size_t)s.N * s.H * s.W * s.K, nw = (size_t)s.K * 9 * s.C;
+  auto x = rnd(nx, gen, 1.f), w = rnd(nw, gen, 0.2f), add = rnd(ny, gen, 1.f), g = rnd(ny, gen, 1.f), ds = rnd(nx, gen, 0.9f);
+  float *dx = dev(x), *dw = dev(w), *dadd = dev(add), *dg = dev(g), *dds = dev(ds), *dy, *dgi, *uf, *ub;
+  CK(hipMalloc(&dy, ny * sizeof(float))); CK(hipMalloc(&dgi, nx * sizeof(float)));
+  CK(hipMalloc(&uf, 16 * nw / 9 * sizeof(float))); CK(hipMalloc(&ub, 16 * nw / 9 * sizeof(float)));
+  int bad = 0;
+  int rc = dl_wino_weights_f32(dw, uf, ub, s.K, s.C, nullptr);
+  if (!rc) rc = dl_wino_conv3x3_nhwc_f32(dx, uf, dy, dadd, nullptr, s.N, s.H, s.W, s.C, s.K, 1, 3, nullptr);
+  if (rc) { printf("  %s wino fwd: rc %d %s\n", s.name, rc, dl_last_error()); return 1; }
+  CK(hipDeviceSynchronize());
+  std::vector<float> y(ny), gi(nx);
+  CK(hipMemcpy(y.data(), dy, ny * sizeof(float), hipMemcpyDeviceToHost));
+  std::uniform_int_distribution<size_t> pick(0, ny - 1), px(0, nx - 1);
+  double worst = 0;
+  for (int t = 0; t < 4000; ++t) {
+    const size_t o = pick(gen);
+    const int k = o % s.K; size_t p = o / s.K;
+    const int wo = p % s.W; p /= s.W;
+    const int ho = p % s.H; const int n = p / s.H;
+    worst = std::max(worst, std::fabs(std::tanh(ref_fwd(x, w, s, n, ho, wo, k) + add[o]) - y[o]));
+  }
+  printf("  %-28s wino fwd(add+tanh) max abs err %.3e\n", s.name, worst);
+  if (!(worst < 5e-5)) bad++;
+  rc = dl_wino_conv3x3_nhwc_f32(dg, ub, dgi, nullptr, dds, s.N, s.H, s.W, s.K, s.C, 1, 4, nullptr);
+  if (rc) { printf("  %s wino dgrad: rc %d %s\n", s.name, rc, dl_last_error()); return bad + 1; }
+  CK(hipDeviceSynchronize());
+  CK(hipMemcpy(gi.data(), dgi, nx * sizeof(float), hipMemcpyDeviceToHost));
+  worst = 0; double scale = 0;
+  for (int t = 0; t < 2000; ++t) {
+    const size_t o = px(gen);
+    const int c = o % s.C; size_t p = o / s.C;
+    const int wi = p % s.W; p /= s.W;
+    const int h = p % s.H; const int n = p / s.H;
+    const double e = ref_dgrad(g, w, s, n, h, wi, c) * (1.0 - (double)ds[o] * ds[o]);
+    worst = std::max(worst, std::fabs(e - gi[o]));
+    scale = std::max(scale, std::fabs(e));
+  }
+  printf("  %-28s wino dgrad(dact)   max abs err %.3e (scale %.2f)\n", s.name, worst, scale);
+  if (!(worst < 5e-5 * std::max(1.0, scale))) bad++;
+  CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dadd)); CK(hipFree(dg)); CK(hipFree(dds)); CK(hipFree(dy)); CK(hipFree(dgi)); CK(hipFree(uf)); CK(hipFree(ub));
+  return bad;
+}
+
+static void time_wino(const Shape& s, int reps, std::mt19937& gen) {
+  const size_t nx = (size_t)s.N * s.H * s.W * s.C, ny = (size_t)s.N * s.H * s.W * s.K, nw = (size_t)s.K * 9 * s.C;
+  auto x = rnd(nx, gen, 1.f), w = rnd(nw, gen, 0.05f), g = rnd(ny, gen, 1.f);
+  float *dx = dev(x), *dw = dev(w), *dg = dev(g), *dy, *dgi, *uf, *ub;
+  CK(hipMalloc(&dy, ny * sizeof(float))); CK(hipMalloc(&dgi, nx * sizeof(float)));
+  CK(hipMalloc(&uf, 16 * nw / 9 * sizeof(float))); CK(hipMalloc(&ub, 16 * nw / 9 * sizeof(float)));
+  hipEvent_t a, b;
+  CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
+  const double flop = 2.0 * s.N * s.H * s.W * (double)s.K * s.C * 9;
+  auto run = [&](const char* what, auto fn) {
+    if (fn()) { printf("%-26s %-10s unsupported: %s\n", s.name, what, dl_last_error()); return; }
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(a));
+    for (int i = 0; i < reps; ++i) fn();
+    CK(hipEventRecord(b));
+    CK(hipEventSynchronize(b));
+    float ms;
+    CK(hipEventElapsedTime(&ms, a, b));
+    const double us = 1e3 * ms / reps;
+    printf("%-26s %-10s %9.1f us  %7.1f TFLOP/s direct-equivalent\n", s.name, what, us, flop / us * 1e-6);
+  };
+  run("wino-wts", [&] { return dl_wino_weights_f32(dw, uf, ub, s.K, s.C, nullptr); });
+  run("wino-fwd", [&] { return dl_wino_conv3x3_nhwc_f32(dx, uf, dy, nullptr, nullptr, s.N, s.H, s.W, s.C, s.K, 1, 2, nullptr); });
+  run("wino-dgrad", [&] { return dl_wino_conv3x3_nhwc_f32(dg, ub, dgi, nullptr, dx, s.N, s.H, s.W, s.K, s.C, 1, 4, nullptr); });
+  CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dg)); CK(hipFree(dy)); CK(hipFree(dgi)); CK(hipFree(uf)); CK(hipFree(ub));
+}
+
 static void time_shape(const Shape& s, int reps, std::mt19937& gen, double* total_us, bool with_wgrad = true) {
   const int Ho = s.H / s.sh, Wo = s.W / s.sw;
   const size_t nx = (size_t)s.N * s.H * s.W * s.C, ny = (size_t)s.N * Ho * Wo * s.K, nw = (size_t)s.K * s.ks * s.ks * s.C;
@@ -285,6 +362,19 @@ static void mfma_peak() {
 int main(int argc, char** argv) {
   std::mt19937 gen(7);
   if (argc >= 2 && !strcmp(argv[1], "peak")) { mfma_peak(); return 0; }
+  if (argc >= 2 && !strcmp(argv[1], "wino")) {
+    const Shape small[] = {{"wino 2x8x128 64->64", 2, 8, 128, 64, 64, 3, 1, 1}, {"wino 1x4x64 128->128", 1, 4, 64, 128, 128, 3, 1, 1},
+                           {"wino 2x8x32 64->128", 2, 8, 32, 64, 128, 3, 1, 1}, {"wino 1x6x256 64->64", 1, 6, 256, 64, 64, 3, 1, 1}};
+    int bad = 0;
+    for (const auto& s : small) bad += check_wino(s, gen);
+    printf(bad ? "WINO CHECK FAILED (%d)\n" : "WINO CHECK OK\n", bad);
+    const int reps = argc >= 3 ? atoi(argv[2]) : 10;
+    const int B = 8;
+    const Shape layers[] = {{"layer1 3x3 64->64", B, 64, 512, 64, 64, 3, 1, 1}, {"layer2 3x3 128->128", B, 64, 256, 128, 128, 3, 1, 1},
+                            {"layer3 3x3 256->256", B, 64, 128, 256, 256, 3, 1, 1}, {"layer4 3x3 512->512", B, 32, 64, 512, 512, 3, 1, 1}};
+    for (const auto& s : layers) time_wino(s, reps, gen);
+    return bad ? 1 : 0;
+  }
   if (argc >= 2 && !strcmp(argv[1], "tune")) {
     const int reps = argc >= 3 ? atoi(argv[2]) : 10;
     const int B = 8;
