@@ -26,7 +26,13 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef WN_EXP_NOLOAD
+#define WN_EXP_LOAD(...) (void)m_;
+#else
+#define WN_EXP_LOAD(...) __VA_ARGS__
+#endif
 #define WN_THREADS 512
 #define WN_CK 8
 #define WN_KB 64
@@ -110,19 +116,20 @@ __global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ 
 }
 
 // TC tile columns x TR tile rows = 64 tiles per workgroup.
+//
+// Pipeline: V and U are double-buffered in LDS.  While the waves multiply chunk c out of buffer [c & 1], every thread
+// turns the raw values of chunk c+1 -- which it fetched itself, straight into registers, during chunk c-1: the eight
+// 16-byte pieces (4 rows x 2 columns) that ITS column of the 4x4 domain combines -- into V and writes them, with its share
+// of U, into the other buffer, then issues the loads of chunk c+2.  One barrier per chunk; no staging of the raw patch
+// in LDS, no phase in which the matrix cores wait for a transform.  In-order issue is what makes this work: a wave's next
+// MFMA on the same accumulator cannot issue for 64 cycles, and the transform / LDS / load instructions placed between two
+// MFMAs run in that shadow.
 template <int TC>
 __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   constexpr int TR = WN_TILES / TC;
-  constexpr int RH = 2 * TR + 2, RW = 2 * TC + 2;
-  constexpr int RAW_FLOATS = RH * RW * WN_CK;
-  constexpr int V_FLOATS = 16 * WN_PLANE, U_FLOATS = 16 * WN_PLANE;
-  constexpr int NRAW = RH * RW * 2;                  // float4 items of the raw patch
-  constexpr int NRAW_IT = (NRAW + WN_THREADS - 1) / WN_THREADS;
+  constexpr int BUF = 2 * 16 * WN_PLANE;             // floats of one (V, U) buffer pair
   constexpr int NU_IT = 16 * WN_KB * 2 / WN_THREADS;  // 4
-  __shared__ __attribute__((aligned(16))) float lds[RAW_FLOATS + V_FLOATS + U_FLOATS];
-  float* raw_lds = lds;
-  float* v_lds = lds + RAW_FLOATS;
-  float* u_lds = v_lds + V_FLOATS;
+  __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, half = lane >> 5;
@@ -136,37 +143,39 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   const int gh = t % tiles_h;
   const int n = t / tiles_h;
   const int k0 = kt * WN_KB;
-  const int h_base = gh * TR * 2 - 1, w_base = gw * TC * 2 - 1;     // image position of raw(0,0)
   const float* xn = a.x + (size_t)n * a.H * a.W * a.C;
 
-  // staging items (ids beyond the patch are clamped: duplicates of the last item, branch-free)
-  int raw_g[NRAW_IT], raw_l[NRAW_IT];
-#pragma unroll
-  for (int it = 0; it < NRAW_IT; ++it) {
-    const int q = min(tid + it * WN_THREADS, NRAW - 1);
-    const int c4 = q & 1, pc = q >> 1;
-    const int col = pc % RW, row = pc / RW;
-    const int h = h_base + row;
-    int w = w_base + col;
-    w = w < 0 ? w + a.W : (w >= a.W ? w - a.W : w);
-    raw_l[it] = pc * WN_CK + c4 * 4;
-    raw_g[it] = (h >= 0 && h < a.H) ? (h * a.W + w) * a.C + c4 * 4 : -1;
-  }
-  int u_g[NU_IT], u_l[NU_IT];
-#pragma unroll
-  for (int it = 0; it < NU_IT; ++it) {
-    const int q = tid + it * WN_THREADS;             // (xi, kk, c4): 16 x 64 x 2
-    const int c4 = q & 1, kk = (q >> 1) & 63, xi = q >> 7;
-    u_g[it] = (xi * a.K + k0 + kk) * 8 + c4 * 4;     // + chunk * 16 * K * 8
-    u_l[it] = xi * WN_PLANE + kk * 8 + ((c4 ^ ((kk >> 3) & 1)) * 4);
-  }
   // transform role of this thread: tile, channel quad, column b of the 4x4 domain
   const int tb = tid & 3, tc4 = (tid >> 2) & 1, ttile = tid >> 3;
   const int ttr = ttile / TC, ttc = ttile % TC;
   const int j0 = tb == 0 ? 0 : 1, j1 = tb == 3 ? 3 : 2;             // the two raw columns column b combines
   const float sg0 = tb == 2 ? -1.f : 1.f, sg1 = (tb == 0 || tb == 3) ? -1.f : 1.f;   // T[.][b] = sg0*d[.][j0] + sg1*d[.][j1]
-  const int t_rd = ((2 * ttr) * RW + 2 * ttc) * WN_CK + tc4 * 4;
   const int t_wr = tb * WN_PLANE + ttile * 8 + ((tc4 ^ ((ttile >> 3) & 1)) * 4);
+  // global offsets of the 8 raw pieces (rows 0..3 x columns j0, j1 of the tile's 4x4 input window); -1: zero row
+  int raw_g[4][2];
+  {
+    const int h0 = (gh * TR + ttr) * 2 - 1, w0 = (gw * TC + ttc) * 2 - 1;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int h = h0 + i;
+#pragma unroll
+      for (int jj = 0; jj < 2; ++jj) {
+        int w = w0 + (jj ? j1 : j0);
+        w = w < 0 ? w + a.W : (w >= a.W ? w - a.W : w);
+        raw_g[i][jj] = (h >= 0 && h < a.H) ? (h * a.W + w) * a.C + tc4 * 4 : -1;
+      }
+    }
+  }
+  // U goes global -> LDS directly (global_load_lds, 16 bytes per lane, no registers): wave w copies the half-planes
+  // 4w .. 4w+3 (plane = id >> 1, rows 32 * (id & 1) ..); a lane's LDS slot is linear in the lane id as the instruction
+  // requires, so the 16-byte XOR swizzle is applied to the SOURCE address instead
+  int u_g[NU_IT], u_l[NU_IT];
+#pragma unroll
+  for (int it = 0; it < NU_IT; ++it) {
+    const int id = wave * NU_IT + it, xi = id >> 1, kk = (id & 1) * 32 + (lane >> 1), slot = lane & 1;
+    u_g[it] = (xi * a.K + k0 + kk) * 8 + ((slot ^ ((kk >> 3) & 1)) * 4);     // + chunk * 16 * K * 8
+    u_l[it] = 16 * WN_PLANE + xi * WN_PLANE + (id & 1) * 256;                // wave-uniform base (floats)
+  }
 
   f32x16 acc[8];
 #pragma unroll
@@ -176,66 +185,137 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
 
   const int arow = mb * 32 + li, brow = nb * 32 + li;
   const int a_off = arow * 8 + ((half ^ ((arow >> 3) & 1)) * 4);
-  const int b_off = brow * 8 + ((half ^ ((brow >> 3) & 1)) * 4);
+  const int b_off = 16 * WN_PLANE + brow * 8 + ((half ^ ((brow >> 3) & 1)) * 4);
 
-  f32x4 raw_r[NRAW_IT], u_r[NU_IT];
+  i32x4 raw_b[4][2];                                 // raw bits of the 8 pieces (masked at use: WN_RAW)
+#define WN_RAW_(I, JJ) __builtin_bit_cast(f32x4, raw_b[I][JJ] & ~(raw_g[I][JJ] >> 31))
 #define WN_FETCH(CH)                                                                                                      \
   {                                                                                                                       \
-    _Pragma("unroll") for (int it = 0; it < NRAW_IT; ++it) {                                                              \
-      const bool in = raw_g[it] >= 0;                                                                                     \
-      const f32x4 v = *reinterpret_cast<const f32x4*>(xn + (in ? raw_g[it] + (CH) * WN_CK : 0));                          \
-      raw_r[it] = in ? v : (f32x4){0.f, 0.f, 0.f, 0.f};                                                                   \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                      \
+      const int off_ = raw_g[i][jj];                                                                                      \
+      const int m_ = ~(off_ >> 31);                                                                                       \
+      raw_b[i][jj] = *reinterpret_cast<const i32x4*>(xn + (off_ & m_) + (CH) * WN_CK);                                    \
     }                                                                                                                     \
-    _Pragma("unroll") for (int it = 0; it < NU_IT; ++it) u_r[it] =                                                        \
-        *reinterpret_cast<const f32x4*>(a.u + (size_t)(CH) * 16 * a.K * 8 + u_g[it]);                                     \
   }
-#define WN_STAGE()                                                                                                        \
+#define WN_U_TO_LDS(CH, BUFP)                                                                                             \
   {                                                                                                                       \
-    _Pragma("unroll") for (int it = 0; it < NRAW_IT; ++it) *reinterpret_cast<f32x4*>(raw_lds + raw_l[it]) = raw_r[it];    \
-    _Pragma("unroll") for (int it = 0; it < NU_IT; ++it) *reinterpret_cast<f32x4*>(u_lds + u_l[it]) = u_r[it];            \
+    _Pragma("unroll") for (int it = 0; it < NU_IT; ++it) __builtin_amdgcn_global_load_lds(                                \
+        (const __attribute__((address_space(1))) void*)(a.u + (size_t)(CH) * 16 * a.K * 8 + u_g[it]),                     \
+        (__attribute__((address_space(3))) void*)((BUFP) + __builtin_amdgcn_readfirstlane(u_l[it])), 16, 0, 0);           \
   }
-#define WN_TRANSFORM()                                                                                                    \
+  // registers of the fetched chunk -> V (B^T d B, this thread's column b) in buffer BUFP
+#define WN_TRANSFORM_STAGE(BUFP)                                                                                          \
   {                                                                                                                       \
     f32x4 tt[4];                                                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                       \
-      const f32x4 d0 = *reinterpret_cast<const f32x4*>(raw_lds + t_rd + (i * RW + j0) * WN_CK);                           \
-      const f32x4 d1 = *reinterpret_cast<const f32x4*>(raw_lds + t_rd + (i * RW + j1) * WN_CK);                           \
-      tt[i] = sg0 * d0 + sg1 * d1;                                                                                        \
-    }                                                                                                                     \
-    *reinterpret_cast<f32x4*>(v_lds + t_wr + 0 * 4 * WN_PLANE) = tt[0] - tt[2];                                           \
-    *reinterpret_cast<f32x4*>(v_lds + t_wr + 1 * 4 * WN_PLANE) = tt[1] + tt[2];                                           \
-    *reinterpret_cast<f32x4*>(v_lds + t_wr + 2 * 4 * WN_PLANE) = tt[2] - tt[1];                                           \
-    *reinterpret_cast<f32x4*>(v_lds + t_wr + 3 * 4 * WN_PLANE) = tt[1] - tt[3];                                           \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) tt[i] = sg0 * WN_RAW_(i, 0) + sg1 * WN_RAW_(i, 1);                      \
+    float* vb = (BUFP) + t_wr;                                                                                            \
+    *reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = tt[0] - tt[2];                                                     \
+    *reinterpret_cast<f32x4*>(vb + 1 * 4 * WN_PLANE) = tt[1] + tt[2];                                                     \
+    *reinterpret_cast<f32x4*>(vb + 2 * 4 * WN_PLANE) = tt[2] - tt[1];                                                     \
+    *reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = tt[1] - tt[3];                                                     \
   }
 
-  const int nchunks = a.C / WN_CK;
-  WN_FETCH(0)
-  WN_STAGE()
-  __syncthreads();
-  WN_TRANSFORM()
-  __syncthreads();
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const bool more = ch + 1 < nchunks;
-    if (more) WN_FETCH(ch + 1)
-#pragma unroll
-    for (int xl = 0; xl < 8; ++xl) {
-      const int xi = xh * 8 + xl;
-      const f32x4 av = *reinterpret_cast<const f32x4*>(v_lds + xi * WN_PLANE + a_off);
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(u_lds + xi * WN_PLANE + b_off);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[xl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[xl], 0, 0, 0);
-    }
-    __syncthreads();
-    if (more) {
-      WN_STAGE()
-      __syncthreads();
-      WN_TRANSFORM()
-      __syncthreads();
-    }
+  // One (V, U) plane of this wave: four MFMAs on one accumulator out of fragments read one step earlier; right after the
+  // first MFMA the step issues the NEXT plane's two 16-byte LDS reads and SLICE, a piece of the next chunk's transform /
+  // staging / fetch -- all of it runs in the shadow of the matrix pipe (in-order issue: the wave's next MFMA on the same
+  // accumulator cannot issue for 64 cycles anyway).  The fences keep hipcc from sinking every piece to its first use.
+#define WN_LOAD_FRAGS(XL)                                                                                                 \
+  {                                                                                                                       \
+    av[(XL) & 1] = *reinterpret_cast<const f32x4*>(cur + (xh * 8 + (XL)) * WN_PLANE + a_off);                             \
+    bv[(XL) & 1] = *reinterpret_cast<const f32x4*>(cur + (xh * 8 + (XL)) * WN_PLANE + b_off);                             \
   }
+#define WN_M(XL, J, ...)                                                                                                  \
+  {                                                                                                                       \
+    acc[XL] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(XL) & 1][J], bv[(XL) & 1][J], acc[XL], 0, 0, 0);                   \
+    __VA_ARGS__                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+  }
+#define WN_U_PIECE(IT, CH, BUFP)                                                                                          \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.u + (size_t)(CH) * 16 * a.K * 8 + u_g[IT]), \
+                                   (__attribute__((address_space(3))) void*)((BUFP) + __builtin_amdgcn_readfirstlane(u_l[IT])), 16, 0, 0);
+#define WN_PLANE_STEP(XL, ...)                                                                                            \
+  {                                                                                                                       \
+    acc[XL] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(XL) & 1][0], bv[(XL) & 1][0], acc[XL], 0, 0, 0);                   \
+    if ((XL) < 7) WN_LOAD_FRAGS((XL) + 1)                                                                                 \
+    __VA_ARGS__                                                                                                           \
+    acc[XL] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(XL) & 1][1], bv[(XL) & 1][1], acc[XL], 0, 0, 0);                   \
+    acc[XL] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(XL) & 1][2], bv[(XL) & 1][2], acc[XL], 0, 0, 0);                   \
+    acc[XL] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(XL) & 1][3], bv[(XL) & 1][3], acc[XL], 0, 0, 0);                   \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+  }
+  // a raw piece: unconditional load of an in-image address, zero rows by AND-ing the bit pattern (a select would let hipcc
+  // sink the load into a branch; a multiply would leak NaNs)
+#define WN_LOAD_RAW(I, JJ, CH)                                                                                            \
+  {                                                                                                                       \
+    const int off_ = raw_g[I][JJ];                                                                                        \
+    const int m_ = ~(off_ >> 31);                                                                                         \
+    WN_EXP_LOAD(raw_b[I][JJ] = *reinterpret_cast<const i32x4*>(xn + (off_ & m_) + (CH) * WN_CK);)                         \
+  }
+  // ... and its use: zero rows are masked when the value is consumed, so that nothing touches a load's result early
+#define WN_RAW(I, JJ) __builtin_bit_cast(f32x4, raw_b[I][JJ] & ~(raw_g[I][JJ] >> 31))
+  const int nchunks = a.C / WN_CK;
+  f32x4 av[2], bv[2];
+  WN_FETCH(0)
+  WN_U_TO_LDS(0, lds)
+  WN_TRANSFORM_STAGE(lds)
+  WN_FETCH(min(1, nchunks - 1))
+  __syncthreads();
+  for (int ch = 0; ch + 1 < nchunks; ++ch) {
+    float* cur = lds + (ch & 1) * BUF;
+    float* nxt = lds + ((ch + 1) & 1) * BUF;
+    const int chf = min(ch + 2, nchunks - 1);        // beyond the end: a harmless re-fetch of the last chunk (no branch)
+    f32x4 tt[4];
+    float* vb = nxt + t_wr;
+    // Schedule: ONE small piece of side work behind EVERY MFMA (a piece runs in the 64-cycle shadow of the MFMA it follows;
+    // a long piece would stall the wave's next MFMA while its partner on the SIMD is doing the same thing).  U of the next
+    // chunk first (LDS DMA); the raw registers are consumed late (planes 4-5) and re-loaded for chunk ch+2 right after
+    // (planes 6-7): those loads stay in flight across the barrier, which waits for everything except the 8 newest
+    // loads (vmcnt(8): the U pieces are older) and for this wave's LDS traffic.
+    WN_LOAD_FRAGS(0)
+    WN_M(0, 0, WN_LOAD_FRAGS(1)) WN_M(0, 1, WN_U_PIECE(0, ch + 1, nxt) WN_U_PIECE(1, ch + 1, nxt))
+    WN_M(0, 2, WN_U_PIECE(2, ch + 1, nxt) WN_U_PIECE(3, ch + 1, nxt)) WN_M(0, 3, )
+    WN_M(1, 0, WN_LOAD_FRAGS(2)) WN_M(1, 1, ) WN_M(1, 2, ) WN_M(1, 3, )
+    WN_M(2, 0, WN_LOAD_FRAGS(3)) WN_M(2, 1, ) WN_M(2, 2, ) WN_M(2, 3, )
+    WN_M(3, 0, WN_LOAD_FRAGS(4)) WN_M(3, 1, ) WN_M(3, 2, ) WN_M(3, 3, )
+    WN_M(4, 0, WN_LOAD_FRAGS(5))
+    WN_M(4, 1, tt[0] = sg0 * WN_RAW(0, 0) + sg1 * WN_RAW(0, 1);)
+    WN_M(4, 2, tt[1] = sg0 * WN_RAW(1, 0) + sg1 * WN_RAW(1, 1);)
+    WN_M(4, 3, tt[2] = sg0 * WN_RAW(2, 0) + sg1 * WN_RAW(2, 1);)
+    WN_M(5, 0, WN_LOAD_FRAGS(6))
+    WN_M(5, 1, tt[3] = sg0 * WN_RAW(3, 0) + sg1 * WN_RAW(3, 1);)
+    WN_M(5, 2, *reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = tt[0] - tt[2];)
+    WN_M(5, 3, *reinterpret_cast<f32x4*>(vb + 1 * 4 * WN_PLANE) = tt[1] + tt[2];)
+    WN_M(6, 0, WN_LOAD_FRAGS(7))
+    WN_M(6, 1, *reinterpret_cast<f32x4*>(vb + 2 * 4 * WN_PLANE) = tt[2] - tt[1];)
+    WN_M(6, 2, *reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = tt[1] - tt[3];)
+    WN_M(6, 3, WN_LOAD_RAW(0, 0, chf) WN_LOAD_RAW(0, 1, chf))
+    WN_M(7, 0, WN_LOAD_RAW(1, 0, chf) WN_LOAD_RAW(1, 1, chf))
+    WN_M(7, 1, WN_LOAD_RAW(2, 0, chf) WN_LOAD_RAW(2, 1, chf))
+    WN_M(7, 2, WN_LOAD_RAW(3, 0, chf) WN_LOAD_RAW(3, 1, chf))
+    WN_M(7, 3, )
+#ifndef WN_EXP_NOBARRIER
+    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  {
+    float* cur = lds + ((nchunks - 1) & 1) * BUF;
+    WN_LOAD_FRAGS(0)
+#pragma unroll
+    for (int xl = 0; xl < 8; ++xl) WN_PLANE_STEP(xl, {})
+  }
+  __syncthreads();
+#undef WN_PLANE_STEP
+#undef WN_M
+#undef WN_U_PIECE
+#undef WN_LOAD_FRAGS
+#undef WN_LOAD_RAW
+#undef WN_RAW
+#undef WN_RAW_
 #undef WN_FETCH
-#undef WN_STAGE
-#undef WN_TRANSFORM
+#undef WN_U_TO_LDS
+#undef WN_TRANSFORM_STAGE
 
   // Output transform.  This wave holds M[a][b] for a = 2xh, 2xh+1 (acc[(a - 2xh) * 4 + b]).  Column pass (over b):
   //   P[a][0] = M[a][0] + M[a][1] + M[a][2],  P[a][1] = M[a][1] - M[a][2] - M[a][3]
