@@ -28,11 +28,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
-#ifdef WN_EXP_NOLOAD
-#define WN_EXP_LOAD(...) (void)m_;
-#else
-#define WN_EXP_LOAD(...) __VA_ARGS__
-#endif
 #define WN_THREADS 512
 #define WN_CK 8
 #define WN_KB 64
@@ -117,19 +112,30 @@ __global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ 
 
 // TC tile columns x TR tile rows = 64 tiles per workgroup.
 //
-// Pipeline: V and U are double-buffered in LDS.  While the waves multiply chunk c out of buffer [c & 1], every thread
-// turns the raw values of chunk c+1 -- which it fetched itself, straight into registers, during chunk c-1: the eight
-// 16-byte pieces (4 rows x 2 columns) that ITS column of the 4x4 domain combines -- into V and writes them, with its share
-// of U, into the other buffer, then issues the loads of chunk c+2.  One barrier per chunk; no staging of the raw patch
-// in LDS, no phase in which the matrix cores wait for a transform.  In-order issue is what makes this work: a wave's next
-// MFMA on the same accumulator cannot issue for 64 cycles, and the transform / LDS / load instructions placed between two
-// MFMAs run in that shadow.
+// Pipeline (one barrier per chunk).  LDS holds two (V, U) buffers and two raw-patch buffers.  While the waves multiply
+// chunk c out of (V, U)[c & 1]:
+//   * the LDS DMA (global_load_lds, no registers) brings U of chunk c+1 into (V, U)[(c+1) & 1] and the raw input patch of
+//     chunk c+2 -- (2TR+2) x (2TC+2) pixels x 8 channels, wrap-around columns by addressing -- into raw[c & 1]; both have
+//     the whole chunk to land;
+//   * every thread turns the raw patch of chunk c+1 (raw[(c+1) & 1], landed during chunk c-1) into its column b of
+//     V = B^T d B for its (tile, channel quad): 8 x 16-byte LDS reads, a few adds, 4 x 16-byte LDS writes.
+// All of that is sliced into small pieces placed behind individual MFMAs: in-order issue means a wave's next MFMA on the
+// same accumulator cannot issue for 64 cycles anyway, and a piece runs in that shadow.  The fences keep hipcc from
+// sinking every piece to its first use.  (Fetching the raw pieces straight into registers -- 8 scattered 16-byte loads
+// per thread and chunk, each 32-byte pixel slice requested by ~4 threads -- measured 15 % slower: the vector-memory
+// path, not the matrix pipe, became the limit.)
 template <int TC>
 __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   constexpr int TR = WN_TILES / TC;
-  constexpr int BUF = 2 * 16 * WN_PLANE;             // floats of one (V, U) buffer pair
-  constexpr int NU_IT = 16 * WN_KB * 2 / WN_THREADS;  // 4
-  __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
+  constexpr int RH = 2 * TR + 2, RW = 2 * TC + 2;
+  constexpr int NPIX = RH * RW, NRI = (NPIX + 31) / 32;      // raw patch: pixels, 1 KiB DMA pieces (32 pixels x 32 B)
+  constexpr int RAWBUF = NRI * 256;                             // floats
+  constexpr int NR_IT = (NRI + 7) / 8;                          // DMA pieces per wave
+  constexpr int BUF = 2 * 16 * WN_PLANE;                        // floats of one (V, U) buffer pair
+  constexpr int NU_IT = 16 * WN_KB * 2 / WN_THREADS;             // 4
+  static_assert((2 * BUF + 2 * RAWBUF) * 4 <= 163840, "LDS budget");
+  __shared__ __attribute__((aligned(16))) float lds[2 * BUF + 2 * RAWBUF];
+  float* rawbase = lds + 2 * BUF;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, half = lane >> 5;
@@ -143,6 +149,7 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   const int gh = t % tiles_h;
   const int n = t / tiles_h;
   const int k0 = kt * WN_KB;
+  const int h_base = gh * TR * 2 - 1, w_base = gw * TC * 2 - 1;     // image position of raw(0,0)
   const float* xn = a.x + (size_t)n * a.H * a.W * a.C;
 
   // transform role of this thread: tile, channel quad, column b of the 4x4 domain
@@ -151,24 +158,30 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   const int j0 = tb == 0 ? 0 : 1, j1 = tb == 3 ? 3 : 2;             // the two raw columns column b combines
   const float sg0 = tb == 2 ? -1.f : 1.f, sg1 = (tb == 0 || tb == 3) ? -1.f : 1.f;   // T[.][b] = sg0*d[.][j0] + sg1*d[.][j1]
   const int t_wr = tb * WN_PLANE + ttile * 8 + ((tc4 ^ ((ttile >> 3) & 1)) * 4);
-  // global offsets of the 8 raw pieces (rows 0..3 x columns j0, j1 of the tile's 4x4 input window); -1: zero row
-  int raw_g[4][2];
-  {
-    const int h0 = (gh * TR + ttr) * 2 - 1, w0 = (gw * TC + ttc) * 2 - 1;
+  const int t_rd = ((2 * ttr) * RW + 2 * ttc) * 8 + tc4 * 4;        // raw(row 0, col 0) of this tile's window
+  int rowmask[4];                                                     // zero rows above / below the image
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int h = h0 + i;
-#pragma unroll
-      for (int jj = 0; jj < 2; ++jj) {
-        int w = w0 + (jj ? j1 : j0);
-        w = w < 0 ? w + a.W : (w >= a.W ? w - a.W : w);
-        raw_g[i][jj] = (h >= 0 && h < a.H) ? (h * a.W + w) * a.C + tc4 * 4 : -1;
-      }
-    }
+  for (int i = 0; i < 4; ++i) {
+    const int h = h_base + 2 * ttr + i;
+    rowmask[i] = (h >= 0 && h < a.H) ? -1 : 0;
   }
-  // U goes global -> LDS directly (global_load_lds, 16 bytes per lane, no registers): wave w copies the half-planes
-  // 4w .. 4w+3 (plane = id >> 1, rows 32 * (id & 1) ..); a lane's LDS slot is linear in the lane id as the instruction
-  // requires, so the 16-byte XOR swizzle is applied to the SOURCE address instead
+  // DMA pieces of this wave: raw pixels r*32 + lane/2, channel quad lane & 1 (ids beyond the patch re-read its last
+  // pixel; rows outside the image read row 0 / H-1 and are masked by the transform)
+  int raw_g[NR_IT], raw_l[NR_IT];
+#pragma unroll
+  for (int it = 0; it < NR_IT; ++it) {
+    const int r = min(wave + it * 8, NRI - 1);
+    const int p = min(r * 32 + (lane >> 1), NPIX - 1);
+    const int row = p / RW, col = p % RW;
+    int h = h_base + row;
+    h = h < 0 ? 0 : (h >= a.H ? a.H - 1 : h);
+    int w = w_base + col;
+    w = w < 0 ? w + a.W : (w >= a.W ? w - a.W : w);
+    raw_g[it] = (h * a.W + w) * a.C + (lane & 1) * 4;
+    raw_l[it] = r * 256;
+  }
+  // U: wave w copies the half-planes 4w .. 4w+3 (plane = id >> 1, rows 32 * (id & 1) ..); a lane's LDS slot is linear in
+  // the lane id as the instruction requires, so the 16-byte XOR swizzle is applied to the SOURCE address instead
   int u_g[NU_IT], u_l[NU_IT];
 #pragma unroll
   for (int it = 0; it < NU_IT; ++it) {
@@ -187,38 +200,21 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   const int a_off = arow * 8 + ((half ^ ((arow >> 3) & 1)) * 4);
   const int b_off = 16 * WN_PLANE + brow * 8 + ((half ^ ((brow >> 3) & 1)) * 4);
 
-  i32x4 raw_b[4][2];                                 // raw bits of the 8 pieces (masked at use: WN_RAW)
-#define WN_RAW_(I, JJ) __builtin_bit_cast(f32x4, raw_b[I][JJ] & ~(raw_g[I][JJ] >> 31))
-#define WN_FETCH(CH)                                                                                                      \
+#define WN_GLDS(GPTR, LPTR)                                                                                               \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(GPTR),                                 \
+                                   (__attribute__((address_space(3))) void*)(LPTR), 16, 0, 0);
+#define WN_U_PIECE(IT, CH, BUFP) WN_GLDS(a.u + (size_t)(CH) * 16 * a.K * 8 + u_g[IT], (BUFP) + __builtin_amdgcn_readfirstlane(u_l[IT]))
+#define WN_RAW_PIECE(IT, CH) \
+  WN_GLDS(xn + raw_g[IT] + (CH) * WN_CK, rawbase + ((CH) & 1) * RAWBUF + __builtin_amdgcn_readfirstlane(raw_l[IT]))
+#define WN_RAW_ALL(CH) { _Pragma("unroll") for (int it = 0; it < NR_IT; ++it) WN_RAW_PIECE(it, CH) }
+#define WN_U_ALL(CH, BUFP) { _Pragma("unroll") for (int it = 0; it < NU_IT; ++it) WN_U_PIECE(it, CH, BUFP) }
+  // row I of T = d B for this thread's column: two 16-byte reads of the raw patch, masked for rows outside the image
+#define WN_TROW(I, RB)                                                                                                    \
   {                                                                                                                       \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) _Pragma("unroll") for (int jj = 0; jj < 2; ++jj) {                      \
-      const int off_ = raw_g[i][jj];                                                                                      \
-      const int m_ = ~(off_ >> 31);                                                                                       \
-      raw_b[i][jj] = *reinterpret_cast<const i32x4*>(xn + (off_ & m_) + (CH) * WN_CK);                                    \
-    }                                                                                                                     \
+    const i32x4 d0 = *reinterpret_cast<const i32x4*>((RB) + t_rd + ((I) * RW + j0) * 8) & rowmask[I];                     \
+    const i32x4 d1 = *reinterpret_cast<const i32x4*>((RB) + t_rd + ((I) * RW + j1) * 8) & rowmask[I];                     \
+    tt[I] = sg0 * __builtin_bit_cast(f32x4, d0) + sg1 * __builtin_bit_cast(f32x4, d1);                                    \
   }
-#define WN_U_TO_LDS(CH, BUFP)                                                                                             \
-  {                                                                                                                       \
-    _Pragma("unroll") for (int it = 0; it < NU_IT; ++it) __builtin_amdgcn_global_load_lds(                                \
-        (const __attribute__((address_space(1))) void*)(a.u + (size_t)(CH) * 16 * a.K * 8 + u_g[it]),                     \
-        (__attribute__((address_space(3))) void*)((BUFP) + __builtin_amdgcn_readfirstlane(u_l[it])), 16, 0, 0);           \
-  }
-  // registers of the fetched chunk -> V (B^T d B, this thread's column b) in buffer BUFP
-#define WN_TRANSFORM_STAGE(BUFP)                                                                                          \
-  {                                                                                                                       \
-    f32x4 tt[4];                                                                                                          \
-    _Pragma("unroll") for (int i = 0; i < 4; ++i) tt[i] = sg0 * WN_RAW_(i, 0) + sg1 * WN_RAW_(i, 1);                      \
-    float* vb = (BUFP) + t_wr;                                                                                            \
-    *reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = tt[0] - tt[2];                                                     \
-    *reinterpret_cast<f32x4*>(vb + 1 * 4 * WN_PLANE) = tt[1] + tt[2];                                                     \
-    *reinterpret_cast<f32x4*>(vb + 2 * 4 * WN_PLANE) = tt[2] - tt[1];                                                     \
-    *reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = tt[1] - tt[3];                                                     \
-  }
-
-  // One (V, U) plane of this wave: four MFMAs on one accumulator out of fragments read one step earlier; right after the
-  // first MFMA the step issues the NEXT plane's two 16-byte LDS reads and SLICE, a piece of the next chunk's transform /
-  // staging / fetch -- all of it runs in the shadow of the matrix pipe (in-order issue: the wave's next MFMA on the same
-  // accumulator cannot issue for 64 cycles anyway).  The fences keep hipcc from sinking every piece to its first use.
 #define WN_LOAD_FRAGS(XL)                                                                                                 \
   {                                                                                                                       \
     av[(XL) & 1] = *reinterpret_cast<const f32x4*>(cur + (xh * 8 + (XL)) * WN_PLANE + a_off);                             \
@@ -230,92 +226,68 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
     __VA_ARGS__                                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                                    \
   }
-#define WN_U_PIECE(IT, CH, BUFP)                                                                                          \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.u + (size_t)(CH) * 16 * a.K * 8 + u_g[IT]), \
-                                   (__attribute__((address_space(3))) void*)((BUFP) + __builtin_amdgcn_readfirstlane(u_l[IT])), 16, 0, 0);
-#define WN_PLANE_STEP(XL, ...)                                                                                            \
-  {                                                                                                                       \
-    acc[XL] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(XL) & 1][0], bv[(XL) & 1][0], acc[XL], 0, 0, 0);                   \
-    if ((XL) < 7) WN_LOAD_FRAGS((XL) + 1)                                                                                 \
-    __VA_ARGS__                                                                                                           \
-    acc[XL] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(XL) & 1][1], bv[(XL) & 1][1], acc[XL], 0, 0, 0);                   \
-    acc[XL] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(XL) & 1][2], bv[(XL) & 1][2], acc[XL], 0, 0, 0);                   \
-    acc[XL] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(XL) & 1][3], bv[(XL) & 1][3], acc[XL], 0, 0, 0);                   \
-    __builtin_amdgcn_sched_barrier(0);                                                                                    \
-  }
-  // a raw piece: unconditional load of an in-image address, zero rows by AND-ing the bit pattern (a select would let hipcc
-  // sink the load into a branch; a multiply would leak NaNs)
-#define WN_LOAD_RAW(I, JJ, CH)                                                                                            \
-  {                                                                                                                       \
-    const int off_ = raw_g[I][JJ];                                                                                        \
-    const int m_ = ~(off_ >> 31);                                                                                         \
-    WN_EXP_LOAD(raw_b[I][JJ] = *reinterpret_cast<const i32x4*>(xn + (off_ & m_) + (CH) * WN_CK);)                         \
-  }
-  // ... and its use: zero rows are masked when the value is consumed, so that nothing touches a load's result early
-#define WN_RAW(I, JJ) __builtin_bit_cast(f32x4, raw_b[I][JJ] & ~(raw_g[I][JJ] >> 31))
+
   const int nchunks = a.C / WN_CK;
-  f32x4 av[2], bv[2];
-  WN_FETCH(0)
-  WN_U_TO_LDS(0, lds)
-  WN_TRANSFORM_STAGE(lds)
-  WN_FETCH(min(1, nchunks - 1))
+  f32x4 av[2], bv[2], tt[4];
+  // prologue: raw(0), raw(1), U(0) -> LDS; V(0) from raw(0)
+  WN_RAW_ALL(0)
+  WN_RAW_ALL(min(1, nchunks - 1))
+  WN_U_ALL(0, lds)
+  __syncthreads();
+  {
+    const float* rb = rawbase;
+    float* vb = lds + t_wr;
+    WN_TROW(0, rb) WN_TROW(1, rb) WN_TROW(2, rb) WN_TROW(3, rb)
+    *reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = tt[0] - tt[2];
+    *reinterpret_cast<f32x4*>(vb + 1 * 4 * WN_PLANE) = tt[1] + tt[2];
+    *reinterpret_cast<f32x4*>(vb + 2 * 4 * WN_PLANE) = tt[2] - tt[1];
+    *reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = tt[1] - tt[3];
+  }
   __syncthreads();
   for (int ch = 0; ch + 1 < nchunks; ++ch) {
     float* cur = lds + (ch & 1) * BUF;
     float* nxt = lds + ((ch + 1) & 1) * BUF;
     const int chf = min(ch + 2, nchunks - 1);        // beyond the end: a harmless re-fetch of the last chunk (no branch)
-    f32x4 tt[4];
+    const float* rb = rawbase + ((ch + 1) & 1) * RAWBUF;
     float* vb = nxt + t_wr;
-    // Schedule: ONE small piece of side work behind EVERY MFMA (a piece runs in the 64-cycle shadow of the MFMA it follows;
-    // a long piece would stall the wave's next MFMA while its partner on the SIMD is doing the same thing).  U of the next
-    // chunk first (LDS DMA); the raw registers are consumed late (planes 4-5) and re-loaded for chunk ch+2 right after
-    // (planes 6-7): those loads stay in flight across the barrier, which waits for everything except the 8 newest
-    // loads (vmcnt(8): the U pieces are older) and for this wave's LDS traffic.
     WN_LOAD_FRAGS(0)
     WN_M(0, 0, WN_LOAD_FRAGS(1)) WN_M(0, 1, WN_U_PIECE(0, ch + 1, nxt) WN_U_PIECE(1, ch + 1, nxt))
-    WN_M(0, 2, WN_U_PIECE(2, ch + 1, nxt) WN_U_PIECE(3, ch + 1, nxt)) WN_M(0, 3, )
-    WN_M(1, 0, WN_LOAD_FRAGS(2)) WN_M(1, 1, ) WN_M(1, 2, ) WN_M(1, 3, )
-    WN_M(2, 0, WN_LOAD_FRAGS(3)) WN_M(2, 1, ) WN_M(2, 2, ) WN_M(2, 3, )
-    WN_M(3, 0, WN_LOAD_FRAGS(4)) WN_M(3, 1, ) WN_M(3, 2, ) WN_M(3, 3, )
-    WN_M(4, 0, WN_LOAD_FRAGS(5))
-    WN_M(4, 1, tt[0] = sg0 * WN_RAW(0, 0) + sg1 * WN_RAW(0, 1);)
-    WN_M(4, 2, tt[1] = sg0 * WN_RAW(1, 0) + sg1 * WN_RAW(1, 1);)
-    WN_M(4, 3, tt[2] = sg0 * WN_RAW(2, 0) + sg1 * WN_RAW(2, 1);)
-    WN_M(5, 0, WN_LOAD_FRAGS(6))
-    WN_M(5, 1, tt[3] = sg0 * WN_RAW(3, 0) + sg1 * WN_RAW(3, 1);)
-    WN_M(5, 2, *reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = tt[0] - tt[2];)
-    WN_M(5, 3, *reinterpret_cast<f32x4*>(vb + 1 * 4 * WN_PLANE) = tt[1] + tt[2];)
-    WN_M(6, 0, WN_LOAD_FRAGS(7))
-    WN_M(6, 1, *reinterpret_cast<f32x4*>(vb + 2 * 4 * WN_PLANE) = tt[2] - tt[1];)
-    WN_M(6, 2, *reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = tt[1] - tt[3];)
-    WN_M(6, 3, WN_LOAD_RAW(0, 0, chf) WN_LOAD_RAW(0, 1, chf))
-    WN_M(7, 0, WN_LOAD_RAW(1, 0, chf) WN_LOAD_RAW(1, 1, chf))
-    WN_M(7, 1, WN_LOAD_RAW(2, 0, chf) WN_LOAD_RAW(2, 1, chf))
-    WN_M(7, 2, WN_LOAD_RAW(3, 0, chf) WN_LOAD_RAW(3, 1, chf))
-    WN_M(7, 3, )
-#ifndef WN_EXP_NOBARRIER
-    asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    WN_M(0, 2, WN_U_PIECE(2, ch + 1, nxt) WN_U_PIECE(3, ch + 1, nxt))
+    // raw(ch+2) overwrites raw(ch), which every wave finished reading before the last barrier
+    WN_M(0, 3, if (ch + 2 < nchunks) WN_RAW_ALL(ch + 2))
+    WN_M(1, 0, WN_LOAD_FRAGS(2)) WN_M(1, 1, WN_TROW(0, rb)) WN_M(1, 2, ) WN_M(1, 3, WN_TROW(1, rb))
+    WN_M(2, 0, WN_LOAD_FRAGS(3)) WN_M(2, 1, WN_TROW(2, rb)) WN_M(2, 2, ) WN_M(2, 3, WN_TROW(3, rb))
+    WN_M(3, 0, WN_LOAD_FRAGS(4)) WN_M(3, 1, ) WN_M(3, 2, *reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = tt[0] - tt[2];) WN_M(3, 3, )
+    WN_M(4, 0, WN_LOAD_FRAGS(5)) WN_M(4, 1, ) WN_M(4, 2, *reinterpret_cast<f32x4*>(vb + 1 * 4 * WN_PLANE) = tt[1] + tt[2];) WN_M(4, 3, )
+    WN_M(5, 0, WN_LOAD_FRAGS(6)) WN_M(5, 1, ) WN_M(5, 2, *reinterpret_cast<f32x4*>(vb + 2 * 4 * WN_PLANE) = tt[2] - tt[1];) WN_M(5, 3, )
+    WN_M(6, 0, WN_LOAD_FRAGS(7)) WN_M(6, 1, ) WN_M(6, 2, *reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = tt[1] - tt[3];) WN_M(6, 3, )
+    WN_M(7, 0, ) WN_M(7, 1, ) WN_M(7, 2, ) WN_M(7, 3, )
+    (void)chf;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-#endif
     __builtin_amdgcn_sched_barrier(0);
   }
   {
     float* cur = lds + ((nchunks - 1) & 1) * BUF;
     WN_LOAD_FRAGS(0)
-#pragma unroll
-    for (int xl = 0; xl < 8; ++xl) WN_PLANE_STEP(xl, {})
+    WN_M(0, 0, WN_LOAD_FRAGS(1)) WN_M(0, 1, ) WN_M(0, 2, ) WN_M(0, 3, )
+    WN_M(1, 0, WN_LOAD_FRAGS(2)) WN_M(1, 1, ) WN_M(1, 2, ) WN_M(1, 3, )
+    WN_M(2, 0, WN_LOAD_FRAGS(3)) WN_M(2, 1, ) WN_M(2, 2, ) WN_M(2, 3, )
+    WN_M(3, 0, WN_LOAD_FRAGS(4)) WN_M(3, 1, ) WN_M(3, 2, ) WN_M(3, 3, )
+    WN_M(4, 0, WN_LOAD_FRAGS(5)) WN_M(4, 1, ) WN_M(4, 2, ) WN_M(4, 3, )
+    WN_M(5, 0, WN_LOAD_FRAGS(6)) WN_M(5, 1, ) WN_M(5, 2, ) WN_M(5, 3, )
+    WN_M(6, 0, WN_LOAD_FRAGS(7)) WN_M(6, 1, ) WN_M(6, 2, ) WN_M(6, 3, )
+    WN_M(7, 0, ) WN_M(7, 1, ) WN_M(7, 2, ) WN_M(7, 3, )
   }
   __syncthreads();
-#undef WN_PLANE_STEP
-#undef WN_M
+#undef WN_GLDS
 #undef WN_U_PIECE
+#undef WN_RAW_PIECE
+#undef WN_RAW_ALL
+#undef WN_U_ALL
+#undef WN_TROW
 #undef WN_LOAD_FRAGS
-#undef WN_LOAD_RAW
-#undef WN_RAW
-#undef WN_RAW_
-#undef WN_FETCH
-#undef WN_U_TO_LDS
-#undef WN_TRANSFORM_STAGE
+#undef WN_M
 
   // Output transform.  This wave holds M[a][b] for a = 2xh, 2xh+1 (acc[(a - 2xh) * 4 + b]).  Column pass (over b):
   //   P[a][0] = M[a][0] + M[a][1] + M[a][2],  P[a][1] = M[a][1] - M[a][2] - M[a][3]
@@ -398,9 +370,7 @@ extern "C" int dl_wino_conv3x3_nhwc_f32(const float* x, const float* u, float* y
   WinoArgs a{x, u, y, add, dsrc, N, H, W, C, K, act, epilogue};
   hipStream_t st = (hipStream_t)stream;
   const int tw = W / 2, th = H / 2;
-  if (tw % 64 == 0) {
-    hipLaunchKernelGGL(k_wino_conv<64>, dim3(N * th * (tw / 64) * (K / WN_KB)), dim3(WN_THREADS), 0, st, a);
-  } else if (tw % 32 == 0 && th % 2 == 0) {
+  if (tw % 32 == 0 && th % 2 == 0) {
     hipLaunchKernelGGL(k_wino_conv<32>, dim3(N * (th / 2) * (tw / 32) * (K / WN_KB)), dim3(WN_THREADS), 0, st, a);
   } else if (tw % 16 == 0 && th % 4 == 0) {
     hipLaunchKernelGGL(k_wino_conv<16>, dim3(N * (th / 4) * (tw / 16) * (K / WN_KB)), dim3(WN_THREADS), 0, st, a);

@@ -75,7 +75,7 @@ def wino_ok(H, W, C, K):
     if H % 2 or W % 2 or C % 8 or K % 64:
         return False
     th, tw = H // 2, W // 2
-    return tw % 64 == 0 or (tw % 32 == 0 and th % 2 == 0) or (tw % 16 == 0 and th % 4 == 0)
+    return (tw % 32 == 0 and th % 2 == 0) or (tw % 16 == 0 and th % 4 == 0)
 
 
 def wino_weights(w_param, want_fwd=True, want_bwd=True):

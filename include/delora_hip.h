@@ -261,7 +261,7 @@ int dl_conv2d_wgrad_nhwc_f32(const float* x, const float* g, float* dw, void* wo
  *                        dl_wino_weights_floats; either may be NULL).  Run once per optimiser step.
  *   dl_wino_conv3x3_nhwc_f32: x [N][H][W][C], u = u_fwd of the layer -> y [N][H][W][K]; for the input gradient pass the
  *                        output gradient as x, u = u_bwd and swap C and K.  epilogue / act / add / dsrc as above.
- *   Shapes: H, W even; C % 8 == 0; K % 64 == 0; W/2 a multiple of 64, or of 32 with H/2 even, or of 16 with H/2 % 4 == 0.
+ *   Shapes: H, W even; C % 8 == 0; K % 64 == 0; W/2 a multiple of 32 with H/2 even, or of 16 with H/2 % 4 == 0.
  */
 size_t dl_wino_weights_floats(int32_t K, int32_t C);
 int dl_wino_weights_f32(const float* w, float* u_fwd, float* u_bwd, int32_t K, int32_t C, dl_stream stream);

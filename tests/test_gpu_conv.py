@@ -73,7 +73,7 @@ def test_conv_forward_and_both_gradients_against_torch(shape):
         util.measured(f"{tag}: fused (dgrad + g) * tanh' vs torch (relative)", _rel(dx2, ref), bound=REL)
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 128, 64, 64), (1, 4, 64, 128, 128), (2, 8, 32, 64, 128), (1, 6, 256, 64, 64), (1, 32, 64, 512, 512)])
+@pytest.mark.parametrize("shape", [(2, 8, 128, 64, 64), (1, 4, 64, 128, 128), (2, 8, 32, 64, 128), (1, 8, 256, 64, 64), (1, 32, 64, 512, 512)])
 def test_winograd_forward_and_input_gradient_against_torch(shape):
     """Fused Winograd F(2x2,3x3) (csrc/wino.hip) against torch's direct convolution of the wrapped image: forward with the
     fused shortcut + tanh, input gradient with the fused activation derivative; all three tile layouts."""
