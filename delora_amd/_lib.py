@@ -52,6 +52,8 @@ SIGNATURES = {
     "dl_ring_act_pad_fwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "dl_ring_act_pad_bwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "dl_conv2d_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _u32, _vp]),
+    "dl_conv2d_dgrad_strided_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                                _u32, _vp]),
     "dl_conv2d_wgrad_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "dl_conv2d_wgrad_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dl_wino_weights_floats": (_sz, [_i32, _i32]),

@@ -36,6 +36,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define CV_EPI_ADD 1u    // v += add[pixel][k]
 #define CV_EPI_ACT 2u    // v = act(v)
 #define CV_EPI_DACT 4u   // v *= act'(dsrc[pixel][k]), dsrc = saved forward OUTPUT of the activation
+#define CV_EPI_ADD_GRID 8u   // v += add[grid pixel][k]: add is indexed on the dense class grid (strided input gradients)
 #define CV_ACT_NONE 0
 #define CV_ACT_TANH 1
 #define CV_ACT_RELU 2
@@ -70,16 +71,57 @@ __device__ __forceinline__ int cv_xcd_swizzle(int id, int n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-template <int BM, int BN, int CK, int TW, int SH, int SW, int KS, bool BT, int WGN>
+// Geometry policies: which offsets of the staged input tile feed which weight tap, and where an output pixel goes.
+//   GeomConv<KS, SH, SW>            the layer itself: output (ho, wo) reads input (ho*SH + r - PAD, wo*SW + s - PAD).
+//   GeomDgrad<KS, SH, SW, PH, PW, SO> its input gradient for the input pixels (SH*i + PH, SW*j + PW): a stride-1 pass over
+//       the OUTPUT-gradient grid with the subset of taps whose stride phase matches -- r with (PH + PAD - r) % SH == 0
+//       reads grid row i + (PH + PAD - r) / SH -- so a strided layer's input gradient is SH*SW such passes, each doing
+//       exactly the multiplications that are not zeros (no zero-stuffed tensor).  SO: scatter the result into the
+//       full-resolution image (stride SH, SW, phase PH, PW) or keep it dense on the grid.
+template <int KS_, int SH_, int SW_>
+struct GeomConv {
+  static constexpr int NT = KS_ * KS_, WTAPS = KS_ * KS_, ISH = SH_, ISW = SW_;
+  static constexpr int H0 = -((KS_ - 1) / 2), W0 = -((KS_ - 1) / 2), EH = KS_, EW = KS_;
+  static constexpr int OSH = 1, OSW = 1, OPH = 0, OPW = 0;
+  static constexpr int dh(int t) { return t / KS_; }
+  static constexpr int dw(int t) { return t % KS_; }
+  static constexpr int wt(int t) { return t; }
+};
+
+template <int KS_, int S_, int P_>
+struct DgradAxis {                                 // one axis of GeomDgrad: valid taps and their grid offsets
+  static constexpr int PAD = (KS_ - 1) / 2;
+  static constexpr bool valid(int r) { return (P_ + PAD - r) % S_ == 0; }
+  static constexpr int off(int r) { return (P_ + PAD - r) / S_; }
+  static constexpr int count() { int n = 0; for (int r = 0; r < KS_; ++r) n += valid(r) ? 1 : 0; return n; }
+  static constexpr int tap(int i) { int n = 0; for (int r = 0; r < KS_; ++r) if (valid(r)) { if (n == i) return r; ++n; } return 0; }
+  static constexpr int lo() { int m = 99; for (int r = 0; r < KS_; ++r) if (valid(r) && off(r) < m) m = off(r); return m; }
+  static constexpr int hi() { int m = -99; for (int r = 0; r < KS_; ++r) if (valid(r) && off(r) > m) m = off(r); return m; }
+};
+
+template <int KS_, int SH_, int SW_, int PH_, int PW_, bool SO_>
+struct GeomDgrad {
+  using AH = DgradAxis<KS_, SH_, PH_>;
+  using AW = DgradAxis<KS_, SW_, PW_>;
+  static constexpr int NR = AH::count(), NS = AW::count();
+  static constexpr int NT = NR * NS, WTAPS = KS_ * KS_, ISH = 1, ISW = 1;
+  static constexpr int H0 = AH::lo(), W0 = AW::lo(), EH = AH::hi() - AH::lo() + 1, EW = AW::hi() - AW::lo() + 1;
+  static constexpr int OSH = SO_ ? SH_ : 1, OSW = SO_ ? SW_ : 1, OPH = SO_ ? PH_ : 0, OPW = SO_ ? PW_ : 0;
+  static constexpr int dh(int t) { return AH::off(AH::tap(t / NS)) - H0; }
+  static constexpr int dw(int t) { return AW::off(AW::tap(t % NS)) - W0; }
+  static constexpr int wt(int t) { return AH::tap(t / NS) * KS_ + AW::tap(t % NS); }
+};
+
+template <int BM, int BN, int CK, int TW, class G, bool BT, int WGN>
 #ifndef CV_MINWAVES
 #define CV_MINWAVES 2
 #endif
 __global__ __launch_bounds__(CV_THREADS, CV_MINWAVES) void k_conv_f32(ConvArgs a) {
   constexpr int TH = BM / TW;
-  constexpr int PAD = (KS - 1) / 2;
-  constexpr int RH = (TH - 1) * SH + KS, RW = (TW - 1) * SW + KS;
+  constexpr int SH = G::ISH, SW = G::ISW;
+  constexpr int RH = (TH - 1) * SH + G::EH, RW = (TW - 1) * SW + G::EW;
   constexpr int S = CK + 4;                       // floats per staged pixel: 4*odd for CK = 8, 16, 32
-  constexpr int TAPS = KS * KS;
+  constexpr int TAPS = G::NT;
   constexpr int C4 = CK / 4;
   constexpr int IN_FLOATS = RH * RW * S;
   constexpr int W_FLOATS = BT ? TAPS * CK * BN : TAPS * BN * S;
@@ -89,9 +131,11 @@ __global__ __launch_bounds__(CV_THREADS, CV_MINWAVES) void k_conv_f32(ConvArgs a
   constexpr int WGM = 4 / WGN;
   constexpr int WM = BM / 32 / WGM, WN = BN / 32 / WGN;
   static_assert(BM % TW == 0 && BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0 && CK % 8 == 0, "tile shape");
-  static_assert(!BT || (SH == 1 && SW == 1), "transposed weights: stride 1 only");
+  static_assert(TAPS > 0, "a stride phase without taps has no launch");
   static_assert((S / 4) % 2 == 1, "pixel stride must be 4*odd floats");
-  __shared__ __attribute__((aligned(16))) float lds[IN_FLOATS + W_FLOATS];
+  constexpr int EPW = WN * 32, ES = EPW + 4;        // epilogue staging: floats per pixel row (+4: the halves hit different banks)
+  constexpr int LDS_FLOATS = IN_FLOATS + W_FLOATS > 4 * 32 * ES ? IN_FLOATS + W_FLOATS : 4 * 32 * ES;
+  __shared__ __attribute__((aligned(16))) float lds[LDS_FLOATS];
   float* in_lds = lds;
   float* w_lds = lds + IN_FLOATS;
 
@@ -108,7 +152,7 @@ __global__ __launch_bounds__(CV_THREADS, CV_MINWAVES) void k_conv_f32(ConvArgs a
   const int th_i = pt % tiles_h;
   const int n = pt / tiles_h;
   const int ho0 = th_i * TH, wo0 = tw_i * TW, k0 = kt * BN;
-  const int h_base = ho0 * SH - PAD, w_base = wo0 * SW - PAD;
+  const int h_base = ho0 * SH + G::H0, w_base = wo0 * SW + G::W0;
   const float* xn = a.x + (size_t)n * a.H * a.W * a.C;
 
   // chunk-invariant staging offsets (element offsets relative to xn / a.w, without the channel chunk).  Item ids beyond
@@ -133,12 +177,12 @@ __global__ __launch_bounds__(CV_THREADS, CV_MINWAVES) void k_conv_f32(ConvArgs a
     if (!BT) {
       const int c4 = q % C4, t2 = q / C4;
       const int tap = t2 % TAPS, kk = t2 / TAPS;
-      w_g[it] = ((k0 + kk) * TAPS + tap) * a.C + c4 * 4;
+      w_g[it] = ((k0 + kk) * G::WTAPS + G::wt(tap)) * a.C + c4 * 4;
       w_l[it] = (tap * BN + kk) * S + c4 * 4;
     } else {
       const int co4 = q % (BN / 4), t2 = q / (BN / 4);
       const int tap = t2 % TAPS, kr = t2 / TAPS;
-      w_g[it] = (kr * TAPS + (TAPS - 1 - tap)) * a.K + k0 + co4 * 4;      // + c0 * TAPS * K per chunk
+      w_g[it] = (kr * G::WTAPS + G::wt(tap)) * a.K + k0 + co4 * 4;        // + c0 * WTAPS * K per chunk
       w_l[it] = (tap * CK + kr) * BN + co4 * 4;
     }
   }
@@ -176,7 +220,7 @@ __global__ __launch_bounds__(CV_THREADS, CV_MINWAVES) void k_conv_f32(ConvArgs a
       in_r[it] = in ? v : (f32x4){0.f, 0.f, 0.f, 0.f};                                                                    \
     }                                                                                                                     \
     _Pragma("unroll") for (int it = 0; it < NW_IT; ++it) w_r[it] = *reinterpret_cast<const f32x4*>(                       \
-        a.w + (BT ? (size_t)w_g[it] + (size_t)(C0) * TAPS * a.K : (size_t)w_g[it] + (C0)));                               \
+        a.w + (BT ? (size_t)w_g[it] + (size_t)(C0) * G::WTAPS * a.K : (size_t)w_g[it] + (C0)));                               \
   }
 #define CV_STAGE()                                                                                                        \
   {                                                                                                                       \
@@ -193,13 +237,12 @@ __global__ __launch_bounds__(CV_THREADS, CV_MINWAVES) void k_conv_f32(ConvArgs a
 #ifdef CV_OLD_LOOP
 #pragma unroll
     for (int tap = 0; tap < TAPS; ++tap) {
-      const int r = tap / KS, s = tap % KS;
 #pragma unroll
       for (int kq = 0; kq < CK / 8; ++kq) {
         float4 af[WM];
 #pragma unroll
         for (int mi = 0; mi < WM; ++mi)
-          af[mi] = *reinterpret_cast<const float4*>(in_lds + a_off[mi] + (r * RW + s) * S + kq * 8);
+          af[mi] = *reinterpret_cast<const float4*>(in_lds + a_off[mi] + (G::dh(tap) * RW + G::dw(tap)) * S + kq * 8);
         float bf[WN][4];
 #pragma unroll
         for (int ni = 0; ni < WN; ++ni) {
@@ -230,10 +273,9 @@ __global__ __launch_bounds__(CV_THREADS, CV_MINWAVES) void k_conv_f32(ConvArgs a
     float bf[2][WN][4];
     auto load_frags = [&](int step, int buf) {
       const int tap = step / KQ, kq = step % KQ;
-      const int r = tap / KS, s = tap % KS;
 #pragma unroll
       for (int mi = 0; mi < WM; ++mi)
-        af[buf][mi] = *reinterpret_cast<const float4*>(in_lds + a_off[mi] + (r * RW + s) * S + kq * 8);
+        af[buf][mi] = *reinterpret_cast<const float4*>(in_lds + a_off[mi] + (G::dh(tap) * RW + G::dw(tap)) * S + kq * 8);
 #pragma unroll
       for (int ni = 0; ni < WN; ++ni) {
         const int col = (wn * WN + ni) * 32 + li;
@@ -279,12 +321,11 @@ __global__ __launch_bounds__(CV_THREADS, CV_MINWAVES) void k_conv_f32(ConvArgs a
   // buffers are free now) so that a lane owns FOUR consecutive channels of one pixel: the elementwise tail then runs on
   // float4s in a rolled loop (compact code: the tanh expansion exists once) with 16-byte loads of the shortcut / saved
   // activation and 16-byte stores of whole 128/256-byte channel rows.
-  constexpr int EW = WN * 32, ES = EW + 4;              // floats per staged pixel row (+4: the two halves hit different banks)
-  static_assert(4 * 32 * ES <= IN_FLOATS + W_FLOATS, "epilogue staging must fit the main-loop LDS");
   __syncthreads();                                       // every wave is done with the last chunk's fragments
   float* ep = lds + wave * (32 * ES);
-  const size_t out_n = (size_t)n * a.Ho * a.Wo;
+  const size_t out_n = (size_t)n * (a.Ho * G::OSH) * (a.Wo * G::OSW), grid_n = (size_t)n * a.Ho * a.Wo;
   const bool f_add = a.epi & CV_EPI_ADD, f_act = a.epi & CV_EPI_ACT, f_dact = a.epi & CV_EPI_DACT;
+  const bool f_addg = a.epi & CV_EPI_ADD_GRID;
 #pragma unroll
   for (int mi = 0; mi < WM; ++mi) {
 #pragma unroll
@@ -293,12 +334,17 @@ __global__ __launch_bounds__(CV_THREADS, CV_MINWAVES) void k_conv_f32(ConvArgs a
       for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * half) * ES + ni * 32 + li] = acc[mi][ni][r];
     // same-wave LDS traffic is ordered; the compiler inserts the lgkmcnt wait before the reads below
 #pragma unroll 2
-    for (int q = lane; q < 32 * (EW / 4); q += 64) {
-      const int row = q / (EW / 4), c4 = q % (EW / 4);
+    for (int q = lane; q < 32 * (EPW / 4); q += 64) {
+      const int row = q / (EPW / 4), c4 = q % (EPW / 4);
       const int p = (wm * WM + mi) * 32 + row;
       const int th = p / TW, tw = p % TW;
-      const size_t o = (out_n + (size_t)(ho0 + th) * a.Wo + (wo0 + tw)) * a.K + k0 + wn * EW + c4 * 4;
+      const size_t o = (out_n + (size_t)((ho0 + th) * G::OSH + G::OPH) * (a.Wo * G::OSW) + ((wo0 + tw) * G::OSW + G::OPW)) * a.K +
+                       k0 + wn * EPW + c4 * 4;
       float4 v = *reinterpret_cast<const float4*>(ep + row * ES + c4 * 4);
+      if (f_addg) {        // an addend that lives on the dense (sub-sampled) grid: the down-sampling branch's gradient
+        const float4 t = *reinterpret_cast<const float4*>(a.add + (grid_n + (size_t)(ho0 + th) * a.Wo + (wo0 + tw)) * a.K + k0 + wn * EPW + c4 * 4);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
       if (f_add) {
         const float4 t = *reinterpret_cast<const float4*>(a.add + o);
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
@@ -475,12 +521,12 @@ __global__ __launch_bounds__(CV_THREADS) void k_wgrad_reduce(const float* __rest
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 
-template <int BM, int BN, int CK, int TW, int SH, int SW, int KS, bool BT, int WGN>
+template <int BM, int BN, int CK, int TW, class G, bool BT, int WGN>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
   constexpr int TH = BM / TW;
   if (a.Wo % TW || a.Ho % TH || a.K % BN || a.C % CK) return 1;
   const int ntiles = a.N * (a.Ho / TH) * (a.Wo / TW) * (a.K / BN);
-  hipLaunchKernelGGL((k_conv_f32<BM, BN, CK, TW, SH, SW, KS, BT, WGN>), dim3(ntiles), dim3(CV_THREADS), 0, st, a);
+  hipLaunchKernelGGL((k_conv_f32<BM, BN, CK, TW, G, BT, WGN>), dim3(ntiles), dim3(CV_THREADS), 0, st, a);
   return 0;
 }
 
@@ -497,30 +543,29 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
 #ifdef CV_TUNE
 // tuning build (tools/conv_harness): the tile variant of the stride-1 3x3 kernels is chosen at run time
 int g_cv_variant = 0;
-template <int SH, int SW, int KS, bool BT, int BM, int BN, int CKK, int WGNN>
+template <class G, bool BT, int BM, int BN, int CKK, int WGNN>
 static int variant_conv(const ConvArgs& a, hipStream_t st) {
-  constexpr int ROWS128 = BM / 128, ROWS64 = BM / 64, ROWS32 = BM / 32;
-  (void)ROWS128; (void)ROWS64; (void)ROWS32;
-  if (a.Wo % 128 == 0 && !launch_conv<BM, BN, CKK, 128, SH, SW, KS, BT, WGNN>(a, st)) return 0;
-  if (a.Wo % 64 == 0 && !launch_conv<BM, BN, CKK, 64, SH, SW, KS, BT, WGNN>(a, st)) return 0;
+  if (a.Wo % 128 == 0 && !launch_conv<BM, BN, CKK, 128, G, BT, WGNN>(a, st)) return 0;
+  if (a.Wo % 64 == 0 && !launch_conv<BM, BN, CKK, 64, G, BT, WGNN>(a, st)) return 0;
   return 1;
 }
 #endif
 
-template <int SH, int SW, int KS, bool BT>
+// G: geometry policy; BIG: a stride-1 3x3 pass (the layer, or its input gradient) that may take the 256-pixel tiles
+template <class G, bool BT, bool BIG>
 static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
 #ifdef CV_TUNE
-  if (SH == 1 && SW == 1 && KS == 3) {
+  if constexpr (BIG) {
     switch (g_cv_variant) {
-      case 1: return variant_conv<1, 1, 3, BT, 128, 64, 8, 2>(a, st);
-      case 2: return variant_conv<1, 1, 3, BT, 128, 64, 32, 2>(a, st);
-      case 3: return variant_conv<1, 1, 3, BT, 128, 128, 8, 2>(a, st);
-      case 4: return variant_conv<1, 1, 3, BT, 128, 128, 16, 2>(a, st);
-      case 5: return variant_conv<1, 1, 3, BT, 256, 64, 8, 1>(a, st);
-      case 6: return variant_conv<1, 1, 3, BT, 256, 64, 16, 1>(a, st);
-      case 7: return variant_conv<1, 1, 3, BT, 256, 128, 8, 2>(a, st);
-      case 8: return variant_conv<1, 1, 3, BT, 128, 64, 16, 1>(a, st);
-      case 9: return variant_conv<1, 1, 3, BT, 256, 128, 16, 2>(a, st);
+      case 1: return variant_conv<G, BT, 128, 64, 8, 2>(a, st);
+      case 2: return variant_conv<G, BT, 128, 64, 32, 2>(a, st);
+      case 3: return variant_conv<G, BT, 128, 128, 8, 2>(a, st);
+      case 4: return variant_conv<G, BT, 128, 128, 16, 2>(a, st);
+      case 5: return variant_conv<G, BT, 256, 64, 8, 1>(a, st);
+      case 6: return variant_conv<G, BT, 256, 64, 16, 1>(a, st);
+      case 7: return variant_conv<G, BT, 256, 128, 8, 2>(a, st);
+      case 8: return variant_conv<G, BT, 128, 64, 16, 1>(a, st);
+      case 9: return variant_conv<G, BT, 256, 128, 16, 2>(a, st);
       default: break;
     }
   }
@@ -530,18 +575,18 @@ static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
   // 8-channel chunks (3 workgroups per CU) for the shallow layers and 16-channel chunks for C >= 256; strided and 1x1
   // layers and images that do not tile by 256 pixels take 128-pixel tiles.  Tile width = the widest of 128 / 64 / 32 that
   // divides the output row; narrow images take several rows per tile.
-  if constexpr (SH == 1 && SW == 1 && KS == 3) {
+  if constexpr (BIG) {
     if (a.C >= 256) {
-      if (a.Wo % 128 == 0 && !launch_conv<256, 64, 16, 128, SH, SW, KS, BT, 1>(a, st)) return 0;
-      if (a.Wo % 64 == 0 && !launch_conv<256, 64, 16, 64, SH, SW, KS, BT, 1>(a, st)) return 0;
+      if (a.Wo % 128 == 0 && !launch_conv<256, 64, 16, 128, G, BT, 1>(a, st)) return 0;
+      if (a.Wo % 64 == 0 && !launch_conv<256, 64, 16, 64, G, BT, 1>(a, st)) return 0;
     } else {
-      if (a.Wo % 128 == 0 && !launch_conv<256, 64, 8, 128, SH, SW, KS, BT, 1>(a, st)) return 0;
-      if (a.Wo % 64 == 0 && !launch_conv<256, 64, 8, 64, SH, SW, KS, BT, 1>(a, st)) return 0;
+      if (a.Wo % 128 == 0 && !launch_conv<256, 64, 8, 128, G, BT, 1>(a, st)) return 0;
+      if (a.Wo % 64 == 0 && !launch_conv<256, 64, 8, 64, G, BT, 1>(a, st)) return 0;
     }
   }
-  if (a.Wo % 128 == 0 && !launch_conv<128, CV_BN, CV_CK, 128, SH, SW, KS, BT, CV_WGN>(a, st)) return 0;
-  if (a.Wo % 64 == 0 && !launch_conv<128, CV_BN, CV_CK, 64, SH, SW, KS, BT, CV_WGN>(a, st)) return 0;
-  if (a.Wo % 32 == 0 && !launch_conv<128, CV_BN, CV_CK, 32, SH, SW, KS, BT, CV_WGN>(a, st)) return 0;
+  if (a.Wo % 128 == 0 && !launch_conv<128, CV_BN, CV_CK, 128, G, BT, CV_WGN>(a, st)) return 0;
+  if (a.Wo % 64 == 0 && !launch_conv<128, CV_BN, CV_CK, 64, G, BT, CV_WGN>(a, st)) return 0;
+  if (a.Wo % 32 == 0 && !launch_conv<128, CV_BN, CV_CK, 32, G, BT, CV_WGN>(a, st)) return 0;
   return 1;
 }
 
@@ -551,8 +596,8 @@ extern "C" int dl_conv2d_nhwc_f32(const float* x, const float* w, float* y, cons
                                   int32_t stride_w, int32_t transposed, int32_t act, uint32_t epilogue, dl_stream stream) {
   if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_nhwc_f32: bad argument");
-  if (((epilogue & CV_EPI_ADD) && !add) || ((epilogue & CV_EPI_DACT) && !dsrc) || act < 0 || act > 2)
-    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_nhwc_f32: epilogue operand missing / bad activation");
+  if (((epilogue & CV_EPI_ADD) && !add) || ((epilogue & CV_EPI_DACT) && !dsrc) || act < 0 || act > 2 || (epilogue & ~7u))
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_nhwc_f32: epilogue operand missing / bad activation or flag");
   if (H % stride_h || W % stride_w)
     return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_f32: image size must be a multiple of the stride");
   if ((size_t)N * H * W * C >= ((size_t)1 << 31) || (size_t)N * H * W * K >= ((size_t)1 << 31))
@@ -560,16 +605,59 @@ extern "C" int dl_conv2d_nhwc_f32(const float* x, const float* w, float* y, cons
   ConvArgs a{x, w, y, add, dsrc, N, H, W, C, K, H / stride_h, W / stride_w, act, epilogue};
   hipStream_t st = (hipStream_t)stream;
   int rc = 1;
-  if (ksize == 3 && stride_h == 1 && stride_w == 1) rc = transposed ? dispatch_conv<1, 1, 3, true>(a, st) : dispatch_conv<1, 1, 3, false>(a, st);
-  else if (transposed) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_f32: transposed weights need stride 1, 3x3");
-  else if (ksize == 3 && stride_h == 1 && stride_w == 2) rc = dispatch_conv<1, 2, 3, false>(a, st);
-  else if (ksize == 3 && stride_h == 2 && stride_w == 2) rc = dispatch_conv<2, 2, 3, false>(a, st);
-  else if (ksize == 1 && stride_h == 1 && stride_w == 2) rc = dispatch_conv<1, 2, 1, false>(a, st);
-  else if (ksize == 1 && stride_h == 2 && stride_w == 2) rc = dispatch_conv<2, 2, 1, false>(a, st);
+  if (ksize == 3 && stride_h == 1 && stride_w == 1)
+    rc = transposed ? dispatch_conv<GeomDgrad<3, 1, 1, 0, 0, false>, true, true>(a, st) : dispatch_conv<GeomConv<3, 1, 1>, false, true>(a, st);
+  else if (transposed) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_f32: transposed weights need stride 1, 3x3 (strided layers: dl_conv2d_dgrad_strided_nhwc_f32)");
+  else if (ksize == 3 && stride_h == 1 && stride_w == 2) rc = dispatch_conv<GeomConv<3, 1, 2>, false, false>(a, st);
+  else if (ksize == 3 && stride_h == 2 && stride_w == 2) rc = dispatch_conv<GeomConv<3, 2, 2>, false, false>(a, st);
+  else if (ksize == 1 && stride_h == 1 && stride_w == 2) rc = dispatch_conv<GeomConv<1, 1, 2>, false, false>(a, st);
+  else if (ksize == 1 && stride_h == 2 && stride_w == 2) rc = dispatch_conv<GeomConv<1, 2, 2>, false, false>(a, st);
   else return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_f32: kernel %d stride (%d,%d) is not built", ksize, stride_h, stride_w);
   if (rc) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_f32: shape N=%d H=%d W=%d C=%d K=%d does not tile (Wo %% 32, K %% %d, C %% %d)",
                          N, H, W, C, K, CV_BN, CV_CK);
   return dl_check_launch("dl_conv2d_nhwc_f32");
+}
+
+// One stride phase of a strided layer's input gradient (GeomDgrad): g [N][Ho][Wo][K] -> the pixels (SH*i + PH, SW*j + PW)
+// of dx [N][Ho*SH][Wo*SW][C].
+template <int KS, int SH, int SW, int PH, int PW>
+static int dgrad_phase(ConvArgs a, bool first_phase, hipStream_t st) {
+  using G = GeomDgrad<KS, SH, SW, PH, PW, true>;
+  if (!first_phase) a.epi &= ~CV_EPI_ADD_GRID;       // the down-sampling branch's gradient lives on phase (0,0) only
+  if constexpr (G::NT > 0) return dispatch_conv<G, true, false>(a, st);
+  return 1;
+}
+
+/* see include/delora_hip.h */
+extern "C" int dl_conv2d_dgrad_strided_nhwc_f32(const float* g, const float* w, float* dx, const float* add_grid, const float* dsrc,
+                                                int32_t N, int32_t Ho, int32_t Wo, int32_t K, int32_t C, int32_t ksize,
+                                                int32_t stride_h, int32_t stride_w, int32_t dense, int32_t act,
+                                                uint32_t epilogue, dl_stream stream) {
+  if (!g || !w || !dx || N <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || K <= 0)
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_dgrad_strided_nhwc_f32: bad argument");
+  if (((epilogue & CV_EPI_ADD_GRID) && !add_grid) || ((epilogue & CV_EPI_DACT) && !dsrc) || act < 0 || act > 2 ||
+      (epilogue & ~(CV_EPI_ADD_GRID | CV_EPI_DACT)))
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_dgrad_strided_nhwc_f32: epilogue operand missing / unsupported flag");
+  if ((size_t)N * Ho * stride_h * Wo * stride_w * C >= ((size_t)1 << 31) || (size_t)N * Ho * Wo * K >= ((size_t)1 << 31))
+    return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_dgrad_strided_nhwc_f32: tensors beyond 2^31 elements are not supported");
+  // in the kernel's terms: input = g (K channels, the reduction), output channels = C
+  ConvArgs a{g, w, dx, add_grid, dsrc, N, Ho, Wo, K, C, Ho, Wo, act, epilogue};
+  hipStream_t st = (hipStream_t)stream;
+  int rc = 1;
+  if (dense) {                                        // 1x1 layer: only phase (0,0) is non-zero; result kept on the grid
+    if (ksize == 1 && stride_h == 1 && stride_w == 2) rc = dispatch_conv<GeomDgrad<1, 1, 2, 0, 0, false>, true, false>(a, st);
+    else if (ksize == 1 && stride_h == 2 && stride_w == 2) rc = dispatch_conv<GeomDgrad<1, 2, 2, 0, 0, false>, true, false>(a, st);
+    else return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_dgrad_strided_nhwc_f32: dense output is the 1x1 strided layers' mode");
+  } else if (ksize == 3 && stride_h == 1 && stride_w == 2) {
+    rc = dgrad_phase<3, 1, 2, 0, 0>(a, true, st) | dgrad_phase<3, 1, 2, 0, 1>(a, false, st);
+  } else if (ksize == 3 && stride_h == 2 && stride_w == 2) {
+    rc = dgrad_phase<3, 2, 2, 0, 0>(a, true, st) | dgrad_phase<3, 2, 2, 0, 1>(a, false, st) | dgrad_phase<3, 2, 2, 1, 0>(a, false, st) |
+         dgrad_phase<3, 2, 2, 1, 1>(a, false, st);
+  } else {
+    return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_dgrad_strided_nhwc_f32: kernel %d stride (%d,%d) is not built", ksize, stride_h, stride_w);
+  }
+  if (rc) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_dgrad_strided_nhwc_f32: shape N=%d Ho=%d Wo=%d K=%d C=%d does not tile", N, Ho, Wo, K, C);
+  return dl_check_launch("dl_conv2d_dgrad_strided_nhwc_f32");
 }
 
 #ifndef WG_PK

@@ -15,8 +15,8 @@ two convolutions.  The wrap-around of the image width and the zero rows above / 
 no padded copy of an activation exists.  Weights are the torch parameters themselves in channels_last memory format
 (``[K][3][3][C]`` storage); weight gradients are written in the same layout.
 
-The three strided 3x3 convolutions and the three 1x1 down-sampling convolutions take their INPUT gradient from the library
-convolution (MIOpen, channels-last) -- the only library calls left in the trunk.
+The strided layers' input gradients run one pass per stride phase with exactly the taps whose phase matches
+(``dgrad_strided``); no library convolution is left in the trunk.
 """
 import ctypes
 
@@ -26,7 +26,7 @@ from .. import _lib
 
 ACT = {"none": 0, "tanh": 1, "relu": 2}
 USE_WINOGRAD = True          # stride-1 3x3 layers as fused Winograd F(2x2,3x3) (csrc/wino.hip); False: the direct kernel
-EPI_ADD, EPI_ACT, EPI_DACT = 1, 2, 4
+EPI_ADD, EPI_ACT, EPI_DACT, EPI_ADD_GRID = 1, 2, 4, 8
 
 
 def _ptr(t):
@@ -118,25 +118,18 @@ def supported(x_shape, blocks):
     return True
 
 
-def _library_dgrad(g_nhwc, w_param, in_shape_nhwc, stride, ks):
-    """Input gradient of a STRIDED convolution from the library (MIOpen), channels-last in and out.  For the 3x3 case the
-    library sees the width padded by one wrapped column on each side; the two wrap columns are folded back here."""
-    N, H, W, C = in_shape_nhwc
-    g = g_nhwc.permute(0, 3, 1, 2)                       # NCHW-shaped view with channels_last strides
-    if ks == 3:
-        shape = (N, C, H, W + 2)
-        dummy = torch.empty((N, H, W + 2, C), dtype=g_nhwc.dtype, device=g_nhwc.device).permute(0, 3, 1, 2)
-        dxp, _, _ = torch.ops.aten.convolution_backward(g, dummy, w_param, None, list(stride), [1, 0], [1, 1], False, [0, 0], 1,
-                                                        [True, False, False])
-        dxp = dxp.permute(0, 2, 3, 1)                    # [N,H,W+2,C]
-        dx = dxp[:, :, 1:W + 1].clone()
-        dx[:, :, W - 1] += dxp[:, :, 0]
-        dx[:, :, 0] += dxp[:, :, W + 1]
-        return dx
-    dummy = torch.empty((N, H, W, C), dtype=g_nhwc.dtype, device=g_nhwc.device).permute(0, 3, 1, 2)
-    dx, _, _ = torch.ops.aten.convolution_backward(g, dummy, w_param, None, list(stride), [0, 0], [1, 1], False, [0, 0], 1,
-                                                   [True, False, False])
-    return dx.permute(0, 2, 3, 1).contiguous()
+def dgrad_strided(g, w_krsc, stride, act=0, epilogue=0, add_grid=None, dsrc=None, dense=False):
+    """Input gradient of a strided layer: g ``[N,Ho,Wo,K]`` with the layer's forward weight ``[K,k,k,C]`` ->
+    ``[N,Ho*sh,Wo*sw,C]`` (``dense``: the 1x1 layers' gradient kept on the grid ``[N,Ho,Wo,C]``)."""
+    lib = _lib.load()
+    N, Ho, Wo, K = g.shape
+    ks, C = w_krsc.shape[1], w_krsc.shape[3]
+    shape = (N, Ho, Wo, C) if dense else (N, Ho * stride[0], Wo * stride[1], C)
+    dx = torch.empty(shape, dtype=torch.float32, device=g.device)
+    _lib.check(lib.dl_conv2d_dgrad_strided_nhwc_f32(_ptr(g), _ptr(w_krsc), _ptr(dx), _ptr(add_grid), _ptr(dsrc), N, Ho, Wo, K, C, ks,
+                                                    stride[0], stride[1], int(dense), int(act), int(epilogue), _stream()),
+               "dl_conv2d_dgrad_strided_nhwc_f32")
+    return dx
 
 
 class RingTrunk(torch.autograd.Function):
@@ -218,11 +211,8 @@ class RingTrunk(torch.autograd.Function):
             else:
                 wdp = weights[wi + 2]
                 grads[wi + 2] = wgrad_nhwc(x, g2, 1, stride=stride).permute(0, 3, 1, 2)
-                dx = _library_dgrad(g1, w1p, x.shape, stride, 3) + _library_dgrad(g2, wdp, x.shape, stride, 1)
-                if first or act == ACT["none"]:
-                    g2 = dx
-                elif act == ACT["tanh"]:
-                    g2 = dx * (1.0 - x * x)
-                else:
-                    g2 = dx * (x > 0).to(dx.dtype)
+                # down-sampling branch on the grid, then one pass per stride phase of the 3x3 layer with it and act'(x) fused
+                dxb = dgrad_strided(g2, weight_storage(wdp), stride, dense=True)
+                epi = EPI_ADD_GRID if first else (EPI_ADD_GRID | EPI_DACT)
+                g2 = dgrad_strided(g1, weight_storage(w1p), stride, act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)
         return (g2, None, None, *grads)

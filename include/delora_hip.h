@@ -244,6 +244,20 @@ int dl_conv2d_nhwc_f32(const float* x, const float* w, float* y, const float* ad
                        int32_t H, int32_t W, int32_t C, int32_t K, int32_t ksize, int32_t stride_h, int32_t stride_w,
                        int32_t transposed, int32_t act, uint32_t epilogue, dl_stream stream);
 
+/* Input gradient of the STRIDED layers (3x3 stride (1,2) / (2,2), 1x1 stride (1,2) / (2,2)), torch autograd of
+ * Conv2d(stride) in the reference.  One pass per stride phase over the output-gradient grid, each with exactly the taps
+ * whose phase matches (no zero-stuffing): g [N][Ho][Wo][K] (K = the layer's output channels), w = the layer's FORWARD
+ * weight [K][ksize][ksize][C], dx [N][Ho*stride_h][Wo*stride_w][C].
+ *   dense != 0 (1x1 layers): only phase (0,0) receives gradient; the result is written densely as [N][Ho][Wo][C] and is
+ *                            meant to be handed to the 3x3 layer's call as add_grid.
+ *   epilogue flags: 8 DL_CONV_ADD_GRID  v += add_grid[n][ho][wo][c] on the phase-(0,0) pixels (the down-sampling
+ *                   branch's gradient), 4 DL_CONV_DACT  v *= act'(dsrc[pixel][c]) with dsrc at full resolution. */
+#define DL_CONV_ADD_GRID 8u
+int dl_conv2d_dgrad_strided_nhwc_f32(const float* g, const float* w, float* dx, const float* add_grid, const float* dsrc,
+                                     int32_t N, int32_t Ho, int32_t Wo, int32_t K, int32_t C, int32_t ksize,
+                                     int32_t stride_h, int32_t stride_w, int32_t dense, int32_t act, uint32_t epilogue,
+                                     dl_stream stream);
+
 /* Weight gradient of the same convolutions: dw[k][tap][c] = sum over output pixels of g[pixel][k] * x[pixel + tap][c]
  * (wrap-around / zero-row addressing as above), slab-wise partial sums added in a fixed order (deterministic).
  *   x [N][H][W][C], g [N][Ho][Wo][K], dw [K][ksize][ksize][C];  workspace: dl_conv2d_wgrad_workspace_bytes(...) bytes.

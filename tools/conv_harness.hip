@@ -84,6 +84,27 @@ static double ref_dgrad(const std::vector<float>& g, const std::vector<float>& w
   return acc;
 }
 
+// host input gradient of a strided layer at one element (full resolution)
+static double ref_dgrad_strided(const std::vector<float>& g, const std::vector<float>& w, const Shape& s, int n, int h, int wi, int c) {
+  const int pad = (s.ks - 1) / 2, Ho = s.H / s.sh, Wo = s.W / s.sw;
+  double acc = 0;
+  for (int r = 0; r < s.ks; ++r) {
+    const int hn = h + pad - r;
+    if (hn % s.sh) continue;
+    const int ho = hn / s.sh;
+    if (hn < 0 || ho >= Ho) continue;
+    for (int q = 0; q < s.ks; ++q) {
+      int wn = wi + pad - q;
+      if (s.ks == 3) wn = wrapc(wn, s.W);
+      if (wn % s.sw) continue;
+      const int wo = wn / s.sw;
+      const float* gp = &g[(((size_t)n * Ho + ho) * Wo + wo) * s.K];
+      for (int k = 0; k < s.K; ++k) acc += (double)gp[k] * (double)w[(((size_t)k * s.ks + r) * s.ks + q) * s.C + c];
+    }
+  }
+  return acc;
+}
+
 static double ref_wgrad(const std::vector<float>& x, const std::vector<float>& g, const Shape& s, int k, int r, int q, int c) {
   const int pad = (s.ks - 1) / 2, Ho = s.H / s.sh, Wo = s.W / s.sw;
   double acc = 0;
@@ -201,6 +222,50 @@ static int check_shape(const Shape& s, std::mt19937& gen) {
     }
     CK(hipFree(dg)); CK(hipFree(dgi)); CK(hipFree(dsrc));
   }
+  // strided layers: input gradient, one pass per stride phase; 3x3 with the 1x1 branch's dense gradient added on phase (0,0)
+  if ((s.sh > 1 || s.sw > 1) && s.C % 64 == 0) {
+    auto g = rnd(ny, gen, 1.f);
+    float* dg = dev(g);
+    float* dgi;
+    CK(hipMalloc(&dgi, nx * sizeof(float)));
+    auto act_src = rnd(nx, gen, 0.9f);
+    float* dsrc = dev(act_src);
+    const size_t ngrid = (size_t)s.N * Ho * Wo * s.C;
+    auto addg = rnd(ngrid, gen, 1.f);
+    float* daddg = dev(addg);
+    if (s.ks == 3) rc = dl_conv2d_dgrad_strided_nhwc_f32(dg, dw, dgi, daddg, dsrc, s.N, Ho, Wo, s.K, s.C, 3, s.sh, s.sw, 0, 1, DL_CONV_ADD_GRID | DL_CONV_DACT, nullptr);
+    else rc = dl_conv2d_dgrad_strided_nhwc_f32(dg, dw, dgi, nullptr, nullptr, s.N, Ho, Wo, s.K, s.C, 1, s.sh, s.sw, 1, 0, 0, nullptr);
+    if (rc) { printf("  %s dgrad-strided: rc %d %s\n", s.name, rc, dl_last_error()); bad++; }
+    else {
+      CK(hipDeviceSynchronize());
+      const size_t nout = s.ks == 3 ? nx : ngrid;
+      std::vector<float> gi(nout);
+      CK(hipMemcpy(gi.data(), dgi, nout * sizeof(float), hipMemcpyDeviceToHost));
+      std::uniform_int_distribution<size_t> px(0, nout - 1);
+      worst = 0; scale = 0;
+      for (int t = 0; t < 3000; ++t) {
+        const size_t o = px(gen);
+        const int c = o % s.C; size_t p = o / s.C;
+        double e;
+        if (s.ks == 3) {
+          const int wi = p % s.W; p /= s.W;
+          const int h = p % s.H; const int n = p / s.H;
+          e = ref_dgrad_strided(g, w, s, n, h, wi, c);
+          if (h % s.sh == 0 && wi % s.sw == 0) e += addg[(((size_t)n * Ho + h / s.sh) * Wo + wi / s.sw) * s.C + c];
+          e *= 1.0 - (double)act_src[o] * act_src[o];
+        } else {
+          const int wo = p % Wo; p /= Wo;
+          const int ho = p % Ho; const int n = p / Ho;
+          e = ref_dgrad_strided(g, w, s, n, ho * s.sh, wo * s.sw, c);
+        }
+        worst = std::max(worst, std::fabs(e - gi[o]));
+        scale = std::max(scale, std::fabs(e));
+      }
+      printf("  %-28s dgrad-strided  max abs err %.3e (scale %.2f)\n", s.name, worst, scale);
+      if (!(worst < 2e-5 * std::max(1.0, scale))) bad++;
+    }
+    CK(hipFree(dg)); CK(hipFree(dgi)); CK(hipFree(dsrc)); CK(hipFree(daddg));
+  }
   CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dadd)); CK(hipFree(dds)); CK(hipFree(dy));
   return bad;
 }
@@ -306,6 +371,9 @@ static void time_shape(const Shape& s, int reps, std::mt19937& gen, double* tota
   run("fwd", [&] { return dl_conv2d_nhwc_f32(dx, dw, dy, nullptr, nullptr, s.N, s.H, s.W, s.C, s.K, s.ks, s.sh, s.sw, 0, 1, DL_CONV_ACT, nullptr); });
   if (s.ks == 3 && s.sh == 1 && s.sw == 1)
     run("dgrad", [&] { return dl_conv2d_nhwc_f32(dg, dw, dgi, nullptr, dx, s.N, s.H, s.W, s.K, s.C, 3, 1, 1, 1, 1, DL_CONV_DACT, nullptr); });
+  if (s.sh > 1 || s.sw > 1)
+    run("dgrad", [&] { return dl_conv2d_dgrad_strided_nhwc_f32(dg, dw, dgi, nullptr, s.ks == 3 ? dx : nullptr, s.N, Ho, Wo, s.K, s.C, s.ks, s.sh, s.sw,
+                                                               s.ks == 1, 1, s.ks == 3 ? DL_CONV_DACT : 0, nullptr); });
   if (with_wgrad) run("wgrad", [&] { return dl_conv2d_wgrad_nhwc_f32(dx, dg, ddw, ws, s.N, s.H, s.W, s.C, s.K, s.ks, s.sh, s.sw, nullptr); });
   CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dg)); CK(hipFree(dy)); CK(hipFree(dgi)); CK(hipFree(ddw)); CK(hipFree(ws));
 }
