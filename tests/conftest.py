@@ -10,6 +10,13 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The CPU oracle is a chain of small torch ops: on the GPU box's many-core host the default thread count (all cores)
+    # makes it an order of magnitude slower than 16 threads (bench.py measured 190 s vs ~10 s per pair).
+    try:
+        import torch
+        torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    except Exception:            # pragma: no cover
+        pass
 
 
 @pytest.fixture(scope="session")

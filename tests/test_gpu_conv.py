@@ -57,7 +57,7 @@ def test_conv_forward_and_both_gradients_against_torch(shape):
     sc = torch.randn(y.shape, generator=g).to(dev)
     y2 = rc.conv_nhwc(x_nhwc, w_krsc, stride=stride, act=rc.ACT["tanh"], epilogue=rc.EPI_ADD | rc.EPI_ACT, add=sc)
     ref2 = torch.tanh(y_ref.detach() + sc.permute(0, 3, 1, 2))
-    util.measured(f"{tag}: forward + shortcut + tanh vs torch (absolute)", float((y2.permute(0, 3, 1, 2) - ref2).abs().max()), bound=2e-5)
+    util.measured(f"{tag}: forward + shortcut + tanh vs torch (absolute)", float((y2.permute(0, 3, 1, 2) - ref2).abs().max()), bound=5e-5)
     # weight gradient
     gy_nhwc = gy.permute(0, 2, 3, 1).contiguous()
     dw = rc.wgrad_nhwc(x_nhwc, gy_nhwc, ks, stride=stride)
