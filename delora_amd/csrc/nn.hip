@@ -41,8 +41,19 @@ struct NNHard {                // one record per query that pass A could not cer
 #define NN_TR 4                 // target tile: 4 rows x 16 columns = 64 pixels = one wave-wide load
 #define NN_TC 16
 
+#ifdef NN_PROFILE
+__device__ int* g_nn_prof = nullptr;
+extern "C" int dl_nn_debug_set(int* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_nn_prof), &p, sizeof(p)); }
+#endif
+
+#define NN_SEED_MIN 8192        // bound windows beyond this many pixels are re-derived after a seed scan around q's pixel
+#ifndef NN_SCAN_MAX
+#define NN_SCAN_MAX 256        // bound windows up to this many pixels are scanned directly, 16 lanes per query
+#endif
+
 struct NNWorkspace {
-  int32_t* counter;            // counter[0] = number of hard queries
+  int capacity;                // records in hard[] (B*H*W)
+  int32_t* counter;            // counter[0] = number of hard queries (tile walk), counter[1] = of scanned queries
   NNHard* hard;                // [B*HW]
   float4* tiles;               // [B][ceil(H/4)][ceil(W/16)] bounding sphere (cx,cy,cz,radius) of every target tile; radius < 0: empty
 };
@@ -54,6 +65,7 @@ static inline size_t nn_tiles(int H, int W) { return (size_t)((H + NN_TR - 1) / 
 
 static inline NNWorkspace carve_nn(void* ws, int B, int H, int W) {
   NNWorkspace w;
+  w.capacity = B * H * W;
   w.counter = (int32_t*)ws;
   w.hard = (NNHard*)((char*)ws + nn_header_bytes(B));
   w.tiles = (float4*)((char*)w.hard + (size_t)B * H * W * sizeof(NNHard));
@@ -241,7 +253,10 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
       mp[0] = p4.x; mp[HW] = p4.y; mp[2 * HW] = p4.z; mp[3 * HW] = n4.x; mp[4 * HW] = n4.y; mp[5 * HW] = n4.z;
     }
   } else {
-    const int pos = atomicAdd(ws.counter, 1);
+    // two lists in one array: windows of at most NN_SCAN_MAX pixels (most of them: a few hundred) grow from the end
+    // and are scanned exhaustively by 16-lane groups (k_nn_scan16); larger ones grow from the front (k_nn_hard: tile walk)
+    const int wpx = (w.r1 - w.r0 + 1) * w.nc;
+    const int pos = wpx <= NN_SCAN_MAX ? ws.capacity - 1 - atomicAdd(ws.counter + 1, 1) : atomicAdd(ws.counter, 1);
     NNHard h;
     h.d2 = best; h.slot = b * HW + px; h.idx = bidx; h.qx = fx; h.qy = fy; h.qz = fz; h.b = b;
     h.rows = (uint32_t)w.r0 | ((uint32_t)w.r1 << 16);
@@ -250,25 +265,48 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
   }
 }
 
+// Wave-wide reductions without LDS traffic: DPP inside each 16-lane row (quad permutes + row rotations: VALU operand
+// modifiers), then the four row results through readlane.  The ds_bpermute butterflies these replace (6 dependent LDS
+// round trips per float, 18 for the (double, index) arg-min) were ~1.5 us of every hard query's ~8 us.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u(unsigned v) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+__device__ __forceinline__ unsigned wave_min_u(unsigned v) {
+  v = min(v, dpp_u<0xB1>(v));        // quad_perm [1,0,3,2]
+  v = min(v, dpp_u<0x4E>(v));        // quad_perm [2,3,0,1]
+  v = min(v, dpp_u<0x124>(v));       // row_ror:4
+  v = min(v, dpp_u<0x128>(v));       // row_ror:8
+  const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16),
+                 c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  return min(min(a, b), min(c, d));
+}
+// non-negative floats order like their bit patterns
+__device__ __forceinline__ float wave_min_f(float v) { return __uint_as_float(wave_min_u(__float_as_uint(v))); }
+
+// lexicographic minimum of (d2 >= 0, idx) over the wave; idx < 0 = no candidate (d2 = 1e300)
 __device__ __forceinline__ void wave_argmin(double& d2, int& idx) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const double od = __shfl_xor(d2, o, DL_WAVE);
-    const int oi = __shfl_xor(idx, o, DL_WAVE);
-    if (od < d2 || (od == d2 && oi >= 0 && (idx < 0 || oi < idx))) { d2 = od; idx = oi; }
-  }
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(d2);
+  const unsigned hi = (unsigned)(bits >> 32), lo = (unsigned)bits;
+  const unsigned mhi = wave_min_u(hi);
+  const unsigned lo2 = hi == mhi ? lo : 0xffffffffu;
+  const unsigned mlo = wave_min_u(lo2);
+  const unsigned id2 = (hi == mhi && lo == mlo) ? (unsigned)idx : 0xffffffffu;   // idx = -1 is 0xffffffff: never wins over a real one
+  const unsigned mid = wave_min_u(id2);
+  d2 = __longlong_as_double((long long)(((unsigned long long)mhi << 32) | mlo));
+  idx = (int)mid;
 }
 
 __device__ __forceinline__ int nn_tiles_dev(int H, int W) { return ((H + NN_TR - 1) / NN_TR) * ((W + NN_TC - 1) / NN_TC); }
 
-__device__ __forceinline__ float wave_min_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, DL_WAVE));
-  return v;
-}
 __device__ __forceinline__ float wave_max_f(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, DL_WAVE));
+  return v;
+}
+__device__ __forceinline__ float wave_min_sf(float v) {       // signed values (k_nn_tiles: coordinates)
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, DL_WAVE));
   return v;
 }
 
@@ -288,9 +326,9 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_tiles(const float4* __restrict_
   if (row < H && col < W) p = (tgt + (size_t)b * tgt_ss4)[row * W + col];
   const bool occ = !(p.x == 0.f && p.y == 0.f && p.z == 0.f);
   const float big = 3.0e38f;
-  const float xmin = wave_min_f(occ ? p.x : big), xmax = wave_max_f(occ ? p.x : -big);
-  const float ymin = wave_min_f(occ ? p.y : big), ymax = wave_max_f(occ ? p.y : -big);
-  const float zmin = wave_min_f(occ ? p.z : big), zmax = wave_max_f(occ ? p.z : -big);
+  const float xmin = wave_min_sf(occ ? p.x : big), xmax = wave_max_f(occ ? p.x : -big);
+  const float ymin = wave_min_sf(occ ? p.y : big), ymax = wave_max_f(occ ? p.y : -big);
+  const float zmin = wave_min_sf(occ ? p.z : big), zmax = wave_max_f(occ ? p.z : -big);
   float4 out = make_float4(0.f, 0.f, 0.f, -1.f);
   if (xmax >= xmin) {
     const float cx = 0.5f * (xmin + xmax), cy = 0.5f * (ymin + ymax), cz = 0.5f * (zmin + zmax);
@@ -337,17 +375,32 @@ __device__ __forceinline__ void scan_tiles(const Window& w, const float4* __rest
     }
     unsigned long long mask = __ballot(survive);
     while (mask) {
-      const int i = __builtin_ctzll(mask);
-      mask &= mask - 1;
-      const int row = __builtin_amdgcn_readlane(tr, i) * NN_TR + lane / NN_TC;
-      const int col = __builtin_amdgcn_readlane(tc, i) * NN_TC + lane % NN_TC;
-      if (row < H && col < W) {
-        const int p = row * W + col;
-        const float4 c4 = tp[p];
-        const float dx = qx - c4.x, dy = qy - c4.y, dz = qz - c4.z;
+      // up to four surviving tiles per trip: their four wave-wide loads are issued before any is consumed (one L2 round trip
+      // instead of four dependent ones)
+      float4 c4[4];
+      int pp[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        pp[u] = -1;
+        c4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mask) {
+          const int i = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          const int row = __builtin_amdgcn_readlane(tr, i) * NN_TR + lane / NN_TC;
+          const int col = __builtin_amdgcn_readlane(tc, i) * NN_TC + lane % NN_TC;
+          if (row < H && col < W) {
+            pp[u] = row * W + col;
+            c4[u] = tp[pp[u]];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = pp[u];
+        const float dx = qx - c4[u].x, dy = qy - c4[u].y, dz = qz - c4[u].z;
         const float d2f = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-        if (!(c4.x == 0.f && c4.y == 0.f && c4.z == 0.f) && d2f <= thr) {
-          const double d2 = dist2(qx, qy, qz, c4.x, c4.y, c4.z);
+        if (p >= 0 && !(c4[u].x == 0.f && c4[u].y == 0.f && c4[u].z == 0.f) && d2f <= thr) {
+          const double d2 = dist2(qx, qy, qz, c4[u].x, c4[u].y, c4[u].z);
           if (d2 < lbest || (d2 == lbest && lidx >= 0 && p < lidx)) {
             lbest = d2; lidx = p;
             thr = (float)lbest * (1.0f + 1e-5f);
@@ -365,6 +418,94 @@ __device__ __forceinline__ void scan_tiles(const Window& w, const float4* __rest
   if (lidx < 0) lbest = 1e300;
   wave_argmin(lbest, lidx);
   if (lidx >= 0 && (lbest < best || (lbest == best && (bidx < 0 || lidx < bidx)))) { best = lbest; bidx = lidx; }
+}
+
+// Row reductions (16 lanes = one DPP row): every lane of a row ends up with the row's minimum.
+__device__ __forceinline__ unsigned row_min_u(unsigned v) {
+  v = min(v, dpp_u<0xB1>(v));
+  v = min(v, dpp_u<0x4E>(v));
+  v = min(v, dpp_u<0x124>(v));
+  v = min(v, dpp_u<0x128>(v));
+  return v;
+}
+__device__ __forceinline__ void row_argmin(double& d2, int& idx) {
+  const unsigned long long bits = (unsigned long long)__double_as_longlong(d2);
+  const unsigned hi = (unsigned)(bits >> 32), lo = (unsigned)bits;
+  const unsigned mhi = row_min_u(hi);
+  const unsigned mlo = row_min_u(hi == mhi ? lo : 0xffffffffu);
+  const unsigned mid = row_min_u((hi == mhi && lo == mlo) ? (unsigned)idx : 0xffffffffu);
+  d2 = __longlong_as_double((long long)(((unsigned long long)mhi << 32) | mlo));
+  idx = (int)mid;
+}
+
+// Pass B for the small bound windows (68 % of the uncertified queries at the bench's residual motion; median window 336
+// pixels): FOUR queries per wave, one per 16-lane row.  A row walks its window 16 consecutive pixels at a time -- one
+// 256-byte contiguous piece of a packed image row per load -- screens in fp32, refines in fp64, and reduces with DPP row
+// operations; no tile tests, no wave-wide synchronisation, four independent dependency chains per wave.  (One wave per
+// query spent ~9k cycles on each of these, almost all of it memory latency of five dependent round trips.)
+__global__ __launch_bounds__(DL_BLOCK) void k_nn_scan16(const float4* __restrict__ tgt, int64_t tgt_ss4,
+                                                        const float4* __restrict__ tgtn, int64_t tgtn_ss4, SensorK sen,
+                                                        int32_t* __restrict__ nn_pix, float* __restrict__ match, NNWorkspace ws) {
+  const int lane = threadIdx.x & (DL_WAVE - 1), l16 = lane & 15;
+  const int group = (blockIdx.x * DL_BLOCK + threadIdx.x) >> 4;
+  const int ngroups = gridDim.x * DL_BLOCK / 16;
+  const int count = ws.counter[1];
+  const int HW = sen.HW, W = sen.W;
+  for (int h = group; h < count; h += ngroups) {
+    const NNHard rec = ws.hard[ws.capacity - 1 - h];
+    const int b = rec.b;
+    const int r0 = (int)(rec.rows & 0xffffu), r1 = (int)(rec.rows >> 16);
+    const int c0 = (int)(rec.cols & 0xffffu), nc = (int)(rec.cols >> 16) + 1;
+    const float qx = rec.qx, qy = rec.qy, qz = rec.qz;
+    const float4* tp = tgt + (size_t)b * tgt_ss4;
+    double lbest = rec.d2;
+    int lidx = -1;
+    float thr = lbest < 1e30 ? (float)lbest * (1.0f + 1e-5f) : 3.0e38f;
+    const int nchunk = (nc + 15) >> 4;
+    const int steps = (r1 - r0 + 1) * nchunk;
+    for (int st = 0; st < steps; st += 4) {               // four independent 16-pixel pieces in flight
+      float4 c4[4];
+      int pp[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int s = st + u;
+        const int r = s / nchunk, j = s - r * nchunk;
+        const int cc = j * 16 + l16;
+        int c = c0 + cc;
+        c = c >= W ? c - W : c;
+        const bool ok = s < steps && cc < nc;
+        pp[u] = ok ? (r0 + r) * W + c : -1;
+        c4[u] = ok ? tp[pp[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float dx = qx - c4[u].x, dy = qy - c4[u].y, dz = qz - c4[u].z;
+        const float d2f = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        if (pp[u] >= 0 && !(c4[u].x == 0.f && c4[u].y == 0.f && c4[u].z == 0.f) && d2f <= thr) {
+          const double d2 = dist2(qx, qy, qz, c4[u].x, c4[u].y, c4[u].z);
+          if (d2 < lbest || (d2 == lbest && lidx >= 0 && pp[u] < lidx)) {
+            lbest = d2; lidx = pp[u];
+            thr = (float)lbest * (1.0f + 1e-5f);
+          }
+        }
+      }
+    }
+    if (lidx < 0) lbest = 1e300;
+    row_argmin(lbest, lidx);
+    double best = rec.d2;
+    int bidx = rec.idx;
+    if (lidx >= 0 && (lbest < best || (lbest == best && (bidx < 0 || lidx < bidx)))) { best = lbest; bidx = lidx; }
+    if (l16 == 0) nn_pix[rec.slot] = bidx;
+    if (match && l16 < 6) {
+      const int px = rec.slot - b * HW;
+      float v = 0.f;
+      if (bidx >= 0) {
+        if (l16 < 3) v = reinterpret_cast<const float*>(tp)[(size_t)bidx * 4 + l16];
+        else if (tgtn) v = reinterpret_cast<const float*>(tgtn + (size_t)b * tgtn_ss4)[(size_t)bidx * 4 + (l16 - 3)];
+      }
+      match[(size_t)b * 6 * HW + (size_t)l16 * HW + px] = v;
+    }
+  }
 }
 
 // Pass B: one wave per query that pass A could not certify.  Everything per-query is wave-uniform (the record is read
@@ -389,6 +530,9 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float4* __restrict__
   }
   const int ntiles_img = nn_tiles_dev(H, W);
   for (int h = wave; h < count; h += nwaves) {
+#ifdef NN_PROFILE
+    const long long t0_ = clock64();
+#endif
     const NNHard rec = ws.hard[h];
     const int b = rec.b;
     Window w;
@@ -397,7 +541,25 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float4* __restrict__
     double best = rec.d2;
     int bidx = rec.idx;
     const float4* tp = tgt + (size_t)b * tgt_ss4;
-    scan_tiles(w, ws.tiles + (size_t)b * ntiles_img, tp, H, W, rec.qx, rec.qy, rec.qz, lane, best, bidx);
+    const float4* tiles_b = ws.tiles + (size_t)b * ntiles_img;
+    if ((w.r1 - w.r0 + 1) * w.nc > NN_SEED_MIN) {
+      // A window this large means pass A found nothing near q's pixel (an empty neighbourhood, q outside the field of view)
+      // or only a far candidate.  Walking it from its top-left corner spends the first trips on far tiles with a useless cull
+      // distance -- a whole-image walk took ~90k cycles, 36 % of this kernel at the bench's motion.  So first SEED: scan the
+      // 13 x 49 pixel neighbourhood of q's pixel (a dozen tiles), then replace the window by the rigorous bound of the distance
+      // found (bound_window is exact for any upper bound of the true distance).  The result is the same; only the order and
+      // the size of the final walk change.
+      const QueryF q = make_query(rec.qx, rec.qy, rec.qz, sen);
+      int v0 = (int)rintf(q.vq);
+      v0 = v0 < 0 ? 0 : (v0 > H - 1 ? H - 1 : v0);
+      const int u0 = wrap_col((int)rintf(q.uq), W);
+      Window s;
+      s.r0 = max(v0 - 6, 0); s.r1 = min(v0 + 6, H - 1);
+      s.c0 = wrap_col(u0 - 24, W); s.nc = min(49, W);
+      scan_tiles(s, tiles_b, tp, H, W, rec.qx, rec.qy, rec.qz, lane, best, bidx);
+      if (bidx >= 0) w = bound_window(q, (float)sqrt(best) * NN_UP, sen);
+    }
+    scan_tiles(w, tiles_b, tp, H, W, rec.qx, rec.qy, rec.qz, lane, best, bidx);
     // the result: lanes 0-2 fetch and store the matched point's coordinates, lanes 3-5 the normal's
     if (lane == 0) nn_pix[rec.slot] = bidx;
     if (match && lane < 6) {
@@ -409,6 +571,12 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float4* __restrict__
       }
       match[(size_t)b * 6 * HW + (size_t)lane * HW + px] = v;
     }
+#ifdef NN_PROFILE
+    if (lane == 0 && g_nn_prof) {
+      g_nn_prof[2 * h] = (int)(clock64() - t0_);
+      g_nn_prof[2 * h + 1] = (w.r1 - w.r0 + 1) * w.nc;
+    }
+#endif
   }
 }
 
@@ -442,6 +610,8 @@ extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const f
                      src_image4, src_ss, src_normals, srcn_ss, (const float4*)tgt_packed, tgt_ss / 4,
                      (const float4*)tgt_normals_packed, tgtn_ss / 4, T, sen, need_without_normals, nn_pix, match, visible,
                      ws);
+  hipLaunchKernelGGL(k_nn_scan16, dim3(2048), dim3(DL_BLOCK), 0, st, (const float4*)tgt_packed, tgt_ss / 4,
+                     (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, ws);
   hipLaunchKernelGGL(k_nn_hard, dim3(2048), dim3(DL_BLOCK), 0, st, (const float4*)tgt_packed, tgt_ss / 4,
                      (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, visible, B, ws);
   return dl_check_launch("dl_nn_correspond");

@@ -5,13 +5,16 @@ import os, sys
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import bench
+if os.environ.get("DL_LIB"):
+    from delora_amd import _lib
+    _lib.LIB_PATH = os.path.join(ROOT, os.environ["DL_LIB"])
 from delora_amd import geometry as G
 from delora_amd.deploy.step_geometry import HipStepGeometry
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 mode, path = (sys.argv[2], sys.argv[3]) if len(sys.argv) > 3 else (None, None)
 dev = torch.device("cuda:0")
-X = type("X", (), dict(height=64, width=2048, batch=8, amp="", channels_last=False))()
+X = type("X", (), dict(height=64, width=2048, batch=8, amp="", channels_last=False, cnn=""))()
 cfg = bench.build_config(X, dev)
 batch = bench.make_batch(X, 0, dev)
 sensor = G.Sensor.from_config(cfg, "kitti")
