@@ -54,7 +54,8 @@ extern "C" int dl_nn_debug_set(int* p) { return (int)hipMemcpyToSymbol(HIP_SYMBO
 struct NNWorkspace {
   int capacity;                // records in hard[] (B*H*W)
   int32_t* counter;            // counter[0] = number of hard queries (tile walk), counter[1] = of scanned queries
-  NNHard* hard;                // [B*HW]
+  NNHard* hard;                // [B*HW]: tile-walk queries with one wave each from the front, scanned queries from the end
+  NNHard* mid;                 // [B*HW]: tile-walk queries with one 16-lane group each (counter[2])
   float4* tiles;               // [B][ceil(H/4)][ceil(W/16)] bounding sphere (cx,cy,cz,radius) of every target tile; radius < 0: empty
 };
 
@@ -68,12 +69,13 @@ static inline NNWorkspace carve_nn(void* ws, int B, int H, int W) {
   w.capacity = B * H * W;
   w.counter = (int32_t*)ws;
   w.hard = (NNHard*)((char*)ws + nn_header_bytes(B));
-  w.tiles = (float4*)((char*)w.hard + (size_t)B * H * W * sizeof(NNHard));
+  w.mid = w.hard + (size_t)B * H * W;
+  w.tiles = (float4*)((char*)w.mid + (size_t)B * H * W * sizeof(NNHard));
   return w;
 }
 
 extern "C" size_t dl_nn_workspace_bytes(int32_t B, int32_t H, int32_t W) {
-  return nn_header_bytes(B) + (size_t)B * H * W * sizeof(NNHard) + (size_t)B * nn_tiles(H, W) * sizeof(float4);
+  return nn_header_bytes(B) + 2 * (size_t)B * H * W * sizeof(NNHard) + (size_t)B * nn_tiles(H, W) * sizeof(float4);
 }
 
 // Angular description of a query in fp32.  The image is only a spatial index here: these values pick WHICH pixels
@@ -256,12 +258,16 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
     // two lists in one array: windows of at most NN_SCAN_MAX pixels (most of them: a few hundred) grow from the end
     // and are scanned exhaustively by 16-lane groups (k_nn_scan16); larger ones grow from the front (k_nn_hard: tile walk)
     const int wpx = (w.r1 - w.r0 + 1) * w.nc;
-    const int pos = wpx <= NN_SCAN_MAX ? ws.capacity - 1 - atomicAdd(ws.counter + 1, 1) : atomicAdd(ws.counter, 1);
+    NNHard* list = ws.hard;
+    int pos;
+    if (wpx <= NN_SCAN_MAX) pos = ws.capacity - 1 - atomicAdd(ws.counter + 1, 1);
+    else if (wpx <= NN_SEED_MIN) { list = ws.mid; pos = atomicAdd(ws.counter + 2, 1); }   // tile walk, 16 lanes (k_nn_hard16)
+    else pos = atomicAdd(ws.counter, 1);                                                   // tile walk, one wave (k_nn_hard)
     NNHard h;
     h.d2 = best; h.slot = b * HW + px; h.idx = bidx; h.qx = fx; h.qy = fy; h.qz = fz; h.b = b;
     h.rows = (uint32_t)w.r0 | ((uint32_t)w.r1 << 16);
     h.cols = (uint32_t)w.c0 | ((uint32_t)(w.nc - 1) << 16);
-    ws.hard[pos] = h;
+    list[pos] = h;
   }
 }
 
@@ -508,6 +514,115 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_scan16(const float4* __restrict
   }
 }
 
+// Pass B for the medium bound windows (a few hundred to a few thousand pixels: 4 to 128 tiles): the tile walk of
+// k_nn_hard with FOUR queries per wave, one per 16-lane row.  A row tests 16 tile spheres per trip (one per lane), its
+// surviving tiles are scanned one 16-pixel tile row per lane step (four contiguous 256-byte loads per tile, issued
+// together), cull distance and result are reduced with DPP row operations.  The dependent chain of one query (record ->
+// spheres -> pixels -> result gather, ~5 us of memory latency) is the same as with a whole wave per query -- but four of
+// them run side by side, which is what a latency-bound kernel needs.  Everything per query is per-lane state here (no
+// wave-uniform control flow): rows whose query is finished idle until the slowest row of the wave is done.
+__global__ __launch_bounds__(DL_BLOCK) void k_nn_hard16(const float4* __restrict__ tgt, int64_t tgt_ss4,
+                                                        const float4* __restrict__ tgtn, int64_t tgtn_ss4, SensorK sen,
+                                                        int32_t* __restrict__ nn_pix, float* __restrict__ match, NNWorkspace ws) {
+  const int lane = threadIdx.x & (DL_WAVE - 1), l16 = lane & 15, rowbase = lane & 48;
+  const int group = (blockIdx.x * DL_BLOCK + threadIdx.x) >> 4;
+  const int ngroups = gridDim.x * DL_BLOCK / 16;
+  const int count = ws.counter[2];
+  const int HW = sen.HW, H = sen.H, W = sen.W;
+  const int ntc_all = (W + NN_TC - 1) / NN_TC;
+  const int ntiles_img = nn_tiles_dev(H, W);
+  const int rounds = (count + ngroups - 1) / ngroups;
+  for (int it = 0; it < rounds; ++it) {
+    const int h = group + it * ngroups;
+    const bool live = h < count;
+    const NNHard rec = ws.mid[live ? h : 0];
+    const int b = rec.b;
+    const float qx = rec.qx, qy = rec.qy, qz = rec.qz;
+    const float4* tp = tgt + (size_t)b * tgt_ss4;
+    const float4* tiles_b = ws.tiles + (size_t)b * ntiles_img;
+    const int r0 = (int)(rec.rows & 0xffffu), r1 = (int)(rec.rows >> 16);
+    const int c0 = (int)(rec.cols & 0xffffu), nc = (int)(rec.cols >> 16) + 1;
+    const int tr0 = r0 / NN_TR, tr1 = r1 / NN_TR;
+    int tc0 = c0 / NN_TC, ntc = (c0 % NN_TC + nc + NN_TC - 1) / NN_TC;
+    if (nc >= W || ntc >= ntc_all || ((W % NN_TC) != 0 && c0 + nc > W)) { tc0 = 0; ntc = ntc_all; }
+    const int ntiles = live ? (tr1 - tr0 + 1) * ntc : 0;
+    double lbest = rec.d2;
+    int lidx = -1;
+    float thr = lbest < 1e30 ? (float)lbest * (1.0f + 1e-5f) : 3.0e38f;
+    float dcur = lbest < 1e30 ? sqrtf((float)lbest) * (1.0f + 1e-6f) : 3.0e38f;      // row-uniform cull distance
+    const float inv = 1.0f / (float)ntc;
+    for (int t0 = 0; __any(t0 < ntiles); t0 += 16) {
+      const int t = t0 + l16;
+      int tr = 0, tc = 0;
+      bool survive = false;
+      if (t < ntiles) {
+        int r = (int)(((float)t + 0.5f) * inv);
+        int c = t - r * ntc;
+        if (c < 0) { --r; c += ntc; } else if (c >= ntc) { ++r; c -= ntc; }
+        tr = tr0 + r;
+        tc = tc0 + c;
+        tc = tc >= ntc_all ? tc - ntc_all : tc;
+        const float4 s4 = tiles_b[tr * ntc_all + tc];
+        const float dx = qx - s4.x, dy = qy - s4.y, dz = qz - s4.z;
+        const float dist = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+        survive = s4.w >= 0.f && (dist - s4.w) <= dcur + 2e-6f * dist;
+      }
+      // this row's 16 survivor bits
+      unsigned gmask = (unsigned)((__ballot(survive) >> rowbase) & 0xffffull);
+      while (__any(gmask != 0)) {
+        // one surviving tile per row and trip: its four 16-pixel rows are loaded together
+        const bool has = gmask != 0;
+        const int i = has ? __builtin_ctz(gmask) : 0;
+        gmask &= gmask - 1;
+        const int src = (rowbase + i) << 2;
+        const int str = __builtin_amdgcn_ds_bpermute(src, tr), stc = __builtin_amdgcn_ds_bpermute(src, tc);
+        float4 c4[NN_TR];
+        int pp[NN_TR];
+#pragma unroll
+        for (int u = 0; u < NN_TR; ++u) {
+          const int row = str * NN_TR + u, col = stc * NN_TC + l16;
+          const bool ok = has && row < H && col < W;
+          pp[u] = ok ? row * W + col : -1;
+          c4[u] = ok ? tp[pp[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < NN_TR; ++u) {
+          const float dx = qx - c4[u].x, dy = qy - c4[u].y, dz = qz - c4[u].z;
+          const float d2f = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+          if (pp[u] >= 0 && !(c4[u].x == 0.f && c4[u].y == 0.f && c4[u].z == 0.f) && d2f <= thr) {
+            const double d2 = dist2(qx, qy, qz, c4[u].x, c4[u].y, c4[u].z);
+            if (d2 < lbest || (d2 == lbest && lidx >= 0 && pp[u] < lidx)) {
+              lbest = d2; lidx = pp[u];
+              thr = (float)lbest * (1.0f + 1e-5f);
+            }
+          }
+        }
+      }
+      // refresh the row's cull distance from its lanes' bests
+      const float tmin = __uint_as_float(row_min_u(__float_as_uint(thr)));
+      thr = fminf(thr, tmin * (1.0f + 1e-5f));
+      dcur = tmin < 3.0e38f ? sqrtf(tmin) * (1.0f + 1e-6f) : dcur;
+    }
+    if (lidx < 0) lbest = 1e300;
+    row_argmin(lbest, lidx);
+    double best = rec.d2;
+    int bidx = rec.idx;
+    if (lidx >= 0 && (lbest < best || (lbest == best && (bidx < 0 || lidx < bidx)))) { best = lbest; bidx = lidx; }
+    if (live) {
+      if (l16 == 0) nn_pix[rec.slot] = bidx;
+      if (match && l16 < 6) {
+        const int px = rec.slot - b * HW;
+        float v = 0.f;
+        if (bidx >= 0) {
+          if (l16 < 3) v = reinterpret_cast<const float*>(tp)[(size_t)bidx * 4 + l16];
+          else if (tgtn) v = reinterpret_cast<const float*>(tgtn + (size_t)b * tgtn_ss4)[(size_t)bidx * 4 + (l16 - 3)];
+        }
+        match[(size_t)b * 6 * HW + (size_t)l16 * HW + px] = v;
+      }
+    }
+  }
+}
+
 // Pass B: one wave per query that pass A could not certify.  Everything per-query is wave-uniform (the record is read
 // through the scalar path): pass A already evaluated the projection of q and the bound window of its best distance at
 // full lane efficiency and stored the window with the query, so this kernel is the tile walk plus the final gather.
@@ -611,6 +726,8 @@ extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const f
                      (const float4*)tgt_normals_packed, tgtn_ss / 4, T, sen, need_without_normals, nn_pix, match, visible,
                      ws);
   hipLaunchKernelGGL(k_nn_scan16, dim3(2048), dim3(DL_BLOCK), 0, st, (const float4*)tgt_packed, tgt_ss / 4,
+                     (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, ws);
+  hipLaunchKernelGGL(k_nn_hard16, dim3(2048), dim3(DL_BLOCK), 0, st, (const float4*)tgt_packed, tgt_ss / 4,
                      (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, ws);
   hipLaunchKernelGGL(k_nn_hard, dim3(2048), dim3(DL_BLOCK), 0, st, (const float4*)tgt_packed, tgt_ss / 4,
                      (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, visible, B, ws);
