@@ -514,3 +514,30 @@ def test_three_ranks_times_two_samples_equal_one_batch_of_six(identity_phase):
             assert torch.allclose(a, b, rtol=2e-3, atol=3e-4 * float(b.abs().max()) + 1e-12), k
     assert np.isclose(sum(ret[r]["loss"] for r in range(world)), float(ep["loss_epoch"]), rtol=1e-5)
     assert np.isclose(sum(ret[r]["loss_pc"] for r in range(world)), float(ep["loss_point_cloud_epoch"]), rtol=1e-5)
+
+
+def test_rotation_head_gradient_does_not_depend_on_which_rows_share_the_batch_norm():
+    """model.py:114 divides the raw quaternions by ONE norm over the whole batch; under data parallelism each rank takes it over
+    its local rows.  Every row is re-normalised inside quaternion -> R, so the loss is homogeneous of degree 0 in each row and
+    the gradient that reaches the rotation head is the same whichever rows share that scalar."""
+    from delora_amd.models.model_parts import GeometryHandler
+    g = torch.Generator().manual_seed(11)
+    raw0 = torch.randn((6, 4), generator=g, dtype=torch.float64)
+    target = torch.randn((6, 3, 3), generator=g, dtype=torch.float64)
+
+    def grad(groups):
+        raw = raw0.clone().requires_grad_(True)
+        loss = 0.0
+        for rows in groups:                       # one "rank" per group: its own whole-batch norm
+            rot = raw[rows] / torch.norm(raw[rows])
+            R = GeometryHandler.quaternion_to_rot_matrix(rot)
+            loss = loss + ((R - target[rows]) ** 2).sum()
+        loss.backward()
+        return raw.grad, float(loss)
+
+    g1, l1 = grad([slice(0, 6)])
+    g2, l2 = grad([slice(0, 3), slice(3, 6)])
+    g3, l3 = grad([slice(0, 1), slice(1, 6)])
+    assert abs(l1 - l2) < 1e-12 * abs(l1) and abs(l1 - l3) < 1e-12 * abs(l1)
+    assert float((g1 - g2).abs().max()) < 1e-12 * float(g1.abs().max())
+    assert float((g1 - g3).abs().max()) < 1e-12 * float(g1.abs().max())

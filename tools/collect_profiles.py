@@ -6,8 +6,8 @@ import csv, json, os, shutil, statistics, subprocess, sys
 R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(ROOT, "gpurun_out", f"profiles_{R}"), os.path.join(ROOT, "profiles")
-OWN = ["k_project_scatter", "k_project_resolve", "k_normals", "k_nn_tiles", "k_nn_window", "k_nn_hard", "k_icp_loss", "k_icp_reduce",
-       "k_probe_read"]
+OWN = ["k_project_scatter", "k_project_resolve", "k_normals", "k_nn_tiles", "k_nn_window", "k_nn_scan16", "k_nn_hard16", "k_nn_hard(",
+       "k_icp_loss", "k_icp_reduce", "k_probe_read"]
 
 
 def last_json(path):
@@ -18,7 +18,7 @@ for a, b in [("bench.json", f"{R}_bench.json"), ("bench_profiled.json", f"{R}_be
     json.dump(last_json(os.path.join(src, a)), open(os.path.join(dst, b), "w"), indent=1)
 shutil.copy(os.path.join(src, "bench_trace", "bench_kernel_stats.csv"), os.path.join(dst, f"{R}_bench_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "geo_trace", "geo_kernel_stats.csv"), os.path.join(dst, f"{R}_geometry_kernel_stats.csv"))
-for name in ("loss_warm.txt", "ring_bench.txt"):
+for name in ("loss_warm.txt", "ring_bench.txt", "conv_harness.txt", "conv_pmc.txt", "miopen_layers.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{R}_{name}"))
 
@@ -52,6 +52,8 @@ trace = os.path.join(src, "bench_trace", "bench_kernel_trace.csv")
 if os.path.exists(trace):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_breakdown.py"), trace, "20", "40"], capture_output=True, text=True)
     open(os.path.join(dst, f"{R}_step_breakdown.txt"), "w").write(out.stdout)
+elif os.path.exists(os.path.join(src, "step_breakdown.txt")):      # computed on the GPU box (the raw trace is too large to travel)
+    shutil.copy(os.path.join(src, "step_breakdown.txt"), os.path.join(dst, f"{R}_step_breakdown.txt"))
 geo = os.path.join(src, "geo_trace", "geo_kernel_trace.csv")
 if os.path.exists(geo):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "loss_calibration.py"), geo, "30"], capture_output=True, text=True)
