@@ -10,9 +10,12 @@ through loss and CNN, gradient all-reduce (N>1) and the Adam update.  Inputs (ra
 HBM when the timed region starts; the timed steps ROTATE over `--rotate` distinct batches (ragged scan lengths) so
 that no step finds the previous step's intermediates of the same data in a cache.  Rank 0 prints ONE JSON line
 (contract in the task statement) that also carries
-  "roofline":     the fused ICP loss kernel: algorithmic bytes / its duration, measured in the timed steps themselves
-                  (begin/end timestamps on HIP events attached to the launch) = the infinity-cache-warm regime the step
-                  runs in, AND behind a cache flush (cold, HBM), vs 8 TB/s
+  "roofline":     the dominant kernel, k_wino_conv (fused Winograd F(2x2,3x3) on the fp32 matrix cores; 36 % of the step):
+                  multiply-adds issued / its duration, measured in the timed steps themselves (begin/end timestamps on HIP
+                  events attached to every launch), vs the 157.3 TFLOP/s fp32 MFMA peak
+  "roofline_loss": the fused ICP loss kernel (HBM-bound): algorithmic bytes / its duration in the timed steps (infinity-cache
+                  warm) AND behind a cache flush (cold, HBM), vs 8 TB/s
+  "roofline_cnn": every stride-1 layer shape and pass, one launch each
   "long_run":     the same loop for `--long-steps` (default 200) steps
   "feed":         the same steps fed from pinned host memory through DataLoader + DevicePrefetcher (H2D in the loop)
   "cpu_baseline": the reference-like step (stored normal lists, B=1) evaluated by the CPU oracle on a bounded sample;
@@ -33,6 +36,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s measured copy rate)
+MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32: 256 flop/clk/CU x 256 CUs x 2.4 GHz)
+MFMA_F32_SUSTAINED_TFLOPS = 140.0  # measured: tools/conv_harness peak (profiles/r02_conv_harness.txt), the clock settles at 2.13 GHz
 
 
 def parse(argv=None):
@@ -193,6 +198,19 @@ def conv_table(args, device, reps=10):
             "layers": rows}
 
 
+def pmc_conv_traffic():
+    """Mean HBM bytes per k_wino_conv launch over the four layer shapes (forward + input gradient) from the committed PMC
+    passes of tools/conv_harness (profiles/*_conv_hbm_pmc.json); None when absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_conv_hbm_pmc.json")))
+    if not files:
+        return None
+    try:
+        return int(json.load(open(files[-1]))["k_wino_conv"]["hbm_bytes_per_launch_mean"])
+    except (KeyError, ValueError):
+        return None
+
+
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC profile of this workload (profiles/*_geometry_pmc.json:
     separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, gfx950 x2 read correction); None when absent."""
@@ -251,6 +269,15 @@ def kernel_table(trainer, batch, reps):
 
     row("dl_project", timed(lambda: G.project(pts, offs, max(lengths), sensor, want_kept=False)), 12 * n_pts + 36 * 2 * B * HW, "hbm",
         f"{2 * B} scans, {n_pts} points -> {2 * B}x{sensor.H}x{sensor.W}; 12 B/point + 36 B/pixel (planar + packed image, map)")
+    # the same points in raster order, as the reference's stored scans are (its preprocessing saves the projected point list,
+    # src/preprocessing/preprocesser.py:60-67): the votes of neighbouring points share cache lines of the key plane
+    uv = G.project(pts, offs, max(lengths), sensor, want_kept=False, want_uv=True)["uv"]
+    scan_id = torch.repeat_interleave(torch.arange(len(lengths), device=pts.device), torch.tensor(lengths, device=pts.device))
+    pix = (torch.round(uv[1]).clamp(0, sensor.H - 1) * sensor.W + torch.round(uv[0]).clamp(0, sensor.W - 1)).long()
+    pts_raster = pts[:, torch.argsort(scan_id * HW + pix)].contiguous()
+    row("dl_project/raster-order", timed(lambda: G.project(pts_raster, offs, max(lengths), sensor, want_kept=False)), 12 * n_pts + 36 * 2 * B * HW,
+        "hbm", "the same points sorted by pixel (the order of the reference's preprocessed scans); the bench feeds randomly permuted points")
+    del uv, scan_id, pix, pts_raster
     row("dl_normals", timed(lambda: G.normals(prepared["stacked"].view(2 * B, 4, sensor.H, sensor.W), want_packed=True)), 40 * 2 * B * HW, "valu",
         "7x11 stencil + 3x3 eigen solve; 40 B/pixel (read xyz, write planar + packed normals)")
     row("dl_nn_correspond", timed(lambda: G.nn_correspond(img[:, 1], nrm[:, 1], tgt_pk, tgt_n_pk, T_small, sensor)), 28 * B * HW + 12 * B * HW, "l2+valu",
@@ -262,6 +289,18 @@ def kernel_table(trainer, batch, reps):
     T_rand = GeometryHandler.get_transformation_matrix_quaternion(torch.randn((B, 3), generator=g), q, torch.device("cpu")).to(trainer.device)
     row("dl_nn_correspond/random-pose", timed(lambda: G.nn_correspond(img[:, 1], nrm[:, 1], tgt_pk, tgt_n_pk, T_rand, sensor)),
         28 * B * HW + 12 * B * HW, "l2+valu", "random rotations + 1 m translations (worst case of the exact search)")
+    # the pose the network itself produces at this point of the run (what the search of the timed steps sees): a network that
+    # trains on unrelated random scenes does not converge to the true motion, so the residual the search faces is larger
+    # than the 0.4 m of the row above
+    with torch.no_grad():
+        t_net, q_net = trainer.raw_model(prepared["stacked"])
+        T_net = GeometryHandler.get_transformation_matrix_quaternion(t_net.float(), q_net.float(), trainer.device)
+        qn = q_net.float() / q_net.float().norm(dim=1, keepdim=True)
+        pose = {"translation_m_mean": round(float(t_net.float().norm(dim=1).mean()), 4),
+                "rotation_deg_mean": round(float(torch.rad2deg(2 * torch.acos(qn[:, 3].abs().clamp(max=1.0))).mean()), 4)}
+    row("dl_nn_correspond/network-pose", timed(lambda: G.nn_correspond(img[:, 1], nrm[:, 1], tgt_pk, tgt_n_pk, T_net, sensor)),
+        28 * B * HW + 12 * B * HW, "l2+valu", f"the pose the network outputs after the timed steps: |t| = {pose['translation_m_mean']} m, "
+        f"rotation {pose['rotation_deg_mean']} deg (mean over the batch); this is the regime of the search inside the timed steps")
     row("dl_icp_loss_fwd", timed(lambda: G.icp_loss(T_small, img[:, 1], nrm[:, 1], match, nn, flags)), 52 * M, "hbm",
         f"both launches (stream + reduce); {M} source points with a correspondence, {K} pairs; 52 B/point")
     # cold: the loss kernel alone right after 1 GiB of unrelated writes has gone through the 256 MiB infinity cache
@@ -278,7 +317,8 @@ def kernel_table(trainer, batch, reps):
     cold = timers.elapsed_ms()[2:]
     timers.close()
     del flush
-    return rows, {"M": M, "K": K, "kept": kept, "loss_cold_ms": float(np.mean(cold)), "loss_cold_min_ms": float(np.min(cold))}
+    return rows, {"M": M, "K": K, "kept": kept, "loss_cold_ms": float(np.mean(cold)), "loss_cold_min_ms": float(np.min(cold)),
+                  "network_pose": pose}
 
 
 def _cpu_step(orc, model, opt, cfg, lists, images):
@@ -420,9 +460,21 @@ def main():
             el = float(tt.item())
         return el, ep
 
+    # in-situ timing of the dominant kernel (k_wino_conv: the stride-1 3x3 layers, forward and input gradient) the same way:
+    # every launch of the timed steps carries its own begin/end timestamps (dl_wino_profile_begin / _end)
+    from delora_amd import _lib
+    wino_prof = None
+    if (graphed is None or not graphed.captured) and not args.amp and "hip trunk" in cnn_impl_in_use(trainer, args):
+        _lib.check(_lib.load().dl_wino_profile_begin(int(args.steps) * 64), "dl_wino_profile_begin")
+        wino_prof = True
     counter["i"] = 0
     elapsed, ep = timed_region(args.steps, run_step)
     G.LOSS_TIMER_FACTORY = None
+    if wino_prof:
+        import ctypes
+        ms_, fl_, n_ = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
+        _lib.check(_lib.load().dl_wino_profile_end(ctypes.byref(ms_), ctypes.byref(fl_), ctypes.byref(n_)), "dl_wino_profile_end")
+        wino_prof = {"ms": ms_.value, "flop": fl_.value, "launches": n_.value}
     final_loss = float(ep["loss_epoch"])
     pairs = world * args.batch * args.steps
     ranks_seen = torch.distributed.get_world_size() if world > 1 else 1
@@ -456,7 +508,7 @@ def main():
         live_bytes = 52 * counts["M"]
         warm = live_bytes / loss_ms / 1e6
         cold = live_bytes / counts["loss_cold_ms"] / 1e6
-        result["roofline"] = {
+        result["roofline_loss"] = {
             "kernel": "k_icp_loss (dl_icp_loss_partial: fused transform + residuals + reduction, 13 planes streamed)",
             "bound": "hbm", "regime_in_step": "infinity-cache (the search kernel has just written/read the 54 MB of operands)",
             "achieved": round(warm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(warm / HBM_PEAK_GBS, 4),
@@ -468,6 +520,24 @@ def main():
             "note": "frac = frac_warm: kernel begin/end timestamps on HIP events attached to the launch (hipExtLaunchKernelGGL) in each of "
                     "the K timed steps, where the operands sit in the 256 MiB infinity cache; frac_cold: the same launch right after 1 GiB "
                     "of unrelated writes (operands come from HBM); 52 B x source points with a correspondence, vs the 8 TB/s HBM peak"}
+        result["network_pose_after_timed_steps"] = counts["network_pose"]
+        if wino_prof and wino_prof["launches"]:
+            L, tf = wino_prof["launches"], wino_prof["flop"] / wino_prof["ms"] * 1e-9
+            result["roofline"] = {
+                "kernel": "k_wino_conv (fused Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: the stride-1 3x3 layers of the pose CNN, forward "
+                          "and input gradient; the largest share of the step)",
+                "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                "traffic": pmc_conv_traffic(), "launches_per_step": round(L / args.steps, 2), "ms_per_launch": round(wino_prof["ms"] / L, 5),
+                "ms_per_step": round(wino_prof["ms"] / args.steps, 4), "share_of_step": round(wino_prof["ms"] / args.steps / result["ms_per_step"], 3),
+                "algorithmic_flop_per_launch": round(wino_prof["flop"] / L), "achieved_direct_equivalent": round(2.25 * tf, 1),
+                "frac_of_sustained_peak": round(tf / MFMA_F32_SUSTAINED_TFLOPS, 4),
+                "note": "achieved = multiply-adds the algorithm issues (16 per 2x2 output tile and (c,k) pair = a direct convolution's / 2.25) x 2 "
+                        "/ kernel time; begin/end timestamps on HIP events attached to every launch (hipExtLaunchKernelGGL) of the K timed steps, "
+                        "summed; peak = 256 CUs x 256 flop/clk x 2.4 GHz = 157.3 TFLOP/s dense fp32 MFMA (MI355X_MICROARCH.md); the chip "
+                        f"sustains {MFMA_F32_SUSTAINED_TFLOPS} TFLOP/s (2.13 GHz) on independent MFMAs with no memory traffic (tools/conv_harness peak); "
+                        "traffic = HBM bytes per launch from the committed FETCH_SIZE / WRITE_SIZE passes over the four layer shapes (mean)"}
+        else:
+            result["roofline"] = result["roofline_loss"]
         result["kernels"] = rows
         if world == 1 and not args.amp and "hip trunk" in result["config"]["cnn_impl"]:
             result["roofline_cnn"] = conv_table(args, device)

@@ -17,6 +17,9 @@ struct SensorK {
   float vf0f, vspanf, hm1f;
   // fp64 geometry for the nearest-neighbour window bounds: radians per pixel and origins.
   double hf0, hres, vf0, vres;
+  // fast projection path: a coordinate computed from atan2f (a few ulp) is trusted when it is further than this from a
+  // rounding boundary k + 1/2 [pixels]
+  float tol_u, tol_v;
 };
 
 static inline SensorK make_sensor(const dl_sensor* s) {
@@ -26,6 +29,10 @@ static inline SensorK make_sensor(const dl_sensor* s) {
   k.vf0f = (float)s->vfov0; k.vspanf = (float)(s->vfov1 - s->vfov0); k.hm1f = (float)(s->H - 1);
   k.hf0 = s->hfov0; k.hres = (s->hfov1 - s->hfov0) / (double)(s->W - 1);
   k.vf0 = s->vfov0; k.vres = (s->vfov1 - s->vfov0) / (double)(s->H - 1);
+  // |atan2f - atan2| <= 8 ulp of pi (2^-22 each) = 1.9e-6 rad, taken as 3e-6, times pixels per radian; plus 4 ulp of the
+  // largest coordinate for the three fp32 operations that follow (the same operations on both paths, perturbed input)
+  k.tol_u = (float)(3e-6 * fabs((double)k.wm1f / (double)k.hspanf) + 2.4e-7 * (double)s->W);
+  k.tol_v = (float)(3e-6 * fabs((double)k.hm1f / (double)k.vspanf) + 2.4e-7 * (double)s->H);
   return k;
 }
 
@@ -51,6 +58,18 @@ __device__ __forceinline__ float coord_u(float x, float y, const SensorK& s) {
 __device__ __forceinline__ float coord_v(float x, float y, float z, const SensorK& s) {
   float e = (float)atan2((double)z, (double)norm2f(x, y));
   return ((e - s.vf0f) / s.vspanf) * s.hm1f;
+}
+
+// The same expressions with atan2f (OCML, a few ulp): used by the projection kernel away from rounding boundaries.
+__device__ __forceinline__ float coord_u_fast(float x, float y, const SensorK& s) {
+  return ((atan2f(y, x) - s.hf0f) / s.hspanf) * s.wm1f;
+}
+__device__ __forceinline__ float coord_v_fast(float x, float y, float z, const SensorK& s) {
+  return ((atan2f(z, norm2f(x, y)) - s.vf0f) / s.vspanf) * s.hm1f;
+}
+// true when rint(c) could differ from rint of a value within tol of c
+__device__ __forceinline__ bool near_rounding_boundary(float c, float tol) {
+  return !(fabsf((c - floorf(c)) - 0.5f) >= tol);   // NaN -> true
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

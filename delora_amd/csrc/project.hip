@@ -8,6 +8,12 @@
 // and a second pass turns winning keys into image channels.  No sort, no host round trip, and the
 // result does not depend on the execution order of the atomics.
 //
+// What bounds the vote (tools/exp/scatter_probe.hip, 16 scans x 141k points): the arithmetic + loads take 17 us; the
+// atomics alone take 89 us when the points arrive in random order (every vote moves another 64-byte line of the key
+// plane into the voting XCD's L2: 2.3 M line transfers) and 23 us when they arrive in sensor / raster order, as the
+// reference's stored scans do (8 neighbouring keys share a line).  Tried and dropped: one XCD per key plane with
+// dynamically claimed scans (4x slower: the claim protocol serialises), 32-bit keys (same line traffic).
+//
 // HBM traffic per scan (N points, P = H*W pixels, fp32): scatter reads 12 B*N (+8 B atomics that stay in
 // L2 for a 1 MiB key plane); resolve reads 8 B*P keys, gathers 12 B per occupied pixel from the (L2
 // resident) point buffer and writes 16 B*P image + 4 B*P map: algorithmic 12N + 20P bytes.
@@ -24,8 +30,16 @@ __global__ __launch_bounds__(DL_BLOCK) void k_project_scatter(
     const int64_t g = (int64_t)n0 + i;
     const float x = pts[g], y = pts[cs + g], z = pts[2 * cs + g];
     const float r = norm3f(x, y, z);
-    const float u = coord_u(x, y, sen);
-    const float v = coord_v(x, y, z, sen);
+    // The pixel is rint() of the reference's fp32 expression on a correctly rounded atan2 (coord_u / coord_v: fp64
+    // evaluation, ~600 instructions per coordinate).  atan2f gives the same pixel unless the coordinate lies within
+    // tol of k + 1/2; only those points (0.3 % of them, ~20 % of the waves) and callers that ask for the coordinates
+    // themselves take the fp64 evaluation.
+    float u = coord_u_fast(x, y, sen);
+    float v = coord_v_fast(x, y, z, sen);
+    if (uvr || near_rounding_boundary(u, sen.tol_u) || near_rounding_boundary(v, sen.tol_v)) {
+      u = coord_u(x, y, sen);
+      v = coord_v(x, y, z, sen);
+    }
     if (uvr) { uvr[g] = u; uvr[cs + g] = v; uvr[2 * cs + g] = r; }
     const float ru = rintf(u), rv = rintf(v);   // torch.round: half to even
     if (ru <= sen.wm1f && ru >= 0.0f && rv <= sen.hm1f && rv >= 0.0f) {   // projection.py:74-75

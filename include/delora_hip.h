@@ -282,6 +282,14 @@ int dl_wino_weights_f32(const float* w, float* u_fwd, float* u_bwd, int32_t K, i
 int dl_wino_conv3x3_nhwc_f32(const float* x, const float* u, float* y, const float* add, const float* dsrc, int32_t N,
                              int32_t H, int32_t W, int32_t C, int32_t K, int32_t act, uint32_t epilogue, dl_stream stream);
 
+/* Measurement aid: between dl_wino_profile_begin and dl_wino_profile_end every dl_wino_conv3x3_nhwc_f32 launch carries its
+ * own begin/end timestamps (two HIP events filled by hipExtLaunchKernelGGL) so that the kernel's duration can be read
+ * inside real training steps; *total_flop = 2 * 16 multiply-adds per (2x2 tile, c, k) of the timed launches (what the
+ * matrix cores are asked to do; a direct convolution would need 2.25x as many).  One profile at a time; launches beyond
+ * max_launches are not timed.  Not graph-capturable while a profile is open. */
+int dl_wino_profile_begin(int32_t max_launches);
+int dl_wino_profile_end(double* total_ms, double* total_flop, int32_t* launches);
+
 #ifdef __cplusplus
 }
 #endif

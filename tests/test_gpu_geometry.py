@@ -174,6 +174,42 @@ def test_projection_idempotent_full_size():
     assert torch.equal(out["kept"], out2["kept"])
 
 
+def test_projection_fast_path_gives_the_pixels_of_the_exact_path():
+    """dl_project takes atan2f + a distance-to-rounding-boundary test per point and falls back to the fp64 evaluation near
+    k + 1/2; with want_uv it evaluates every point in fp64.  Both must give the same image -- on 4 M points spread over
+    magnitudes from 1e-3 to 1e3 m, on points planted within a few ulp of pixel boundaries, and on the coordinate axes."""
+    rng = np.random.default_rng(77)
+    H, W = 64, 2048
+    vf, hf = util.kitti_fov()
+    sensor = gpu_sensor(H, W, vf, hf)
+    n = 1_000_000
+    scans = []
+    for scale in (1e-3, 1.0, 30.0, 1e3):
+        p = rng.normal(size=(3, n)).astype(np.float32) * np.float32(scale)
+        p[2] *= np.float32(0.15)                       # keep most of them inside the vertical field of view
+        scans.append(p)
+    # planted: azimuths exactly on / next to pixel boundaries (k + 1/2) * 2 pi / (W - 1), all elevations likewise
+    k = np.arange(-2, W + 2, dtype=np.float64) + 0.5
+    az = hf[0] + k * (hf[1] - hf[0]) / (W - 1)
+    j = np.arange(-2, H + 2, dtype=np.float64) + 0.5
+    el = vf[0] + j * (vf[1] - vf[0]) / (H - 1)
+    azg, elg = np.meshgrid(az, el)
+    planted = []
+    for r in (0.7, 9.3, 61.0):
+        for d in (-2e-7, 0.0, 2e-7):
+            a_, e_ = azg.ravel() * (1 + d), elg.ravel() * (1 + d)
+            planted.append(np.stack([r * np.cos(e_) * np.cos(a_), r * np.cos(e_) * np.sin(a_), r * np.sin(e_)]).astype(np.float32))
+    axes = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [0, 0, 0], [1e-30, 1e-30, 0], [-5, 1e-38, 0.1],
+                     [-5, -1e-38, 0.1]], dtype=np.float32).T
+    scans.append(np.concatenate(planted + [axes], axis=1))
+    fast = run_project(scans, sensor, want_uv=False)
+    exact = run_project(scans, sensor, want_uv=True)
+    for key in ("image4", "pix2pt", "kept"):
+        assert torch.equal(fast[key], exact[key]), key
+    util.measured(f"projection fast path: pixels that differ from the all-fp64 path ({sum(s.shape[1] for s in scans)} points)",
+                  int((fast["pix2pt"] != exact["pix2pt"]).sum()), bound=0)
+
+
 # ------------------------------------------------------------------------------------------ normals
 def _angle(a, b):
     # atan2(|a x b|, a.b): arccos of the dot product has a noise floor of sqrt(2 eps32) ~ 3e-4 rad on fp32 unit vectors

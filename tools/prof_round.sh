@@ -17,6 +17,9 @@ PYTHONPATH=. python tools/ring_bench.py 20 > $out/ring_bench.txt 2>/dev/null
 (tools/bin/conv_harness peak; tools/bin/conv_harness all 10; tools/bin/conv_harness wino 10) > $out/conv_harness.txt 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $out/conv_pmc -o conv -- tools/bin/conv_harness wino 2 > /dev/null 2>&1
 python tools/exp/conv_pmc.py $(find $out/conv_pmc -name "*counter_collection.csv" | head -1) > $out/conv_pmc.txt 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/conv_fetch -o conv -- tools/bin/conv_harness wino 2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/conv_write -o conv -- tools/bin/conv_harness wino 2 > /dev/null 2>&1
+python tools/exp/conv_hbm.py $(find $out/conv_fetch -name "*counter_collection.csv" | head -1) $(find $out/conv_write -name "*counter_collection.csv" | head -1) > $out/conv_hbm_pmc.json 2>$out/conv_hbm.err
 python tools/miopen_layers.py 10 2>/dev/null | grep miopen > $out/miopen_layers.txt
 find $out -name "*.csv" | head -30
 # keep only summaries (the raw traces are large)
