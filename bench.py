@@ -442,6 +442,8 @@ def main():
     if graphed is None or not graphed.captured:            # event-carrying launches cannot be captured into a graph
         G.LOSS_TIMER_FACTORY = timers.new
 
+    enqueue = {}
+
     def timed_region(steps, step_fn):
         torch.cuda.synchronize()
         if world > 1:
@@ -450,6 +452,7 @@ def main():
         ep = None
         for _ in range(steps):
             ep = step_fn()
+        enqueue["ms_per_step"] = 1e3 * (time.perf_counter() - t0) / steps      # host time to enqueue the steps (no sync yet)
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
@@ -470,6 +473,7 @@ def main():
     counter["i"] = 0
     elapsed, ep = timed_region(args.steps, run_step)
     G.LOSS_TIMER_FACTORY = None
+    host_enqueue_ms = enqueue["ms_per_step"]
     if wino_prof:
         import ctypes
         ms_, fl_, n_ = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
@@ -490,7 +494,7 @@ def main():
                    "cnn_impl": cnn_impl_in_use(trainer, args),
                    "channels_last": bool(args.channels_last), "hip_graph": bool(graphed is not None and graphed.captured),
                    "distinct_batches": len(batches)},
-        "final_loss": final_loss,
+        "final_loss": final_loss, "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
         "rccl_ranks": ranks_seen, "collective_backend": (backend if world > 1 else None),
     }
     if rank == 0:

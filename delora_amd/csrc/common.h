@@ -81,3 +81,4 @@ __device__ __forceinline__ float wave_sum(float v) {
 extern thread_local char g_dl_err[256];
 int dl_fail(int code, const char* fmt, ...);
 int dl_check_launch(const char* what);
+int dl_fill_words(void* p, uint32_t value, size_t n_words, hipStream_t st);   // abi.hip: memset as a kernel (graph-safe)

@@ -584,6 +584,13 @@ static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
       if (a.Wo % 64 == 0 && !launch_conv<256, 64, 8, 64, G, BT, 1>(a, st)) return 0;
     }
   }
+  if constexpr (std::is_same<G, GeomConv<3, 1, 2>>::value && !BT) {
+    if (a.C % CV_CK) {   // the stem: 8 input channels, one 8-channel chunk per tap
+      if (a.Wo % 128 == 0 && !launch_conv<128, CV_BN, 8, 128, G, BT, CV_WGN>(a, st)) return 0;
+      if (a.Wo % 64 == 0 && !launch_conv<128, CV_BN, 8, 64, G, BT, CV_WGN>(a, st)) return 0;
+      return 1;
+    }
+  }
   if (a.Wo % 128 == 0 && !launch_conv<128, CV_BN, CV_CK, 128, G, BT, CV_WGN>(a, st)) return 0;
   if (a.Wo % 64 == 0 && !launch_conv<128, CV_BN, CV_CK, 64, G, BT, CV_WGN>(a, st)) return 0;
   if (a.Wo % 32 == 0 && !launch_conv<128, CV_BN, CV_CK, 32, G, BT, CV_WGN>(a, st)) return 0;

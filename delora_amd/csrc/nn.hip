@@ -713,9 +713,7 @@ extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const f
     return dl_fail(DL_ERR_UNSUPPORTED, "dl_nn_correspond: images beyond 65535 rows or columns are not supported");
   NNWorkspace ws = carve_nn(workspace, B, sen.H, sen.W);
   // the hard-query counter indexes ws.hard[]: never launch the search on an uninitialised header
-  if (hipMemsetAsync(ws.counter, 0, nn_header_bytes(B), st) != hipSuccess)
-    return dl_fail(DL_ERR_LAUNCH, "dl_nn_correspond: hipMemsetAsync(workspace header) failed: %s",
-                   hipGetErrorString(hipGetLastError()));
+  dl_fill_words(ws.counter, 0u, nn_header_bytes(B) / 4, st);
   {
     const int waves = (int)(B * nn_tiles(sen.H, sen.W));
     hipLaunchKernelGGL(k_nn_tiles, dim3((waves * DL_WAVE + DL_BLOCK - 1) / DL_BLOCK), dim3(DL_BLOCK), 0, st,

@@ -113,12 +113,10 @@ extern "C" int dl_project(const float* pts, int64_t pts_cs, const int32_t* offs,
   if (packed_aux && C < 6) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_project: packed_aux needs C >= 6 (got %d)", C);
   hipStream_t st = (hipStream_t)stream;
   const SensorK sen = make_sensor(sensor);
-  // the key plane and the counters MUST be initialised before the kernels run: a failed memset (stream in an error state,
-  // unsupported capture mode) would let stale keys be resolved as points
-  if (hipMemsetAsync(keys_ws, 0xff, dl_project_workspace_bytes(S, sen.H, sen.W), st) != hipSuccess)
-    return dl_fail(DL_ERR_LAUNCH, "dl_project: hipMemsetAsync(key plane) failed: %s", hipGetErrorString(hipGetLastError()));
-  if (kept && hipMemsetAsync(kept, 0, sizeof(int32_t) * S, st) != hipSuccess)
-    return dl_fail(DL_ERR_LAUNCH, "dl_project: hipMemsetAsync(kept) failed: %s", hipGetErrorString(hipGetLastError()));
+  // the key plane and the counters are initialised by a kernel on the same stream (dl_fill_words: a kernel node, not a
+  // memset node, when the step is captured into a HIP graph); a launch failure is reported by dl_check_launch below
+  dl_fill_words(keys_ws, 0xffffffffu, dl_project_workspace_bytes(S, sen.H, sen.W) / 4, st);
+  if (kept) dl_fill_words(kept, 0u, (size_t)S, st);
   if (max_n > 0) {
     int gx = (max_n + DL_BLOCK - 1) / DL_BLOCK;
     if (gx > 4096) gx = 4096;

@@ -7,6 +7,8 @@ shapes per batch (scan lengths: pad with far-away points, the projection drops t
 ``capturable=True``, and world_size == 1 (DDP's bucketed all-reduce is left eager).  ``GraphedStep`` falls back to the
 eager step if capture fails.
 """
+import os
+
 import torch
 
 
@@ -31,6 +33,8 @@ class GraphedStep:
                     self._eager(self.static_batch)
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+            if os.environ.get("DL_GRAPH_DEBUG"):
+                print("[graph_step] warm-up on the side stream finished; capturing", flush=True)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self.outputs = self._eager(self.static_batch)

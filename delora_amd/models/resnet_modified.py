@@ -118,7 +118,18 @@ class ResNetModified(torch.nn.Module):
 
     def forward(self, x):
         act = "relu" if self.activation_fct == "relu" else "tanh"
-        p = ring_act_pad(self.dropout_values(x), "none", pad=True)
+        x = self.dropout_values(x)
+        N, Cin, Hin, Win = x.shape
+        C0 = self.conv1.out_channels
+        if (self.hip_trunk_applicable((N, Hin, Win // 4, C0), x) and Win % 4 == 0
+                and ring_conv.stem_supported(tuple(x.shape), C0)):
+            # channels-last from the first layer on: stem (conv1 + act + pool) and layer1..layer4 on the HIP kernels
+            blocks, weights = self._trunk_blocks()
+            x0 = ring_conv.RingStem.apply(x, self.conv1.weight, ring_conv.ACT[act])              # [N,H,W/4,C0]
+            x4 = ring_conv.RingTrunk.apply(x0, ring_conv.ACT[act], blocks, *weights)          # [N,H',W',C']
+            out = self.dropout_values(self.fc(ring_conv.MeanHW.apply(x4)))
+            return [None, None, None, x4.permute(0, 3, 1, 2), out]
+        p = ring_act_pad(x, "none", pad=True)
         p = ring_act_pool_pad(self.conv1(p), act)                    # act + wrap + self.maxpool + wrap, fused
         N, C0, H0, Wp = p.shape
         if self.hip_trunk_applicable((N, H0, Wp - 2, C0), p):
@@ -126,7 +137,7 @@ class ResNetModified(torch.nn.Module):
             blocks, weights = self._trunk_blocks()
             x0 = p[..., 1:-1].permute(0, 2, 3, 1).contiguous()
             x4 = ring_conv.RingTrunk.apply(x0, ring_conv.ACT[act], blocks, *weights)          # [N,H',W',C']
-            out = self.dropout_values(self.fc(x4.mean(dim=(1, 2))))
+            out = self.dropout_values(self.fc(ring_conv.MeanHW.apply(x4)))
             return [None, None, None, x4.permute(0, 3, 1, 2), out]
         if self.impl == "hip":
             raise RuntimeError(f"cnn_impl 'hip': the HIP trunk does not support input {tuple(x.shape)} / dtype {x.dtype}")

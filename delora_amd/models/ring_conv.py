@@ -132,6 +132,85 @@ def dgrad_strided(g, w_krsc, stride, act=0, epilogue=0, add_grid=None, dsrc=None
     return dx
 
 
+def pool_fwd(a):
+    """Stem max-pooling (3x3, stride (1,2), wrap-around width) of a ``[N,H,W,C]`` -> (y ``[N,H,W/2,C]``, win int8)."""
+    lib = _lib.load()
+    N, H, W, C = a.shape
+    y = torch.empty((N, H, W // 2, C), dtype=torch.float32, device=a.device)
+    win = torch.empty((N, H, W // 2, C), dtype=torch.int8, device=a.device)
+    _lib.check(lib.dl_pool3x3s12_nhwc_fwd(_ptr(a), N, H, W, C, _ptr(y), _ptr(win), _stream()), "dl_pool3x3s12_nhwc_fwd")
+    return y, win
+
+
+def pool_bwd(g, a, win, act):
+    """Gradient of ``pool_fwd(act(.))`` with respect to the PRE-activation conv1 output: ``[N,H,W,C]``."""
+    lib = _lib.load()
+    N, H, W, C = a.shape
+    out = torch.empty_like(a)
+    _lib.check(lib.dl_pool3x3s12_nhwc_bwd(_ptr(g), _ptr(a), _ptr(win), N, H, W, C, int(act), _ptr(out), _stream()),
+               "dl_pool3x3s12_nhwc_bwd")
+    return out
+
+
+class MeanHW(torch.autograd.Function):
+    """Global average pooling of a channels-last map ``[N,H,W,C]`` -> ``[N,C]`` (avgpool + flatten of the reference) as one
+    deterministic kernel; the backward is the broadcast of ``g / (H*W)``."""
+
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib.load()
+        x = x.contiguous()
+        N, H, W, C = x.shape
+        y = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        _lib.check(lib.dl_mean_hw_nhwc_f32(_ptr(x), N, H * W, C, _ptr(y), _stream()), "dl_mean_hw_nhwc_f32")
+        ctx.shape = (N, H, W, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        N, H, W, C = ctx.shape
+        return (g * (1.0 / (H * W))).view(N, 1, 1, C).expand(N, H, W, C)
+
+
+def stem_supported(x_shape, out_channels):
+    """Whether RingStem takes an input ``[N,C,H,W]``: 8 input channels per chunk, 64-channel output tiles, width 4 x 64."""
+    N, C, H, W = x_shape
+    return C % 8 == 0 and C % 16 != 0 and out_channels % 64 == 0 and W % 256 == 0 and H % 2 == 0
+
+
+class RingStem(torch.autograd.Function):
+    """conv1 (3x3, stride (1,2), wrap-around width) + activation + the 3x3 / stride (1,2) max-pooling of the stem on
+    channels-last tensors (reference resnet_modified.py:97-102): ``[N,8,H,W]`` planar input -> ``[N,H,W/4,64]``.  Forward:
+    one transposing copy of the 8-channel input, the direct MFMA convolution with the activation in its epilogue, the
+    pooling kernel.  Backward: pooling + activation derivative in one gather kernel, then the weight gradient (8 input
+    channels are below the tile of dl_conv2d_wgrad_nhwc_f32: the library's channels-last kernel on views, no layout
+    conversion).  The 134 MB pre-pooling map is kept for the backward (the pooled output is not: the trunk saves it)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, act):
+        x8 = x.permute(0, 2, 3, 1).contiguous()
+        a = conv_nhwc(x8, weight_storage(w1), stride=(1, 2), act=act, epilogue=EPI_ACT if act else 0)
+        y, win = pool_fwd(a)
+        ctx.save_for_backward(x8, a, win, w1)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x8, a, win, w1 = ctx.saved_tensors
+        gc = pool_bwd(g.contiguous(), a, win, ctx.act)
+        xp = torch.cat((x8[:, :, -1:], x8, x8[:, :, :1]), dim=2).permute(0, 3, 1, 2)       # wrapped, channels_last strides
+        want_x = ctx.needs_input_grad[0]
+        gx, dw, _ = torch.ops.aten.convolution_backward(gc.permute(0, 3, 1, 2), xp, w1, None, (1, 2), (1, 0), (1, 1), False,
+                                                        (0, 0), 1, (want_x, True, False))
+        if want_x:                                     # fold the two wrap columns back
+            gxp = gx
+            gx = gxp[..., 1:-1].clone()
+            gx[..., -1] += gxp[..., 0]
+            gx[..., 0] += gxp[..., -1]
+        return (gx if want_x else None), dw, None
+
+
 class RingTrunk(torch.autograd.Function):
     """layer1..layer4 of the pose CNN.  ``forward(x0, act, blocks, *weights)``: x0 ``[N,H,W,C0]`` channels-last, already
     activated (the pooled stem output); blocks = tuple of (cin, cout, stride, has_downsample); weights in block order

@@ -282,6 +282,24 @@ int dl_wino_weights_f32(const float* w, float* u_fwd, float* u_bwd, int32_t K, i
 int dl_wino_conv3x3_nhwc_f32(const float* x, const float* u, float* y, const float* add, const float* dsrc, int32_t N,
                              int32_t H, int32_t W, int32_t C, int32_t K, int32_t act, uint32_t epilogue, dl_stream stream);
 
+/*
+ * The stem's max-pooling on channels-last activations (reference src/models/resnet_modified.py:100-102: F.pad(circular) +
+ * MaxPool2d(kernel 3, stride (1,2), padding (1,0)) after conv1 + activation), between the convolution kernels above:
+ *   dl_pool3x3s12_nhwc_fwd: a [N][H][W][C] (activated conv1 output) -> y [N][H][W/2][C], win [N][H][W/2][C] int8 = position
+ *                           0..8 of each maximum, row-major in the window (torch's rule: rows first, the first strictly
+ *                           greater value wins, NaN propagates; the column left of column 0 is column W-1)
+ *   dl_pool3x3s12_nhwc_bwd: g [N][H][W/2][C], a, win -> g_conv [N][H][W][C] = act'(a) * (sum of g over the windows that
+ *                           selected the element); act: 0 none, 1 tanh (1 - a^2), 2 relu (a > 0)
+ *   W even, C % 4 == 0.
+ */
+int dl_pool3x3s12_nhwc_fwd(const float* a, int32_t N, int32_t H, int32_t W, int32_t C, float* y, int8_t* win, dl_stream stream);
+int dl_pool3x3s12_nhwc_bwd(const float* g, const float* a, const int8_t* win, int32_t N, int32_t H, int32_t W, int32_t C,
+                           int32_t act, float* g_conv, dl_stream stream);
+
+/* Global average pooling of a channels-last feature map (reference resnet_modified.py: avgpool + flatten before fc):
+ * x [N][P][C] (P = H*W pixels) -> y [N][C]; fixed summation order; C % 4 == 0. */
+int dl_mean_hw_nhwc_f32(const float* x, int32_t N, int32_t P, int32_t C, float* y, dl_stream stream);
+
 /* Measurement aid: between dl_wino_profile_begin and dl_wino_profile_end every dl_wino_conv3x3_nhwc_f32 launch carries its
  * own begin/end timestamps (two HIP events filled by hipExtLaunchKernelGGL) so that the kernel's duration can be read
  * inside real training steps; *total_flop = 2 * 16 multiply-adds per (2x2 tile, c, k) of the timed launches (what the

@@ -372,3 +372,27 @@ def test_ddp_wrapping_uses_small_buckets_and_bucket_views():
         assert wrapped.bucket_bytes_cap == 10 * 1024 * 1024 and wrapped.gradient_as_bucket_view
     finally:
         dist.destroy_process_group()
+
+
+def test_full_size_step_replays_as_a_hip_graph():
+    """The whole bench step (64x2048, B=8, HIP stem + trunk) captured once and replayed: three replays must run (a memset
+    node in the captured graph used to fault on the second replay: the library initialises its buffers with a kernel
+    instead) and follow the eager trajectory."""
+    from delora_amd.deploy.graph_step import GraphedStep
+    dev = _dev()
+    args, cfg, samples, tr_e = _bench_setup(8, dev)
+    eager = []
+    for _ in range(6):
+        ep, _ = _one_step(tr_e, samples)
+        eager.append(float(ep["loss_epoch"]))
+    args, cfg, samples, tr_g = _bench_setup(8, dev)
+    gs = GraphedStep(tr_g, samples, warmup=3)
+    assert gs.captured
+    got = []
+    for _ in range(3):
+        ep, _ = gs()
+        torch.cuda.synchronize()
+        got.append(float(ep["loss_epoch"]))
+    print("eager", eager, "graph", got)
+    util.measured("full-size graph replay: worst relative deviation of the loss from the eager trajectory",
+                  float(np.max(np.abs(np.array(got) - np.array(eager[3:6])) / np.abs(np.array(eager[3:6])))), bound=1e-3)

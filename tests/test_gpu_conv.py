@@ -159,3 +159,73 @@ def test_hip_trunk_is_used_by_the_full_size_step_and_falls_back_for_small_networ
     assert not small.resnet.hip_trunk_applicable((2, 16, 32, 8), torch.zeros(1, device=dev))
     with torch.autocast("cuda", dtype=torch.bfloat16):
         assert not big.resnet.hip_trunk_applicable((8, 64, 512, 64), torch.zeros(1, device=dev))
+
+
+def _ref_stem(x, w1, act):
+    a = _ref_conv(x, w1, (1, 2), 3)
+    a = torch.tanh(a) if act == "tanh" else torch.relu(a)
+    return F.max_pool2d(F.pad(a, (1, 1, 0, 0), mode="circular"), kernel_size=3, stride=(1, 2), padding=(1, 0))
+
+
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+def test_stem_pooling_kernels_against_torch(act):
+    """dl_pool3x3s12_nhwc_fwd / _bwd against F.max_pool2d of the wrapped map and torch autograd through act + pooling:
+    values bit-equal, gradient with respect to the pre-activation within rounding of the sums."""
+    from delora_amd.models import ring_conv as rc
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    pre = torch.randn((2, 8, 6, 64), generator=g).to(dev).requires_grad_(True)            # NCHW
+    pre.data[0, :, 0, :4] = 3.0                                                          # ties: the first position must win
+    a = torch.tanh(pre) if act == "tanh" else torch.relu(pre)
+    y_ref = F.max_pool2d(F.pad(a, (1, 1, 0, 0), mode="circular"), kernel_size=3, stride=(1, 2), padding=(1, 0))
+    gy = torch.randn(y_ref.shape, generator=g).to(dev)
+    y_ref.backward(gy)
+    a_nhwc = a.detach().permute(0, 2, 3, 1).contiguous()
+    y, win = rc.pool_fwd(a_nhwc)
+    assert torch.equal(y.permute(0, 3, 1, 2), y_ref.detach())
+    assert int(win.min()) >= 0 and int(win.max()) <= 8
+    gc = rc.pool_bwd(gy.permute(0, 2, 3, 1).contiguous(), a_nhwc, win, rc.ACT[act])
+    util.measured(f"stem pooling[{act}]: gradient w.r.t. the pre-activation vs torch autograd (absolute)",
+                  float((gc.permute(0, 3, 1, 2) - pre.grad).abs().max()), bound=2e-6)
+
+
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+def test_stem_function_against_torch(act):
+    """RingStem (transposing copy + MFMA conv1 with the activation in the epilogue + pooling; backward: pooling gather +
+    weight gradient) against F.pad(circular) + conv2d + act + F.pad(circular) + max_pool2d under torch autograd."""
+    from delora_amd.models import ring_conv as rc
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(9)
+    x = (torch.randn((2, 8, 16, 1024), generator=g) * 3.0).to(dev)
+    w1 = (torch.randn((64, 8, 3, 3), generator=g) * 0.05).to(dev).requires_grad_(True)
+    assert rc.stem_supported(tuple(x.shape), 64)
+    y = rc.RingStem.apply(x, w1, rc.ACT[act])                                            # [N,H,W/4,64]
+    gy = torch.randn(y.shape, generator=g).to(dev)
+    y.backward(gy)
+    dw = w1.grad.clone()
+    w1.grad = None
+    xr = x.clone().requires_grad_(True)
+    y_ref = _ref_stem(xr, w1, act)
+    y_ref.backward(gy.permute(0, 3, 1, 2))
+    util.measured(f"stem[{act}]: pooled output vs torch (absolute)", float((y.permute(0, 3, 1, 2) - y_ref.detach()).abs().max()), bound=2e-5)
+    util.measured(f"stem[{act}]: conv1 weight gradient vs torch autograd (relative)", _rel(dw, w1.grad), bound=(REL if act == "tanh" else 1e-2))
+    # and the input gradient (not needed by the training step: the image carries none)
+    x2 = x.clone().requires_grad_(True)
+    rc.RingStem.apply(x2, w1, rc.ACT[act]).backward(gy)
+    util.measured(f"stem[{act}]: input gradient vs torch autograd (relative)", _rel(x2.grad, xr.grad), bound=(REL if act == "tanh" else 1e-2))
+
+
+def test_mean_hw_kernel_against_torch():
+    from delora_amd.models import ring_conv as rc
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    x = torch.randn((3, 8, 64, 512), generator=g).to(dev).requires_grad_(True)
+    y = rc.MeanHW.apply(x)
+    gy = torch.randn(y.shape, generator=g).to(dev)
+    y.backward(gy)
+    gx = x.grad.clone()
+    x.grad = None
+    y_ref = x.mean(dim=(1, 2))
+    y_ref.backward(gy)
+    util.measured("global average pooling (channels-last): kernel vs torch.mean (absolute)", float((y - y_ref).abs().max()), bound=1e-6)
+    assert torch.allclose(gx, x.grad, rtol=0, atol=1e-9)

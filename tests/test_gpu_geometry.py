@@ -678,3 +678,33 @@ def test_loss_ragged_image_sizes_against_torch_ops(shape):
         for b in range(2):
             _close(terms[b][use[b]].detach().cpu().numpy(), exp[b][use[b]].detach().cpu().numpy(), what=f"{mode} sample {b} terms")
             _close(T.grad[b, :3].cpu().numpy(), Tr.grad[b, :3].cpu().numpy(), what=f"{mode} sample {b} dL/dT")
+
+
+def test_search_and_loss_survive_non_finite_and_huge_poses():
+    """A diverged network can emit NaN / inf / 1e30 poses: the search must neither fault nor return indices outside the
+    image, and the sample with a sane pose in the same batch must be unaffected."""
+    from delora_amd.data import synthetic
+    dev = _dev()
+    H, W, B = 64, 512, 4
+    vf, hf = util.kitti_fov()
+    sensor = gpu_sensor(H, W, vf, hf)
+    s1, s2, _ = synthetic.make_pair(41, rings=64, azimuth_steps=560)
+    prj = run_project([s1, s2] * B, sensor, want_uv=False)
+    nrm, nrm_pk = _geo().normals(prj["image4"], want_packed=True)
+    img, nr = prj["image4"].view(B, 2, 4, H, W), nrm.view(B, 2, 3, H, W)
+    tpk, tn = prj["packed"].view(B, 2, H, W, 4)[:, 0], nrm_pk.view(B, 2, H, W, 4)[:, 0]
+    flags = _geo().LOSS_POINT_TO_PLANE | _geo().LOSS_PLANE_TO_PLANE
+    ref = None
+    for name, val in (("nan", float("nan")), ("inf", float("inf")), ("huge", 1e30), ("-huge", -1e30)):
+        T = torch.eye(4, device=dev).repeat(B, 1, 1)
+        T[0, 0, 3] = val
+        T[1, 1, 1] = val
+        T[2, :3, :3] = val
+        nn, vis, match = _geo().nn_correspond(img[:, 1], nr[:, 1], tpk, tn, T, sensor)
+        terms, counts = _geo().icp_loss(T, img[:, 1], nr[:, 1], match, nn, flags)
+        torch.cuda.synchronize()
+        assert int(nn.max()) < H * W and int(nn.min()) >= -1, name
+        sane = terms[3].cpu().numpy()
+        assert np.all(np.isfinite(sane)) and int(counts[3, 0]) > 1000, name
+        ref = sane if ref is None else ref
+        assert np.array_equal(sane, ref), name                     # the sample with T = I does not see its neighbours' poses
