@@ -36,7 +36,10 @@ class Trainer(deployer.Deployer):
         self.raw_model = self.model
         if self.world_size > 1:
             self.model = self._wrap_ddp(self.raw_model)
-        self.optimizer = torch.optim.Adam(params=self.raw_model.parameters(), lr=config["learning_rate"])
+        # torch.optim.Adam as the reference (src/deploy/trainer.py:23); on the GPU its single-kernel implementation: the
+        # default multi-tensor one takes a per-tensor slow path for the channels-last trunk weights (65 launches, 0.4 ms)
+        fused = torch.device(self.device).type == "cuda" and str(config.get("adam_impl", "fused")) == "fused"
+        self.optimizer = torch.optim.Adam(params=self.raw_model.parameters(), lr=config["learning_rate"], **({"fused": True} if fused else {}))
         if config["checkpoint"]:
             checkpoint = torch.load(config["checkpoint"], map_location=self.device, weights_only=False)
             self.raw_model.load_state_dict(checkpoint["model_state_dict"])
