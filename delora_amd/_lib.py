@@ -61,6 +61,8 @@ SIGNATURES = {
     "dl_wino_conv3x3_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _u32, _vp]),
     "dl_pool3x3s12_nhwc_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "dl_pool3x3s12_nhwc_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "dl_quat_to_T_fwd": (_i32, [_vp, _vp, _i32, ctypes.c_float, _vp, _vp]),
+    "dl_quat_to_T_bwd": (_i32, [_vp, _vp, _i32, ctypes.c_float, _vp, _vp, _vp]),
     "dl_mean_hw_nhwc_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "dl_wino_profile_begin": (_i32, [_i32]),
     "dl_wino_profile_end": (_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),

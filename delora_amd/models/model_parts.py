@@ -19,6 +19,39 @@ class CircularPad(torch.nn.Module):
         return f"padding={self.padding}"
 
 
+class _QuatToT(torch.autograd.Function):
+    EPS = 1e-12
+
+    @staticmethod
+    def forward(ctx, translation, quaternion):
+        import ctypes
+        from .. import _lib
+        lib = _lib.load()
+        t, q = translation.contiguous(), quaternion.contiguous()
+        B = q.shape[0]
+        T = torch.empty((B, 4, 4), dtype=torch.float32, device=q.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.dl_quat_to_T_fwd(ctypes.c_void_p(t.data_ptr()), ctypes.c_void_p(q.data_ptr()), B, _QuatToT.EPS,
+                                        ctypes.c_void_p(T.data_ptr()), st), "dl_quat_to_T_fwd")
+        ctx.save_for_backward(q)
+        return T
+
+    @staticmethod
+    def backward(ctx, grad_T):
+        import ctypes
+        from .. import _lib
+        lib = _lib.load()
+        (q,) = ctx.saved_tensors
+        g = grad_T.contiguous()
+        B = q.shape[0]
+        gt = torch.empty((B, 3), dtype=torch.float32, device=q.device)
+        gq = torch.empty((B, 4), dtype=torch.float32, device=q.device)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(lib.dl_quat_to_T_bwd(ctypes.c_void_p(q.data_ptr()), ctypes.c_void_p(g.data_ptr()), B, _QuatToT.EPS,
+                                        ctypes.c_void_p(gt.data_ptr()), ctypes.c_void_p(gq.data_ptr()), st), "dl_quat_to_T_bwd")
+        return gt, gq
+
+
 class GeometryHandler:
     """Quaternion (x, y, z, w) + translation -> homogeneous transform, differentiable torch ops.
 
@@ -44,7 +77,10 @@ class GeometryHandler:
 
     @staticmethod
     def get_transformation_matrix_quaternion(translation, quaternion, device):
-        """``T[B,4,4] = [[R, t], [0, 1]]`` (reference model_parts.py:38-44)."""
+        """``T[B,4,4] = [[R, t], [0, 1]]`` (reference model_parts.py:38-44).  fp32 CUDA tensors take one HIP kernel each way
+        (dl_quat_to_T_fwd / _bwd: the ~35 element-wise torch ops below and their autograd are ~100 launches per step)."""
+        if translation.is_cuda and quaternion.is_cuda and translation.dtype == torch.float32 and quaternion.dtype == torch.float32:
+            return _QuatToT.apply(translation.reshape(-1, 3), quaternion.reshape(-1, 4))
         R = GeometryHandler.quaternion_to_rot_matrix(quaternion)
         B = R.shape[0]
         top = torch.cat((R, translation.reshape(B, 3, 1).to(R.dtype)), dim=2)

@@ -296,6 +296,14 @@ int dl_pool3x3s12_nhwc_fwd(const float* a, int32_t N, int32_t H, int32_t W, int3
 int dl_pool3x3s12_nhwc_bwd(const float* g, const float* a, const int8_t* win, int32_t N, int32_t H, int32_t W, int32_t C,
                            int32_t act, float* g_conv, dl_stream stream);
 
+/* Quaternion (x,y,z,w) + translation -> T [B][4][4] = [[R, t], [0, 1]] and its backward (reference src/models/model_parts.py:
+ * 24-44; R = kornia 0.3.0 quaternion_to_rotation_matrix: normalise with eps, then the element-wise formula):
+ *   dl_quat_to_T_fwd: translation [B][3], quaternion [B][4] -> T
+ *   dl_quat_to_T_bwd: quaternion, grad_T [B][4][4] -> grad_translation [B][3], grad_quaternion [B][4] */
+int dl_quat_to_T_fwd(const float* translation, const float* quaternion, int32_t B, float eps, float* T, dl_stream stream);
+int dl_quat_to_T_bwd(const float* quaternion, const float* grad_T, int32_t B, float eps, float* grad_translation,
+                     float* grad_quaternion, dl_stream stream);
+
 /* Global average pooling of a channels-last feature map (reference resnet_modified.py: avgpool + flatten before fc):
  * x [N][P][C] (P = H*W pixels) -> y [N][C]; fixed summation order; C % 4 == 0. */
 int dl_mean_hw_nhwc_f32(const float* x, int32_t N, int32_t P, int32_t C, float* y, dl_stream stream);

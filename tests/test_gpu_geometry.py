@@ -708,3 +708,29 @@ def test_search_and_loss_survive_non_finite_and_huge_poses():
         assert np.all(np.isfinite(sane)) and int(counts[3, 0]) > 1000, name
         ref = sane if ref is None else ref
         assert np.array_equal(sane, ref), name                     # the sample with T = I does not see its neighbours' poses
+
+
+def test_quaternion_to_transform_kernel_against_the_torch_formulation():
+    """dl_quat_to_T_fwd / _bwd (one kernel each way on the GPU) against the element-wise torch formulation of
+    GeometryHandler (what CPU tensors take) and torch autograd through it: unnormalised, tiny and huge quaternions."""
+    from delora_amd.models.model_parts import GeometryHandler
+    dev = _dev()
+    g = torch.Generator().manual_seed(12)
+    q = torch.randn((10, 4), generator=g)
+    q[1] *= 1e-3
+    q[2] *= 1e4
+    q[3] = torch.tensor([0.0, 0.0, 0.0, 1.0])
+    q[4] = torch.tensor([1e-20, 0.0, 0.0, 0.0])          # below the normalisation eps: clamped branch
+    t = torch.randn((10, 3), generator=g)
+    G = torch.randn((10, 4, 4), generator=g)
+    qc, tc = q.clone().requires_grad_(True), t.clone().requires_grad_(True)
+    T_ref = GeometryHandler.get_transformation_matrix_quaternion(tc, qc, torch.device("cpu"))
+    (T_ref * G).sum().backward()
+    qg, tg = q.to(dev).requires_grad_(True), t.to(dev).requires_grad_(True)
+    T = GeometryHandler.get_transformation_matrix_quaternion(tg, qg, dev)
+    (T * G.to(dev)).sum().backward()
+    util.measured("quaternion -> T kernel vs torch formulation (absolute)", float((T.detach().cpu() - T_ref.detach()).abs().max()), bound=1e-6)
+    scale = qc.grad.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+    util.measured("quaternion -> T kernel: dL/dq vs torch autograd (relative to the row's largest component)",
+                  float(((qg.grad.cpu() - qc.grad).abs() / scale).max()), bound=2e-5)
+    assert torch.equal(tg.grad.cpu(), tc.grad)

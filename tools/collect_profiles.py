@@ -18,7 +18,7 @@ for a, b in [("bench.json", f"{R}_bench.json"), ("bench_profiled.json", f"{R}_be
     json.dump(last_json(os.path.join(src, a)), open(os.path.join(dst, b), "w"), indent=1)
 shutil.copy(os.path.join(src, "bench_trace", "bench_kernel_stats.csv"), os.path.join(dst, f"{R}_bench_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "geo_trace", "geo_kernel_stats.csv"), os.path.join(dst, f"{R}_geometry_kernel_stats.csv"))
-for name in ("loss_warm.txt", "ring_bench.txt", "conv_harness.txt", "conv_pmc.txt", "conv_hbm_pmc.json", "miopen_layers.txt"):
+for name in ("loss_warm.txt", "ring_bench.txt", "conv_harness.txt", "conv_pmc.txt", "conv_hbm_pmc.json", "scatter_probe.txt", "step_breakdown.txt", "miopen_layers.txt"):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, f"{R}_{name}"))
 

@@ -20,6 +20,7 @@ python tools/exp/conv_pmc.py $(find $out/conv_pmc -name "*counter_collection.csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/conv_fetch -o conv -- tools/bin/conv_harness wino 2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/conv_write -o conv -- tools/bin/conv_harness wino 2 > /dev/null 2>&1
 python tools/exp/conv_hbm.py $(find $out/conv_fetch -name "*counter_collection.csv" | head -1) $(find $out/conv_write -name "*counter_collection.csv" | head -1) > $out/conv_hbm_pmc.json 2>$out/conv_hbm.err
+(tools/bin/scatter_probe 20; echo "-- points in raster order"; tools/bin/scatter_probe 20 1) > $out/scatter_probe.txt 2>&1
 python tools/miopen_layers.py 10 2>/dev/null | grep miopen > $out/miopen_layers.txt
 find $out -name "*.csv" | head -30
 # keep only summaries (the raw traces are large)
