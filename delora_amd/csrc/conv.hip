@@ -584,11 +584,14 @@ static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
       if (a.Wo % 64 == 0 && !launch_conv<256, 64, 8, 64, G, BT, 1>(a, st)) return 0;
     }
   }
-  if constexpr (std::is_same<G, GeomConv<3, 1, 2>>::value && !BT) {
-    if (a.C % CV_CK) {   // the stem: 8 input channels, one 8-channel chunk per tap
+  if constexpr (G::WTAPS == 9 && !BIG) {
+    // strided 3x3 layers and their input-gradient phases: 8-channel chunks (half the LDS, two workgroups per CU) are
+    // 5-9 % faster up to 256 reduction channels (tools/conv_harness time; the 512-channel phases and the 1x1 layers keep
+    // 16); the stem (8 input channels) has no other choice
+    if (a.C % CV_CK || a.C <= 256) {
       if (a.Wo % 128 == 0 && !launch_conv<128, CV_BN, 8, 128, G, BT, CV_WGN>(a, st)) return 0;
       if (a.Wo % 64 == 0 && !launch_conv<128, CV_BN, 8, 64, G, BT, CV_WGN>(a, st)) return 0;
-      return 1;
+      if (a.C % CV_CK) return 1;
     }
   }
   if (a.Wo % 128 == 0 && !launch_conv<128, CV_BN, CV_CK, 128, G, BT, CV_WGN>(a, st)) return 0;
