@@ -674,9 +674,15 @@ extern "C" int dl_conv2d_dgrad_strided_nhwc_f32(const float* g, const float* w, 
 #define WG_PK 32
 #endif
 
+#ifdef CV_TUNE
+int g_wg_want = 512;
+#else
+static const int g_wg_want = 512;
+#endif
+
 static int wgrad_slabs(int total_chunks, int tiles) {
   // enough workgroups to fill 256 CUs twice over (2 resident per CU); a slab is a run of pixel chunks
-  int want = (512 + tiles - 1) / tiles;
+  int want = (g_wg_want + tiles - 1) / tiles;
   if (want > total_chunks) want = total_chunks;
   if (want < 1) want = 1;
   const int per = (total_chunks + want - 1) / want;

@@ -457,6 +457,7 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  if (getenv("WG_WANT")) g_wg_want = atoi(getenv("WG_WANT"));
   const bool do_check = argc < 2 || !strcmp(argv[1], "check") || !strcmp(argv[1], "all");
   const bool do_time = argc >= 2 && (!strcmp(argv[1], "time") || !strcmp(argv[1], "all"));
   int bad = 0;
