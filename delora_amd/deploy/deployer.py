@@ -88,6 +88,40 @@ class Deployer(object):
         return self.model(*args)
 
     # ------------------------------------------------------------------------------------------------ the step
+    def _loss_weights(self, B, Bg, lam, device, dtype):
+        """Cached constants of the loss weighting: W_pc[j,k] = (Bg - j_global) / Bg * (1, lambda, 1)[k] and the column
+        weights (1, lambda, 1) / Bg of the logged per-term sums."""
+        key = (B, Bg, self.rank, lam, str(device), dtype)
+        cache = self.__dict__.setdefault("_loss_weight_cache", {})
+        if key not in cache:
+            j = torch.arange(B, dtype=torch.float64) + float(self.rank * B)
+            col = torch.tensor([1.0, lam, 1.0], dtype=torch.float64)
+            cache[key] = ((((Bg - j) / Bg)[:, None] * col[None, :]).to(dtype).to(device), (col / Bg).to(dtype).to(device))
+        return cache[key]
+
+    @staticmethod
+    def _accumulate(epoch_losses, keys, vals):
+        """epoch_losses[k] += v for 0-d device tensors.  While the accumulators are still the initial python zeros the values
+        are stacked into ONE fresh vector whose elements become the accumulators (no aliasing of the step's own tensors);
+        afterwards one multi-tensor add -- instead of one kernel per key and step."""
+        if all(not torch.is_tensor(epoch_losses[k]) and epoch_losses[k] == 0.0 for k in keys):
+            stacked = torch.stack([v.to(torch.float32) for v in vals])
+            for i, k in enumerate(keys):
+                epoch_losses[k] = stacked[i]
+            return
+        acc, add = [], []
+        for k, v in zip(keys, vals):
+            if torch.is_tensor(epoch_losses[k]):
+                acc.append(epoch_losses[k])
+                add.append(v.to(epoch_losses[k].dtype))
+            else:
+                epoch_losses[k] = epoch_losses[k] + v
+        if acc and all(a.is_cuda for a in acc):
+            torch._foreach_add_(acc, add)
+        else:
+            for a, v in zip(acc, add):
+                a += v
+
     def step(self, preprocessed_dicts, epoch_losses=None, log_images_bool=False):
         cfg = self.config
         B = len(preprocessed_dicts)
@@ -143,15 +177,15 @@ class Deployer(object):
         terms = terms_g if single else torch.stack(term_rows)
         counts = counts_g if single else (torch.stack(count_rows) if count_rows[0] is not None else None)
         visible = vis_g if single else (torch.stack(vis_rows) if vis_rows[0] is not None else None)
-        # global batch bookkeeping: this rank holds samples [rank*B, (rank+1)*B) of a batch of world_size*B
+        # global batch bookkeeping: this rank holds samples [rank*B, (rank+1)*B) of a batch of world_size*B.
+        # lambda_po2pl scales the point-to-plane column only (deployer.py:309-311); the running sums added inside the sample
+        # loop (:312) put the weight (Bg - j) on sample j, then everything is divided by Bg (:329).  Both are constants of the
+        # run: one cached [B,3] weight matrix, so the weighted loss is a multiply and a sum (and two kernels in the backward)
         Bg = B * self.world_size
-        j_global = torch.arange(B, device=terms.device, dtype=terms.dtype) + float(self.rank * B)
-        # lambda_po2pl scales the point-to-plane column only (deployer.py:309-311); built from device-side ops (capturable)
-        weighted = torch.stack((terms[:, 0], terms[:, 1] * float(cfg["lambda_po2pl"]), terms[:, 2]), dim=1)
-        sums = weighted.sum(dim=0)
-        losses = {"loss_po2po": sums[0] / Bg, "loss_po2pl": sums[1] / Bg, "loss_pl2pl": sums[2] / Bg,
-                  # running sums added inside the sample loop (:312) <=> weight (Bg - j) on sample j; then /Bg (:329)
-                  "loss_pc": ((Bg - j_global) * weighted.sum(dim=1)).sum() / Bg}
+        W_pc, w_col = self._loss_weights(B, Bg, float(cfg["lambda_po2pl"]), terms.device, terms.dtype)
+        with torch.no_grad():
+            sums = (terms.detach() * w_col).sum(dim=0)                    # [po2po, lambda * po2pl, pl2pl] / Bg
+        losses = {"loss_po2po": sums[0], "loss_po2pl": sums[1], "loss_pl2pl": sums[2], "loss_pc": (terms * W_pc).sum()}
         if not cfg["unsupervised_at_start"]:
             # identity pre-training (:324-338): the reference overwrites loss_transformation in every loop pass, so
             # only the LAST sample of the batch is fitted to the identity
@@ -167,12 +201,11 @@ class Deployer(object):
             self.optimizer.step()
         computed_transformations = rescale(computed_transformations)
         if epoch_losses is not None:
-            epoch_losses["loss_epoch"] += loss.detach()
-            epoch_losses["loss_point_cloud_epoch"] += losses["loss_pc"].detach()
-            epoch_losses["loss_po2po_epoch"] += losses["loss_po2po"].detach()
-            epoch_losses["loss_po2pl_epoch"] += losses["loss_po2pl"].detach()
-            epoch_losses["loss_pl2pl_epoch"] += losses["loss_pl2pl"].detach()
+            keys = ["loss_epoch", "loss_point_cloud_epoch", "loss_po2po_epoch", "loss_po2pl_epoch", "loss_pl2pl_epoch"]
+            vals = [loss.detach(), losses["loss_pc"].detach(), losses["loss_po2po"], losses["loss_po2pl"], losses["loss_pl2pl"]]
             if visible is not None:
-                epoch_losses["visible_pixels_epoch"] += visible[B - 1].detach()   # last sample only (:349-352)
+                keys.append("visible_pixels_epoch")
+                vals.append(visible[B - 1].detach())                      # last sample only (:349-352)
+            self._accumulate(epoch_losses, keys, vals)
         self.last_step = {"loss_terms": terms.detach(), "pair_counts": counts, "losses": {k: v.detach() for k, v in losses.items()}}
         return epoch_losses, computed_transformations
