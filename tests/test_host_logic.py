@@ -541,3 +541,28 @@ def test_rotation_head_gradient_does_not_depend_on_which_rows_share_the_batch_no
     assert abs(l1 - l2) < 1e-12 * abs(l1) and abs(l1 - l3) < 1e-12 * abs(l1)
     assert float((g1 - g2).abs().max()) < 1e-12 * float(g1.abs().max())
     assert float((g1 - g3).abs().max()) < 1e-12 * float(g1.abs().max())
+
+
+def test_loss_weight_matrix_and_epoch_accumulation():
+    """Deployer._loss_weights = the reference's in-loop weighting written as a matrix ((Bg - j)/Bg on sample j of the global
+    batch, lambda on the point-to-plane column); Deployer._accumulate adds step values into the epoch dict without aliasing
+    the step's own tensors."""
+    from delora_amd.deploy.deployer import Deployer
+
+    class Stub:
+        rank = 1
+    stub = Stub()
+    W, col = Deployer._loss_weights(stub, 2, 6, 0.5, torch.device("cpu"), torch.float32)
+    assert torch.allclose(W, torch.tensor([[4 / 6, 2 / 6, 4 / 6], [3 / 6, 1.5 / 6, 3 / 6]]))           # j_global = 2, 3
+    assert torch.allclose(col, torch.tensor([1 / 6, 0.5 / 6, 1 / 6]))
+    assert Deployer._loss_weights(stub, 2, 6, 0.5, torch.device("cpu"), torch.float32)[0] is W      # cached
+    ep = {"a": 0.0, "b": 0.0, "untouched": 0.0}
+    v1 = [torch.tensor(1.5), torch.tensor(2, dtype=torch.int32)]
+    Deployer._accumulate(ep, ["a", "b"], v1)
+    assert float(ep["a"]) == 1.5 and float(ep["b"]) == 2.0 and ep["untouched"] == 0.0
+    shared = torch.tensor(0.25)
+    Deployer._accumulate(ep, ["a", "b"], [shared, shared])                                         # the same tensor twice
+    assert float(ep["a"]) == 1.75 and float(ep["b"]) == 2.25 and float(shared) == 0.25 and float(v1[0]) == 1.5
+    ep2 = {"a": 3.0, "b": 0.0}                                                                       # a non-zero python start
+    Deployer._accumulate(ep2, ["a", "b"], [torch.tensor(1.0), torch.tensor(1.0)])
+    assert float(ep2["a"]) == 4.0 and float(ep2["b"]) == 1.0
