@@ -3,10 +3,17 @@
 Same topology and parameter names as the reference so that its checkpoints load unchanged
 (``conv1``, ``layer{1..4}.{i}.conv{1,2}``, ``layer{2,3,4}.0.downsample.0``, ``fc``): no normalisation layers,
 tanh (or relu) activations, every 3x3 convolution sees one wrapped column on each side of W and one zero row on
-each side of H, strides (1,2) in the stem/pool/layer2/layer3 and (2,2) in layer4.  Activations travel between
-convolutions in wrapped form: activation (+ residual add) and the wrap-around padding are ONE fused HIP elementwise
-op (``ring_ops.ring_act_pad``) instead of the reference's separate tanh, add and three-copy F.pad per layer; the stem's
-activation + padding + max-pooling + padding is one more (``ring_ops.ring_act_pool_pad``).
+each side of H, strides (1,2) in the stem/pool/layer2/layer3 and (2,2) in layer4.
+
+Two GPU paths compute it (``cnn_impl``; both are compared with each other and with torch-CPU in the tests):
+  * fp32 tensors on shapes that tile (the reference's full-size network on 64/128-ring images): three autograd
+    Functions on channels-last activations -- ``ring_conv.RingStem`` (conv1 + activation + max-pooling), ``RingTrunk``
+    (layer1..layer4: fused Winograd / direct MFMA convolutions with the wrap-around as addressing and the elementwise
+    tail in their epilogues) and ``MeanHW`` before ``fc``;
+  * everything else (narrow test networks, autocast, dropout): the modules below -- library convolutions on inputs that
+    travel in wrapped form, with activation (+ residual add) and the wrap-around padding as ONE fused HIP elementwise op
+    (``ring_ops.ring_act_pad``) instead of the reference's separate tanh, add and three-copy F.pad per layer, and the
+    stem's activation + padding + max-pooling + padding as one more (``ring_ops.ring_act_pool_pad``).
 """
 import torch
 
@@ -102,8 +109,8 @@ class ResNetModified(torch.nn.Module):
 
     def trunk_weights_channels_last(self):
         """Store the trunk's convolution weights as ``[K][k][k][C]`` (torch channels_last): the HIP trunk then reads the
-        parameters and writes their gradients in place.  Shapes, names and values of the state_dict do not change; the stem
-        convolution (library, NCHW input) keeps the default layout."""
+        parameters and writes their gradients in place.  Shapes, names and values of the state_dict do not change; conv1
+        (8 input channels, re-laid out per call: 4.6 kB) keeps the default layout."""
         for w in self._trunk_blocks()[1]:
             w.data = w.data.contiguous(memory_format=torch.channels_last)
         return self
