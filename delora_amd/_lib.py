@@ -51,6 +51,10 @@ SIGNATURES = {
     "dl_nn_bruteforce": (_i32, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp]),
     "dl_ring_act_pad_fwd": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _vp, _vp]),
     "dl_ring_act_pad_bwd": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "dl_ring_act_pad_fwd_t": (_i32, [_vp, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "dl_ring_act_pad_bwd_t": (_i32, [_vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "dl_ring_act_pool_pad_fwd_t": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "dl_ring_act_pool_pad_bwd_t": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     "dl_conv2d_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _u32, _vp]),
     "dl_conv2d_dgrad_strided_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                                 _u32, _vp]),

@@ -29,6 +29,27 @@ __device__ __forceinline__ float act_bwd(float y, int act) {
   return 1.f;
 }
 
+// Storage types: the kernels compute in fp32; under autocast the activations are stored as fp16 / bf16 (one rounding per
+// stored element, as the separate torch ops do).  dtype codes of the *_t entry points: 0 fp32, 1 fp16, 2 bf16.
+struct bf16_t { uint16_t b; };
+template <typename T> __device__ __forceinline__ float ldf(const T* p, int64_t i) { return (float)p[i]; }
+template <> __device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p, int64_t i) { return __uint_as_float((uint32_t)p[i].b << 16); }
+template <typename T> __device__ __forceinline__ void stf(T* p, int64_t i, float v) { p[i] = (T)v; }
+template <> __device__ __forceinline__ void stf<bf16_t>(bf16_t* p, int64_t i, float v) {
+  uint32_t u = __float_as_uint(v);
+  u = (v != v) ? 0x7fc00000u : u + 0x7fffu + ((u >> 16) & 1u);      // round to nearest even; NaN stays NaN
+  p[i].b = (uint16_t)(u >> 16);
+}
+
+// v rounded to the storage type (what a separate activation kernel would have stored before the pooling compares values)
+template <typename T> __device__ __forceinline__ float rnd(float v) { return (float)(T)v; }
+template <> __device__ __forceinline__ float rnd<float>(float v) { return v; }
+template <> __device__ __forceinline__ float rnd<bf16_t>(float v) {
+  uint32_t u = __float_as_uint(v);
+  u = (v != v) ? 0x7fc00000u : u + 0x7fffu + ((u >> 16) & 1u);
+  return __uint_as_float(u & 0xffff0000u);
+}
+
 // rows = N*C*H.  x: dense [rows][W].  res: rows of width W at pitch res_pitch, first element at res_off (so the
 // interior of a padded tensor can be used in place).  out: [rows][W + 2*pad].
 // One thread produces RING_UN output elements DL_BLOCK apart (coalesced dword accesses, RING_UN independent loads in
@@ -36,11 +57,11 @@ __device__ __forceinline__ float act_bwd(float y, int act) {
 // element instead of an emulated 64-bit one -- the 64-bit form ran at 2.2 TB/s, ALU-bound on the division).
 #define RING_UN 4
 
-template <typename I>
-__global__ __launch_bounds__(DL_BLOCK) void k_ring_act_pad_fwd(const float* __restrict__ x,
-                                                               const float* __restrict__ res, int64_t res_pitch,
+template <typename T, typename I>
+__global__ __launch_bounds__(DL_BLOCK) void k_ring_act_pad_fwd(const T* __restrict__ x,
+                                                               const T* __restrict__ res, int64_t res_pitch,
                                                                int64_t res_off, I total, int W, int pad, int act,
-                                                               float* __restrict__ out) {
+                                                               T* __restrict__ out) {
   const I Wp = (I)(W + 2 * pad);
   const I base = (I)blockIdx.x * (DL_BLOCK * RING_UN) + threadIdx.x;
   float v[RING_UN];
@@ -52,25 +73,25 @@ __global__ __launch_bounds__(DL_BLOCK) void k_ring_act_pad_fwd(const float* __re
       const I r = i / Wp;
       int w = (int)(i - r * Wp) - pad;
       w = w < 0 ? w + W : (w >= W ? w - W : w);
-      v[u] = x[(int64_t)r * W + w];
-      if (res) v[u] += res[(int64_t)r * res_pitch + res_off + w];
+      v[u] = ldf(x, (int64_t)r * W + w);
+      if (res) v[u] += ldf(res, (int64_t)r * res_pitch + res_off + w);
     }
   }
 #pragma unroll
   for (int u = 0; u < RING_UN; ++u) {
     const I i = base + (I)u * DL_BLOCK;
-    if (i < total) out[i] = act_fwd(v[u], act);
+    if (i < total) stf(out, (int64_t)i, act_fwd(v[u], act));
   }
 }
 
 // grad_out: [rows][W + 2*pad]; y = saved forward output (same shape); grad_x: dense [rows][W];
 // grad_res_padded (optional): [rows][W + 2] receiving grad_x in its interior and zeros in its two border columns
 // (the gradient of "interior of a padded tensor used as residual").
-template <typename I>
-__global__ __launch_bounds__(DL_BLOCK) void k_ring_act_pad_bwd(const float* __restrict__ grad_out,
-                                                               const float* __restrict__ y, I total, int W, int pad,
-                                                               int act, float* __restrict__ grad_x,
-                                                               float* __restrict__ grad_res_padded) {
+template <typename T, typename I>
+__global__ __launch_bounds__(DL_BLOCK) void k_ring_act_pad_bwd(const T* __restrict__ grad_out,
+                                                               const T* __restrict__ y, I total, int W, int pad,
+                                                               int act, T* __restrict__ grad_x,
+                                                               T* __restrict__ grad_res_padded) {
   const int Wp = W + 2 * pad;
   const I base = (I)blockIdx.x * (DL_BLOCK * RING_UN) + threadIdx.x;
   float s[RING_UN], yv[RING_UN];
@@ -82,13 +103,13 @@ __global__ __launch_bounds__(DL_BLOCK) void k_ring_act_pad_bwd(const float* __re
     if (i < total) {
       const I r = i / (I)W;
       const int w = (int)(i - r * (I)W);
-      const float* g = grad_out + (int64_t)r * Wp;
-      s[u] = g[pad + w];
+      const T* g = grad_out + (int64_t)r * Wp;
+      s[u] = ldf(g, pad + w);
       if (pad) {
-        if (w == W - 1) s[u] += g[0];
-        if (w == 0) s[u] += g[W + 1];
+        if (w == W - 1) s[u] += ldf(g, 0);
+        if (w == 0) s[u] += ldf(g, W + 1);
       }
-      yv[u] = y[(int64_t)r * Wp + pad + w];
+      yv[u] = ldf(y, (int64_t)r * Wp + pad + w);
     }
   }
 #pragma unroll
@@ -96,14 +117,14 @@ __global__ __launch_bounds__(DL_BLOCK) void k_ring_act_pad_bwd(const float* __re
     const I i = base + (I)u * DL_BLOCK;
     if (i < total) {
       const float d = s[u] * act_bwd(yv[u], act);
-      grad_x[i] = d;
+      stf(grad_x, (int64_t)i, d);
       if (grad_res_padded) {
         const I r = i / (I)W;
         const int w = (int)(i - r * (I)W);
-        float* q = grad_res_padded + (int64_t)r * (W + 2);
-        q[1 + w] = d;
-        if (w == 0) q[0] = 0.f;
-        if (w == W - 1) q[W + 1] = 0.f;
+        T* q = grad_res_padded + (int64_t)r * (W + 2);
+        stf(q, 1 + w, d);
+        if (w == 0) stf(q, 0, 0.f);
+        if (w == W - 1) stf(q, W + 1, 0.f);
       }
     }
   }
@@ -114,36 +135,65 @@ static unsigned grid_for(int64_t total) { return (unsigned)((total + DL_BLOCK * 
 // tensors beyond 2^41 elements would exceed the 1-D grid limit; nothing in this domain comes within orders of magnitude
 static const int64_t RING_MAX_ELEMS = (int64_t)1 << 40;
 
-extern "C" int dl_ring_act_pad_fwd(const float* x, const float* res, int64_t res_pitch, int64_t res_off, int64_t rows,
-                                   int32_t W, int32_t pad, int32_t act, float* out, dl_stream stream) {
-  if (!x || !out || rows < 0 || W <= 0 || (pad != 0 && pad != 1) || act < 0 || act > 2)
+template <typename T>
+static int launch_act_pad_fwd(const void* x, const void* res, int64_t res_pitch, int64_t res_off, int64_t total, int W, int pad,
+                              int act, void* out, hipStream_t st) {
+  if (total < ((int64_t)1 << 31))
+    hipLaunchKernelGGL((k_ring_act_pad_fwd<T, uint32_t>), dim3(grid_for(total)), dim3(DL_BLOCK), 0, st, (const T*)x, (const T*)res,
+                       res_pitch, res_off, (uint32_t)total, W, pad, act, (T*)out);
+  else
+    hipLaunchKernelGGL((k_ring_act_pad_fwd<T, uint64_t>), dim3(grid_for(total)), dim3(DL_BLOCK), 0, st, (const T*)x, (const T*)res,
+                       res_pitch, res_off, (uint64_t)total, W, pad, act, (T*)out);
+  return dl_check_launch("dl_ring_act_pad_fwd");
+}
+
+template <typename T>
+static int launch_act_pad_bwd(const void* grad_out, const void* y, int64_t rows, int64_t total, int W, int pad, int act, void* grad_x,
+                              void* grad_res_padded, hipStream_t st) {
+  if (rows * (W + 2) < ((int64_t)1 << 31))
+    hipLaunchKernelGGL((k_ring_act_pad_bwd<T, uint32_t>), dim3(grid_for(total)), dim3(DL_BLOCK), 0, st, (const T*)grad_out,
+                       (const T*)y, (uint32_t)total, W, pad, act, (T*)grad_x, (T*)grad_res_padded);
+  else
+    hipLaunchKernelGGL((k_ring_act_pad_bwd<T, uint64_t>), dim3(grid_for(total)), dim3(DL_BLOCK), 0, st, (const T*)grad_out,
+                       (const T*)y, (uint64_t)total, W, pad, act, (T*)grad_x, (T*)grad_res_padded);
+  return dl_check_launch("dl_ring_act_pad_bwd");
+}
+
+/* dtype: 0 fp32, 1 fp16, 2 bf16 (storage of every tensor argument; the arithmetic is fp32) */
+extern "C" int dl_ring_act_pad_fwd_t(const void* x, const void* res, int64_t res_pitch, int64_t res_off, int64_t rows, int32_t W,
+                                     int32_t pad, int32_t act, int32_t dtype, void* out, dl_stream stream) {
+  if (!x || !out || rows < 0 || W <= 0 || (pad != 0 && pad != 1) || act < 0 || act > 2 || dtype < 0 || dtype > 2)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_ring_act_pad_fwd: bad argument");
   if (rows == 0) return DL_OK;
   const int64_t total = rows * (W + 2 * pad);
   if (total > RING_MAX_ELEMS) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_ring_act_pad_fwd: tensor too large");
-  if (total < ((int64_t)1 << 31))
-    hipLaunchKernelGGL(k_ring_act_pad_fwd<uint32_t>, dim3(grid_for(total)), dim3(DL_BLOCK), 0, (hipStream_t)stream, x,
-                       res, res_pitch, res_off, (uint32_t)total, W, pad, act, out);
-  else
-    hipLaunchKernelGGL(k_ring_act_pad_fwd<uint64_t>, dim3(grid_for(total)), dim3(DL_BLOCK), 0, (hipStream_t)stream, x,
-                       res, res_pitch, res_off, (uint64_t)total, W, pad, act, out);
-  return dl_check_launch("dl_ring_act_pad_fwd");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 1) return launch_act_pad_fwd<_Float16>(x, res, res_pitch, res_off, total, W, pad, act, out, st);
+  if (dtype == 2) return launch_act_pad_fwd<bf16_t>(x, res, res_pitch, res_off, total, W, pad, act, out, st);
+  return launch_act_pad_fwd<float>(x, res, res_pitch, res_off, total, W, pad, act, out, st);
 }
 
-extern "C" int dl_ring_act_pad_bwd(const float* grad_out, const float* y, int64_t rows, int32_t W, int32_t pad,
-                                   int32_t act, float* grad_x, float* grad_res_padded, dl_stream stream) {
-  if (!grad_out || !y || !grad_x || rows < 0 || W <= 0 || (pad != 0 && pad != 1) || act < 0 || act > 2)
+extern "C" int dl_ring_act_pad_bwd_t(const void* grad_out, const void* y, int64_t rows, int32_t W, int32_t pad, int32_t act,
+                                     int32_t dtype, void* grad_x, void* grad_res_padded, dl_stream stream) {
+  if (!grad_out || !y || !grad_x || rows < 0 || W <= 0 || (pad != 0 && pad != 1) || act < 0 || act > 2 || dtype < 0 || dtype > 2)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_ring_act_pad_bwd: bad argument");
   if (rows == 0) return DL_OK;
   const int64_t total = rows * W;
   if (total > RING_MAX_ELEMS) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_ring_act_pad_bwd: tensor too large");
-  if (rows * (W + 2) < ((int64_t)1 << 31))
-    hipLaunchKernelGGL(k_ring_act_pad_bwd<uint32_t>, dim3(grid_for(total)), dim3(DL_BLOCK), 0, (hipStream_t)stream,
-                       grad_out, y, (uint32_t)total, W, pad, act, grad_x, grad_res_padded);
-  else
-    hipLaunchKernelGGL(k_ring_act_pad_bwd<uint64_t>, dim3(grid_for(total)), dim3(DL_BLOCK), 0, (hipStream_t)stream,
-                       grad_out, y, (uint64_t)total, W, pad, act, grad_x, grad_res_padded);
-  return dl_check_launch("dl_ring_act_pad_bwd");
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == 1) return launch_act_pad_bwd<_Float16>(grad_out, y, rows, total, W, pad, act, grad_x, grad_res_padded, st);
+  if (dtype == 2) return launch_act_pad_bwd<bf16_t>(grad_out, y, rows, total, W, pad, act, grad_x, grad_res_padded, st);
+  return launch_act_pad_bwd<float>(grad_out, y, rows, total, W, pad, act, grad_x, grad_res_padded, st);
+}
+
+extern "C" int dl_ring_act_pad_fwd(const float* x, const float* res, int64_t res_pitch, int64_t res_off, int64_t rows,
+                                   int32_t W, int32_t pad, int32_t act, float* out, dl_stream stream) {
+  return dl_ring_act_pad_fwd_t(x, res, res_pitch, res_off, rows, W, pad, act, 0, out, stream);
+}
+
+extern "C" int dl_ring_act_pad_bwd(const float* grad_out, const float* y, int64_t rows, int32_t W, int32_t pad,
+                                   int32_t act, float* grad_x, float* grad_res_padded, dl_stream stream) {
+  return dl_ring_act_pad_bwd_t(grad_out, y, rows, W, pad, act, 0, grad_x, grad_res_padded, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -157,8 +207,9 @@ extern "C" int dl_ring_act_pad_bwd(const float* grad_out, const float* y, int64_
 // whose pre-activation value does not exceed the current best's cannot win and its activation is never evaluated.
 // x: dense [rows][W], rows = N*C*H.  out: [rows][Wo + 2] (pooled map with one wrapped column on each side),
 // Wo = (W-1)/2 + 1.  win: [rows][Wo] position (0..8, row-major in the 3x3 window) of each maximum, for the backward.
-__global__ __launch_bounds__(DL_BLOCK) void k_ring_act_pool_pad_fwd(const float* __restrict__ x, uint32_t total, int H,
-                                                                    int W, int Wo, int act, float* __restrict__ out,
+template <typename T>
+__global__ __launch_bounds__(DL_BLOCK) void k_ring_act_pool_pad_fwd(const T* __restrict__ x, uint32_t total, int H,
+                                                                    int W, int Wo, int act, T* __restrict__ out,
                                                                     int8_t* __restrict__ win) {
   const uint32_t i = blockIdx.x * DL_BLOCK + threadIdx.x;
   if (i >= total) return;
@@ -171,14 +222,14 @@ __global__ __launch_bounds__(DL_BLOCK) void k_ring_act_pool_pad_fwd(const float*
   for (int dh = -1; dh <= 1; ++dh) {
     const int hh = h + dh;
     if (hh < 0 || hh >= H) continue;
-    const float* row = x + ((int64_t)r + dh) * W;
+    const T* row = x + ((int64_t)r + dh) * W;
 #pragma unroll
     for (int dw = -1; dw <= 1; ++dw) {
       int ww = 2 * wo + dw;
       ww = ww < 0 ? ww + W : (ww >= W ? ww - W : ww);
-      const float xv = row[ww];
+      const float xv = ldf(row, ww);
       if (!(xv <= best_x)) {
-        const float a = act_fwd(xv, act);
+        const float a = rnd<T>(act_fwd(xv, act));
         if (a > best_a || a != a) {
           best_a = a;
           best_x = xv;
@@ -187,20 +238,21 @@ __global__ __launch_bounds__(DL_BLOCK) void k_ring_act_pool_pad_fwd(const float*
       }
     }
   }
-  float* o = out + (int64_t)r * (Wo + 2);
-  o[1 + wo] = best_a;
-  if (wo == 0) o[Wo + 1] = best_a;
-  if (wo == Wo - 1) o[0] = best_a;
+  T* o = out + (int64_t)r * (Wo + 2);
+  stf(o, 1 + wo, best_a);
+  if (wo == 0) stf(o, Wo + 1, best_a);
+  if (wo == Wo - 1) stf(o, 0, best_a);
   win[i] = (int8_t)k;
 }
 
 // grad_out, y: [rows][Wo + 2] (y = saved forward output); grad_x: dense [rows][W].  Gather form: every input element
 // looks up the (at most 3 x 4) windows that contain it and takes the gradient of those that selected it.
-__global__ __launch_bounds__(DL_BLOCK) void k_ring_act_pool_pad_bwd(const float* __restrict__ grad_out,
-                                                                    const float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(DL_BLOCK) void k_ring_act_pool_pad_bwd(const T* __restrict__ grad_out,
+                                                                    const T* __restrict__ y,
                                                                     const int8_t* __restrict__ win, uint32_t total,
                                                                     int H, int W, int Wo, int act,
-                                                                    float* __restrict__ grad_x) {
+                                                                    T* __restrict__ grad_x) {
   const uint32_t i = blockIdx.x * DL_BLOCK + threadIdx.x;
   if (i >= total) return;
   const uint32_t r = i / (uint32_t)W;
@@ -226,15 +278,15 @@ __global__ __launch_bounds__(DL_BLOCK) void k_ring_act_pool_pad_bwd(const float*
         if (ho < 0 || ho >= H) continue;
         const int64_t rr = (int64_t)r + d;
         if (win[rr * Wo + wo] != (1 - d) * 3 + c) continue;
-        const float* g = grad_out + rr * Wq;
-        float gv = g[1 + wo];
-        if (wo == Wo - 1) gv += g[0];
-        if (wo == 0) gv += g[Wo + 1];
-        acc += gv * act_bwd(y[rr * Wq + 1 + wo], act);
+        const T* g = grad_out + rr * Wq;
+        float gv = ldf(g, 1 + wo);
+        if (wo == Wo - 1) gv += ldf(g, 0);
+        if (wo == 0) gv += ldf(g, Wo + 1);
+        acc += gv * act_bwd(ldf(y, rr * Wq + 1 + wo), act);
       }
     }
   }
-  grad_x[i] = acc;
+  stf(grad_x, (int64_t)i, acc);
 }
 
 // Fast path for even W (every real sensor; the kernels above stay as the general form).  One thread owns STEM_RH
@@ -407,7 +459,7 @@ extern "C" int dl_ring_act_pool_pad_fwd(const float* x, int64_t planes, int32_t 
     return dl_check_launch("dl_ring_act_pool_pad_fwd");
   }
   const uint32_t total = (uint32_t)(planes * H * Wo);
-  hipLaunchKernelGGL(k_ring_act_pool_pad_fwd, dim3((total + DL_BLOCK - 1) / DL_BLOCK), dim3(DL_BLOCK), 0,
+  hipLaunchKernelGGL(k_ring_act_pool_pad_fwd<float>, dim3((total + DL_BLOCK - 1) / DL_BLOCK), dim3(DL_BLOCK), 0,
                      (hipStream_t)stream, x, total, H, W, Wo, act, out, win);
   return dl_check_launch("dl_ring_act_pool_pad_fwd");
 }
@@ -428,7 +480,48 @@ extern "C" int dl_ring_act_pool_pad_bwd(const float* grad_out, const float* y, c
     return dl_check_launch("dl_ring_act_pool_pad_bwd");
   }
   const uint32_t total = (uint32_t)(planes * H * W);
-  hipLaunchKernelGGL(k_ring_act_pool_pad_bwd, dim3((total + DL_BLOCK - 1) / DL_BLOCK), dim3(DL_BLOCK), 0,
+  hipLaunchKernelGGL(k_ring_act_pool_pad_bwd<float>, dim3((total + DL_BLOCK - 1) / DL_BLOCK), dim3(DL_BLOCK), 0,
                      (hipStream_t)stream, grad_out, y, win, total, H, W, Wo, act, grad_x);
+  return dl_check_launch("dl_ring_act_pool_pad_bwd");
+}
+
+/* fp16 / bf16 storage (dtype 1 / 2; 0 forwards to the fp32 entry points above): the general kernels, fp32 arithmetic */
+extern "C" int dl_ring_act_pool_pad_fwd_t(const void* x, int64_t planes, int32_t H, int32_t W, int32_t act, int32_t dtype, void* out,
+                                          int8_t* win, dl_stream stream) {
+  if (dtype == 0) return dl_ring_act_pool_pad_fwd((const float*)x, planes, H, W, act, (float*)out, win, stream);
+  if (!x || !out || !win || planes < 0 || H <= 0 || W < 2 || act < 0 || act > 2 || dtype < 0 || dtype > 2)
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_ring_act_pool_pad_fwd: bad argument");
+  if (planes == 0) return DL_OK;
+  const int Wo = (W - 1) / 2 + 1;
+  if (planes * H * (int64_t)(W + 2) >= ((int64_t)1 << 31))
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_ring_act_pool_pad_fwd: tensor too large (2^31 elements)");
+  const uint32_t total = (uint32_t)(planes * H * Wo);
+  const dim3 grid((total + DL_BLOCK - 1) / DL_BLOCK);
+  if (dtype == 1)
+    hipLaunchKernelGGL(k_ring_act_pool_pad_fwd<_Float16>, grid, dim3(DL_BLOCK), 0, (hipStream_t)stream, (const _Float16*)x, total, H, W,
+                       Wo, act, (_Float16*)out, win);
+  else
+    hipLaunchKernelGGL(k_ring_act_pool_pad_fwd<bf16_t>, grid, dim3(DL_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)x, total, H, W, Wo,
+                       act, (bf16_t*)out, win);
+  return dl_check_launch("dl_ring_act_pool_pad_fwd");
+}
+
+extern "C" int dl_ring_act_pool_pad_bwd_t(const void* grad_out, const void* y, const int8_t* win, int64_t planes, int32_t H, int32_t W,
+                                          int32_t act, int32_t dtype, void* grad_x, dl_stream stream) {
+  if (dtype == 0) return dl_ring_act_pool_pad_bwd((const float*)grad_out, (const float*)y, win, planes, H, W, act, (float*)grad_x, stream);
+  if (!grad_out || !y || !win || !grad_x || planes < 0 || H <= 0 || W < 2 || act < 0 || act > 2 || dtype < 0 || dtype > 2)
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_ring_act_pool_pad_bwd: bad argument");
+  if (planes == 0) return DL_OK;
+  const int Wo = (W - 1) / 2 + 1;
+  if (planes * H * (int64_t)(W + 2) >= ((int64_t)1 << 31))
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_ring_act_pool_pad_bwd: tensor too large (2^31 elements)");
+  const uint32_t total = (uint32_t)(planes * H * W);
+  const dim3 grid((total + DL_BLOCK - 1) / DL_BLOCK);
+  if (dtype == 1)
+    hipLaunchKernelGGL(k_ring_act_pool_pad_bwd<_Float16>, grid, dim3(DL_BLOCK), 0, (hipStream_t)stream, (const _Float16*)grad_out,
+                       (const _Float16*)y, win, total, H, W, Wo, act, (_Float16*)grad_x);
+  else
+    hipLaunchKernelGGL(k_ring_act_pool_pad_bwd<bf16_t>, grid, dim3(DL_BLOCK), 0, (hipStream_t)stream, (const bf16_t*)grad_out,
+                       (const bf16_t*)y, win, total, H, W, Wo, act, (bf16_t*)grad_x);
   return dl_check_launch("dl_ring_act_pool_pad_bwd");
 }

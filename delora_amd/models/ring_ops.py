@@ -16,6 +16,7 @@ import torch.nn.functional as F
 from .. import _lib
 
 ACT = {"none": 0, "tanh": 1, "relu": 2}
+DTYPE = {torch.float32: 0, torch.float16: 1, torch.bfloat16: 2}      # storage types of the *_t entry points (fp32 arithmetic)
 
 
 def _ptr(t):
@@ -44,8 +45,8 @@ class _RingActPad(torch.autograd.Function):
                 res_pitch, res_off, res_kind = W + 2, 1, 2
             else:
                 raise ValueError(f"residual shape {tuple(residual.shape)} fits neither [N,C,H,W] nor [N,C,H,W+2]")
-        _lib.check(lib.dl_ring_act_pad_fwd(_ptr(x), _ptr(residual), res_pitch, res_off, rows, W, pad, act,
-                                           _ptr(out), _stream()), "dl_ring_act_pad_fwd")
+        _lib.check(lib.dl_ring_act_pad_fwd_t(_ptr(x), _ptr(residual), res_pitch, res_off, rows, W, pad, act, DTYPE[x.dtype],
+                                             _ptr(out), _stream()), "dl_ring_act_pad_fwd")
         ctx.save_for_backward(out)
         ctx.meta = (rows, W, pad, act, res_kind)
         return out
@@ -55,12 +56,12 @@ class _RingActPad(torch.autograd.Function):
         lib = _lib.load()
         (y,) = ctx.saved_tensors
         rows, W, pad, act, res_kind = ctx.meta
-        grad_out = grad_out.contiguous()
+        grad_out = grad_out.contiguous() if grad_out.dtype == y.dtype else grad_out.to(y.dtype).contiguous()
         N, C, H = y.shape[:3]
         grad_x = torch.empty((N, C, H, W), dtype=y.dtype, device=y.device)
         grad_res = torch.empty((N, C, H, W + 2), dtype=y.dtype, device=y.device) if res_kind == 2 else None
-        _lib.check(lib.dl_ring_act_pad_bwd(_ptr(grad_out), _ptr(y), rows, W, pad, act, _ptr(grad_x), _ptr(grad_res),
-                                           _stream()), "dl_ring_act_pad_bwd")
+        _lib.check(lib.dl_ring_act_pad_bwd_t(_ptr(grad_out), _ptr(y), rows, W, pad, act, DTYPE[y.dtype], _ptr(grad_x),
+                                             _ptr(grad_res), _stream()), "dl_ring_act_pad_bwd")
         if res_kind == 1:
             grad_res = grad_x                          # d(x + r)/dr = d/dx: the same tensor serves both
         return grad_x, grad_res, None, None
@@ -75,7 +76,7 @@ class _RingActPoolPad(torch.autograd.Function):
         Wo = (W - 1) // 2 + 1
         out = torch.empty((N, C, H, Wo + 2), dtype=x.dtype, device=x.device)
         win = torch.empty((N, C, H, Wo), dtype=torch.int8, device=x.device)
-        _lib.check(lib.dl_ring_act_pool_pad_fwd(_ptr(x), N * C, H, W, act, _ptr(out), _ptr(win), _stream()),
+        _lib.check(lib.dl_ring_act_pool_pad_fwd_t(_ptr(x), N * C, H, W, act, DTYPE[x.dtype], _ptr(out), _ptr(win), _stream()),
                    "dl_ring_act_pool_pad_fwd")
         ctx.save_for_backward(out, win)
         ctx.meta = (N, C, H, W, act)
@@ -86,10 +87,10 @@ class _RingActPoolPad(torch.autograd.Function):
         lib = _lib.load()
         y, win = ctx.saved_tensors
         N, C, H, W, act = ctx.meta
-        grad_out = grad_out.contiguous()
+        grad_out = grad_out.contiguous() if grad_out.dtype == y.dtype else grad_out.to(y.dtype).contiguous()
         grad_x = torch.empty((N, C, H, W), dtype=y.dtype, device=y.device)
-        _lib.check(lib.dl_ring_act_pool_pad_bwd(_ptr(grad_out), _ptr(y), _ptr(win), N * C, H, W, act, _ptr(grad_x),
-                                                _stream()), "dl_ring_act_pool_pad_bwd")
+        _lib.check(lib.dl_ring_act_pool_pad_bwd_t(_ptr(grad_out), _ptr(y), _ptr(win), N * C, H, W, act, DTYPE[y.dtype],
+                                                  _ptr(grad_x), _stream()), "dl_ring_act_pool_pad_bwd")
         return grad_x, None
 
 
@@ -97,7 +98,7 @@ def ring_act_pool_pad(x, act="tanh"):
     """Stem of the pose CNN: ``act``, wrap-around padding, ``MaxPool2d(3, stride=(1,2), padding=(1,0))`` and the
     wrap-around padding of the pooled map (reference resnet_modified.py:100-102 + the F.pad of the next convolution) --
     one HIP kernel each way on CUDA fp32 tensors, the separate torch ops otherwise."""
-    if x.is_cuda and x.dtype == torch.float32:
+    if x.is_cuda and x.dtype in DTYPE:
         N, C, H, W = x.shape
         per_sample = C * H * (W + 2)
         if N * per_sample >= 2 ** 31 and N > 1:          # the stem kernels index with 32 bits: split the batch
@@ -112,9 +113,11 @@ def ring_act_pool_pad(x, act="tanh"):
 def ring_act_pad(x, act="none", pad=True, residual=None):
     """``act(x + residual)`` with one wrapped column added on each side of W (``pad=False``: unpadded).  ``residual`` is
     either dense ``[N,C,H,W]`` or a padded ``[N,C,H,W+2]`` tensor whose interior is the residual."""
-    if x.is_cuda and x.dtype == torch.float32 and (residual is None or residual.dtype == torch.float32):
+    if x.is_cuda and x.dtype in DTYPE:
+        if residual is not None and residual.dtype != x.dtype:
+            residual = residual.to(x.dtype)
         return _RingActPad.apply(x, residual, ACT[act], 1 if pad else 0)
-    # CPU device (or autocast dtypes): plain torch ops, same function
+    # CPU device: plain torch ops, same function
     v = x
     if residual is not None:
         v = x + (residual if residual.shape[-1] == x.shape[-1] else residual[..., 1:-1]).to(x.dtype)

@@ -219,6 +219,17 @@ int dl_ring_act_pool_pad_fwd(const float* x, int64_t planes, int32_t H, int32_t 
 int dl_ring_act_pool_pad_bwd(const float* grad_out, const float* y, const int8_t* win, int64_t planes, int32_t H,
                              int32_t W, int32_t act, float* grad_x, dl_stream stream);
 
+/* The same four entry points for fp16 / bf16 storage (autocast): dtype 0 fp32, 1 fp16, 2 bf16 for every tensor argument;
+ * the arithmetic is fp32 and every stored element is rounded once, as the separate torch ops would. */
+int dl_ring_act_pad_fwd_t(const void* x, const void* res, int64_t res_pitch, int64_t res_off, int64_t rows, int32_t W, int32_t pad,
+                          int32_t act, int32_t dtype, void* out, dl_stream stream);
+int dl_ring_act_pad_bwd_t(const void* grad_out, const void* y, int64_t rows, int32_t W, int32_t pad, int32_t act, int32_t dtype,
+                          void* grad_x, void* grad_res_padded, dl_stream stream);
+int dl_ring_act_pool_pad_fwd_t(const void* x, int64_t planes, int32_t H, int32_t W, int32_t act, int32_t dtype, void* out, int8_t* win,
+                               dl_stream stream);
+int dl_ring_act_pool_pad_bwd_t(const void* grad_out, const void* y, const int8_t* win, int64_t planes, int32_t H, int32_t W,
+                               int32_t act, int32_t dtype, void* grad_x, dl_stream stream);
+
 /*
  * Convolutions of the pose CNN on 360-degree range images, channels-last fp32 on the fp32 matrix cores (exact fp32
  * products, v_mfma_f32_32x32x2_f32), with the wrap-around width padding as addressing and the elementwise tail fused.

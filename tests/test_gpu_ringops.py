@@ -116,3 +116,43 @@ def test_ring_ops_propagate_nan_like_torch():
     want = _stem_reference(x0.to(dev), "relu", own_activation=False)
     assert torch.equal(torch.isnan(out), torch.isnan(want))
     assert torch.equal(torch.nan_to_num(out, nan=7.0), torch.nan_to_num(want, nan=7.0))
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("act", ["tanh", "relu"])
+def test_ring_ops_half_storage_match_the_separate_torch_ops(dtype, act):
+    """fp16 / bf16 storage (autocast): the fused kernels compute in fp32 and round every stored element once; the separate
+    torch ops round after the add as well, so values agree to one rounding step of the storage type, and the stem's
+    arg-max (compared on ROUNDED activations, like a max-pool fed by a separate activation kernel) routes identically up
+    to ties of the differently rounded sums."""
+    dev = _dev()
+    eps = 1e-3 if dtype == torch.float16 else 8e-3
+    gen = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn((2, 4, 6, 64), generator=gen).to(dev, dtype).requires_grad_(True)
+    res = torch.randn((2, 4, 6, 66), generator=gen).to(dev, dtype).requires_grad_(True)
+    y = ring_act_pad(x, act, pad=True, residual=res)
+    assert y.dtype == dtype
+    gy = torch.randn(y.shape, generator=gen).to(dev, dtype)
+    y.backward(gy)
+    xr, rr = x.detach().float().requires_grad_(True), res.detach().float().requires_grad_(True)
+    y_ref = _wrap(_act(xr + rr[..., 1:-1], act))
+    y_ref.backward(gy.float())
+    assert float((y.float() - y_ref).abs().max()) <= 2 * eps * max(1.0, float(y_ref.abs().max()))
+    assert float((x.grad.float() - xr.grad).abs().max()) <= 4 * eps * float(xr.grad.abs().max())
+    assert float((res.grad.float() - rr.grad).abs().max()) <= 4 * eps * float(rr.grad.abs().max())
+    # stem
+    xs = torch.randn((2, 3, 6, 64), generator=gen).to(dev, dtype).requires_grad_(True)
+    ys = ring_act_pool_pad(xs, act)
+    assert ys.dtype == dtype
+    gs = torch.randn(ys.shape, generator=gen).to(dev, dtype)
+    ys.backward(gs)
+    xsr = xs.detach().float().requires_grad_(True)
+    a = ring_act_pad(xs.detach(), act, pad=False).float()   # the activation as a separate kernel stores it (same libm)
+    ref = _wrap(F.max_pool2d(_wrap(a), kernel_size=3, stride=(1, 2), padding=(1, 0)))
+    assert torch.equal(ys.float(), ref.detach())
+    # gradient: route through the same windows with the fp32 activation derivative of the rounded output
+    a2 = _act(xsr, act)
+    ref2 = _wrap(F.max_pool2d(_wrap(a2), kernel_size=3, stride=(1, 2), padding=(1, 0)))
+    ref2.backward(gs.float())
+    close = (xs.grad.float() - xsr.grad).abs() <= 4 * eps * float(xsr.grad.abs().max()) + 1e-6
+    assert float(close.float().mean()) >= 0.98              # a few windows tie differently after rounding
