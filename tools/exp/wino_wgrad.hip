@@ -1,5 +1,6 @@
-// DRAFT (end of round 2; `wino_wgrad check` passes on MI355X: 2-3e-7 relative; v0 timing 106 / 112 TFLOP/s direct-equivalent on
-// layer3 / layer4, the slab reduction is serial and ruins layer1 / layer2 -- not used by the library yet):
+// DRAFT v1 (end of round 2; `wino_wgrad check` passes on MI355X: 2-3e-7 relative; `time`: layer1 215 us, layer2 306, layer3 572,
+// layer4 574 = 90 / 126 / 135 / 135 TFLOP/s direct-equivalent against 204 / 335 / 607 / 608 us of k_wgrad_f32 -- not used by the
+// library yet; next: transforms sliced behind the MFMAs, one barrier per chunk):
 // weight gradient of a stride-1 3x3 layer in the Winograd domain, DESIGN.md section 8 "blueprint of next step (1)".
 //
 //   dw_tile = G^T [ (A g A^T) .* (B^T d B) ] G        g: 2x2 tile of the output gradient, d: 4x4 input patch around it
@@ -31,6 +32,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define WW_THREADS 512
 #define WW_PLANE 528                     // floats per plane: 64 rows x 8 tiles + 16 of padding
 #define WW_BUF (2 * 16 * WW_PLANE)       // one (Gh, Dh) pair
+#define WW_RAWPIX 72                     // raw input patch of a chunk: 4 rows x 18 columns (8 tiles), 64 channels each
+#define WW_RAW (WW_RAWPIX * 64)          // floats
 
 struct WWArgs {
   const float* x;    // [N][H][W][C]
@@ -40,7 +43,9 @@ struct WWArgs {
 };
 
 __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
-  __shared__ __attribute__((aligned(16))) float lds[2 * WW_BUF];
+  static_assert((2 * WW_BUF + WW_RAW) * 4 <= 163840, "LDS budget");
+  __shared__ __attribute__((aligned(16))) float lds[2 * WW_BUF + WW_RAW];
+  float* raw = lds + 2 * WW_BUF;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, half = lane >> 5;
   const int mb = wave & 1, nb = (wave >> 1) & 1, xh = wave >> 2;
@@ -61,30 +66,36 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
   const float sg0 = bcol == 2 ? -1.f : 1.f, sg1 = (bcol == 0 || bcol == 3) ? -1.f : 1.f;
   const int w_off = r * 8 + ((tq ^ ((r >> 3) & 1)) * 4);                           // 16-byte slot of (row r, tiles 4tq..4tq+3)
 
-  float xr[4][4][2], gr[4][2][2];                                                  // raw values of the chunk in flight
+  float gr[4][2][2];                                                               // output-gradient values of the chunk in flight
   unsigned rowmask[4];
 
+  // raw x patch of a chunk -> LDS by DMA (global_load_lds, 16 bytes per lane, no registers): 18 pieces of 4 pixels x 64 channels
+  // (1 KiB, linear in the lane id as the instruction requires); wave w brings pieces w, w+8, w+16 (clamped: a harmless
+  // re-write of piece 17).  Rows outside the image read row 0 / H-1 and are masked when the patch is consumed.
   auto load_raw = [&](int ch) {
     int u = ch;
     const int b8 = u % tw8; u /= tw8;
     const int ta = u % th;
     const int n = u / th;
-    const float* xn = a.x + ((size_t)n * a.H * a.W) * a.C + c0 + r;
+    const float* xn = a.x + ((size_t)n * a.H * a.W) * a.C + c0;
     const float* gn = a.g + ((size_t)n * a.H * a.W) * a.K + k0 + r;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = 2 * ta - 1 + i;
       rowmask[i] = (row >= 0 && row < a.H) ? 0xffffffffu : 0u;
-      const int rc = row < 0 ? 0 : (row >= a.H ? a.H - 1 : row);
+    }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int tb = b8 * 8 + tq * 4 + e;
-        int ca = 2 * tb - 1 + j0, cb = 2 * tb - 1 + j1;
-        ca = ca < 0 ? ca + a.W : (ca >= a.W ? ca - a.W : ca);
-        cb = cb < 0 ? cb + a.W : (cb >= a.W ? cb - a.W : cb);
-        xr[e][i][0] = xn[((size_t)rc * a.W + ca) * a.C];
-        xr[e][i][1] = xn[((size_t)rc * a.W + cb) * a.C];
-      }
+    for (int it = 0; it < 3; ++it) {
+      const int piece = min(wave + 8 * it, WW_RAWPIX / 4 - 1);
+      const int pix = piece * 4 + (lane >> 4);
+      const int pi = pix / 18, pj = pix % 18;
+      int row = 2 * ta - 1 + pi;
+      row = row < 0 ? 0 : (row >= a.H ? a.H - 1 : row);
+      int col = 16 * b8 - 1 + pj;
+      col = col < 0 ? col + a.W : (col >= a.W ? col - a.W : col);
+      const float* src = xn + ((size_t)row * a.W + col) * a.C + (lane & 15) * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(raw + __builtin_amdgcn_readfirstlane(piece * 256)), 16, 0, 0);
     }
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -106,8 +117,8 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
       float tt[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const float d0 = __uint_as_float(__float_as_uint(xr[e][i][0]) & rowmask[i]);
-        const float d1 = __uint_as_float(__float_as_uint(xr[e][i][1]) & rowmask[i]);
+        const float d0 = __uint_as_float(__float_as_uint(raw[(i * 18 + 2 * (4 * tq + e) + j0) * 64 + r]) & rowmask[i]);
+        const float d1 = __uint_as_float(__float_as_uint(raw[(i * 18 + 2 * (4 * tq + e) + j1) * 64 + r]) & rowmask[i]);
         tt[i] = sg0 * d0 + sg1 * d1;
       }
       v[0][e] = tt[0] - tt[2]; v[1][e] = tt[1] + tt[2]; v[2][e] = tt[2] - tt[1]; v[3][e] = tt[1] - tt[3];
@@ -138,8 +149,13 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
   const int a_off = arow * 8 + ((half ^ ((arow >> 3) & 1)) * 4);
   const int b_off = 16 * WW_PLANE + brow * 8 + ((half ^ ((brow >> 3) & 1)) * 4);
 
+  // Pipeline: operands of chunk ch in buf[ch & 1]; the raw patch / gradient values of chunk ch+1 travel during the MFMAs of
+  // chunk ch; barrier A: every wave's DMA pieces have landed; transforms into buf[(ch+1) & 1]; barrier B: operands visible,
+  // raw buffer free again.
   if (ch_begin < ch_end) {
     load_raw(ch_begin);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
     transform_write(lds);
   }
   __syncthreads();
@@ -147,7 +163,7 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
     const float* cur = lds + ((ch - ch_begin) & 1) * WW_BUF;
     float* nxt = lds + ((ch - ch_begin + 1) & 1) * WW_BUF;
     const bool more = ch + 1 < ch_end;
-    if (more) load_raw(ch + 1);                    // in flight during the MFMAs below
+    if (more) load_raw(ch + 1);
 #pragma unroll
     for (int xl = 0; xl < 8; ++xl) {
       const f32x4 av = *reinterpret_cast<const f32x4*>(cur + (xh * 8 + xl) * WW_PLANE + a_off);
@@ -155,8 +171,10 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
 #pragma unroll
       for (int j = 0; j < 4; ++j) acc[xl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[xl], 0, 0, 0);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                               // A
     if (more) transform_write(nxt);
-    __syncthreads();
+    __syncthreads();                               // B
   }
   // partial of this slab: ws[slab][xi][k0 + m][c0 + n]; accumulator register q of lane (li, half) is
   // row m = mb*32 + 8*(q/4) + 4*half + q%4, column n = nb*32 + li
@@ -172,18 +190,23 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
   }
 }
 
-// dw[k][r][s][c] = (G^T U G)[r][s],  U[xi] = sum over slabs of ws[slab][xi][k][c]   (fixed order: deterministic)
-__global__ __launch_bounds__(256) void k_wino_wgrad_reduce(const float* __restrict__ ws, int nslabs, int K, int C, float* __restrict__ dw) {
+// U[xi][k][c] = sum over slabs of ws[slab][xi][k][c] in a fixed order (deterministic), four channels per thread
+__global__ __launch_bounds__(256) void k_wino_wgrad_sum(const float* __restrict__ ws, int nslabs, size_t count4, float* __restrict__ u) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count4) return;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int sl = 0; sl < nslabs; ++sl) s += reinterpret_cast<const f32x4*>(ws)[(size_t)sl * count4 + i];
+  reinterpret_cast<f32x4*>(u)[i] = s;
+}
+
+// dw[k][r][s][c] = (G^T U G)[r][s]
+__global__ __launch_bounds__(256) void k_wino_wgrad_out(const float* __restrict__ uu, int K, int C, float* __restrict__ dw) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= (size_t)K * C) return;
   const int k = (int)(i / C), c = (int)(i % C);
   float u[4][4];
 #pragma unroll
-  for (int xi = 0; xi < 16; ++xi) {
-    float s = 0.f;
-    for (int sl = 0; sl < nslabs; ++sl) s += ws[(((size_t)sl * 16 + xi) * K + k) * C + c];
-    u[xi / 4][xi % 4] = s;
-  }
+  for (int xi = 0; xi < 16; ++xi) u[xi / 4][xi % 4] = uu[((size_t)xi * K + k) * C + c];
   // G^T = [[1, 1/2, 1/2, 0], [0, 1/2, -1/2, 0], [0, 1/2, 1/2, 1]]
   float p[3][4];
 #pragma unroll
@@ -194,12 +217,9 @@ __global__ __launch_bounds__(256) void k_wino_wgrad_reduce(const float* __restri
   }
 #pragma unroll
   for (int rr = 0; rr < 3; ++rr) {
-    const float o0 = p[rr][0] + 0.5f * (p[rr][1] + p[rr][2]);
-    const float o1 = 0.5f * (p[rr][1] - p[rr][2]);
-    const float o2 = 0.5f * (p[rr][1] + p[rr][2]) + p[rr][3];
-    dw[(((size_t)k * 3 + rr) * 3 + 0) * C + c] = o0;
-    dw[(((size_t)k * 3 + rr) * 3 + 1) * C + c] = o1;
-    dw[(((size_t)k * 3 + rr) * 3 + 2) * C + c] = o2;
+    dw[(((size_t)k * 3 + rr) * 3 + 0) * C + c] = p[rr][0] + 0.5f * (p[rr][1] + p[rr][2]);
+    dw[(((size_t)k * 3 + rr) * 3 + 1) * C + c] = 0.5f * (p[rr][1] - p[rr][2]);
+    dw[(((size_t)k * 3 + rr) * 3 + 2) * C + c] = 0.5f * (p[rr][1] + p[rr][2]) + p[rr][3];
   }
 }
 
@@ -214,7 +234,7 @@ static int ww_slabs(int total_chunks, int tiles) {
 // x [N][H][W][C], g [N][H][W][K] -> dw [K][3][3][C]; ws >= ww_ws_floats floats.  H even, (W/2) % 8 == 0, C, K % 64 == 0.
 static size_t ww_ws_floats(int N, int H, int W, int C, int K) {
   const int tiles = (K / 64) * (C / 64);
-  return (size_t)ww_slabs(N * (H / 2) * ((W / 2) / 8), tiles) * 16 * K * C;
+  return ((size_t)ww_slabs(N * (H / 2) * ((W / 2) / 8), tiles) + 1) * 16 * K * C;     // slab partials + their sum
 }
 static int wino_wgrad(const float* x, const float* g, float* dw, float* ws, int N, int H, int W, int C, int K, hipStream_t st) {
   if ((H & 1) || ((W / 2) % 8) || (W & 1) || C % 64 || K % 64) return 1;
@@ -223,7 +243,10 @@ static int wino_wgrad(const float* x, const float* g, float* dw, float* ws, int 
   const int nslabs = ww_slabs(total_chunks, tiles);
   WWArgs a{x, g, ws, N, H, W, C, K, (total_chunks + nslabs - 1) / nslabs, nslabs};
   hipLaunchKernelGGL(k_wino_wgrad, dim3(tiles * nslabs), dim3(WW_THREADS), 0, st, a);
-  hipLaunchKernelGGL(k_wino_wgrad_reduce, dim3((unsigned)(((size_t)K * C + 255) / 256)), dim3(256), 0, st, (const float*)ws, nslabs, K, C, dw);
+  const size_t count4 = (size_t)16 * K * C / 4;
+  float* usum = ws + (size_t)nslabs * 16 * K * C;
+  hipLaunchKernelGGL(k_wino_wgrad_sum, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nslabs, count4, usum);
+  hipLaunchKernelGGL(k_wino_wgrad_out, dim3((unsigned)(((size_t)K * C + 255) / 256)), dim3(256), 0, st, (const float*)usum, K, C, dw);
   return 0;
 }
 

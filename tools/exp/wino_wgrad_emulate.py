@@ -29,6 +29,19 @@ def run(N, H, W, C, K, nslabs_want=3):
                     b8 = u % tw8; u //= tw8
                     ta = u % th
                     n = u // th
+                    # raw patch by "DMA": wave w brings pieces w, w+8, w+16 (clamped) of 4 pixels x 64 channels, 16 bytes per lane
+                    raw = np.full(72 * 64, np.nan)
+                    for wave in range(8):
+                        for it in range(3):
+                            piece = min(wave + 8 * it, 17)
+                            for lane in range(64):
+                                pix = piece * 4 + (lane >> 4)
+                                pi, pj = divmod(pix, 18)
+                                row = min(max(2 * ta - 1 + pi, 0), H - 1)
+                                col = (16 * b8 - 1 + pj) % W
+                                cq = lane & 15
+                                raw[piece * 256 + lane * 4:piece * 256 + lane * 4 + 4] = x[n, row, col, c0 + cq * 4:c0 + cq * 4 + 4]
+                    assert not np.isnan(raw).any()
                     for tid in range(512):
                         r, tq, bcol = tid & 63, (tid >> 6) & 1, tid >> 7
                         j0, j1 = (0 if bcol == 0 else 1), (3 if bcol == 3 else 2)
@@ -40,11 +53,9 @@ def run(N, H, W, C, K, nslabs_want=3):
                             tt = []
                             for i in range(4):
                                 row = 2 * ta - 1 + i
-                                if 0 <= row < H:
-                                    d0 = x[n, row, (2 * tb - 1 + j0) % W, c0 + r]
-                                    d1 = x[n, row, (2 * tb - 1 + j1) % W, c0 + r]
-                                else:
-                                    d0 = d1 = 0.0
+                                mask = 1.0 if 0 <= row < H else 0.0
+                                d0 = raw[(i * 18 + 2 * (4 * tq + e) + j0) * 64 + r] * mask
+                                d1 = raw[(i * 18 + 2 * (4 * tq + e) + j1) * 64 + r] * mask
                                 tt.append(sg0 * d0 + sg1 * d1)
                             vD[0, e], vD[1, e], vD[2, e], vD[3, e] = tt[0] - tt[2], tt[1] + tt[2], tt[2] - tt[1], tt[1] - tt[3]
                             h = []
