@@ -362,6 +362,252 @@ extern "C" int dl_wino_weights_f32(const float* w, float* u_fwd, float* u_bwd, i
   return dl_check_launch("dl_wino_weights_f32");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of a stride-1 3x3 layer in the Winograd domain:
+//   dw_tile = G^T [ (A g A^T) .* (B^T d B) ] G        g: 2x2 tile of the output gradient, d: the 4x4 input patch around it
+//   dU[xi][k][c] += Gh[xi][tile][k] * Dh[xi][tile][c]   (16 products per tile and (k,c) pair instead of 36)
+// Workgroup = 512 threads, output block 64 k x 64 c x 16 planes (the accumulator layout of k_wino_conv), reduction index =
+// tiles, 8 consecutive tiles of one tile row per chunk; a workgroup walks a slab of chunks and writes one partial
+// [16][K][C] block; k_wino_wgrad_sum adds the slabs in a fixed order (deterministic), k_wino_wgrad_out applies G^T . G.
+// Per chunk every thread produces, for ONE channel and FOUR tiles, one column of B^T d B (from the raw patch that the LDS
+// DMA brought in) and one column of A g A^T (16 scalar loads of g, coalesced over the 64 channels of a wave), written as
+// 16-byte rows [xi][channel][4 tiles]: lane (i, half) reads tiles 4 half .. 4 half+3 of its row, MFMA j reduces over tiles
+// {j, 4 + j}.  Addressing validated by tools/exp/wino_wgrad_emulate.py; tools/exp/wino_wgrad.hip is the stand-alone check.
+// Measured (B=8): layer2 306 us (direct kernel 335), layer3 572 (607), layer4 574 (608); 64-channel layers stay direct.
+#define WW_THREADS 512
+#define WW_PLANE 528                     // floats per plane: 64 rows x 8 tiles + 16 of padding
+#define WW_BUF (2 * 16 * WW_PLANE)       // one (Gh, Dh) pair
+#define WW_RAWPIX 72                     // raw input patch of a chunk: 4 rows x 18 columns (8 tiles), 64 channels each
+#define WW_RAW (WW_RAWPIX * 64)          // floats
+
+struct WWArgs {
+  const float* x;    // [N][H][W][C]
+  const float* g;    // [N][H][W][K]
+  float* ws;         // [nslabs][16][K][C]
+  int N, H, W, C, K, chunks_per_slab, nslabs;
+};
+
+__global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
+  static_assert((2 * WW_BUF + WW_RAW) * 4 <= 163840, "LDS budget");
+  __shared__ __attribute__((aligned(16))) float lds[2 * WW_BUF + WW_RAW];
+  float* raw = lds + 2 * WW_BUF;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, half = lane >> 5;
+  const int mb = wave & 1, nb = (wave >> 1) & 1, xh = wave >> 2;
+  const int CT = a.C / 64;
+  int t = blockIdx.x;
+  const int slab = t % a.nslabs; t /= a.nslabs;
+  const int ct = t % CT;
+  const int kt = t / CT;
+  const int k0 = kt * 64, c0 = ct * 64;
+  const int th = a.H / 2, tw8 = (a.W / 2) / 8;
+  const int total_chunks = a.N * th * tw8;
+  const int ch_begin = slab * a.chunks_per_slab;
+  const int ch_end = min(ch_begin + a.chunks_per_slab, total_chunks);
+
+  // transform role: channel r of the block (c for Dh, k for Gh), tile quad tq, column bcol of the 4x4 domain
+  const int r = tid & 63, tq = (tid >> 6) & 1, bcol = tid >> 7;
+  const int j0 = bcol == 0 ? 0 : 1, j1 = bcol == 3 ? 3 : 2;                       // (d B)[.][bcol] = sg0 d[.][j0] + sg1 d[.][j1]
+  const float sg0 = bcol == 2 ? -1.f : 1.f, sg1 = (bcol == 0 || bcol == 3) ? -1.f : 1.f;
+  const int w_off = r * 8 + ((tq ^ ((r >> 3) & 1)) * 4);                           // 16-byte slot of (row r, tiles 4tq..4tq+3)
+
+  float gr[4][2][2];                                                               // output-gradient values of the chunk in flight
+  unsigned rowmask[4];
+
+  // raw x patch of a chunk -> LDS by DMA (global_load_lds, 16 bytes per lane, no registers): 18 pieces of 4 pixels x 64 channels
+  // (1 KiB, linear in the lane id as the instruction requires); wave w brings pieces w, w+8, w+16 (clamped: a harmless
+  // re-write of piece 17).  Rows outside the image read row 0 / H-1 and are masked when the patch is consumed.
+  auto load_raw = [&](int ch) {
+    int u = ch;
+    const int b8 = u % tw8; u /= tw8;
+    const int ta = u % th;
+    const int n = u / th;
+    const float* xn = a.x + ((size_t)n * a.H * a.W) * a.C + c0;
+    const float* gn = a.g + ((size_t)n * a.H * a.W) * a.K + k0 + r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 2 * ta - 1 + i;
+      rowmask[i] = (row >= 0 && row < a.H) ? 0xffffffffu : 0u;
+    }
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const int piece = min(wave + 8 * it, WW_RAWPIX / 4 - 1);
+      const int pix = piece * 4 + (lane >> 4);
+      const int pi = pix / 18, pj = pix % 18;
+      int row = 2 * ta - 1 + pi;
+      row = row < 0 ? 0 : (row >= a.H ? a.H - 1 : row);
+      int col = 16 * b8 - 1 + pj;
+      col = col < 0 ? col + a.W : (col >= a.W ? col - a.W : col);
+      const float* src = xn + ((size_t)row * a.W + col) * a.C + (lane & 15) * 4;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(raw + __builtin_amdgcn_readfirstlane(piece * 256)), 16, 0, 0);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int tb = b8 * 8 + tq * 4 + e;
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) gr[e][p][q] = gn[((size_t)(2 * ta + p) * a.W + (2 * tb + q)) * a.K];
+    }
+  };
+
+  auto transform_write = [&](float* buf) {
+    float* gh = buf + w_off;                       // planes 0..15: Gh
+    float* dh = buf + 16 * WW_PLANE + w_off;       // planes 16..31: Dh
+    f32x4 v[4];
+    // Dh = B^T d B, column bcol, for the four tiles
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float tt[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float d0 = __uint_as_float(__float_as_uint(raw[(i * 18 + 2 * (4 * tq + e) + j0) * 64 + r]) & rowmask[i]);
+        const float d1 = __uint_as_float(__float_as_uint(raw[(i * 18 + 2 * (4 * tq + e) + j1) * 64 + r]) & rowmask[i]);
+        tt[i] = sg0 * d0 + sg1 * d1;
+      }
+      v[0][e] = tt[0] - tt[2]; v[1][e] = tt[1] + tt[2]; v[2][e] = tt[2] - tt[1]; v[3][e] = tt[1] - tt[3];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dh + (i * 4 + bcol) * WW_PLANE) = v[i];
+    // Gh = A g A^T, column bcol:  (g A^T)[p][bcol] then A .
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float h[2];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const float g0 = gr[e][p][0], g1 = gr[e][p][1];
+        h[p] = bcol == 0 ? g0 : (bcol == 1 ? g0 + g1 : (bcol == 2 ? g0 - g1 : -g1));
+      }
+      v[0][e] = h[0]; v[1][e] = h[0] + h[1]; v[2][e] = h[0] - h[1]; v[3][e] = -h[1];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(gh + (i * 4 + bcol) * WW_PLANE) = v[i];
+  };
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+  const int arow = mb * 32 + li, brow = nb * 32 + li;
+  const int a_off = arow * 8 + ((half ^ ((arow >> 3) & 1)) * 4);
+  const int b_off = 16 * WW_PLANE + brow * 8 + ((half ^ ((brow >> 3) & 1)) * 4);
+
+  // Pipeline: operands of chunk ch in buf[ch & 1]; the raw patch / gradient values of chunk ch+1 travel during the MFMAs of
+  // chunk ch; barrier A: every wave's DMA pieces have landed; transforms into buf[(ch+1) & 1]; barrier B: operands visible,
+  // raw buffer free again.
+  if (ch_begin < ch_end) {
+    load_raw(ch_begin);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    transform_write(lds);
+  }
+  __syncthreads();
+  for (int ch = ch_begin; ch < ch_end; ++ch) {
+    const float* cur = lds + ((ch - ch_begin) & 1) * WW_BUF;
+    float* nxt = lds + ((ch - ch_begin + 1) & 1) * WW_BUF;
+    const bool more = ch + 1 < ch_end;
+    if (more) load_raw(ch + 1);
+#pragma unroll
+    for (int xl = 0; xl < 8; ++xl) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(cur + (xh * 8 + xl) * WW_PLANE + a_off);
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(cur + (xh * 8 + xl) * WW_PLANE + b_off);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[xl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[xl], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                               // A
+    if (more) transform_write(nxt);
+    __syncthreads();                               // B
+  }
+  // partial of this slab: ws[slab][xi][k0 + m][c0 + n]; accumulator register q of lane (li, half) is
+  // row m = mb*32 + 8*(q/4) + 4*half + q%4, column n = nb*32 + li
+  float* wp = a.ws + ((size_t)slab * 16) * a.K * a.C;
+#pragma unroll
+  for (int xl = 0; xl < 8; ++xl) {
+    const int xi = xh * 8 + xl;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = mb * 32 + 8 * (q / 4) + 4 * half + (q % 4);
+      wp[((size_t)xi * a.K + k0 + m) * a.C + c0 + nb * 32 + li] = acc[xl][q];
+    }
+  }
+}
+
+// U[xi][k][c] = sum over slabs of ws[slab][xi][k][c] in a fixed order (deterministic), four channels per thread
+__global__ __launch_bounds__(256) void k_wino_wgrad_sum(const float* __restrict__ ws, int nslabs, size_t count4, float* __restrict__ u) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count4) return;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int sl = 0; sl < nslabs; ++sl) s += reinterpret_cast<const f32x4*>(ws)[(size_t)sl * count4 + i];
+  reinterpret_cast<f32x4*>(u)[i] = s;
+}
+
+// dw[k][r][s][c] = (G^T U G)[r][s]
+__global__ __launch_bounds__(256) void k_wino_wgrad_out(const float* __restrict__ uu, int K, int C, float* __restrict__ dw) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)K * C) return;
+  const int k = (int)(i / C), c = (int)(i % C);
+  float u[4][4];
+#pragma unroll
+  for (int xi = 0; xi < 16; ++xi) u[xi / 4][xi % 4] = uu[((size_t)xi * K + k) * C + c];
+  // G^T = [[1, 1/2, 1/2, 0], [0, 1/2, -1/2, 0], [0, 1/2, 1/2, 1]]
+  float p[3][4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    p[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
+    p[1][j] = 0.5f * (u[1][j] - u[2][j]);
+    p[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
+  }
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr) {
+    dw[(((size_t)k * 3 + rr) * 3 + 0) * C + c] = p[rr][0] + 0.5f * (p[rr][1] + p[rr][2]);
+    dw[(((size_t)k * 3 + rr) * 3 + 1) * C + c] = 0.5f * (p[rr][1] - p[rr][2]);
+    dw[(((size_t)k * 3 + rr) * 3 + 2) * C + c] = 0.5f * (p[rr][1] + p[rr][2]) + p[rr][3];
+  }
+}
+
+static int ww_slabs(int total_chunks, int tiles) {
+  int want = (256 + tiles - 1) / tiles;              // one 512-thread workgroup per CU
+  if (want > total_chunks) want = total_chunks;
+  if (want < 1) want = 1;
+  const int per = (total_chunks + want - 1) / want;
+  return (total_chunks + per - 1) / per;
+}
+
+static bool ww_supported(int N, int H, int W, int C, int K) {
+  return N > 0 && H > 0 && W > 0 && !(H & 1) && !(W & 1) && ((W / 2) % 8) == 0 && C % 64 == 0 && K % 64 == 0 &&
+         (size_t)N * H * W * (C > K ? C : K) < ((size_t)1 << 31);
+}
+
+/* see include/delora_hip.h */
+extern "C" size_t dl_wino_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K) {
+  if (!ww_supported(N, H, W, C, K)) return 0;
+  const int tiles = (K / 64) * (C / 64);
+  return ((size_t)ww_slabs(N * (H / 2) * ((W / 2) / 8), tiles) + 1) * 16 * K * C * sizeof(float);     // slab partials + their sum
+}
+
+extern "C" int dl_wino_wgrad3x3_nhwc_f32(const float* x, const float* g, float* dw, void* workspace, int32_t N, int32_t H,
+                                         int32_t W, int32_t C, int32_t K, dl_stream stream) {
+  if (!x || !g || !dw || !workspace) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wino_wgrad3x3_nhwc_f32: null pointer argument");
+  if (!ww_supported(N, H, W, C, K))
+    return dl_fail(DL_ERR_UNSUPPORTED, "dl_wino_wgrad3x3_nhwc_f32: shape N=%d H=%d W=%d C=%d K=%d not supported (H even, W/2 %% 8, C, K %% 64)",
+                   N, H, W, C, K);
+  hipStream_t st = (hipStream_t)stream;
+  float* ws = (float*)workspace;
+  const int tiles = (K / 64) * (C / 64);
+  const int total_chunks = N * (H / 2) * ((W / 2) / 8);
+  const int nslabs = ww_slabs(total_chunks, tiles);
+  WWArgs a{x, g, ws, N, H, W, C, K, (total_chunks + nslabs - 1) / nslabs, nslabs};
+  hipLaunchKernelGGL(k_wino_wgrad, dim3(tiles * nslabs), dim3(WW_THREADS), 0, st, a);
+  const size_t count4 = (size_t)16 * K * C / 4;
+  float* usum = ws + (size_t)nslabs * 16 * K * C;
+  hipLaunchKernelGGL(k_wino_wgrad_sum, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nslabs, count4, usum);
+  hipLaunchKernelGGL(k_wino_wgrad_out, dim3((unsigned)(((size_t)K * C + 255) / 256)), dim3(256), 0, st, (const float*)usum, K, C, dw);
+  return dl_check_launch("dl_wino_wgrad3x3_nhwc_f32");
+}
+
 // Measurement aid (bench.py: the roofline of the dominant kernel, read inside real training steps): between
 // dl_wino_profile_begin and dl_wino_profile_end every dl_wino_conv3x3_nhwc_f32 launch carries its own begin/end
 // timestamps (two HIP events filled by hipExtLaunchKernelGGL) and its multiply-add count is added up.  One profile at a

@@ -57,12 +57,24 @@ def conv_nhwc(x, w_krsc, stride=(1, 1), act=0, epilogue=0, add=None, dsrc=None, 
     return y
 
 
+USE_WINOGRAD_WGRAD = True    # stride-1 3x3 weight gradients with >= 128 input channels in the Winograd domain (csrc/wino.hip)
+
+
 def wgrad_nhwc(x, g, ks, stride=(1, 1)):
-    """``dW [K,k,k,C]`` (channels_last storage of the parameter gradient) from input x ``[N,H,W,C]`` and output gradient g."""
+    """``dW [K,k,k,C]`` (channels_last storage of the parameter gradient) from input x ``[N,H,W,C]`` and output gradient g.
+    Stride-1 3x3 layers with at least 128 input channels take the Winograd-domain kernel (6-9 % faster there; the 64-channel
+    layers and everything strided stay on the direct kernel)."""
     lib = _lib.load()
     N, H, W, C = x.shape
     K = g.shape[3]
     dw = torch.empty((K, ks, ks, C), dtype=torch.float32, device=x.device)
+    if USE_WINOGRAD_WGRAD and ks == 3 and tuple(stride) == (1, 1) and C >= 128:
+        nbytes = lib.dl_wino_wgrad_workspace_bytes(N, H, W, C, K)
+        if nbytes:
+            ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
+            _lib.check(lib.dl_wino_wgrad3x3_nhwc_f32(_ptr(x), _ptr(g), _ptr(dw), _ptr(ws), N, H, W, C, K, _stream()),
+                       "dl_wino_wgrad3x3_nhwc_f32")
+            return dw
     ws = torch.empty((lib.dl_conv2d_wgrad_workspace_bytes(N, H, W, C, K, ks, stride[0], stride[1]) // 4,), dtype=torch.float32,
                      device=x.device)
     _lib.check(lib.dl_conv2d_wgrad_nhwc_f32(_ptr(x), _ptr(g), _ptr(dw), _ptr(ws), N, H, W, C, K, ks, stride[0], stride[1],

@@ -294,6 +294,15 @@ int dl_wino_conv3x3_nhwc_f32(const float* x, const float* u, float* y, const flo
                              int32_t H, int32_t W, int32_t C, int32_t K, int32_t act, uint32_t epilogue, dl_stream stream);
 
 /*
+ * Weight gradient of a stride-1 3x3 layer in the Winograd domain (2.25x fewer multiplications than
+ * dl_conv2d_wgrad_nhwc_f32; partial sums in a fixed order): x [N][H][W][C], g [N][H][W][K] -> dw [K][3][3][C].
+ * H even, W/2 a multiple of 8, C and K multiples of 64; dl_wino_wgrad_workspace_bytes returns 0 for other shapes.
+ */
+size_t dl_wino_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K);
+int dl_wino_wgrad3x3_nhwc_f32(const float* x, const float* g, float* dw, void* workspace, int32_t N, int32_t H, int32_t W,
+                              int32_t C, int32_t K, dl_stream stream);
+
+/*
  * The stem's max-pooling on channels-last activations (reference src/models/resnet_modified.py:100-102: F.pad(circular) +
  * MaxPool2d(kernel 3, stride (1,2), padding (1,0)) after conv1 + activation), between the convolution kernels above:
  *   dl_pool3x3s12_nhwc_fwd: a [N][H][W][C] (activated conv1 output) -> y [N][H][W/2][C], win [N][H][W/2][C] int8 = position
