@@ -229,3 +229,27 @@ def test_mean_hw_kernel_against_torch():
     y_ref.backward(gy)
     util.measured("global average pooling (channels-last): kernel vs torch.mean (absolute)", float((y - y_ref).abs().max()), bound=1e-6)
     assert torch.allclose(gx, x.grad, rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 64, 128, 128), (1, 4, 32, 256, 64)])
+def test_winograd_domain_weight_gradient_against_the_direct_kernel_and_torch(shape, monkeypatch):
+    """dl_wino_wgrad3x3_nhwc_f32 (weight gradient accumulated in the Winograd domain, csrc/wino.hip) against this library's direct
+    kernel and torch autograd on the same data, incl. image rows at the zero-padded border and the wrap-around columns."""
+    from delora_amd.models import ring_conv as rc
+    dev = _dev()
+    N, H, W, C, K = shape
+    g = torch.Generator(device="cpu").manual_seed(sum(shape))
+    x = torch.randn((N, C, H, W), generator=g).to(dev)
+    w = (torch.randn((K, C, 3, 3), generator=g) * 0.05).to(dev).requires_grad_(True)
+    y = _ref_conv(x, w, (1, 1), 3)
+    gy = torch.randn(y.shape, generator=g).to(dev)
+    y.backward(gy)
+    x_nhwc, gy_nhwc = x.permute(0, 2, 3, 1).contiguous(), gy.permute(0, 2, 3, 1).contiguous()
+    monkeypatch.setattr(rc, "USE_WINOGRAD_WGRAD", True)
+    dw_wino = rc.wgrad_nhwc(x_nhwc, gy_nhwc, 3)
+    monkeypatch.setattr(rc, "USE_WINOGRAD_WGRAD", False)
+    dw_direct = rc.wgrad_nhwc(x_nhwc, gy_nhwc, 3)
+    tag = f"winograd-domain wgrad {N}x{H}x{W} {C}->{K}"
+    util.measured(f"{tag}: vs torch autograd (relative)", _rel(dw_wino.permute(0, 3, 1, 2), w.grad), bound=REL)
+    util.measured(f"{tag}: vs the direct MFMA kernel (relative)", _rel(dw_wino, dw_direct), bound=REL)
+    assert not torch.equal(dw_wino, dw_direct)          # the two paths really are different kernels
