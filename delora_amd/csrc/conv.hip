@@ -28,6 +28,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "conv_geom.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -70,47 +71,6 @@ __device__ __forceinline__ int cv_xcd_swizzle(int id, int n) {
   const int q = n / 8, r = n % 8, xcd = id % 8, k = id / 8;
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
-
-// Geometry policies: which offsets of the staged input tile feed which weight tap, and where an output pixel goes.
-//   GeomConv<KS, SH, SW>            the layer itself: output (ho, wo) reads input (ho*SH + r - PAD, wo*SW + s - PAD).
-//   GeomDgrad<KS, SH, SW, PH, PW, SO> its input gradient for the input pixels (SH*i + PH, SW*j + PW): a stride-1 pass over
-//       the OUTPUT-gradient grid with the subset of taps whose stride phase matches -- r with (PH + PAD - r) % SH == 0
-//       reads grid row i + (PH + PAD - r) / SH -- so a strided layer's input gradient is SH*SW such passes, each doing
-//       exactly the multiplications that are not zeros (no zero-stuffed tensor).  SO: scatter the result into the
-//       full-resolution image (stride SH, SW, phase PH, PW) or keep it dense on the grid.
-template <int KS_, int SH_, int SW_>
-struct GeomConv {
-  static constexpr int NT = KS_ * KS_, WTAPS = KS_ * KS_, ISH = SH_, ISW = SW_;
-  static constexpr int H0 = -((KS_ - 1) / 2), W0 = -((KS_ - 1) / 2), EH = KS_, EW = KS_;
-  static constexpr int OSH = 1, OSW = 1, OPH = 0, OPW = 0;
-  static constexpr int dh(int t) { return t / KS_; }
-  static constexpr int dw(int t) { return t % KS_; }
-  static constexpr int wt(int t) { return t; }
-};
-
-template <int KS_, int S_, int P_>
-struct DgradAxis {                                 // one axis of GeomDgrad: valid taps and their grid offsets
-  static constexpr int PAD = (KS_ - 1) / 2;
-  static constexpr bool valid(int r) { return (P_ + PAD - r) % S_ == 0; }
-  static constexpr int off(int r) { return (P_ + PAD - r) / S_; }
-  static constexpr int count() { int n = 0; for (int r = 0; r < KS_; ++r) n += valid(r) ? 1 : 0; return n; }
-  static constexpr int tap(int i) { int n = 0; for (int r = 0; r < KS_; ++r) if (valid(r)) { if (n == i) return r; ++n; } return 0; }
-  static constexpr int lo() { int m = 99; for (int r = 0; r < KS_; ++r) if (valid(r) && off(r) < m) m = off(r); return m; }
-  static constexpr int hi() { int m = -99; for (int r = 0; r < KS_; ++r) if (valid(r) && off(r) > m) m = off(r); return m; }
-};
-
-template <int KS_, int SH_, int SW_, int PH_, int PW_, bool SO_>
-struct GeomDgrad {
-  using AH = DgradAxis<KS_, SH_, PH_>;
-  using AW = DgradAxis<KS_, SW_, PW_>;
-  static constexpr int NR = AH::count(), NS = AW::count();
-  static constexpr int NT = NR * NS, WTAPS = KS_ * KS_, ISH = 1, ISW = 1;
-  static constexpr int H0 = AH::lo(), W0 = AW::lo(), EH = AH::hi() - AH::lo() + 1, EW = AW::hi() - AW::lo() + 1;
-  static constexpr int OSH = SO_ ? SH_ : 1, OSW = SO_ ? SW_ : 1, OPH = SO_ ? PH_ : 0, OPW = SO_ ? PW_ : 0;
-  static constexpr int dh(int t) { return AH::off(AH::tap(t / NS)) - H0; }
-  static constexpr int dw(int t) { return AW::off(AW::tap(t % NS)) - W0; }
-  static constexpr int wt(int t) { return AH::tap(t / NS) * KS_ + AW::tap(t % NS); }
-};
 
 template <int BM, int BN, int CK, int TW, class G, bool BT, int WGN>
 #ifndef CV_MINWAVES
@@ -608,6 +568,8 @@ extern "C" int dl_conv2d_nhwc_f32(const float* x, const float* w, float* y, cons
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_nhwc_f32: bad argument");
   if (((epilogue & CV_EPI_ADD) && !add) || ((epilogue & CV_EPI_DACT) && !dsrc) || act < 0 || act > 2 || (epilogue & ~7u))
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_nhwc_f32: epilogue operand missing / bad activation or flag");
+  if ((stride_h != 1 && stride_h != 2) || (stride_w != 1 && stride_w != 2) || (ksize != 1 && ksize != 3))
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_nhwc_f32: kernel size must be 1 or 3, strides 1 or 2 (got %d, %d, %d)", ksize, stride_h, stride_w);
   if (H % stride_h || W % stride_w)
     return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_f32: image size must be a multiple of the stride");
   if ((size_t)N * H * W * C >= ((size_t)1 << 31) || (size_t)N * H * W * K >= ((size_t)1 << 31))
@@ -648,6 +610,8 @@ extern "C" int dl_conv2d_dgrad_strided_nhwc_f32(const float* g, const float* w, 
   if (((epilogue & CV_EPI_ADD_GRID) && !add_grid) || ((epilogue & CV_EPI_DACT) && !dsrc) || act < 0 || act > 2 ||
       (epilogue & ~(CV_EPI_ADD_GRID | CV_EPI_DACT)))
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_dgrad_strided_nhwc_f32: epilogue operand missing / unsupported flag");
+  if ((stride_h != 1 && stride_h != 2) || (stride_w != 1 && stride_w != 2) || (ksize != 1 && ksize != 3))
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_dgrad_strided_nhwc_f32: kernel size must be 1 or 3, strides 1 or 2 (got %d, %d, %d)", ksize, stride_h, stride_w);
   if ((size_t)N * Ho * stride_h * Wo * stride_w * C >= ((size_t)1 << 31) || (size_t)N * Ho * Wo * K >= ((size_t)1 << 31))
     return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_dgrad_strided_nhwc_f32: tensors beyond 2^31 elements are not supported");
   // in the kernel's terms: input = g (K channels, the reduction), output channels = C
@@ -691,6 +655,7 @@ static int wgrad_slabs(int total_chunks, int tiles) {
 
 extern "C" size_t dl_conv2d_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, int32_t ksize,
                                                   int32_t stride_h, int32_t stride_w) {
+  if (stride_h < 1 || stride_w < 1 || ksize < 1 || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return 0;
   const int Ho = H / stride_h, Wo = W / stride_w;
   const int tiles = (K / 64 > 0 ? K / 64 : 1) * (C / 64 > 0 ? C / 64 : 1);
   return (size_t)wgrad_slabs(N * Ho * (Wo / WG_PK > 0 ? Wo / WG_PK : 1), tiles) * K * ksize * ksize * C * sizeof(float);
@@ -718,6 +683,8 @@ extern "C" int dl_conv2d_wgrad_nhwc_f32(const float* x, const float* g, float* d
                                         dl_stream stream) {
   if (!x || !g || !dw || !workspace || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_wgrad_nhwc_f32: bad argument");
+  if ((stride_h != 1 && stride_h != 2) || (stride_w != 1 && stride_w != 2) || (ksize != 1 && ksize != 3))
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_wgrad_nhwc_f32: kernel size must be 1 or 3, strides 1 or 2 (got %d, %d, %d)", ksize, stride_h, stride_w);
   if (H % stride_h || W % stride_w)
     return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_wgrad_nhwc_f32: image size must be a multiple of the stride");
   hipStream_t st = (hipStream_t)stream;

@@ -1,0 +1,507 @@
+// Convolutions of the pose CNN in half precision (bf16 or fp16 storage, fp32 accumulation) on the gfx950 matrix cores
+// (v_mfma_f32_32x32x16_bf16 / _f16), channels-last, wrap-around width by addressing -- the autocast mode of the network
+// (BASELINE.json configs[4] "fp16 CNN on MFMA").  Same operator contract as conv.hip (fp32):
+//     forward          y  = act(conv(x, w) [+ shortcut])
+//     backward-data    g' = (conv(g, w^T) [+ g_shortcut]) * act'(x)
+//     backward-weight  dw[k][tap][c] = sum_pixels g[pixel][k] * x[pixel + tap][c]          (fp32 result)
+// for the reference's 3x3 / 1x1 layers, stride (1,1), (1,2), (2,2) (src/models/resnet_modified.py:40-42, :159-177).
+//
+// The matrix pipe is 16x faster than in fp32, so the kernels are organised around DATA MOVEMENT, not around the MFMAs:
+//
+//  * operands reach LDS by DMA only (global_load_lds, 16 bytes per lane, no registers, no staging instructions); the image
+//    in LDS is linear in the lane id as the instruction requires, every layout decision -- wrap-around column, stride phase
+//    planes, the XOR swizzle that makes the fragment reads bank-conflict free -- is made on the per-lane SOURCE address;
+//    rows above / below the image are lanes switched off (the DMA leaves their LDS bytes untouched: zeroed once);
+//  * forward / input gradient (k_convh): a workgroup owns BM = TH x TW output pixels x BN output channels and walks the
+//    reduction in steps of (32 input channels) x (one row of taps): per step 41 KB of DMA against 384 MFMAs (BM 512, BN 128);
+//    the input halo tile of a channel chunk is staged ONCE for all nine taps (taps read it at shifted pixel offsets), the
+//    weights of a tap row at a time, both double-buffered, one barrier per step.  A fragment = 8 consecutive channels of
+//    one pixel = one ds_read_b128; the 64-byte pixel rows are swizzled in 16-byte granules by (column >> 2) & 3.
+//    Weights arrive pre-laid-out by k_wprep_h as [tap][K][C] (forward) / [tap][C][K] (input gradient) in half precision;
+//  * weight gradient (k_wgradh): the reduction index is the PIXEL, which is the slow axis of both operands in memory;
+//    fragments are built by ds_read_b64_tr_b16 (hardware transpose: 4 pixels x 16 channels -> 4 pixels per lane), layout
+//    probed on the GPU by tools/exp/hw_probe.hip.  Slabs of pixels per workgroup, fp32 partials summed in a fixed order.
+//
+// Numerics: products of half-precision inputs are exact in fp32, accumulation is fp32 (one rounding per MFMA partial sum),
+// every stored activation / gradient is rounded to the storage type once, elementwise tails run in fp32 on the accumulators.
+#include <type_traits>
+
+#include "common.h"
+#include "conv_geom.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+#define CH_EPI_ADD 1u
+#define CH_EPI_ACT 2u
+#define CH_EPI_DACT 4u
+#define CH_EPI_ADD_GRID 8u
+
+template <bool F16>
+__device__ __forceinline__ f32x16 ch_mfma(s16x8 a, s16x8 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ float ch_h2f(u16 v) {
+  if constexpr (F16) return (float)__builtin_bit_cast(_Float16, v);
+  else return __builtin_bit_cast(float, (uint32_t)v << 16);
+}
+template <bool F16>
+__device__ __forceinline__ u16 ch_f2h(float f) {      // round to nearest even
+  if constexpr (F16) return __builtin_bit_cast(u16, (_Float16)f);
+  else return __builtin_bit_cast(u16, (__bf16)f);
+}
+// tanh for a result that is rounded to 8 / 11 significant bits: 1 - 2 / (exp(2x) + 1) with the hardware exp2 / rcp
+// (relative error ~1e-6; exp overflow gives 1 - 0, underflow 1 - 2)
+__device__ __forceinline__ float ch_tanh(float x) { return 1.f - 2.f * __frcp_rn(__expf(2.f * x) + 1.f); }
+__device__ __forceinline__ float ch_act(float v, int act) {
+  if (act == 1) return ch_tanh(v);
+  if (act == 2) return v < 0.f ? 0.f : v;
+  return v;
+}
+__device__ __forceinline__ float ch_dact(float y, int act) {
+  if (act == 1) return 1.f - y * y;
+  if (act == 2) return y <= 0.f ? 0.f : 1.f;
+  return 1.f;
+}
+__device__ __forceinline__ int ch_xcd_swizzle(int id, int n) {
+  const int q = n / 8, r = n % 8, xcd = id % 8, k = id / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+struct ConvHArgs {
+  const u16* x;      // [N][H][W][C]
+  const u16* w;      // [WTAPS][K][C]  prepared weights (k_wprep_h): rows = output channels of THIS pass, C = its reduction
+  u16* y;            // [N][Ho*OSH][Wo*OSW][K]
+  const u16* add;    // [N][Ho][Wo][K] (ADD: output-shaped; ADD_GRID: on the dense grid) or null
+  const u16* dsrc;   // output-shaped or null
+  int N, H, W, C, K, Ho, Wo;
+  int act;
+  unsigned epi;
+};
+
+#define CH_GLDS(GPTR, LOFF)                                                                  \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(GPTR),   \
+                                   (__attribute__((address_space(3))) void*)(lds + (LOFF)), 16, 0, 0)
+
+// BM = TH x TW output pixels, BN output channels, WGM x WGN waves (each (BM/WGM) x (BN/WGN)), G the geometry policy,
+// NG tap groups per channel chunk (3: one row of a 3x3 stencil per step; 1: all taps of the pass in one step).
+template <bool F16, int BM, int BN, int WGM, int WGN, int TW, class G, int NG>
+__global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
+  constexpr int NWV = WGM * WGN;
+  constexpr int TH = BM / TW, SH = G::ISH, SW = G::ISW;
+  constexpr int RH = (TH - 1) * SH + G::EH, RW = (TW - 1) * SW + G::EW;
+  constexpr int RWC = (RW + SW - 1) / SW, RWP = (RWC + 3) & ~3;     // columns of a stride-phase plane, padded to 4
+  constexpr int NPL = RH * SW;                                       // (row, phase) planes of the staged input tile
+  constexpr int NII = (NPL * RWP * 4 + 63) / 64;                     // 1 KiB DMA pieces (16 pixels x 64 B) of the input tile
+  constexpr int NII_W = (NII + NWV - 1) / NWV;
+  constexpr int IN_BYTES = NII * 1024;
+  constexpr int TAPS = G::NT, TG = TAPS / NG;
+  constexpr int NWI = TG * BN / 16, NWI_W = (NWI + NWV - 1) / NWV;   // DMA pieces of one tap group's weights (16 rows each)
+  constexpr int W_BYTES = TG * BN * 64;
+  constexpr int WM = BM / 32 / WGM, WN = BN / 32 / WGN;
+  constexpr int NCS = (G::EW - 1) / SW + 1;                          // distinct column shifts (in plane columns) of the taps
+  constexpr int ES = WN * 32 + 4;                                    // epilogue staging: floats per pixel row
+  constexpr int MAIN_BYTES = 2 * IN_BYTES + 2 * W_BYTES, EPI_BYTES = NWV * 32 * ES * 4;
+  constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
+  static_assert(TW % 32 == 0 && BM % TW == 0 && BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0 && BN % 16 == 0, "tile shape");
+  static_assert(TAPS % NG == 0 && TAPS > 0, "tap groups");
+  static_assert(NG == 1 || G::wt(TAPS - 1) == TAPS - 1, "tap groups need the identity tap -> weight-slab map");
+  static_assert(LDS_BYTES <= 163840, "LDS budget");
+  __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+  constexpr int W_BASE = 2 * IN_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, half = lane >> 5;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int KT = a.K / BN;
+  const int tiles_w = a.Wo / TW, tiles_h = a.Ho / TH;
+  const int ntiles = a.N * tiles_h * tiles_w * KT;
+  const int t = ch_xcd_swizzle(blockIdx.x, ntiles);
+  const int kt = t % KT;
+  int pt = t / KT;
+  const int tw_i = pt % tiles_w; pt /= tiles_w;
+  const int th_i = pt % tiles_h;
+  const int n = pt / tiles_h;
+  const int ho0 = th_i * TH, wo0 = tw_i * TW, k0 = kt * BN;
+  const int h_base = ho0 * SH + G::H0, w_base = wo0 * SW + G::W0;
+  const char* xn = reinterpret_cast<const char*>(a.x + (size_t)n * a.H * a.W * a.C);
+  const char* wb = reinterpret_cast<const char*>(a.w);
+
+  // DMA pieces of this wave.  Input: piece j = wave + it * NWV, lane -> (pixel of the LDS image, 16-byte slot); byte offset
+  // of its source relative to xn, -1 = lane off (beyond the tile, or a zero row above / below the image).
+  int in_off[NII_W], in_l[NII_W];
+#pragma unroll
+  for (int it = 0; it < NII_W; ++it) {
+    const int j = wave + it * NWV;
+    const int q = j * 64 + lane;
+    const int pix = q >> 2, sslot = q & 3;
+    const int rp = pix / RWP, colp = pix % RWP;
+    const int row = rp / SW, phase = rp % SW;
+    const int col = colp * SW + phase;
+    const int h = h_base + row;
+    int w = w_base + col;
+    w = w < 0 ? w + a.W : (w >= a.W ? w - a.W : w);
+    const bool ok = j < NII && rp < NPL && col < RW && h >= 0 && h < a.H;
+    in_off[it] = ok ? ((h * a.W + w) * a.C + ((sslot ^ ((colp >> 2) & 3)) * 8)) * 2 : -1;
+    in_l[it] = j * 1024;
+  }
+  // Weights of a tap group: piece j covers 16 rows (tap-local tap, output channel) x 64 B
+  int w_off[NWI_W], w_l[NWI_W];
+#pragma unroll
+  for (int it = 0; it < NWI_W; ++it) {
+    const int j = wave + it * NWV;
+    const int q = j * 64 + lane;
+    const int rowl = q >> 2, sslot = q & 3;
+    const int tl = rowl / BN, nn = rowl % BN;
+    w_off[it] = j < NWI ? ((G::wt(tl) * a.K + k0 + nn) * a.C + ((sslot ^ ((rowl >> 2) & 3)) * 8)) * 2 : -1;
+    w_l[it] = W_BASE + j * 1024;
+  }
+  const int w_group_stride = TG * a.K * a.C * 2;       // bytes from one tap group's slabs to the next (NG > 1: wt(t) = t)
+
+  // LDS byte offsets of this lane's fragments: A = pixel (subtile mi, lane li) at column shift cs, tap (0,0), slot of
+  // reduction step 0 (the second step's slot is the address ^ 32); B = output channel (subtile ni, lane li)
+  int a_base[NCS][WM], b_base[WN];
+#pragma unroll
+  for (int mi = 0; mi < WM; ++mi) {
+    const int p = (wm * WM + mi) * 32 + li;
+    const int th = p / TW, tw = p % TW;
+#pragma unroll
+    for (int cs = 0; cs < NCS; ++cs) {
+      const int colp = tw + cs, g = (colp >> 2) & 3;
+      a_base[cs][mi] = ((th * SH * SW) * RWP + colp) * 64 + ((half ^ (g & 1)) * 16) + ((g >> 1) * 32);
+    }
+  }
+#pragma unroll
+  for (int ni = 0; ni < WN; ++ni) {
+    const int r = (wn * WN + ni) * 32 + li, g = (r >> 2) & 3;
+    b_base[ni] = r * 64 + ((half ^ (g & 1)) * 16) + ((g >> 1) * 32);
+  }
+
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // rows outside the image are never written by the DMA: zero both input buffers once if this tile touches the border
+  if (h_base < 0 || h_base + RH > a.H) {
+    for (int i = tid * 16; i < 2 * IN_BYTES; i += 64 * NWV * 16) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+  }
+
+#define CH_ISSUE_IN(CH, PART)                                                                                   \
+  {                                                                                                             \
+    const int lb_ = ((CH) & 1) * IN_BYTES, go_ = (CH) * 64;                                                     \
+    _Pragma("unroll") for (int it = 0; it < NII_W; ++it)                                                        \
+      if ((PART) < 0 || it % NG == (PART)) { if (in_off[it] >= 0) CH_GLDS(xn + in_off[it] + go_, lb_ + in_l[it]); } \
+  }
+#define CH_ISSUE_W(STEP)                                                                                        \
+  {                                                                                                             \
+    const int s_ = (STEP), lb_ = (s_ & 1) * W_BYTES, go_ = (s_ / NG) * 64 + (s_ % NG) * w_group_stride;         \
+    _Pragma("unroll") for (int it = 0; it < NWI_W; ++it)                                                        \
+      if (w_off[it] >= 0) CH_GLDS(wb + w_off[it] + go_, lb_ + w_l[it]);                                         \
+  }
+
+  const int nchunks = a.C / 32, nsteps = nchunks * NG;
+  CH_ISSUE_IN(0, -1)
+  CH_ISSUE_W(0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int inb = (ch & 1) * IN_BYTES;
+#pragma unroll
+    for (int tg = 0; tg < NG; ++tg) {
+      const int step = ch * NG + tg;
+      const int wbb = W_BASE + (step & 1) * W_BYTES;
+      // next step's weights and this step's share of the next chunk's input tile: they have the whole step to land
+      if (step + 1 < nsteps) CH_ISSUE_W(step + 1)
+      if (ch + 1 < nchunks) CH_ISSUE_IN(ch + 1, tg)
+#pragma unroll
+      for (int tl = 0; tl < TG; ++tl) {
+        const int tap = tg * TG + tl;
+        const int dwv = G::dw(tap), cs = dwv / SW, phase = dwv % SW;
+        const int tap_off = ((G::dh(tap) * SW + phase) * RWP) * 64;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          s16x8 af[WM], bf[WN];
+#pragma unroll
+          for (int mi = 0; mi < WM; ++mi) af[mi] = *reinterpret_cast<const s16x8*>(lds + inb + tap_off + (a_base[cs][mi] ^ (ks * 32)));
+#pragma unroll
+          for (int ni = 0; ni < WN; ++ni) bf[ni] = *reinterpret_cast<const s16x8*>(lds + wbb + tl * BN * 64 + (b_base[ni] ^ (ks * 32)));
+#pragma unroll
+          for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = ch_mfma<F16>(af[mi], bf[ni], acc[mi][ni]);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+#undef CH_ISSUE_IN
+#undef CH_ISSUE_W
+
+  // Epilogue.  Accumulator (mi, ni) register r = pixel (r & 3) + 8 (r >> 2) + 4 half, channel li of its 32x32 tile.  Each wave
+  // transposes its 32-pixel slabs through its own LDS region (fp32) so that a lane owns EIGHT consecutive channels of one
+  // pixel: fp32 tail arithmetic, 16-byte loads of the half-precision shortcut / saved activation, 16-byte stores.
+  float* ep = reinterpret_cast<float*>(lds) + wave * (32 * ES);
+  const size_t out_n = (size_t)n * (a.Ho * G::OSH) * (a.Wo * G::OSW), grid_n = (size_t)n * a.Ho * a.Wo;
+  const bool f_add = a.epi & CH_EPI_ADD, f_act = a.epi & CH_EPI_ACT, f_dact = a.epi & CH_EPI_DACT, f_addg = a.epi & CH_EPI_ADD_GRID;
+  constexpr int C8 = WN * 4;                              // 8-channel groups per pixel row of the wave's slab
+#pragma unroll
+  for (int mi = 0; mi < WM; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < WN; ++ni)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ep[((r & 3) + 8 * (r >> 2) + 4 * half) * ES + ni * 32 + li] = acc[mi][ni][r];
+#pragma unroll 2
+    for (int q = lane; q < 32 * C8; q += 64) {
+      const int row = q / C8, c8 = q % C8;
+      const int p = (wm * WM + mi) * 32 + row;
+      const int th = p / TW, tw = p % TW;
+      const size_t ch_o = (size_t)k0 + wn * (WN * 32) + c8 * 8;
+      const size_t o = (out_n + (size_t)((ho0 + th) * G::OSH + G::OPH) * (a.Wo * G::OSW) + ((wo0 + tw) * G::OSW + G::OPW)) * a.K + ch_o;
+      float v[8];
+      {
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(ep + row * ES + c8 * 8), hi = *reinterpret_cast<const f32x4*>(ep + row * ES + c8 * 8 + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+      }
+      if (f_addg) {
+        const u16x8 tv = *reinterpret_cast<const u16x8*>(a.add + (grid_n + (size_t)(ho0 + th) * a.Wo + (wo0 + tw)) * a.K + ch_o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += ch_h2f<F16>(tv[e]);
+      }
+      if (f_add) {
+        const u16x8 tv = *reinterpret_cast<const u16x8*>(a.add + o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += ch_h2f<F16>(tv[e]);
+      }
+      if (f_act) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = ch_act(v[e], a.act);
+      }
+      if (f_dact) {
+        const u16x8 tv = *reinterpret_cast<const u16x8*>(a.dsrc + o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= ch_dact(ch_h2f<F16>(tv[e]), a.act);
+      }
+      u16x8 ov;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) ov[e] = ch_f2h<F16>(v[e]);
+      *reinterpret_cast<u16x8*>(a.y + o) = ov;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight preparation: the fp32 parameter [K][T][C] (channels_last storage of the torch tensor [K,C,k,k]) ->
+//   w_fwd [T][K][C]  (rows = output channels, reduction = input channels: forward pass)
+//   w_bwd [T][C][K]  (rows = input channels, reduction = output channels: input-gradient pass; the geometry policy picks
+//                     the taps, so no flip here)
+// in half precision, once per optimiser step (11.9 M parameters: 47 MB read, 2 x 24 MB written).
+template <bool F16>
+__global__ __launch_bounds__(256) void k_wprep_h(const float* __restrict__ w, u16* __restrict__ w_fwd, u16* __restrict__ w_bwd, int K,
+                                                 int T, int C) {
+  // tile of 32 k x 32 c for one tap through LDS (the transposed copy needs k contiguous)
+  __shared__ float tile[32][33];
+  const int c0 = blockIdx.x * 32, k0 = blockIdx.y * 32, tp = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 8 rows per pass
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, c = c0 + tx;
+    const float v = (k < K && c < C) ? w[((size_t)k * T + tp) * C + c] : 0.f;
+    tile[r][tx] = v;
+    if (w_fwd && k < K && c < C) w_fwd[((size_t)tp * K + k) * C + c] = ch_f2h<F16>(v);
+  }
+  __syncthreads();
+  if (w_bwd) {
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+      const int c = c0 + r, k = k0 + tx;
+      if (k < K && c < C) w_bwd[((size_t)tp * C + c) * K + k] = ch_f2h<F16>(tile[tx][r]);
+    }
+  }
+}
+
+// fp32 -> half and half -> fp32 copies (network input, head features)
+template <bool F16>
+__global__ __launch_bounds__(256) void k_cast_f2h(const float* __restrict__ src, u16* __restrict__ dst, size_t n8) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n8) return;
+  const f32x4 lo = reinterpret_cast<const f32x4*>(src)[2 * i], hi = reinterpret_cast<const f32x4*>(src)[2 * i + 1];
+  u16x8 o;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { o[e] = ch_f2h<F16>(lo[e]); o[4 + e] = ch_f2h<F16>(hi[e]); }
+  reinterpret_cast<u16x8*>(dst)[i] = o;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+
+template <bool F16, int BM, int BN, int WGM, int WGN, int TW, class G, int NG>
+static int launch_convh(const ConvHArgs& a, hipStream_t st) {
+  constexpr int TH = BM / TW;
+  if (a.Wo % TW || a.Ho % TH || a.K % BN || a.C % 32) return 1;
+  const int ntiles = a.N * (a.Ho / TH) * (a.Wo / TW) * (a.K / BN);
+  hipLaunchKernelGGL((k_convh<F16, BM, BN, WGM, WGN, TW, G, NG>), dim3(ntiles), dim3(64 * WGM * WGN), 0, st, a);
+  return 0;
+}
+
+#ifdef CH_TUNE
+int g_ch_variant = 0;
+#endif
+
+// Tile choice.  STRIDE1: a stride-1 3x3 pass (layer or input gradient): tall tiles, 3 tap groups.
+template <bool F16, class G, bool STRIDE1>
+static int dispatch_convh(const ConvHArgs& a, hipStream_t st) {
+  constexpr int NG = (G::NT == 9) ? 3 : 1;
+  const long pixels = (long)a.N * a.Ho * a.Wo;
+  if constexpr (STRIDE1) {
+#ifdef CH_TUNE
+    switch (g_ch_variant) {
+      case 1: return launch_convh<F16, 512, 128, 4, 2, 64, G, NG>(a, st);
+      case 2: return launch_convh<F16, 512, 64, 8, 1, 64, G, NG>(a, st);
+      case 3: return launch_convh<F16, 256, 128, 4, 2, 64, G, NG>(a, st);
+      case 4: return launch_convh<F16, 256, 64, 4, 2, 64, G, NG>(a, st);
+      case 5: return launch_convh<F16, 256, 128, 2, 2, 64, G, NG>(a, st);
+      case 6: return launch_convh<F16, 512, 128, 4, 2, 128, G, NG>(a, st);
+      case 7: return launch_convh<F16, 512, 128, 4, 2, 32, G, NG>(a, st);
+      case 8: return launch_convh<F16, 256, 64, 2, 2, 64, G, NG>(a, st);
+      case 9: return launch_convh<F16, 128, 64, 2, 2, 64, G, NG>(a, st);
+      case 10: return launch_convh<F16, 128, 128, 2, 2, 64, G, NG>(a, st);
+      default: break;
+    }
+#endif
+    // 512 x 128 tiles while they still give every CU a workgroup; 256-pixel tiles for the small late layers
+    if (a.K % 128 == 0 && pixels / 512 * (a.K / 128) >= 256 && !launch_convh<F16, 512, 128, 4, 2, 64, G, NG>(a, st)) return 0;
+    if (a.K % 128 == 0 && !launch_convh<F16, 256, 128, 4, 2, 64, G, NG>(a, st)) return 0;
+    if (pixels / 512 >= 256 && !launch_convh<F16, 512, 64, 8, 1, 64, G, NG>(a, st)) return 0;
+    if (!launch_convh<F16, 256, 64, 4, 2, 64, G, NG>(a, st)) return 0;
+    if (!launch_convh<F16, 128, 64, 2, 2, 32, G, NG>(a, st)) return 0;
+    return 1;
+  } else {
+    // strided layers, their input-gradient phases, 1x1 layers: 128-pixel tiles (the strided input tile is 2-4x the output tile)
+    if (a.K % 128 == 0 && !launch_convh<F16, 128, 128, 2, 2, 64, G, NG>(a, st)) return 0;
+    if (!launch_convh<F16, 128, 64, 2, 2, 64, G, NG>(a, st)) return 0;
+    if (a.K % 128 == 0 && !launch_convh<F16, 128, 128, 2, 2, 32, G, NG>(a, st)) return 0;
+    if (!launch_convh<F16, 128, 64, 2, 2, 32, G, NG>(a, st)) return 0;
+    return 1;
+  }
+}
+
+static int convh_check(const void* x, const void* w, const void* y, const void* add, const void* dsrc, int N, int H, int W, int C,
+                       int K, int ksize, int sh, int sw, int dtype, int act, unsigned epi, unsigned allowed, const char* who) {
+  if (!x || !w || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return dl_fail(DL_ERR_INVALID_ARGUMENT, "%s: bad argument", who);
+  if (dtype != DL_DTYPE_F16 && dtype != DL_DTYPE_BF16) return dl_fail(DL_ERR_INVALID_ARGUMENT, "%s: dtype must be DL_DTYPE_F16 or DL_DTYPE_BF16", who);
+  if ((sh != 1 && sh != 2) || (sw != 1 && sw != 2) || (ksize != 1 && ksize != 3))
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "%s: kernel size must be 1 or 3, strides 1 or 2 (got %d, %d, %d)", who, ksize, sh, sw);
+  if (((epi & (CH_EPI_ADD | CH_EPI_ADD_GRID)) && !add) || ((epi & CH_EPI_DACT) && !dsrc) || act < 0 || act > 2 || (epi & ~allowed))
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "%s: epilogue operand missing / unsupported flag / bad activation", who);
+  return DL_OK;
+}
+
+template <bool F16>
+static int conv2d_h(const ConvHArgs& a, int ksize, int sh, int sw, int transposed, hipStream_t st) {
+  if (ksize == 3 && sh == 1 && sw == 1)
+    return transposed ? dispatch_convh<F16, GeomDgrad<3, 1, 1, 0, 0, false>, true>(a, st) : dispatch_convh<F16, GeomConv<3, 1, 1>, true>(a, st);
+  if (transposed) return 2;
+  if (ksize == 3 && sh == 1 && sw == 2) return dispatch_convh<F16, GeomConv<3, 1, 2>, false>(a, st);
+  if (ksize == 3 && sh == 2 && sw == 2) return dispatch_convh<F16, GeomConv<3, 2, 2>, false>(a, st);
+  if (ksize == 1 && sh == 1 && sw == 2) return dispatch_convh<F16, GeomConv<1, 1, 2>, false>(a, st);
+  if (ksize == 1 && sh == 2 && sw == 2) return dispatch_convh<F16, GeomConv<1, 2, 2>, false>(a, st);
+  return 2;
+}
+
+/* see include/delora_hip.h */
+extern "C" int dl_conv2d_nhwc_h(const void* x, const void* w, void* y, const void* add, const void* dsrc, int32_t N, int32_t H,
+                                int32_t W, int32_t C, int32_t K, int32_t ksize, int32_t stride_h, int32_t stride_w,
+                                int32_t transposed, int32_t dtype, int32_t act, uint32_t epilogue, dl_stream stream) {
+  const int rc0 = convh_check(x, w, y, add, dsrc, N, H, W, C, K, ksize, stride_h, stride_w, dtype, act, epilogue,
+                              CH_EPI_ADD | CH_EPI_ACT | CH_EPI_DACT, "dl_conv2d_nhwc_h");
+  if (rc0) return rc0;
+  if (H % stride_h || W % stride_w) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_h: image size must be a multiple of the stride");
+  if ((size_t)N * H * W * C >= ((size_t)1 << 30) || (size_t)N * H * W * K >= ((size_t)1 << 30))
+    return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_h: tensors beyond 2^30 elements are not supported (split the batch)");
+  ConvHArgs a{(const u16*)x, (const u16*)w, (u16*)y, (const u16*)add, (const u16*)dsrc, N, H, W, C, K, H / stride_h, W / stride_w, act, epilogue};
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = dtype == DL_DTYPE_F16 ? conv2d_h<true>(a, ksize, stride_h, stride_w, transposed, st)
+                                       : conv2d_h<false>(a, ksize, stride_h, stride_w, transposed, st);
+  if (rc == 2) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_h: kernel %d stride (%d,%d) transposed %d is not built", ksize, stride_h, stride_w, transposed);
+  if (rc) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_h: shape N=%d H=%d W=%d C=%d K=%d does not tile (Wo %% 32, K %% 64, C %% 32)", N, H, W, C, K);
+  return dl_check_launch("dl_conv2d_nhwc_h");
+}
+
+template <bool F16, int KS, int SH, int SW, int PH, int PW>
+static int dgrad_phase_h(ConvHArgs a, bool first_phase, hipStream_t st) {
+  using G = GeomDgrad<KS, SH, SW, PH, PW, true>;
+  if (!first_phase) a.epi &= ~CH_EPI_ADD_GRID;
+  if constexpr (G::NT > 0) return dispatch_convh<F16, G, false>(a, st);
+  return 1;
+}
+
+template <bool F16>
+static int dgrad_strided_h(const ConvHArgs& a, int ksize, int sh, int sw, int dense, hipStream_t st) {
+  if (dense) {
+    if (ksize == 1 && sh == 1 && sw == 2) return dispatch_convh<F16, GeomDgrad<1, 1, 2, 0, 0, false>, false>(a, st);
+    if (ksize == 1 && sh == 2 && sw == 2) return dispatch_convh<F16, GeomDgrad<1, 2, 2, 0, 0, false>, false>(a, st);
+    return 2;
+  }
+  if (ksize == 3 && sh == 1 && sw == 2) return dgrad_phase_h<F16, 3, 1, 2, 0, 0>(a, true, st) | dgrad_phase_h<F16, 3, 1, 2, 0, 1>(a, false, st);
+  if (ksize == 3 && sh == 2 && sw == 2)
+    return dgrad_phase_h<F16, 3, 2, 2, 0, 0>(a, true, st) | dgrad_phase_h<F16, 3, 2, 2, 0, 1>(a, false, st) |
+           dgrad_phase_h<F16, 3, 2, 2, 1, 0>(a, false, st) | dgrad_phase_h<F16, 3, 2, 2, 1, 1>(a, false, st);
+  return 2;
+}
+
+/* see include/delora_hip.h */
+extern "C" int dl_conv2d_dgrad_strided_nhwc_h(const void* g, const void* w, void* dx, const void* add_grid, const void* dsrc, int32_t N,
+                                              int32_t Ho, int32_t Wo, int32_t K, int32_t C, int32_t ksize, int32_t stride_h,
+                                              int32_t stride_w, int32_t dense, int32_t dtype, int32_t act, uint32_t epilogue,
+                                              dl_stream stream) {
+  const int rc0 = convh_check(g, w, dx, add_grid, dsrc, N, Ho, Wo, C, K, ksize, stride_h, stride_w, dtype, act, epilogue,
+                              CH_EPI_ADD_GRID | CH_EPI_DACT, "dl_conv2d_dgrad_strided_nhwc_h");
+  if (rc0) return rc0;
+  if ((size_t)N * Ho * stride_h * Wo * stride_w * C >= ((size_t)1 << 30) || (size_t)N * Ho * Wo * K >= ((size_t)1 << 30))
+    return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_dgrad_strided_nhwc_h: tensors beyond 2^30 elements are not supported");
+  // in the kernel's terms: input = g (K channels, the reduction), output channels = C
+  ConvHArgs a{(const u16*)g, (const u16*)w, (u16*)dx, (const u16*)add_grid, (const u16*)dsrc, N, Ho, Wo, K, C, Ho, Wo, act, epilogue};
+  hipStream_t st = (hipStream_t)stream;
+  const int rc = dtype == DL_DTYPE_F16 ? dgrad_strided_h<true>(a, ksize, stride_h, stride_w, dense, st)
+                                       : dgrad_strided_h<false>(a, ksize, stride_h, stride_w, dense, st);
+  if (rc == 2) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_dgrad_strided_nhwc_h: kernel %d stride (%d,%d) dense %d is not built", ksize, stride_h, stride_w, dense);
+  if (rc) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_dgrad_strided_nhwc_h: shape N=%d Ho=%d Wo=%d K=%d C=%d does not tile", N, Ho, Wo, K, C);
+  return dl_check_launch("dl_conv2d_dgrad_strided_nhwc_h");
+}
+
+/* see include/delora_hip.h */
+extern "C" int dl_conv_weights_h(const float* w, void* w_fwd, void* w_bwd, int32_t K, int32_t taps, int32_t C, int32_t dtype,
+                                 dl_stream stream) {
+  if (!w || (!w_fwd && !w_bwd) || K <= 0 || C <= 0 || (taps != 1 && taps != 9) || (dtype != DL_DTYPE_F16 && dtype != DL_DTYPE_BF16))
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv_weights_h: bad argument (taps 1 or 9, dtype F16 / BF16)");
+  const dim3 grid((C + 31) / 32, (K + 31) / 32, taps);
+  if (dtype == DL_DTYPE_F16) hipLaunchKernelGGL(k_wprep_h<true>, grid, dim3(256), 0, (hipStream_t)stream, w, (u16*)w_fwd, (u16*)w_bwd, K, taps, C);
+  else hipLaunchKernelGGL(k_wprep_h<false>, grid, dim3(256), 0, (hipStream_t)stream, w, (u16*)w_fwd, (u16*)w_bwd, K, taps, C);
+  return dl_check_launch("dl_conv_weights_h");
+}
+
+/* see include/delora_hip.h */
+extern "C" int dl_cast_f32_to_h(const float* src, void* dst, int64_t n, int32_t dtype, dl_stream stream) {
+  if (!src || !dst || n <= 0 || n % 8 || (dtype != DL_DTYPE_F16 && dtype != DL_DTYPE_BF16))
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_cast_f32_to_h: bad argument (n a positive multiple of 8, dtype F16 / BF16)");
+  const size_t n8 = (size_t)n / 8;
+  const dim3 grid((unsigned)((n8 + 255) / 256));
+  if (dtype == DL_DTYPE_F16) hipLaunchKernelGGL(k_cast_f2h<true>, grid, dim3(256), 0, (hipStream_t)stream, src, (u16*)dst, n8);
+  else hipLaunchKernelGGL(k_cast_f2h<false>, grid, dim3(256), 0, (hipStream_t)stream, src, (u16*)dst, n8);
+  return dl_check_launch("dl_cast_f32_to_h");
+}

@@ -69,8 +69,19 @@ __device__ __forceinline__ void smallest_eigenvector(double a00, double a01, dou
     else if (d1 >= d2)        { x0 = k01; x1 = k11; x2 = k12; }
     else                      { x0 = k02; x1 = k12; x2 = k22; }
     const double big = fmax(fabs(x0), fmax(fabs(x1), fabs(x2)));
-    if (!(big > 1e-280)) { x0 = 1.0; x1 = 0.0; x2 = 0.0; }
-    else { const int e = -ilogb(big); x0 = ldexp(x0, e); x1 = ldexp(x1, e); x2 = ldexp(x2, e); }
+    if (!(big > 1e-280)) {
+      // adj = 0: the covariance has rank <= 1 (all neighbours on a line).  Every vector perpendicular to the line has
+      // eigenvalue 0; take the dominant column c of A (a multiple of the line direction) and cross it with the axis it is
+      // least aligned with -- a fixed vector like (1,0,0) could BE the line direction, the largest eigenvector.
+      double c0, c1, c2;
+      if (a00 >= a11 && a00 >= a22) { c0 = a00; c1 = a01; c2 = a02; }
+      else if (a11 >= a22)          { c0 = a01; c1 = a11; c2 = a12; }
+      else                          { c0 = a02; c1 = a12; c2 = a22; }
+      const double f0 = fabs(c0), f1 = fabs(c1), f2 = fabs(c2);
+      if (f0 <= f1 && f0 <= f2) { x0 = 0.0; x1 = c2; x2 = -c1; }
+      else if (f1 <= f2)        { x0 = -c2; x1 = 0.0; x2 = c0; }
+      else                      { x0 = c1; x1 = -c0; x2 = 0.0; }
+    } else { const int e = -ilogb(big); x0 = ldexp(x0, e); x1 = ldexp(x1, e); x2 = ldexp(x2, e); }
   }
   // Rayleigh-quotient iteration, division free: x <- adj((x.x) A - (x.A x) I) x
 #pragma unroll
@@ -122,11 +133,16 @@ __global__ __launch_bounds__(NTH * NTW) void k_normals(
     v = v < 0 ? 0 : (v > H - 1 ? H - 1 : v);
     u = u < 0 ? 0 : (u > W - 1 ? W - 1 : u);
     const int p = v * W + u;
-    const float x = img[p], y = img[HW + p], z = img[2 * HW + p];
-    sx[i] = x; sy[i] = y; sz[i] = z;
+    float x = img[p], y = img[HW + p], z = img[2 * HW + p];
     // torch.norm of the neighbour / centre (normal_computation.py:56-57); an empty pixel (all components 0: absent
-    // from the covariance, linalg.py:34-37) gets a range that fails every gate
-    sr[i] = (x == 0.f && y == 0.f && z == 0.f) ? 3.0e38f : norm3f(x, y, z);
+    // from the covariance, linalg.py:34-37) gets a range that fails every gate.  A point with an infinite coordinate has an
+    // infinite range: the reference's gate zeroes it as a neighbour (:55-59) -- it is staged as an empty pixel, because the
+    // gate below is a 0/1 weight and inf * 0 would poison the moments.  (NaN passes the reference's gate and poisons
+    // its covariance too; it does the same here.)
+    float r = norm3f(x, y, z);
+    if (r == __builtin_inff()) { x = y = z = 0.f; }
+    sx[i] = x; sy[i] = y; sz[i] = z;
+    sr[i] = (x == 0.f && y == 0.f && z == 0.f) ? 3.0e38f : r;
   }
   __syncthreads();
   const int lx = threadIdx.x % NTW, ly = threadIdx.x / NTW;

@@ -30,7 +30,13 @@ class Deployer(object):
         if config.get("channels_last", False):
             self.model = self.model.to(memory_format=torch.channels_last)
         elif getattr(self.device, "type", "cpu") == "cuda" and config.get("cnn_impl", "auto") != "modules":
-            self.model.resnet.trunk_weights_channels_last()
+            # the HIP trunk reads the parameters in channels_last storage in place.  Only worth it -- and only harmless --
+            # when every configured image size actually takes that path: the module path (library convolutions on NCHW
+            # activations) would re-lay-out channels_last weights or activations on every call.
+            sizes = [(config[d]["vertical_cells"], config[d]["horizontal_cells"]) for d in config["datasets"]]
+            if not config.get("pre_feature_extraction", False) and all(
+                    self.model.resnet.hip_path_takes(H, W) for (H, W) in sizes):
+                self.model.resnet.trunk_weights_channels_last()
         if config["use_jit"]:
             first = config["datasets"][0]
             example = torch.zeros((1, 4, config[first]["vertical_cells"], config[first]["horizontal_cells"]), device=self.device)

@@ -115,6 +115,16 @@ class ResNetModified(torch.nn.Module):
             w.data = w.data.contiguous(memory_format=torch.channels_last)
         return self
 
+    def hip_path_takes(self, H, W, in_channels=8, batch=1):
+        """Whether an ``[N,in_channels,H,W]`` fp32 CUDA input would run on the channels-last HIP stem + trunk (shape test
+        only: the image must tile, see ``ring_conv.supported`` / ``stem_supported``).  The reference's default KITTI image
+        (64 x 720: W/4 = 180 is not a multiple of 32) does NOT -- it takes the module path."""
+        if self.impl == "modules" or W % 4:
+            return False
+        C0 = self.conv1.out_channels
+        return (ring_conv.stem_supported((batch, in_channels, H, W), C0)
+                and ring_conv.supported((batch, H, W // 4, C0), self._trunk_blocks()[0]))
+
     def hip_trunk_applicable(self, x_pooled_shape_nhwc, x):
         """The HIP trunk runs fp32 CUDA tensors, no dropout, outside autocast, on shapes that tile."""
         if self.impl == "modules" or not x.is_cuda or x.dtype != torch.float32 or torch.is_autocast_enabled():

@@ -116,7 +116,9 @@ def wino_conv(x, u, K, act=0, epilogue=0, add=None, dsrc=None):
 def supported(x_shape, blocks):
     """Whether the HIP trunk can run these shapes: channel counts multiples of 64, every feature-map width a multiple of
     32 (and the rows a tile takes must divide the height) -- true for the reference's full-size network on 64/128-ring
-    images; narrower test networks use the module path."""
+    images of 1024 or 2048 columns (BASELINE.json's configurations).  NOT true for the reference's default KITTI image of
+    720 columns (the pooled map is 180 wide) nor for 512 columns (layer4 would be 16 wide): those, and narrower test
+    networks, use the module path."""
     N, H, W, C = x_shape
     if C % 64:
         return False
@@ -259,8 +261,10 @@ class RingTrunk(torch.autograd.Function):
             saved += [y1, y2]
             x = y2
         ctx.act, ctx.blocks = act, blocks
-        ctx.ubwd = ubwd
-        ctx.save_for_backward(*saved, *weights)
+        # the Winograd-domain backward weights travel with the saved tensors (released with the graph, covered by autograd's
+        # in-place version check like the raw weights); layers on the direct kernel have none
+        ctx.ubwd_mask = tuple(u is not None for u in ubwd)
+        ctx.save_for_backward(*saved, *weights, *[u for u in ubwd if u is not None])
         return x
 
     @staticmethod
@@ -268,7 +272,10 @@ class RingTrunk(torch.autograd.Function):
         act, blocks = ctx.act, ctx.blocks
         nb = len(blocks)
         saved = ctx.saved_tensors
-        acts, weights = saved[:1 + 2 * nb], saved[1 + 2 * nb:]
+        nu = sum(ctx.ubwd_mask)
+        acts, weights = saved[:1 + 2 * nb], saved[1 + 2 * nb:len(saved) - nu]
+        u_it = iter(saved[len(saved) - nu:])
+        ubwd = [next(u_it) if has else None for has in ctx.ubwd_mask]
         grads = [None] * len(weights)
         # gradient with respect to the pre-activation of the last block's output
         y_last = acts[-1]
@@ -287,7 +294,7 @@ class RingTrunk(torch.autograd.Function):
             x, y1 = acts[2 * b], acts[2 * b + 1]
             first = b == 0                                 # x0 is the pooled stem output: its act' belongs to the stem
             grads[wi + 1] = wgrad_nhwc(y1, g2, 3).permute(0, 3, 1, 2)
-            ub1, ub2 = ctx.ubwd[2 * b], ctx.ubwd[2 * b + 1]
+            ub1, ub2 = ubwd[2 * b], ubwd[2 * b + 1]
             if ub2 is not None:
                 g1 = wino_conv(g2, ub2, cout, act=act, epilogue=EPI_DACT, dsrc=y1)
             else:
