@@ -1,0 +1,55 @@
+// Types and small device helpers shared by the half-precision convolution kernels (convh.hip, wgradh.hip).
+#pragma once
+#include "common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16;
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+#define CH_EPI_ADD 1u
+#define CH_EPI_ACT 2u
+#define CH_EPI_DACT 4u
+#define CH_EPI_ADD_GRID 8u
+
+template <bool F16>
+__device__ __forceinline__ f32x16 ch_mfma(s16x8 a, s16x8 b, f32x16 c) {
+  if constexpr (F16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+template <bool F16>
+__device__ __forceinline__ float ch_h2f(u16 v) {
+  if constexpr (F16) return (float)__builtin_bit_cast(_Float16, v);
+  else return __builtin_bit_cast(float, (uint32_t)v << 16);
+}
+template <bool F16>
+__device__ __forceinline__ u16 ch_f2h(float f) {      // round to nearest even
+  if constexpr (F16) return __builtin_bit_cast(u16, (_Float16)f);
+  else return __builtin_bit_cast(u16, (__bf16)f);
+}
+// tanh for a result that is rounded to 8 / 11 significant bits: 1 - 2 / (exp(2x) + 1) with the hardware exp2 / rcp
+// (relative error ~1e-6; exp overflow gives 1 - 0, underflow 1 - 2)
+__device__ __forceinline__ float ch_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
+__device__ __forceinline__ float ch_act(float v, int act) {
+  if (act == 1) return ch_tanh(v);
+  if (act == 2) return v < 0.f ? 0.f : v;
+  return v;
+}
+__device__ __forceinline__ float ch_dact(float y, int act) {
+  if (act == 1) return 1.f - y * y;
+  if (act == 2) return y <= 0.f ? 0.f : 1.f;
+  return 1.f;
+}
+__device__ __forceinline__ int ch_xcd_swizzle(int id, int n) {
+  const int q = n / 8, r = n % 8, xcd = id % 8, k = id / 8;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+#define CH_GLDS(GPTR, LOFF)                                                                  \
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(GPTR),   \
+                                   (__attribute__((address_space(3))) void*)(lds + (LOFF)), 16, 0, 0)
+

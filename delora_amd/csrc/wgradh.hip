@@ -1,0 +1,282 @@
+// Weight gradient of the pose CNN's convolutions from half-precision activations / gradients (fp32 accumulation, fp32 result):
+//     dw[k][tap][c] = sum over output pixels of g[pixel][k] * x[pixel shifted by tap][c]
+// (reference: torch autograd of Conv2d, src/models/resnet_modified.py:40-42, :159-177, under autocast).  GEMM view: M = k,
+// N = c, reduction = pixels -- the SLOW axis of both operands in memory (channels-last), while v_mfma_f32_32x32x16_* wants 8
+// consecutive reduction elements per lane.  The operands therefore go to LDS exactly as they lie in memory (row = pixel, DMA,
+// no staging instructions) and the fragments are built by ds_read_b64_tr_b16, the transposing LDS read of gfx950: lane s
+// of a 16-lane group addresses 8 bytes = channels 4(s&3).. of pixel row (s>>2) of a [4 pixels][16 channels] block and receives
+// the 4 pixels of channel s (layout probed by tools/exp/hw_probe.hip).  Two such reads = one MFMA operand (8 pixels per
+// lane half).  Every lane supplies its own address, so a stride-2 layer's pixel sequence and the tap shifts are address
+// arithmetic; the 64-byte units of a pixel row are XOR-swizzled by the pixel index (applied to the DMA's SOURCE address)
+// so that the four pixel rows of a block fall into different bank quarters.
+//
+// Workgroup: BMK (64 / 128) output channels x 64 input channels x all taps; wave (k subtile, c subtile) holds one 32x32
+// accumulator per tap (9 x 16 registers) and shares its g fragment between the taps.  A workgroup reduces a SLAB of pixel
+// chunks (PR output rows x PK columns each, double-buffered, one barrier per chunk); fp32 slab partials are summed in a fixed
+// order by k_wgradh_reduce (deterministic, no float atomics).  Rows outside the image are read from a page of zeros.
+#include "convh_common.h"
+
+__device__ __attribute__((aligned(64))) const uint32_t g_ch_zero_page[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+struct WgradHArgs {
+  const u16* x;     // [N][H][W][C]
+  const u16* g;     // [N][Ho][Wo][K]
+  float* part;      // [nslabs][K][taps][C]
+  int N, H, W, C, K, Ho, Wo, chunks_per_slab, nslabs;
+};
+
+// 64-byte unit swizzle of pixel row p of an image with U units per row: the four pixels of a transposing read hit 4 bank quarters
+template <int U>
+__device__ __forceinline__ int ch_unit_swz(int p) {
+  if constexpr (U == 2) return (p >> 1) & 1;
+  else if constexpr (U == 4) return p & 3;
+  else return 0;
+}
+
+template <bool F16, int BMK, int PK, int PR, int SH, int SW, int KS>
+__global__ __launch_bounds__(64 * (BMK / 32) * 2, 2) void k_wgradh(WgradHArgs a) {
+  constexpr int BNC = 64;
+  constexpr int NWV = (BMK / 32) * 2;                       // wave = (k subtile, c subtile)
+  constexpr int PAD = (KS - 1) / 2, TAPS = KS * KS;
+  constexpr int UG = BMK / 32, UX = BNC / 32;                 // 64-byte units per pixel row
+  constexpr int PG = BMK * 2, PX = BNC * 2;                   // bytes per pixel row
+  constexpr int RHX = (PR - 1) * SH + KS, RWX = (PK - 1) * SW + KS;
+  constexpr int RWC = (RWX + SW - 1) / SW, RWXP = (RWC + 3) & ~3;      // columns of a stride-phase plane, padded to 4
+  constexpr int NPLX = RHX * SW;
+  constexpr int G_BYTES = PR * PK * PG, X_BYTES = ((NPLX * RWXP * PX + 1023) / 1024) * 1024;
+  constexpr int NGI = G_BYTES / 1024, NXI = X_BYTES / 1024;   // 1 KiB DMA pieces
+  constexpr int NGI_W = (NGI + NWV - 1) / NWV, NXI_W = (NXI + NWV - 1) / NWV;
+  constexpr int BUF = G_BYTES + X_BYTES;
+  constexpr int NCS = (KS - 1) / SW + 1;                      // distinct column shifts of the taps (plane columns)
+  static_assert(PK % 16 == 0 && G_BYTES % 1024 == 0 && 2 * BUF <= 163840, "chunk shape / LDS budget");
+  __shared__ __attribute__((aligned(1024))) char lds[2 * BUF];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, half = lane >> 5;
+  const int ksub = wave >> 1, csub = wave & 1;
+  const int KT = a.K / BMK, CT = a.C / BNC;
+  int t = blockIdx.x;
+  const int ct = t % CT; t /= CT;
+  const int kt = t % KT; t /= KT;
+  const int slab = t;
+  const int k0 = kt * BMK, c0 = ct * BNC;
+  const int cols = a.Wo / PK, rows = a.Ho / PR;
+  const int total_chunks = a.N * rows * cols;
+  const int ch_begin = slab * a.chunks_per_slab;
+  const int ch_end = min(ch_begin + a.chunks_per_slab, total_chunks);
+
+  // DMA pieces of this wave: chunk-invariant lane roles.  g: pixel (prow, pcol) of the chunk, 16-byte slot of its BMK channels
+  int g_pix[NGI_W], g_ch[NGI_W];
+#pragma unroll
+  for (int it = 0; it < NGI_W; ++it) {
+    const int j = wave + it * NWV;
+    const int q = j * 64 + lane;
+    constexpr int PP = PG / 16;
+    const int pix = q / PP, s16 = q % PP;
+    g_pix[it] = j < NGI ? pix : -1;
+    g_ch[it] = (((s16 >> 2) ^ ch_unit_swz<UG>(pix)) * 32 + (s16 & 3) * 8);
+  }
+  int x_row[NXI_W], x_col[NXI_W], x_ch[NXI_W];
+#pragma unroll
+  for (int it = 0; it < NXI_W; ++it) {
+    const int j = wave + it * NWV;
+    const int q = j * 64 + lane;
+    constexpr int PP = PX / 16;
+    const int pix = q / PP, s16 = q % PP;
+    const int rp = pix / RWXP, colp = pix % RWXP;
+    const int row = rp / SW, phase = rp % SW;
+    const int col = colp * SW + phase;
+    // a 1x1 strided layer reads only the pixels (SH i, SW j): the other rows / phases of the window are never used
+    const bool used = j < NXI && rp < NPLX && col < RWX && (KS == 3 || (phase == 0 && row % SH == 0));
+    x_row[it] = used ? row : -1;
+    x_col[it] = col;
+    x_ch[it] = (((s16 >> 2) ^ ch_unit_swz<UX>(pix)) * 32 + (s16 & 3) * 8);
+  }
+
+  // fragment addresses (bytes, relative to the buffer's g / x image).  Lane (h = half, gq = 16-lane group of the half,
+  // s = lane & 15): pixel 8h + (s >> 2) [+ 4 for the second read] of the 16-pixel reduction step, channels 16 gq + 4 (s & 3)..
+  const int s4 = lane & 15, jrow = s4 >> 2, gq = (lane >> 4) & 1;
+  const int g_lane = (8 * half + jrow) * PG + ((ksub ^ ch_unit_swz<UG>(jrow)) * 64) + gq * 32 + (s4 & 3) * 8;
+  int x_lane[NCS];
+#pragma unroll
+  for (int cs = 0; cs < NCS; ++cs)
+    x_lane[cs] = (8 * half + jrow + cs) * PX + ((csub ^ ch_unit_swz<UX>(jrow + cs)) * 64) + gq * 32 + (s4 & 3) * 8;
+
+  f32x16 acc[TAPS];
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
+
+  const char* zero = reinterpret_cast<const char*>(g_ch_zero_page);
+#define WH_ISSUE(CH, BUFSEL)                                                                                          \
+  {                                                                                                                   \
+    int u_ = (CH);                                                                                                    \
+    const int cb_ = u_ % cols; u_ /= cols;                                                                            \
+    const int rb_ = u_ % rows;                                                                                        \
+    const int n_ = u_ / rows;                                                                                         \
+    const int ho0_ = rb_ * PR, wo0_ = cb_ * PK;                                                                       \
+    const u16* gn_ = a.g + ((size_t)n_ * a.Ho * a.Wo) * a.K + k0;                                                     \
+    const u16* xn_ = a.x + ((size_t)n_ * a.H * a.W) * a.C + c0;                                                       \
+    const int lb_ = (BUFSEL) * BUF;                                                                                   \
+    _Pragma("unroll") for (int it = 0; it < NGI_W; ++it) if (g_pix[it] >= 0) {                                        \
+      const int pr_ = g_pix[it] / PK, pc_ = g_pix[it] % PK;                                                           \
+      CH_GLDS(gn_ + ((size_t)(ho0_ + pr_) * a.Wo + wo0_ + pc_) * a.K + g_ch[it], lb_ + (wave + it * NWV) * 1024);    \
+    }                                                                                                                 \
+    _Pragma("unroll") for (int it = 0; it < NXI_W; ++it) if (x_row[it] >= 0) {                                        \
+      const int h_ = ho0_ * SH - PAD + x_row[it];                                                                     \
+      int w_ = wo0_ * SW - PAD + x_col[it];                                                                           \
+      w_ = w_ < 0 ? w_ + a.W : (w_ >= a.W ? w_ - a.W : w_);                                                           \
+      const char* src_ = (h_ >= 0 && h_ < a.H) ? reinterpret_cast<const char*>(xn_ + ((size_t)h_ * a.W + w_) * a.C + x_ch[it]) : zero; \
+      CH_GLDS(src_, lb_ + G_BYTES + (wave + it * NWV) * 1024);                                                        \
+    }                                                                                                                 \
+  }
+
+  if (ch_begin < ch_end) WH_ISSUE(ch_begin, 0)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  for (int ch = ch_begin; ch < ch_end; ++ch) {
+    const int cur = (ch - ch_begin) & 1;
+    if (ch + 1 < ch_end) WH_ISSUE(ch + 1, cur ^ 1)
+    const char* gb = lds + cur * BUF;
+    const char* xb = gb + G_BYTES;
+#pragma unroll
+    for (int pr = 0; pr < PR; ++pr)
+#pragma unroll 2
+      for (int i0 = 0; i0 < PK; i0 += 16) {
+        // A: g[pixels i0 + 8 half ..+7][k subtile]; B per tap: x[the same output pixels shifted by the tap][c subtile]
+        const int gpix = pr * PK + i0;
+        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(gb + g_lane + gpix * PG));
+        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(gb + g_lane + (gpix + 4) * PG));
+        const s16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+#pragma unroll
+        for (int tp = 0; tp < TAPS; ++tp) {
+          const int r = tp / KS, s = tp % KS;
+          const int cs = s / SW, phase = s % SW;
+          const int xpix = ((pr * SH + r) * SW + phase) * RWXP + i0;
+          const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xb + x_lane[cs] + xpix * PX));
+          const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xb + x_lane[cs] + (xpix + 4) * PX));
+          const s16x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[tp] = ch_mfma<F16>(af, bf, acc[tp]);
+        }
+      }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  }
+#undef WH_ISSUE
+  // partial of this slab: part[slab][k][tap][c]; accumulator register r of lane (li, half) = row k = (r & 3) + 8 (r >> 2) + 4 half,
+  // column c = li of the wave's 32x32 tile
+  float* dst = a.part + (size_t)slab * a.K * TAPS * a.C;
+#pragma unroll
+  for (int tp = 0; tp < TAPS; ++tp)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = k0 + ksub * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      dst[((size_t)k * TAPS + tp) * a.C + c0 + csub * 32 + li] = acc[tp][r];
+    }
+}
+
+// dw = sum of the slab partials in a fixed order (slab 0, 1, 2, ...), eight 16-byte loads in flight per lane
+__global__ __launch_bounds__(256) void k_wgradh_reduce(const float* __restrict__ part, int nslabs, size_t count, float* __restrict__ dw) {
+  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= count) return;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int k = 0;
+  for (; k + 8 <= nslabs; k += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(part + (size_t)(k + u) * count + i));
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k < nslabs; ++k) s += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(part + (size_t)k * count + i));
+  *reinterpret_cast<f32x4*>(dw + i) = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+#ifdef CH_TUNE
+int g_wh_want = 256;
+#else
+static const int g_wh_want = 256;
+#endif
+
+struct WgradHPlan {
+  int bmk, pk, pr, tiles, total_chunks, nslabs, chunks_per_slab;
+};
+
+// chunk = PR = 2 output rows x PK columns; PK = 64 for stride-1 layers (32 when the row is narrower), 32 for strided ones
+// (their input window is twice / four times as large)
+static bool wgradh_plan(int N, int H, int W, int C, int K, int ks, int sh, int sw, WgradHPlan* p) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || (ks != 1 && ks != 3) || (sh != 1 && sh != 2) || (sw != 1 && sw != 2)) return false;
+  if (H % sh || W % sw || C % 64 || K % 64) return false;
+  const int Ho = H / sh, Wo = W / sw;
+  p->pr = 2;
+  p->bmk = K % 128 == 0 ? 128 : 64;
+  // 64-channel tiles run 4 waves per workgroup: the short chunk keeps two workgroups resident per CU
+  p->pk = (sh == 1 && sw == 1 && Wo % 64 == 0 && p->bmk == 128) ? 64 : 32;
+  if (Ho % p->pr || Wo % p->pk) return false;
+  p->tiles = (K / p->bmk) * (C / 64);
+  p->total_chunks = N * (Ho / p->pr) * (Wo / p->pk);
+  int want = (g_wh_want + p->tiles - 1) / p->tiles;
+  if (want > p->total_chunks) want = p->total_chunks;
+  if (want < 1) want = 1;
+  p->chunks_per_slab = (p->total_chunks + want - 1) / want;
+  p->nslabs = (p->total_chunks + p->chunks_per_slab - 1) / p->chunks_per_slab;
+  return true;
+}
+
+/* see include/delora_hip.h */
+extern "C" size_t dl_conv2d_wgrad_h_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, int32_t ksize,
+                                                    int32_t stride_h, int32_t stride_w) {
+  WgradHPlan p;
+  if (!wgradh_plan(N, H, W, C, K, ksize, stride_h, stride_w, &p)) return 0;
+  return (size_t)p.nslabs * K * ksize * ksize * C * sizeof(float);
+}
+
+template <bool F16, int BMK, int PK, int SH, int SW, int KS>
+static void launch_wgradh(const WgradHArgs& a, const WgradHPlan& p, hipStream_t st) {
+  hipLaunchKernelGGL((k_wgradh<F16, BMK, PK, 2, SH, SW, KS>), dim3(p.tiles * p.nslabs), dim3(64 * (BMK / 32) * 2), 0, st, a);
+}
+
+template <bool F16, int SH, int SW, int KS>
+static int wgradh_geom(const WgradHArgs& a, const WgradHPlan& p, hipStream_t st) {
+  if constexpr (SH == 1 && SW == 1) {
+    if (p.pk == 64 && p.bmk == 128) { launch_wgradh<F16, 128, 64, SH, SW, KS>(a, p, st); return 0; }
+  }
+  if (p.pk != 32) return 1;
+  if (p.bmk == 128) launch_wgradh<F16, 128, 32, SH, SW, KS>(a, p, st);
+  else launch_wgradh<F16, 64, 32, SH, SW, KS>(a, p, st);
+  return 0;
+}
+
+template <bool F16>
+static int wgradh_dispatch(const WgradHArgs& a, const WgradHPlan& p, int ks, int sh, int sw, hipStream_t st) {
+  if (ks == 3 && sh == 1 && sw == 1) return wgradh_geom<F16, 1, 1, 3>(a, p, st);
+  if (ks == 3 && sh == 1 && sw == 2) return wgradh_geom<F16, 1, 2, 3>(a, p, st);
+  if (ks == 3 && sh == 2 && sw == 2) return wgradh_geom<F16, 2, 2, 3>(a, p, st);
+  if (ks == 1 && sh == 1 && sw == 2) return wgradh_geom<F16, 1, 2, 1>(a, p, st);
+  if (ks == 1 && sh == 2 && sw == 2) return wgradh_geom<F16, 2, 2, 1>(a, p, st);
+  return 1;
+}
+
+/* see include/delora_hip.h */
+extern "C" int dl_conv2d_wgrad_nhwc_h(const void* x, const void* g, float* dw, void* workspace, int32_t N, int32_t H, int32_t W,
+                                      int32_t C, int32_t K, int32_t ksize, int32_t stride_h, int32_t stride_w, int32_t dtype,
+                                      dl_stream stream) {
+  if (!x || !g || !dw || !workspace) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_wgrad_nhwc_h: null pointer argument");
+  if (dtype != DL_DTYPE_F16 && dtype != DL_DTYPE_BF16) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_wgrad_nhwc_h: dtype must be DL_DTYPE_F16 or DL_DTYPE_BF16");
+  WgradHPlan p;
+  if (!wgradh_plan(N, H, W, C, K, ksize, stride_h, stride_w, &p))
+    return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_wgrad_nhwc_h: N=%d H=%d W=%d C=%d K=%d kernel %d stride (%d,%d) is not supported (C, K %% 64; Ho even; Wo %% 32)",
+                   N, H, W, C, K, ksize, stride_h, stride_w);
+  if ((size_t)N * H * W * C >= ((size_t)1 << 30) || (size_t)N * (H / stride_h) * (W / stride_w) * K >= ((size_t)1 << 30))
+    return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_wgrad_nhwc_h: tensors beyond 2^30 elements are not supported");
+  hipStream_t st = (hipStream_t)stream;
+  WgradHArgs a{(const u16*)x, (const u16*)g, (float*)workspace, N, H, W, C, K, H / stride_h, W / stride_w, p.chunks_per_slab, p.nslabs};
+  const int rc = dtype == DL_DTYPE_F16 ? wgradh_dispatch<true>(a, p, ksize, stride_h, stride_w, st)
+                                       : wgradh_dispatch<false>(a, p, ksize, stride_h, stride_w, st);
+  if (rc) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_wgrad_nhwc_h: no kernel for this shape");
+  const size_t count = (size_t)K * ksize * ksize * C;
+  hipLaunchKernelGGL(k_wgradh_reduce, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, st, (const float*)workspace, p.nslabs, count, dw);
+  return dl_check_launch("dl_conv2d_wgrad_nhwc_h");
+}

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 1
+#define DL_ABI_VERSION 3   /* 3: half-precision convolution family, launch profiler; 2 was never shipped */
 
 typedef void* dl_stream;
 
@@ -219,6 +219,11 @@ int dl_ring_act_pool_pad_fwd(const float* x, int64_t planes, int32_t H, int32_t 
 int dl_ring_act_pool_pad_bwd(const float* grad_out, const float* y, const int8_t* win, int64_t planes, int32_t H,
                              int32_t W, int32_t act, float* grad_x, dl_stream stream);
 
+/* Storage types of the *_t / *_h entry points. */
+#define DL_DTYPE_F32  0
+#define DL_DTYPE_F16  1
+#define DL_DTYPE_BF16 2
+
 /* The same four entry points for fp16 / bf16 storage (autocast): dtype 0 fp32, 1 fp16, 2 bf16 for every tensor argument;
  * the arithmetic is fp32 and every stored element is rounded once, as the separate torch ops would. */
 int dl_ring_act_pad_fwd_t(const void* x, const void* res, int64_t res_pitch, int64_t res_off, int64_t rows, int32_t W, int32_t pad,
@@ -301,6 +306,36 @@ int dl_wino_conv3x3_nhwc_f32(const float* x, const float* u, float* y, const flo
 size_t dl_wino_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K);
 int dl_wino_wgrad3x3_nhwc_f32(const float* x, const float* g, float* dw, void* workspace, int32_t N, int32_t H, int32_t W,
                               int32_t C, int32_t K, dl_stream stream);
+
+/*
+ * The same convolutions in HALF precision (dtype DL_DTYPE_F16 or DL_DTYPE_BF16 for every activation / gradient tensor,
+ * fp32 accumulation on v_mfma_f32_32x32x16_f16 / _bf16): the network's autocast mode (torch.autocast around
+ * src/models/resnet_modified.py:95-120 in a reference run with mixed precision; BASELINE.json configs[4]).  Operands reach
+ * LDS by DMA; every stored element is rounded to the storage type once; epilogue arithmetic is fp32 (csrc/convh.hip).
+ *   dl_conv_weights_h     the fp32 parameter w [K][taps][C] (taps = ksize^2) -> w_fwd [taps][K][C] and / or w_bwd [taps][C][K] in
+ *                         half precision (either may be NULL); once per optimiser step.
+ *   dl_conv2d_nhwc_h      as dl_conv2d_nhwc_f32 with x, y, add, dsrc in half precision; w = w_fwd of the layer
+ *                         (transposed == 0) or w_bwd of the layer whose input gradient is wanted (transposed == 1, stride 1,
+ *                         3x3 only; x is then the output gradient and C / K swap roles).  Wo % 32 == 0, K % 64 == 0, C % 32 == 0.
+ *   dl_conv2d_dgrad_strided_nhwc_h   as dl_conv2d_dgrad_strided_nhwc_f32; w = w_bwd of the layer.
+ *   dl_cast_f32_to_h      n fp32 values -> half precision (n % 8 == 0).
+ */
+int dl_conv_weights_h(const float* w, void* w_fwd, void* w_bwd, int32_t K, int32_t taps, int32_t C, int32_t dtype, dl_stream stream);
+int dl_conv2d_nhwc_h(const void* x, const void* w, void* y, const void* add, const void* dsrc, int32_t N, int32_t H, int32_t W,
+                     int32_t C, int32_t K, int32_t ksize, int32_t stride_h, int32_t stride_w, int32_t transposed, int32_t dtype,
+                     int32_t act, uint32_t epilogue, dl_stream stream);
+int dl_conv2d_dgrad_strided_nhwc_h(const void* g, const void* w, void* dx, const void* add_grid, const void* dsrc, int32_t N,
+                                   int32_t Ho, int32_t Wo, int32_t K, int32_t C, int32_t ksize, int32_t stride_h, int32_t stride_w,
+                                   int32_t dense, int32_t dtype, int32_t act, uint32_t epilogue, dl_stream stream);
+int dl_cast_f32_to_h(const float* src, void* dst, int64_t n, int32_t dtype, dl_stream stream);
+/* Weight gradient from half-precision x [N][H][W][C] and g [N][Ho][Wo][K]: dw [K][ksize][ksize][C] in FP32 (the layout and type of
+ * the parameter's gradient), fp32 accumulation, slab partials summed in a fixed order.  Fragments are built by the transposing
+ * LDS read (ds_read_b64_tr_b16).  C % 64 == 0, K % 64 == 0, Ho even, Wo % 32 == 0; workspace bytes from the first function
+ * (0 = shape not supported). */
+size_t dl_conv2d_wgrad_h_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, int32_t ksize, int32_t stride_h,
+                                         int32_t stride_w);
+int dl_conv2d_wgrad_nhwc_h(const void* x, const void* g, float* dw, void* workspace, int32_t N, int32_t H, int32_t W, int32_t C,
+                           int32_t K, int32_t ksize, int32_t stride_h, int32_t stride_w, int32_t dtype, dl_stream stream);
 
 /*
  * The stem's max-pooling on channels-last activations (reference src/models/resnet_modified.py:100-102: F.pad(circular) +
