@@ -70,6 +70,15 @@ SIGNATURES = {
     "dl_quat_to_T_fwd": (_i32, [_vp, _vp, _i32, ctypes.c_float, _vp, _vp]),
     "dl_quat_to_T_bwd": (_i32, [_vp, _vp, _i32, ctypes.c_float, _vp, _vp, _vp]),
     "dl_mean_hw_nhwc_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "dl_conv_weights_h": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "dl_conv2d_nhwc_h": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _u32, _vp]),
+    "dl_conv2d_dgrad_strided_nhwc_h": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                              _u32, _vp]),
+    "dl_cast_f32_to_h": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "dl_mean_hw_nhwc_h": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "dl_mean_hw_bwd_act_h": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "dl_conv2d_wgrad_h_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
+    "dl_conv2d_wgrad_nhwc_h": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dl_wino_profile_begin": (_i32, [_i32]),
     "dl_wino_profile_end": (_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),
 }

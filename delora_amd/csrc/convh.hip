@@ -296,6 +296,58 @@ __global__ __launch_bounds__(256) void k_cast_f2h(const float* __restrict__ src,
   reinterpret_cast<u16x8*>(dst)[i] = o;
 }
 
+// Global average pooling of the last (half-precision) feature map and its backward fused with the activation derivative of
+// the last block (reference resnet_modified.py:116-118: avgpool + flatten; autograd of it and of the block's tanh / relu):
+//   k_mean_hw_h:      x [N][P][C] half -> y [N][C] fp32, pixels summed in a fixed order (as k_mean_hw_nhwc of stem.hip)
+//   k_mean_bwd_act_h: g[n][p][c] = gy[n][c] / P * act'(x[n][p][c])   -- the gradient with respect to the last block's
+//                     PRE-activation, in half precision, which is what the trunk's backward starts from
+template <bool F16>
+__global__ __launch_bounds__(256) void k_mean_hw_h(const u16* __restrict__ x, int P, int C, float* __restrict__ y) {
+  __shared__ float part[16][16][9];                       // [pixel lane][channel octet][8 + pad]
+  const int n = blockIdx.y, c8 = blockIdx.x * 16 + (threadIdx.x & 15), pl = threadIdx.x >> 4;
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (8 * c8 < C) {
+    const u16* px = x + ((size_t)n * P) * C + 8 * c8;
+    for (int p = pl; p < P; p += 16) {
+      const u16x8 v = *reinterpret_cast<const u16x8*>(px + (size_t)p * C);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += ch_h2f<F16>(v[e]);
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) part[pl][threadIdx.x & 15][e] = acc[e];
+  __syncthreads();
+#pragma unroll
+  for (int s = 8; s > 0; s >>= 1) {
+    if (pl < s)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) part[pl][threadIdx.x & 15][e] += part[pl + s][threadIdx.x & 15][e];
+    __syncthreads();
+  }
+  if (pl == 0 && 8 * c8 < C) {
+    const float inv = 1.0f / (float)P;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) y[(size_t)n * C + 8 * c8 + e] = part[0][threadIdx.x & 15][e] * inv;
+  }
+}
+
+template <bool F16>
+__global__ __launch_bounds__(256) void k_mean_bwd_act_h(const float* __restrict__ gy, const u16* __restrict__ x, int P, int C8, int act,
+                                                        size_t total, u16* __restrict__ g) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;       // one 8-channel group of one pixel
+  if (i >= total) return;
+  const int c8 = (int)(i % C8);
+  const size_t n = i / ((size_t)P * C8);
+  const float inv = 1.0f / (float)P;
+  const float* gp = gy + n * (size_t)C8 * 8 + (size_t)c8 * 8;
+  const f32x4 g0 = *reinterpret_cast<const f32x4*>(gp), g1 = *reinterpret_cast<const f32x4*>(gp + 4);
+  const u16x8 xv = reinterpret_cast<const u16x8*>(x)[i];
+  u16x8 o;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) o[e] = ch_f2h<F16>((e < 4 ? g0[e] : g1[e - 4]) * inv * ch_dact(ch_h2f<F16>(xv[e]), act));
+  reinterpret_cast<u16x8*>(g)[i] = o;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 
@@ -454,4 +506,26 @@ extern "C" int dl_cast_f32_to_h(const float* src, void* dst, int64_t n, int32_t 
   if (dtype == DL_DTYPE_F16) hipLaunchKernelGGL(k_cast_f2h<true>, grid, dim3(256), 0, (hipStream_t)stream, src, (u16*)dst, n8);
   else hipLaunchKernelGGL(k_cast_f2h<false>, grid, dim3(256), 0, (hipStream_t)stream, src, (u16*)dst, n8);
   return dl_check_launch("dl_cast_f32_to_h");
+}
+
+/* see include/delora_hip.h */
+extern "C" int dl_mean_hw_nhwc_h(const void* x, int32_t N, int32_t P, int32_t C, int32_t dtype, float* y, dl_stream stream) {
+  if (!x || !y || N <= 0 || P <= 0 || C <= 0 || C % 8 || (dtype != DL_DTYPE_F16 && dtype != DL_DTYPE_BF16))
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_mean_hw_nhwc_h: bad argument (C %% 8, dtype F16 / BF16)");
+  const dim3 grid((C / 8 + 15) / 16, N);
+  if (dtype == DL_DTYPE_F16) hipLaunchKernelGGL(k_mean_hw_h<true>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)x, P, C, y);
+  else hipLaunchKernelGGL(k_mean_hw_h<false>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)x, P, C, y);
+  return dl_check_launch("dl_mean_hw_nhwc_h");
+}
+
+/* see include/delora_hip.h */
+extern "C" int dl_mean_hw_bwd_act_h(const float* grad_y, const void* x, int32_t N, int32_t P, int32_t C, int32_t act, int32_t dtype,
+                                    void* grad_pre, dl_stream stream) {
+  if (!grad_y || !x || !grad_pre || N <= 0 || P <= 0 || C <= 0 || C % 8 || act < 0 || act > 2 || (dtype != DL_DTYPE_F16 && dtype != DL_DTYPE_BF16))
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_mean_hw_bwd_act_h: bad argument (C %% 8, act 0..2, dtype F16 / BF16)");
+  const size_t total = (size_t)N * P * (C / 8);
+  const dim3 grid((unsigned)((total + 255) / 256));
+  if (dtype == DL_DTYPE_F16) hipLaunchKernelGGL(k_mean_bwd_act_h<true>, grid, dim3(256), 0, (hipStream_t)stream, grad_y, (const u16*)x, P, C / 8, act, total, (u16*)grad_pre);
+  else hipLaunchKernelGGL(k_mean_bwd_act_h<false>, grid, dim3(256), 0, (hipStream_t)stream, grad_y, (const u16*)x, P, C / 8, act, total, (u16*)grad_pre);
+  return dl_check_launch("dl_mean_hw_bwd_act_h");
 }

@@ -133,11 +133,34 @@ class ResNetModified(torch.nn.Module):
             return False
         return ring_conv.supported(x_pooled_shape_nhwc, self._trunk_blocks()[0])
 
+    def hip_half_applicable(self, x):
+        """The half-precision HIP trunk (``ring_conv.RingTrunkH``) runs CUDA inputs inside ``torch.autocast`` (fp16 / bf16), no
+        dropout, on shapes that tile; returns the autocast dtype or None."""
+        if self.impl == "modules" or not x.is_cuda or not torch.is_autocast_enabled():
+            return None
+        if self.use_dropout and self.training:
+            return None
+        dtype = torch.get_autocast_dtype("cuda")
+        N, Cin, Hin, Win = x.shape
+        C0 = self.conv1.out_channels
+        if dtype not in ring_conv.DTYPE_CODE or Win % 4 or not ring_conv.stem_supported((N, Cin, Hin, Win), C0):
+            return None
+        return dtype if ring_conv.supported_h((N, Hin, Win // 4, C0), self._trunk_blocks()[0]) else None
+
     def forward(self, x):
         act = "relu" if self.activation_fct == "relu" else "tanh"
         x = self.dropout_values(x)
         N, Cin, Hin, Win = x.shape
         C0 = self.conv1.out_channels
+        half = self.hip_half_applicable(x)
+        if half is not None:
+            # autocast: fp32 stem (8 input channels: 0.4 ms), then layer1..layer4 + pooling on the half-precision MFMA kernels
+            blocks, weights = self._trunk_blocks()
+            with torch.autocast("cuda", enabled=False):
+                x0 = ring_conv.RingStem.apply(x.float(), self.conv1.weight, ring_conv.ACT[act])          # [N,H,W/4,C0] fp32
+                feat = ring_conv.RingTrunkH.apply(x0, ring_conv.ACT[act], blocks, half, *weights)     # [N,C'] fp32
+            out = self.dropout_values(self.fc(feat))
+            return [None, None, None, None, out]
         if (self.hip_trunk_applicable((N, Hin, Win // 4, C0), x) and Win % 4 == 0
                 and ring_conv.stem_supported(tuple(x.shape), C0)):
             # channels-last from the first layer on: stem (conv1 + act + pool) and layer1..layer4 on the HIP kernels

@@ -314,3 +314,146 @@ class RingTrunk(torch.autograd.Function):
                 epi = EPI_ADD_GRID if first else (EPI_ADD_GRID | EPI_DACT)
                 g2 = dgrad_strided(g1, weight_storage(w1p), stride, act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)
         return (g2, None, None, *grads)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Half precision (autocast): the same trunk on v_mfma_f32_32x32x16_bf16 / _f16 (csrc/convh.hip, wgradh.hip).  Activations and
+# gradients live in bf16 / fp16 channels-last, accumulation and elementwise tails are fp32, the parameters stay fp32 (their
+# half-precision copies in the two layouts the kernels read are rebuilt per call), weight gradients come back in fp32.
+
+DTYPE_CODE = {torch.float16: 1, torch.bfloat16: 2}          # DL_DTYPE_F16 / DL_DTYPE_BF16
+
+
+def weights_h(w_param, dtype, want_fwd=True, want_bwd=True):
+    """Half-precision copies of a convolution parameter ``[K,C,k,k]``: (w_fwd ``[k*k,K,C]``, w_bwd ``[k*k,C,K]``)."""
+    lib = _lib.load()
+    w = weight_storage(w_param)
+    K, ks, _, C = w.shape
+    wf = torch.empty((ks * ks, K, C), dtype=dtype, device=w.device) if want_fwd else None
+    wb = torch.empty((ks * ks, C, K), dtype=dtype, device=w.device) if want_bwd else None
+    _lib.check(lib.dl_conv_weights_h(_ptr(w), _ptr(wf), _ptr(wb), K, ks * ks, C, DTYPE_CODE[dtype], _stream()), "dl_conv_weights_h")
+    return wf, wb
+
+
+def conv_nhwc_h(x, w_prepared, ks, stride=(1, 1), act=0, epilogue=0, add=None, dsrc=None, transposed=False):
+    """``y = epilogue(conv(x, w))`` on half-precision channels-last tensors; ``w_prepared`` = ``w_fwd`` of the layer, or (``transposed``)
+    ``w_bwd`` of the layer whose input gradient is wanted, x then being the output gradient."""
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    K = w_prepared.shape[1]
+    y = torch.empty((N, H // stride[0], W // stride[1], K), dtype=x.dtype, device=x.device)
+    _lib.check(lib.dl_conv2d_nhwc_h(_ptr(x), _ptr(w_prepared), _ptr(y), _ptr(add), _ptr(dsrc), N, H, W, C, K, ks, stride[0], stride[1],
+                                    int(transposed), DTYPE_CODE[x.dtype], int(act), int(epilogue), _stream()), "dl_conv2d_nhwc_h")
+    return y
+
+
+def dgrad_strided_h(g, w_bwd, ks, stride, act=0, epilogue=0, add_grid=None, dsrc=None, dense=False):
+    """Input gradient of a strided layer from its half-precision output gradient ``[N,Ho,Wo,K]`` and ``w_bwd [k*k,C,K]``."""
+    lib = _lib.load()
+    N, Ho, Wo, K = g.shape
+    C = w_bwd.shape[1]
+    shape = (N, Ho, Wo, C) if dense else (N, Ho * stride[0], Wo * stride[1], C)
+    dx = torch.empty(shape, dtype=g.dtype, device=g.device)
+    _lib.check(lib.dl_conv2d_dgrad_strided_nhwc_h(_ptr(g), _ptr(w_bwd), _ptr(dx), _ptr(add_grid), _ptr(dsrc), N, Ho, Wo, K, C, ks, stride[0],
+                                                  stride[1], int(dense), DTYPE_CODE[g.dtype], int(act), int(epilogue), _stream()),
+               "dl_conv2d_dgrad_strided_nhwc_h")
+    return dx
+
+
+def wgrad_nhwc_h(x, g, ks, stride=(1, 1)):
+    """fp32 ``dW [K,k,k,C]`` (channels_last storage of the parameter gradient) from half-precision input x and output gradient g."""
+    lib = _lib.load()
+    N, H, W, C = x.shape
+    K = g.shape[3]
+    nbytes = lib.dl_conv2d_wgrad_h_workspace_bytes(N, H, W, C, K, ks, stride[0], stride[1])
+    if not nbytes:
+        raise _lib.DeloraHipError(f"dl_conv2d_wgrad_nhwc_h does not support x {tuple(x.shape)} -> K={K}, kernel {ks}, stride {stride}")
+    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
+    dw = torch.empty((K, ks, ks, C), dtype=torch.float32, device=x.device)
+    _lib.check(lib.dl_conv2d_wgrad_nhwc_h(_ptr(x), _ptr(g), _ptr(dw), _ptr(ws), N, H, W, C, K, ks, stride[0], stride[1], DTYPE_CODE[x.dtype],
+                                          _stream()), "dl_conv2d_wgrad_nhwc_h")
+    return dw
+
+
+def supported_h(x_shape, blocks):
+    """Whether the half-precision HIP trunk can run these shapes: channel counts multiples of 64; every feature map 128-pixel
+    tiles (width a multiple of 64 with an even height, or of 32 with a height divisible by 4)."""
+    N, H, W, C = x_shape
+    if C % 64:
+        return False
+    for (cin, cout, stride, _) in blocks:
+        if cin % 64 or cout % 64 or H % stride[0] or W % stride[1]:
+            return False
+        H, W = H // stride[0], W // stride[1]
+        if not ((W % 64 == 0 and H % 2 == 0) or (W % 32 == 0 and H % 4 == 0)):
+            return False
+    return True
+
+
+class RingTrunkH(torch.autograd.Function):
+    """layer1..layer4 + global average pooling of the pose CNN in half precision.  ``forward(x0, act, blocks, dtype, *weights)``:
+    x0 ``[N,H,W,C0]`` fp32 channels-last, already activated (the pooled stem output); weights = the fp32 parameters in block
+    order (conv1, conv2[, downsample]).  Returns the pooled features ``[N,C']`` in fp32.  Same launch structure as
+    ``RingTrunk`` (2 (+1) convolutions per block forward, 4 (+2) backward, every elementwise tail in an epilogue); in
+    addition one weight-conversion launch per convolution and one cast of x0."""
+
+    @staticmethod
+    def forward(ctx, x0, act, blocks, dtype, *weights):
+        lib = _lib.load()
+        code = DTYPE_CODE[dtype]
+        need_bwd = any(ctx.needs_input_grad)
+        x = torch.empty(x0.shape, dtype=dtype, device=x0.device)
+        _lib.check(lib.dl_cast_f32_to_h(_ptr(x0.contiguous()), _ptr(x), x0.numel(), code, _stream()), "dl_cast_f32_to_h")
+        saved, wbs, wi = [x], [], 0
+        for (cin, cout, stride, has_ds) in blocks:
+            w1f, w1b = weights_h(weights[wi], dtype, want_bwd=need_bwd)
+            w2f, w2b = weights_h(weights[wi + 1], dtype, want_bwd=need_bwd)
+            wdf, wdb = weights_h(weights[wi + 2], dtype, want_bwd=need_bwd) if has_ds else (None, None)
+            wi += 3 if has_ds else 2
+            y1 = conv_nhwc_h(x, w1f, 3, stride=stride, act=act, epilogue=EPI_ACT)
+            shortcut = conv_nhwc_h(x, wdf, 1, stride=stride) if has_ds else x
+            y2 = conv_nhwc_h(y1, w2f, 3, act=act, epilogue=EPI_ADD | EPI_ACT, add=shortcut)
+            wbs += [w1b, w2b] + ([wdb] if has_ds else [])
+            saved += [y1, y2]
+            x = y2
+        N, H, W, C = x.shape
+        feat = torch.empty((N, C), dtype=torch.float32, device=x.device)
+        _lib.check(lib.dl_mean_hw_nhwc_h(_ptr(x), N, H * W, C, code, _ptr(feat), _stream()), "dl_mean_hw_nhwc_h")
+        ctx.act, ctx.blocks, ctx.code = act, blocks, code
+        ctx.n_w = len(weights)
+        ctx.save_for_backward(*saved, *(wbs if need_bwd else []))
+        return feat
+
+    @staticmethod
+    def backward(ctx, gfeat):
+        lib = _lib.load()
+        act, blocks, code = ctx.act, ctx.blocks, ctx.code
+        nb = len(blocks)
+        saved = ctx.saved_tensors
+        acts, wbs = saved[:1 + 2 * nb], saved[1 + 2 * nb:]
+        grads = [None] * ctx.n_w
+        y_last = acts[-1]
+        N, H, W, C = y_last.shape
+        # gradient with respect to the pre-activation of the last block's output: pooling backward + act' in one launch
+        g2 = torch.empty_like(y_last)
+        _lib.check(lib.dl_mean_hw_bwd_act_h(_ptr(gfeat.contiguous().float()), _ptr(y_last), N, H * W, C, act, code, _ptr(g2), _stream()),
+                   "dl_mean_hw_bwd_act_h")
+        wi = ctx.n_w
+        for b in range(nb - 1, -1, -1):
+            cin, cout, stride, has_ds = blocks[b]
+            wi -= 3 if has_ds else 2
+            w1b, w2b = wbs[wi], wbs[wi + 1]
+            x, y1 = acts[2 * b], acts[2 * b + 1]
+            first = b == 0                                 # x0 is the pooled stem output: its act' belongs to the stem
+            grads[wi + 1] = wgrad_nhwc_h(y1, g2, 3).permute(0, 3, 1, 2)
+            g1 = conv_nhwc_h(g2, w2b, 3, act=act, epilogue=EPI_DACT, dsrc=y1, transposed=True)
+            grads[wi] = wgrad_nhwc_h(x, g1, 3, stride=stride).permute(0, 3, 1, 2)
+            if not has_ds:
+                epi = EPI_ADD if first else (EPI_ADD | EPI_DACT)
+                g2 = conv_nhwc_h(g1, w1b, 3, act=act, epilogue=epi, add=g2, dsrc=None if first else x, transposed=True)
+            else:
+                grads[wi + 2] = wgrad_nhwc_h(x, g2, 1, stride=stride).permute(0, 3, 1, 2)
+                dxb = dgrad_strided_h(g2, wbs[wi + 2], 1, stride, dense=True)
+                epi = EPI_ADD_GRID if first else (EPI_ADD_GRID | EPI_DACT)
+                g2 = dgrad_strided_h(g1, w1b, 3, stride, act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)
+        return (g2.float(), None, None, None, *grads)

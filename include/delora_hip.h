@@ -328,6 +328,12 @@ int dl_conv2d_dgrad_strided_nhwc_h(const void* g, const void* w, void* dx, const
                                    int32_t Ho, int32_t Wo, int32_t K, int32_t C, int32_t ksize, int32_t stride_h, int32_t stride_w,
                                    int32_t dense, int32_t dtype, int32_t act, uint32_t epilogue, dl_stream stream);
 int dl_cast_f32_to_h(const float* src, void* dst, int64_t n, int32_t dtype, dl_stream stream);
+/* Global average pooling of a half-precision channels-last map x [N][P][C] -> y [N][C] fp32 (fixed summation order), and its
+ * backward fused with the activation derivative of the layer that produced x:
+ * grad_pre[n][p][c] = grad_y[n][c] / P * act'(x[n][p][c]) in half precision (act 0 none, 1 tanh: 1 - x^2, 2 relu).  C % 8 == 0. */
+int dl_mean_hw_nhwc_h(const void* x, int32_t N, int32_t P, int32_t C, int32_t dtype, float* y, dl_stream stream);
+int dl_mean_hw_bwd_act_h(const float* grad_y, const void* x, int32_t N, int32_t P, int32_t C, int32_t act, int32_t dtype,
+                         void* grad_pre, dl_stream stream);
 /* Weight gradient from half-precision x [N][H][W][C] and g [N][Ho][Wo][K]: dw [K][ksize][ksize][C] in FP32 (the layout and type of
  * the parameter's gradient), fp32 accumulation, slab partials summed in a fixed order.  Fragments are built by the transposing
  * LDS read (ds_read_b64_tr_b16).  C % 64 == 0, K % 64 == 0, Ho even, Wo % 32 == 0; workspace bytes from the first function
