@@ -51,6 +51,7 @@ def parse(argv=None):
     ap.add_argument("--rotate", type=int, default=8, help="distinct batches the steps rotate over (HBM resident)")
     ap.add_argument("--long-steps", type=int, default=200, help="extra timed run of this many steps (0 = skip); N=1 only")
     ap.add_argument("--feed-steps", type=int, default=64, help="steps of the host-fed leg (0 = skip); N=1 only")
+    ap.add_argument("--autocast-steps", type=int, default=20, help="timed steps of the extra bf16-autocast leg of the fp32 run (0 = skip); N=1 only")
     ap.add_argument("--amp", default="", help="optional autocast dtype for the CNN (bfloat16/float16); default fp32 = parity mode")
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--cnn", default="", help="CNN implementation override (config key cnn_impl)")
@@ -152,7 +153,41 @@ def cnn_impl_in_use(trainer, args):
     x = torch.zeros(1, device=trainer.device)
     if not args.amp and r.hip_trunk_applicable((args.batch, args.height, args.width // 4, r.layer1[0].conv1.in_channels), x):
         return "hip trunk: fp32 MFMA, " + ("fused Winograd F(2x2,3x3) + direct implicit GEMM" if ring_conv.USE_WINOGRAD else "direct implicit GEMM")
+    if args.amp:
+        with torch.autocast("cuda", dtype=getattr(torch, args.amp)):
+            if r.hip_half_applicable(torch.zeros((args.batch, 8, args.height, args.width), device=trainer.device)) is not None:
+                return f"hip trunk: {args.amp} MFMA (v_mfma_f32_32x32x16), LDS-DMA implicit GEMM + transposing-read weight gradient; fp32 stem"
     return "modules: library convolutions + fused ring ops"
+
+
+def autocast_leg(args, device, host_batches, batches, timed_region):
+    """The same training step with the CNN in half precision (config key amp_dtype = torch.autocast around the model, as a
+    mixed-precision run of the reference would; BASELINE.json configs[4]): a second trainer on the same batches, the trunk on
+    the bf16 MFMA kernels (csrc/convh.hip, wgradh.hip).  Reported next to the fp32 headline, never as it."""
+    import argparse
+    from delora_amd.deploy.trainer import Trainer
+    from delora_amd.data.dataset import ListDataset
+    a2 = argparse.Namespace(**vars(args))
+    a2.amp = "bfloat16"
+    cfg = build_config(a2, device)
+    torch.manual_seed(1234)
+    trainer = Trainer(cfg, dataset=ListDataset([d for b in host_batches for d in b]))
+    identity_pretrained_state(trainer.raw_model)
+    counter = {"i": 0}
+
+    def step():
+        batch = batches[counter["i"] % len(batches)]
+        counter["i"] += 1
+        trainer.optimizer.zero_grad(set_to_none=True)
+        ep, _ = trainer.step(preprocessed_dicts=[dict(s) for s in batch], epoch_losses=trainer.new_epoch_losses())
+        return ep
+    for _ in range(max(3, args.warmup)):
+        step()
+    el, ep = timed_region(args.autocast_steps, step)
+    return {"dtype": "bfloat16", "steps": args.autocast_steps, "value": round(args.batch * args.autocast_steps / el, 3), "unit": "scan-pairs/s",
+            "ms_per_step": round(1e3 * el / args.autocast_steps, 3), "final_loss": float(ep["loss_epoch"]), "cnn_impl": cnn_impl_in_use(trainer, a2),
+            "note": "autocast(bfloat16) around the pose CNN: fp32 stem, layer1-4 on v_mfma_f32_32x32x16_bf16 with bf16 activations, fp32 "
+                    "accumulation, fp32 master weights and weight gradients; geometry kernels, loss and Adam unchanged (fp32)"}
 
 
 def conv_table(args, device, reps=10):
@@ -574,6 +609,8 @@ def main():
                                   "MB_per_pair": round(moved["bytes"] / (args.batch * args.feed_steps) / 1e6, 3),
                                   "note": "same steps with every batch read from pinned host memory through DataLoader + DevicePrefetcher "
                                           "(async H2D one batch ahead on a side stream)"}
+            if not args.amp and args.autocast_steps > 0 and (graphed is None or not graphed.captured):
+                result["autocast"] = autocast_leg(args, device, host_batches, batches, timed_region)
             if not args.no_cpu_baseline:
                 result["cpu_baseline"], result["cpu_baseline_online_normals"] = cpu_baseline(args, cfg)
         print(json.dumps(result))

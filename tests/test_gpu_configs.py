@@ -254,7 +254,28 @@ def test_config1_full_model_gradients_against_cpu_reference():
         if err > worst:
             worst, worst_name = err, k
     # ||g_gpu - g_cpu|| / ||g_cpu|| per parameter tensor: fp32 convolutions of two different libraries (MIOpen / oneDNN)
-    util.measured(f"config1 B=2: worst relative gradient error over the 30 parameter tensors ({worst_name})", worst, bound=2e-4)
+    util.measured(f"config1 B=2: worst relative gradient error over the 30 parameter tensors ({worst_name})", worst, bound=3e-5)      # measured 2.6e-6 (round 2)
+
+
+def test_config1_step_at_a_non_identity_network_pose_against_oracle():
+    """The bench workload (64x2048, full network) with heads that predict a MODERATE motion (a few degrees, ~0.6 m) instead of the
+    identity the other full-size tests evaluate at: the correspondence search then runs its uncertified passes (window lists,
+    tile walk, seed scan) on most queries, and the loss / pair counts / weighted batch loss must still equal the oracle's
+    KD-tree evaluation at the pose the GPU network produced."""
+    dev = _dev()
+    args, cfg, samples, trainer = _bench_setup(4, dev)
+    with torch.no_grad():
+        trainer.raw_model.fully_connected_rotation[-1].bias.copy_(torch.tensor([0.03, -0.02, 0.05, 1.0]))
+        trainer.raw_model.fully_connected_translation[-1].bias.copy_(torch.tensor([0.5, -0.3, 0.1]))
+    ep, T = _one_step(trainer, samples)
+    ang = torch.rad2deg(torch.acos(((T[:, 0, 0] + T[:, 1, 1] + T[:, 2, 2] - 1) / 2).clamp(-1, 1)))
+    assert float(ang.min()) > 3.0 and float(T[:, :3, 3].norm(dim=1).min()) > 0.5, "the step must not run at the identity"
+    last = trainer.last_step
+    per = []
+    for j, s in enumerate(samples):
+        per.append(_check_sample_against_oracle(trainer, s, T[j], last["loss_terms"][j], last["pair_counts"][j],
+                                                f"config1 64x2048 non-identity pose sample {j}", check_images=False, check_normals=False))
+    _check_batch_loss(trainer, ep, per, "config1 64x2048 B=4 non-identity pose")
 
 
 def test_bench_final_loss_reproduces():

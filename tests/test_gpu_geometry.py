@@ -311,8 +311,10 @@ def oracle_nn_pixels(tgt_img, src_img, src_nrm, T, need_wo):
 
 
 @pytest.mark.parametrize("case", ["identity", "true", "small_error", "random", "random_far"])
-@pytest.mark.parametrize("shape", [(16, 128, 16, 160), (64, 512, 64, 600)])
+@pytest.mark.parametrize("shape", [(16, 128, 16, 160), (64, 512, 64, 600), (64, 2048, 64, 2250)])
 def test_nn_matches_kdtree(case, shape):
+    """Exact k=1 correspondences against cKDTree in five pose regimes, up to the FULL image size (64x2048: 131 k target points,
+    where the hard regimes -- random rotation, 30 m translation -- run the seed scan and the whole-image tile walk)."""
     H, W, rings, az = shape
     sensor, img, nrm, T_true = _pair_images(77, H, W, rings, az)
     rng = np.random.default_rng(3)
