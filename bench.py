@@ -37,7 +37,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (about 6.3 TB/s measured copy rate)
 MFMA_F32_PEAK_TFLOPS = 157.3     # MI355X_MICROARCH.md: dense fp32 matrix peak (v_mfma_f32_32x32x2_f32: 256 flop/clk/CU x 256 CUs x 2.4 GHz)
-MFMA_F32_SUSTAINED_TFLOPS = 140.0  # measured: tools/conv_harness peak (profiles/r02_conv_harness.txt), the clock settles at 2.13 GHz
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16 matrix peak (v_mfma_f32_32x32x16_bf16)
 
 
 def parse(argv=None):
@@ -51,6 +51,7 @@ def parse(argv=None):
     ap.add_argument("--rotate", type=int, default=8, help="distinct batches the steps rotate over (HBM resident)")
     ap.add_argument("--long-steps", type=int, default=200, help="extra timed run of this many steps (0 = skip); N=1 only")
     ap.add_argument("--feed-steps", type=int, default=64, help="steps of the host-fed leg (0 = skip); N=1 only")
+    ap.add_argument("--conv-table", action="store_true", help="also time every stride-1 layer shape and pass back to back (roofline_cnn)")
     ap.add_argument("--autocast-steps", type=int, default=20, help="timed steps of the extra bf16-autocast leg of the fp32 run (0 = skip); N=1 only")
     ap.add_argument("--amp", default="", help="optional autocast dtype for the CNN (bfloat16/float16); default fp32 = parity mode")
     ap.add_argument("--channels-last", action="store_true")
@@ -228,9 +229,73 @@ def conv_table(args, device, reps=10):
             tot_ms += ms; tot_flop += flop; tot_mfma += flop * mfma_share
     return {"bound": "mfma", "peak": 157.3, "unit": "TFLOP/s", "achieved": round(tot_mfma / tot_ms * 1e-9, 1),
             "frac": round(tot_mfma / tot_ms * 1e-9 / 157.3, 3), "achieved_direct_equivalent": round(tot_flop / tot_ms * 1e-9, 1),
-            "note": "stride-1 3x3 layers of the trunk (85 % of the network's multiplications), one launch per layer shape and pass; "
-                    "sustained fp32 MFMA rate of the whole chip measured by tools/conv_harness peak: ~140 TFLOP/s (2.13 GHz under load)",
+            "note": "stride-1 3x3 layers of the trunk (85 % of the network's multiplications), one launch per layer shape and pass",
             "layers": rows}
+
+
+def conv_roofline(rows, args, step_ms):
+    """The `roofline` object of the JSON line from the launch profile of the timed steps (delora_amd/_lib.py: profile_end): the
+    kernel family with the largest share of the step, its algorithmic flop / its summed kernel time against the dense MFMA peak
+    of its arithmetic type, one row per layer shape with the HBM traffic of the committed PMC passes next to the compulsory
+    bytes.  Also returns the whole profile (every instrumented kernel) as per-step rows."""
+    fam = {}
+    for r in rows:
+        k = r["name"].split(" ")[0]
+        f = fam.setdefault(k, {"ms": 0.0, "flop": 0.0, "launches": 0})
+        f["ms"] += r["ms"]; f["flop"] += r["flop"]; f["launches"] += r["launches"]
+    dom = max(fam, key=lambda k: fam[k]["ms"])
+    half = dom in ("k_convh", "k_wgradh")
+    peak = MFMA_BF16_PEAK_TFLOPS if half else MFMA_F32_PEAK_TFLOPS
+    traffic = pmc_layer_traffic(dom)
+    layers = []
+    for r in sorted((r for r in rows if r["name"].startswith(dom + " ")), key=lambda r: -r["ms"]):
+        per = r["ms"] / r["launches"]
+        t = traffic.get(r["name"])
+        layers.append({"launch": r["name"], "launches_per_step": round(r["launches"] / args.steps, 2), "ms_per_launch": round(per, 5),
+                       "TFLOPs": round(r["flop"] / r["ms"] * 1e-9, 1), "frac": round(r["flop"] / r["ms"] * 1e-9 / peak, 4),
+                       "compulsory_MB_per_launch": round(r["bytes"] / r["launches"] / 1e6, 2),
+                       "traffic_MB_per_launch": None if t is None else round(t / 1e6, 2)})
+    d = fam[dom]
+    tf = d["flop"] / d["ms"] * 1e-9
+    known = [(l["traffic_MB_per_launch"], l["launches_per_step"]) for l in layers if l["traffic_MB_per_launch"] is not None]
+    what = {"k_wino_conv": "fused Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: the stride-1 3x3 layers of the pose CNN, forward and input gradient",
+            "k_wino_wgrad": "Winograd-domain weight gradient of the stride-1 3x3 layers on v_mfma_f32_32x32x2_f32",
+            "k_wgrad_f32": "direct weight gradient on v_mfma_f32_32x32x2_f32", "k_conv_f32": "direct implicit-GEMM convolution on v_mfma_f32_32x32x2_f32",
+            "k_convh": "half-precision implicit-GEMM convolution (LDS DMA) on v_mfma_f32_32x32x16_bf16",
+            "k_wgradh": "half-precision weight gradient (transposing LDS reads) on v_mfma_f32_32x32x16_bf16"}[dom]
+    roof = {"kernel": f"{dom} ({what}; the largest share of the step)", "bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s",
+            "frac": round(tf / peak, 4),
+            "traffic": None if not known else int(1e6 * sum(t * n for t, n in known) / sum(n for _, n in known)),
+            "launches_per_step": round(d["launches"] / args.steps, 2), "ms_per_launch": round(d["ms"] / d["launches"], 5),
+            "ms_per_step": round(d["ms"] / args.steps, 4), "share_of_step": round(d["ms"] / args.steps / step_ms, 3),
+            "algorithmic_flop_per_launch": round(d["flop"] / d["launches"]), "layers": layers,
+            "note": "achieved = flop the algorithm issues on the matrix cores (Winograd: 16 multiply-adds per 2x2 output tile and (c,k) pair = a direct "
+                    "convolution's / 2.25; direct kernels: 36) / kernel time; begin/end timestamps on HIP events attached to every launch "
+                    "(hipExtLaunchKernelGGL) of the K timed steps, summed per layer shape; peak = dense MFMA peak of the arithmetic type "
+                    "(MI355X_MICROARCH.md: 157.3 TFLOP/s fp32, 2500 bf16/fp16); traffic = HBM bytes per launch (launch-weighted mean of the "
+                    "layer rows) from the committed rocprofv3 FETCH_SIZE (x2: gfx950 correction) / WRITE_SIZE passes, profiles/r*_conv_hbm_pmc.json"}
+    if dom == "k_wino_conv":
+        roof["achieved_direct_equivalent"] = round(2.25 * tf, 1)
+    prof = [{"launch": r["name"], "launches_per_step": round(r["launches"] / args.steps, 2), "ms_per_step": round(r["ms"] / args.steps, 4),
+             "TFLOPs": round(r["flop"] / r["ms"] * 1e-9, 1), "compulsory_GB_s": round(r["bytes"] / r["ms"] * 1e-6, 0)}
+            for r in sorted(rows, key=lambda r: -r["ms"])]
+    return roof, {"families_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}, "rows": prof}
+
+
+def pmc_layer_traffic(family):
+    """HBM bytes per launch by profile-row name from the newest committed PMC bundle (profiles/r*_conv_hbm_pmc.json:
+    {"launches": {row name: {"hbm_bytes_per_launch": ...}}}); {} when absent."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_conv_hbm_pmc.json")))
+    out = {}
+    for f in files[-1:]:
+        try:
+            for name, v in json.load(open(f)).get("launches", {}).items():
+                if name.startswith(family + " "):
+                    out[name] = int(v["hbm_bytes_per_launch"])
+        except (ValueError, KeyError, TypeError):
+            pass
+    return out
 
 
 def pmc_conv_traffic():
@@ -498,22 +563,21 @@ def main():
             el = float(tt.item())
         return el, ep
 
-    # in-situ timing of the dominant kernel (k_wino_conv: the stride-1 3x3 layers, forward and input gradient) the same way:
-    # every launch of the timed steps carries its own begin/end timestamps (dl_wino_profile_begin / _end)
+    # in-situ timing of the convolution kernels the same way: every launch of the timed steps carries its own begin/end
+    # timestamps (dl_profile_begin / dl_profile_end: one row per kernel, pass and layer shape)
     from delora_amd import _lib
-    wino_prof = None
-    if (graphed is None or not graphed.captured) and not args.amp and "hip trunk" in cnn_impl_in_use(trainer, args):
-        _lib.check(_lib.load().dl_wino_profile_begin(int(args.steps) * 64), "dl_wino_profile_begin")
-        wino_prof = True
+    conv_prof = None
+    dominant = "k_convh" if args.amp else "k_wino_conv"          # the family with the largest share of the step (conv_profile below)
+    if (graphed is None or not graphed.captured) and "hip trunk" in cnn_impl_in_use(trainer, args):
+        _lib.profile_begin(int(args.steps) * 64, dominant)         # the headline's timed steps time this family only
+        conv_prof = True
     counter["i"] = 0
     elapsed, ep = timed_region(args.steps, run_step)
     G.LOSS_TIMER_FACTORY = None
     host_enqueue_ms = enqueue["ms_per_step"]
-    if wino_prof:
-        import ctypes
-        ms_, fl_, n_ = ctypes.c_double(), ctypes.c_double(), ctypes.c_int32()
-        _lib.check(_lib.load().dl_wino_profile_end(ctypes.byref(ms_), ctypes.byref(fl_), ctypes.byref(n_)), "dl_wino_profile_end")
-        wino_prof = {"ms": ms_.value, "flop": fl_.value, "launches": n_.value}
+    if conv_prof:
+        conv_prof, untimed = _lib.profile_end()
+        assert untimed == 0, f"{untimed} launches were not timed: raise the profile capacity"
     final_loss = float(ep["loss_epoch"])
     pairs = world * args.batch * args.steps
     ranks_seen = torch.distributed.get_world_size() if world > 1 else 1
@@ -560,25 +624,19 @@ def main():
                     "the K timed steps, where the operands sit in the 256 MiB infinity cache; frac_cold: the same launch right after 1 GiB "
                     "of unrelated writes (operands come from HBM); 52 B x source points with a correspondence, vs the 8 TB/s HBM peak"}
         result["network_pose_after_timed_steps"] = counts["network_pose"]
-        if wino_prof and wino_prof["launches"]:
-            L, tf = wino_prof["launches"], wino_prof["flop"] / wino_prof["ms"] * 1e-9
-            result["roofline"] = {
-                "kernel": "k_wino_conv (fused Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32: the stride-1 3x3 layers of the pose CNN, forward "
-                          "and input gradient; the largest share of the step)",
-                "bound": "mfma", "achieved": round(tf, 1), "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / MFMA_F32_PEAK_TFLOPS, 4),
-                "traffic": pmc_conv_traffic(), "launches_per_step": round(L / args.steps, 2), "ms_per_launch": round(wino_prof["ms"] / L, 5),
-                "ms_per_step": round(wino_prof["ms"] / args.steps, 4), "share_of_step": round(wino_prof["ms"] / args.steps / result["ms_per_step"], 3),
-                "algorithmic_flop_per_launch": round(wino_prof["flop"] / L), "achieved_direct_equivalent": round(2.25 * tf, 1),
-                "frac_of_sustained_peak": round(tf / MFMA_F32_SUSTAINED_TFLOPS, 4),
-                "note": "achieved = multiply-adds the algorithm issues (16 per 2x2 output tile and (c,k) pair = a direct convolution's / 2.25) x 2 "
-                        "/ kernel time; begin/end timestamps on HIP events attached to every launch (hipExtLaunchKernelGGL) of the K timed steps, "
-                        "summed; peak = 256 CUs x 256 flop/clk x 2.4 GHz = 157.3 TFLOP/s dense fp32 MFMA (MI355X_MICROARCH.md); the chip "
-                        f"sustains {MFMA_F32_SUSTAINED_TFLOPS} TFLOP/s (2.13 GHz) on independent MFMAs with no memory traffic (tools/conv_harness peak); "
-                        "traffic = HBM bytes per launch from the committed FETCH_SIZE / WRITE_SIZE passes over the four layer shapes (mean)"}
+        if conv_prof:
+            result["roofline"], _ = conv_roofline(conv_prof, args, result["ms_per_step"])
+            # every instrumented convolution launch, in a second run of the same K steps (untimed for the headline)
+            _lib.profile_begin(int(args.steps) * 200)
+            timed_region(args.steps, run_step)
+            rows_all, untimed = _lib.profile_end(1024)
+            _, result["conv_profile"] = conv_roofline(rows_all, args, result["ms_per_step"])
+            result["conv_profile"]["note"] = ("kernel begin/end timestamps of every convolution launch in a second run of the same steps; "
+                                              "the headline's timed steps instrument the dominant family only")
         else:
             result["roofline"] = result["roofline_loss"]
         result["kernels"] = rows
-        if world == 1 and not args.amp and "hip trunk" in result["config"]["cnn_impl"]:
+        if world == 1 and not args.amp and "hip trunk" in result["config"]["cnn_impl"] and args.conv_table:
             result["roofline_cnn"] = conv_table(args, device)
         if world == 1:
             if args.long_steps > 0:

@@ -79,9 +79,30 @@ SIGNATURES = {
     "dl_mean_hw_bwd_act_h": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "dl_conv2d_wgrad_h_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "dl_conv2d_wgrad_nhwc_h": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
-    "dl_wino_profile_begin": (_i32, [_i32]),
-    "dl_wino_profile_end": (_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_int32)]),
+    "dl_profile_begin": (_i32, [_i32, ctypes.c_char_p]),
+    "dl_profile_end": (_i32, [_vp, _i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
 }
+
+
+class ProfileRow(ctypes.Structure):
+    """``dl_profile_row`` of include/delora_hip.h."""
+    _fields_ = [("name", ctypes.c_char * 96), ("launches", ctypes.c_int32), ("ms", ctypes.c_double), ("flop", ctypes.c_double),
+                ("bytes", ctypes.c_double)]
+
+
+def profile_begin(max_launches, only_kernel=None):
+    """Open the launch profile; ``only_kernel`` restricts it to one kernel family (e.g. "k_wino_conv")."""
+    check(load().dl_profile_begin(int(max_launches), only_kernel.encode() if only_kernel else None), "dl_profile_begin")
+
+
+def profile_end(capacity=512):
+    """Close the launch profile: list of dicts (name, launches, ms, flop, bytes), plus the number of untimed launches."""
+    rows = (ProfileRow * capacity)()
+    n, untimed = ctypes.c_int32(), ctypes.c_int32()
+    check(load().dl_profile_end(ctypes.cast(rows, ctypes.c_void_p), capacity, ctypes.byref(n), ctypes.byref(untimed)), "dl_profile_end")
+    out = [{"name": rows[i].name.decode(), "launches": rows[i].launches, "ms": rows[i].ms, "flop": rows[i].flop, "bytes": rows[i].bytes}
+           for i in range(min(n.value, capacity))]
+    return out, untimed.value
 
 _lib = None
 

@@ -3,6 +3,12 @@
 #include <stdint.h>
 #include <stdio.h>
 
+#include <atomic>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
 #include "common.h"
 
 thread_local char g_dl_err[256] = {0};
@@ -43,3 +49,77 @@ int dl_fill_words(void* p, uint32_t value, size_t n_words, hipStream_t st) {
 
 extern "C" int dl_abi_version(void) { return DL_ABI_VERSION; }
 extern "C" const char* dl_last_error(void) { return g_dl_err; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Launch profiler: measurement aid of bench.py / tools (the roofline of a kernel read INSIDE real training steps).  The only
+// mutable process-wide state of the library; guarded by a mutex, and a single relaxed atomic load per launch when closed.
+namespace {
+struct ProfAgg { int launches = 0; double flop = 0, bytes = 0; std::vector<int> ev; };
+struct Profiler {
+  std::mutex mu;
+  std::atomic<bool> open{false};
+  std::vector<hipEvent_t> ev;                 // start, stop, start, stop ...
+  int used = 0, skipped = 0;
+  std::string only;                           // kernel family filter ("" = every instrumented launch)
+  std::map<std::string, ProfAgg> rows;
+};
+Profiler g_prof;
+}  // namespace
+
+bool dl_prof_is_open() { return g_prof.open.load(std::memory_order_relaxed); }
+
+void dl_prof_events(const DlProfTag& tag, hipEvent_t* e0, hipEvent_t* e1) {
+  std::lock_guard<std::mutex> lock(g_prof.mu);
+  if (!g_prof.open.load(std::memory_order_relaxed)) return;
+  if (!g_prof.only.empty() && g_prof.only != tag.kernel) return;
+  if (2 * g_prof.used + 1 >= (int)g_prof.ev.size()) { ++g_prof.skipped; return; }
+  char name[96];
+  snprintf(name, sizeof(name), "%s %s N%d %dx%d C%d K%d", tag.kernel, tag.pass, tag.N, tag.H, tag.W, tag.C, tag.K);
+  ProfAgg& a = g_prof.rows[name];
+  a.launches++; a.flop += tag.flop; a.bytes += tag.bytes; a.ev.push_back(g_prof.used);
+  *e0 = g_prof.ev[2 * g_prof.used]; *e1 = g_prof.ev[2 * g_prof.used + 1];
+  ++g_prof.used;
+}
+
+/* see include/delora_hip.h */
+extern "C" int dl_profile_begin(int32_t max_launches, const char* only_kernel) {
+  std::lock_guard<std::mutex> lock(g_prof.mu);
+  if (g_prof.open.load() || max_launches <= 0) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_profile_begin: a profile is already open / bad size");
+  g_prof.ev.resize((size_t)2 * max_launches);
+  for (auto& e : g_prof.ev)
+    if (hipEventCreate(&e) != hipSuccess) return dl_fail(DL_ERR_LAUNCH, "dl_profile_begin: hipEventCreate failed");
+  g_prof.used = g_prof.skipped = 0;
+  g_prof.rows.clear();
+  g_prof.only = only_kernel ? only_kernel : "";
+  g_prof.open.store(true);
+  return DL_OK;
+}
+
+/* see include/delora_hip.h */
+extern "C" int dl_profile_end(dl_profile_row* rows, int32_t capacity, int32_t* count, int32_t* untimed) {
+  std::lock_guard<std::mutex> lock(g_prof.mu);
+  if (!g_prof.open.load() || !count || (capacity > 0 && !rows)) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_profile_end: no open profile / null argument");
+  g_prof.open.store(false);
+  int rc = DL_OK, n = 0;
+  for (auto& kv : g_prof.rows) {
+    double ms = 0.0;
+    for (int i : kv.second.ev) {
+      float t = 0.f;
+      if (hipEventSynchronize(g_prof.ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&t, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]) != hipSuccess)
+        rc = dl_fail(DL_ERR_LAUNCH, "dl_profile_end: %s", hipGetErrorString(hipGetLastError()));
+      ms += t;
+    }
+    if (n < capacity) {
+      dl_profile_row& r = rows[n];
+      snprintf(r.name, sizeof(r.name), "%s", kv.first.c_str());
+      r.launches = kv.second.launches; r.ms = ms; r.flop = kv.second.flop; r.bytes = kv.second.bytes;
+    }
+    ++n;
+  }
+  for (auto& e : g_prof.ev) (void)hipEventDestroy(e);
+  g_prof.ev.clear();
+  g_prof.rows.clear();
+  *count = n;
+  if (untimed) *untimed = g_prof.skipped;
+  return rc;
+}

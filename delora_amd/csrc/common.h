@@ -82,3 +82,24 @@ extern thread_local char g_dl_err[256];
 int dl_fail(int code, const char* fmt, ...);
 int dl_check_launch(const char* what);
 int dl_fill_words(void* p, uint32_t value, size_t n_words, hipStream_t st);   // abi.hip: memset as a kernel (graph-safe)
+
+// Launch profiler (abi.hip; dl_profile_begin / dl_profile_end of the C ABI): while a profile is open, every launch that goes
+// through DL_LAUNCH carries a pair of HIP events that receive the kernel's own begin / end timestamps (hipExtLaunchKernelGGL,
+// on the launch stream), and its algorithmic work is accumulated under its tag.  Closed: one relaxed atomic load per launch.
+#include <hip/hip_ext.h>
+struct DlProfTag {
+  const char* kernel;     // kernel family, e.g. "k_wino_conv"
+  const char* pass;       // "fwd", "dgrad", "wgrad", ...
+  int N, H, W, C, K;      // shape of the launch (input image, channels)
+  double flop;            // floating-point operations the algorithm issues on the matrix cores (2 per multiply-add)
+  double bytes;           // compulsory HBM bytes (operands read once + result written once)
+};
+bool dl_prof_is_open();
+void dl_prof_events(const DlProfTag& tag, hipEvent_t* e0, hipEvent_t* e1);
+#define DL_LAUNCH(TAG, KERNEL, GRID, BLOCK, STREAM, ...)                                             \
+  do {                                                                                                \
+    hipEvent_t dl_e0_ = nullptr, dl_e1_ = nullptr;                                                    \
+    if (dl_prof_is_open()) dl_prof_events((TAG), &dl_e0_, &dl_e1_);                                   \
+    if (dl_e0_) hipExtLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, STREAM, dl_e0_, dl_e1_, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(KERNEL, GRID, BLOCK, 0, STREAM, __VA_ARGS__);                             \
+  } while (0)

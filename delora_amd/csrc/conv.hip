@@ -486,7 +486,10 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   constexpr int TH = BM / TW;
   if (a.Wo % TW || a.Ho % TH || a.K % BN || a.C % CK) return 1;
   const int ntiles = a.N * (a.Ho / TH) * (a.Wo / TW) * (a.K / BN);
-  hipLaunchKernelGGL((k_conv_f32<BM, BN, CK, TW, G, BT, WGN>), dim3(ntiles), dim3(CV_THREADS), 0, st, a);
+  const double px_ = (double)a.N * a.Ho * a.Wo;
+  const DlProfTag tag{"k_conv_f32", BT ? "dgrad" : "fwd", a.N, a.H, a.W, a.C, a.K, 2.0 * px_ * a.K * a.C * G::NT,
+                      4.0 * ((double)a.N * a.H * a.W * a.C + px_ * a.K + (double)G::WTAPS * a.K * a.C)};
+  DL_LAUNCH(tag, (k_conv_f32<BM, BN, CK, TW, G, BT, WGN>), dim3(ntiles), dim3(CV_THREADS), st, a);
   return 0;
 }
 
@@ -670,8 +673,10 @@ static int launch_wgrad(const float* x, const float* g, float* dw, float* ws, in
   const int total_chunks = N * Ho * (Wo / WG_PK);
   const int nslabs = wgrad_slabs(total_chunks, tiles);
   const int chunks_per_slab = (total_chunks + nslabs - 1) / nslabs;
-  hipLaunchKernelGGL((k_wgrad_f32<BMK, BNC, WG_PK, SH, SW, KS>), dim3(tiles * nslabs), dim3(CV_THREADS), 0, st, x, g, ws, N,
-                     H, W, C, K, Ho, Wo, chunks_per_slab, nslabs);
+  const DlProfTag tag{"k_wgrad_f32", "wgrad", N, H, W, C, K, 2.0 * N * Ho * Wo * (double)K * C * KS * KS,
+                      4.0 * ((double)N * H * W * C + (double)N * Ho * Wo * K + (double)K * KS * KS * C)};
+  DL_LAUNCH(tag, (k_wgrad_f32<BMK, BNC, WG_PK, SH, SW, KS>), dim3(tiles * nslabs), dim3(CV_THREADS), st, x, g, ws, N,
+            H, W, C, K, Ho, Wo, chunks_per_slab, nslabs);
   const size_t count = (size_t)K * KS * KS * C;
   hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((count / 4 + CV_THREADS - 1) / CV_THREADS)), dim3(CV_THREADS), 0, st,
                      (const float*)ws, nslabs, count, dw);

@@ -22,10 +22,6 @@
 //
 // Numerics: fp32 throughout; Winograd F(2x2,3x3) adds/subtracts before and after the products, error ~1e-6 relative to the
 // layer's output scale (tests/test_gpu_conv.py bounds it against torch's direct convolution at 1e-4).
-#include <hip/hip_ext.h>
-
-#include <vector>
-
 #include "common.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -600,52 +596,14 @@ extern "C" int dl_wino_wgrad3x3_nhwc_f32(const float* x, const float* g, float* 
   const int total_chunks = N * (H / 2) * ((W / 2) / 8);
   const int nslabs = ww_slabs(total_chunks, tiles);
   WWArgs a{x, g, ws, N, H, W, C, K, (total_chunks + nslabs - 1) / nslabs, nslabs};
-  hipLaunchKernelGGL(k_wino_wgrad, dim3(tiles * nslabs), dim3(WW_THREADS), 0, st, a);
+  const DlProfTag tag{"k_wino_wgrad", "wgrad", N, H, W, C, K, 2.0 * 16.0 * (double)N * (H / 2) * (W / 2) * (double)C * K,
+                      4.0 * ((double)N * H * W * (C + K) + 9.0 * C * K)};
+  DL_LAUNCH(tag, k_wino_wgrad, dim3(tiles * nslabs), dim3(WW_THREADS), st, a);
   const size_t count4 = (size_t)16 * K * C / 4;
   float* usum = ws + (size_t)nslabs * 16 * K * C;
   hipLaunchKernelGGL(k_wino_wgrad_sum, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nslabs, count4, usum);
   hipLaunchKernelGGL(k_wino_wgrad_out, dim3((unsigned)(((size_t)K * C + 255) / 256)), dim3(256), 0, st, (const float*)usum, K, C, dw);
   return dl_check_launch("dl_wino_wgrad3x3_nhwc_f32");
-}
-
-// Measurement aid (bench.py: the roofline of the dominant kernel, read inside real training steps): between
-// dl_wino_profile_begin and dl_wino_profile_end every dl_wino_conv3x3_nhwc_f32 launch carries its own begin/end
-// timestamps (two HIP events filled by hipExtLaunchKernelGGL) and its multiply-add count is added up.  One profile at a
-// time, launches beyond max_launches are not timed.  Not graph-capturable while a profile is open.
-struct WinoProfile {
-  std::vector<hipEvent_t> ev;   // start, stop, start, stop ...
-  int used = 0, skipped = 0;
-  double flop = 0.0;            // 2 * 16 multiply-adds per (tile, c, k): what the matrix cores are asked to do
-  bool open = false;
-};
-static WinoProfile g_wino_profile;
-
-extern "C" int dl_wino_profile_begin(int32_t max_launches) {
-  WinoProfile& p = g_wino_profile;
-  if (p.open || max_launches <= 0) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wino_profile_begin: profile already open / bad size");
-  p.ev.resize((size_t)2 * max_launches);
-  for (auto& e : p.ev)
-    if (hipEventCreate(&e) != hipSuccess) return dl_fail(DL_ERR_LAUNCH, "dl_wino_profile_begin: hipEventCreate failed");
-  p.used = p.skipped = 0; p.flop = 0.0; p.open = true;
-  return DL_OK;
-}
-
-extern "C" int dl_wino_profile_end(double* total_ms, double* total_flop, int32_t* launches) {
-  WinoProfile& p = g_wino_profile;
-  if (!p.open || !total_ms || !total_flop || !launches) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wino_profile_end: no open profile / null argument");
-  double ms = 0.0;
-  int rc = DL_OK;
-  for (int i = 0; i < p.used; ++i) {
-    float t = 0.f;
-    if (hipEventSynchronize(p.ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&t, p.ev[2 * i], p.ev[2 * i + 1]) != hipSuccess)
-      rc = dl_fail(DL_ERR_LAUNCH, "dl_wino_profile_end: %s", hipGetErrorString(hipGetLastError()));
-    ms += t;
-  }
-  for (auto& e : p.ev) (void)hipEventDestroy(e);
-  p.ev.clear();
-  *total_ms = ms; *total_flop = p.flop; *launches = p.used;
-  p.open = false;
-  return rc;
 }
 
 extern "C" int dl_wino_conv3x3_nhwc_f32(const float* x, const float* u, float* y, const float* add, const float* dsrc,
@@ -662,25 +620,15 @@ extern "C" int dl_wino_conv3x3_nhwc_f32(const float* x, const float* u, float* y
   const int tw = W / 2, th = H / 2;
   if (!((tw % 32 == 0 && th % 2 == 0) || (tw % 16 == 0 && th % 4 == 0)))
     return dl_fail(DL_ERR_UNSUPPORTED, "dl_wino_conv3x3_nhwc_f32: image %dx%d does not tile (W/2 %% 16, rows)", H, W);
-  WinoProfile& p = g_wino_profile;
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  if (p.open) {
-    if (2 * p.used + 1 < (int)p.ev.size()) {
-      e0 = p.ev[2 * p.used]; e1 = p.ev[2 * p.used + 1];
-      ++p.used;
-      p.flop += 2.0 * 16.0 * (double)N * th * tw * (double)C * K;
-    } else {
-      ++p.skipped;
-    }
-  }
+  // what the algorithm asks of the matrix cores: 16 multiply-adds per 2x2 output tile and (c, k) pair (a direct convolution: 36)
+  const DlProfTag tag{"k_wino_conv", "conv", N, H, W, C, K, 2.0 * 16.0 * (double)N * th * tw * (double)C * K,
+                      4.0 * ((double)N * H * W * (C + K) + 16.0 * C * K)};
   if (tw % 32 == 0 && th % 2 == 0) {
     const dim3 grid(N * (th / 2) * (tw / 32) * (K / WN_KB));
-    if (e0) hipExtLaunchKernelGGL(k_wino_conv<32>, grid, dim3(WN_THREADS), 0, st, e0, e1, 0, a);
-    else hipLaunchKernelGGL(k_wino_conv<32>, grid, dim3(WN_THREADS), 0, st, a);
+    DL_LAUNCH(tag, k_wino_conv<32>, grid, dim3(WN_THREADS), st, a);
   } else {
     const dim3 grid(N * (th / 4) * (tw / 16) * (K / WN_KB));
-    if (e0) hipExtLaunchKernelGGL(k_wino_conv<16>, grid, dim3(WN_THREADS), 0, st, e0, e1, 0, a);
-    else hipLaunchKernelGGL(k_wino_conv<16>, grid, dim3(WN_THREADS), 0, st, a);
+    DL_LAUNCH(tag, k_wino_conv<16>, grid, dim3(WN_THREADS), st, a);
   }
   return dl_check_launch("dl_wino_conv3x3_nhwc_f32");
 }

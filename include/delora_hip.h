@@ -10,8 +10,9 @@
  * Conventions
  *   - plain C: raw DEVICE pointers, sizes, strides in ELEMENTS; no torch/HIP types in signatures
  *     (dl_stream is the hipStream_t handle passed as void*, e.g. torch's current stream).
- *   - the caller owns every buffer; the library allocates nothing, keeps no mutable global state,
- *     never synchronises the device: all work is enqueued on the given stream (graph-capturable).
+ *   - the caller owns every buffer; the library allocates nothing and keeps no mutable global state (the one exception is
+ *     the opt-in launch profiler at the end of this header), never synchronises the device: all work is enqueued on the given
+ *     stream (graph-capturable).
  *   - return 0 on success, negative dl_status otherwise; dl_last_error() (thread-local) has the text.
  *   - data layout: a batch of S scans is a planar fp32 buffer pts[C][sumN] + CSR offsets offs[S+1];
  *     a range image is planar fp32 [S][4][H][W] = (x, y, z, range), empty pixels are all-zero;
@@ -369,13 +370,23 @@ int dl_quat_to_T_bwd(const float* quaternion, const float* grad_T, int32_t B, fl
  * x [N][P][C] (P = H*W pixels) -> y [N][C]; fixed summation order; C % 4 == 0. */
 int dl_mean_hw_nhwc_f32(const float* x, int32_t N, int32_t P, int32_t C, float* y, dl_stream stream);
 
-/* Measurement aid: between dl_wino_profile_begin and dl_wino_profile_end every dl_wino_conv3x3_nhwc_f32 launch carries its
- * own begin/end timestamps (two HIP events filled by hipExtLaunchKernelGGL) so that the kernel's duration can be read
- * inside real training steps; *total_flop = 2 * 16 multiply-adds per (2x2 tile, c, k) of the timed launches (what the
- * matrix cores are asked to do; a direct convolution would need 2.25x as many).  One profile at a time; launches beyond
- * max_launches are not timed.  Not graph-capturable while a profile is open. */
-int dl_wino_profile_begin(int32_t max_launches);
-int dl_wino_profile_end(double* total_ms, double* total_flop, int32_t* launches);
+/* Measurement aid (bench.py, tools/): between dl_profile_begin and dl_profile_end every launch of the convolution families
+ * (fp32 direct / Winograd / weight gradient, half-precision forward / weight gradient) carries its own begin / end timestamps
+ * (two HIP events filled by hipExtLaunchKernelGGL on the launch stream), so that a kernel's duration can be read inside real
+ * training steps.  dl_profile_end returns one row per (kernel, pass, shape): launches, summed kernel time [ms], the
+ * floating-point operations the algorithm issued on the matrix cores (Winograd: 16 multiply-adds per 2x2 tile and (c,k) pair,
+ * a direct convolution: 36) and the compulsory HBM bytes (operands once + result once).  One profile at a time (mutex-guarded;
+ * the only mutable process-wide state of the library); only_kernel restricts the timing to one kernel family (an event-carrying
+ * launch costs the host a few microseconds more); launches beyond max_launches are counted in *untimed; not
+ * graph-capturable while a profile is open.  capacity < the number of rows: the first `capacity` rows are written, *count is
+ * the full number. */
+typedef struct {
+  char name[96];     /* "<kernel> <pass> N<n> <H>x<W> C<c> K<k>" */
+  int32_t launches;
+  double ms, flop, bytes;
+} dl_profile_row;
+int dl_profile_begin(int32_t max_launches, const char* only_kernel /* NULL: all; else one kernel family, e.g. "k_wino_conv" */);
+int dl_profile_end(dl_profile_row* rows, int32_t capacity, int32_t* count, int32_t* untimed);
 
 #ifdef __cplusplus
 }
