@@ -225,95 +225,118 @@ class RingStem(torch.autograd.Function):
         return (gx if want_x else None), dw, None
 
 
-class RingTrunk(torch.autograd.Function):
-    """layer1..layer4 of the pose CNN.  ``forward(x0, act, blocks, *weights)``: x0 ``[N,H,W,C0]`` channels-last, already
-    activated (the pooled stem output); blocks = tuple of (cin, cout, stride, has_downsample); weights in block order
-    (conv1, conv2[, downsample]).  Returns the last feature map ``[N,H',W',C']``."""
+# Order in which the block Functions finished their backward passes in this process (tests: DDP overlap) -- appended to by
+# RingBlock / RingBlockH when it is a list
+BACKWARD_TRACE = None
+
+
+class RingBlock(torch.autograd.Function):
+    """One residual block of the pose CNN (reference BasicBlock.forward, src/models/resnet_modified.py:159-177) on channels-last
+    fp32 activations: ``forward(x, act, cfg, first, last, w1, w2[, wd])`` with cfg = (cin, cout, stride, has_downsample); returns the
+    block's activated output ``[N,H',W',cout]``.
+
+    One Function PER BLOCK (round 2 had one for the whole trunk): its weight gradients are handed to autograd as soon as the
+    block's backward has run, so under DistributedDataParallel the all-reduce of layer4 / layer3 (85 % of the gradient bytes)
+    overlaps with the rest of the backward pass instead of waiting for the whole trunk.
+
+    Private gradient convention BETWEEN two RingBlocks (the tensors never leave ``ring_trunk``): the gradient a block receives
+    for its output is already multiplied by ``act'(output)`` -- i.e. it is the gradient with respect to the block's
+    pre-activation -- because the consumer block folds that factor into the epilogue of its input-gradient convolution
+    (``EPI_DACT``): no elementwise kernel runs between two convolutions.  Only the LAST block receives a true ``dL/dy`` (from
+    the pooling) and applies ``act'`` itself; only the FIRST block returns a true ``dL/dx`` (x = the pooled stem output, whose
+    activation derivative belongs to the stem)."""
 
     @staticmethod
-    def forward(ctx, x0, act, blocks, *weights):
-        """Stride-1 3x3 layers run as fused Winograd F(2x2,3x3) when ``USE_WINOGRAD`` and the shape tiles (their
-        Winograd-domain weights for the backward pass are produced by the same launch and kept for it); the strided and 1x1
-        layers run the direct kernel."""
-        saved, x, wi = [x0], x0, 0
-        ubwd = []
+    def forward(ctx, x, act, cfg, first, last, *weights):
+        cin, cout, stride, has_ds = cfg
+        w1p, w2p = weights[0], weights[1]
+        wd = weight_storage(weights[2]) if has_ds else None
         need_bwd = any(ctx.needs_input_grad)
-        for (cin, cout, stride, has_ds) in blocks:
-            w1p, w2p = weights[wi], weights[wi + 1]
-            wd = weight_storage(weights[wi + 2]) if has_ds else None
-            wi += 3 if has_ds else 2
-            N, H, W, _ = x.shape
-            if USE_WINOGRAD and stride == (1, 1) and wino_ok(H, W, cin, cout):
-                uf, ub1 = wino_weights(w1p, want_bwd=need_bwd)
-                y1 = wino_conv(x, uf, cout, act=act, epilogue=EPI_ACT)
-            else:
-                ub1 = None
-                y1 = conv_nhwc(x, weight_storage(w1p), stride=stride, act=act, epilogue=EPI_ACT)
-            shortcut = conv_nhwc(x, wd, stride=stride) if has_ds else x
-            Ho, Wo = y1.shape[1], y1.shape[2]
-            if USE_WINOGRAD and wino_ok(Ho, Wo, cout, cout):
-                uf, ub2 = wino_weights(w2p, want_bwd=need_bwd)
-                y2 = wino_conv(y1, uf, cout, act=act, epilogue=EPI_ADD | EPI_ACT, add=shortcut)
-            else:
-                ub2 = None
-                y2 = conv_nhwc(y1, weight_storage(w2p), act=act, epilogue=EPI_ADD | EPI_ACT, add=shortcut)
-            ubwd += [ub1, ub2]
-            saved += [y1, y2]
-            x = y2
-        ctx.act, ctx.blocks = act, blocks
+        N, H, W, _ = x.shape
+        if USE_WINOGRAD and stride == (1, 1) and wino_ok(H, W, cin, cout):
+            uf, ub1 = wino_weights(w1p, want_bwd=need_bwd)
+            y1 = wino_conv(x, uf, cout, act=act, epilogue=EPI_ACT)
+        else:
+            ub1 = None
+            y1 = conv_nhwc(x, weight_storage(w1p), stride=stride, act=act, epilogue=EPI_ACT)
+        shortcut = conv_nhwc(x, wd, stride=stride) if has_ds else x
+        Ho, Wo = y1.shape[1], y1.shape[2]
+        if USE_WINOGRAD and wino_ok(Ho, Wo, cout, cout):
+            uf, ub2 = wino_weights(w2p, want_bwd=need_bwd)
+            y2 = wino_conv(y1, uf, cout, act=act, epilogue=EPI_ADD | EPI_ACT, add=shortcut)
+        else:
+            ub2 = None
+            y2 = conv_nhwc(y1, weight_storage(w2p), act=act, epilogue=EPI_ADD | EPI_ACT, add=shortcut)
+        ctx.act, ctx.cfg, ctx.first, ctx.last = act, cfg, first, last
         # the Winograd-domain backward weights travel with the saved tensors (released with the graph, covered by autograd's
         # in-place version check like the raw weights); layers on the direct kernel have none
+        ubwd = [ub1, ub2]
         ctx.ubwd_mask = tuple(u is not None for u in ubwd)
-        ctx.save_for_backward(*saved, *weights, *[u for u in ubwd if u is not None])
-        return x
+        ctx.save_for_backward(x, y1, y2, *weights, *[u for u in ubwd if u is not None])
+        return y2
 
     @staticmethod
-    def backward(ctx, dy):
-        act, blocks = ctx.act, ctx.blocks
-        nb = len(blocks)
+    def backward(ctx, g):
+        act, (cin, cout, stride, has_ds), first = ctx.act, ctx.cfg, ctx.first
         saved = ctx.saved_tensors
-        nu = sum(ctx.ubwd_mask)
-        acts, weights = saved[:1 + 2 * nb], saved[1 + 2 * nb:len(saved) - nu]
-        u_it = iter(saved[len(saved) - nu:])
-        ubwd = [next(u_it) if has else None for has in ctx.ubwd_mask]
-        grads = [None] * len(weights)
-        # gradient with respect to the pre-activation of the last block's output
-        y_last = acts[-1]
-        dy = dy.contiguous()
-        if act == ACT["tanh"]:
-            g2 = dy * (1.0 - y_last * y_last)
-        elif act == ACT["relu"]:
-            g2 = dy * (y_last > 0).to(dy.dtype)
+        nw = 3 if has_ds else 2
+        x, y1, y2 = saved[:3]
+        weights = saved[3:3 + nw]
+        u_it = iter(saved[3 + nw:])
+        ub1, ub2 = [next(u_it) if has else None for has in ctx.ubwd_mask]
+        g2 = g.contiguous()
+        if ctx.last:                                    # a true dL/dy: apply the activation derivative here
+            if act == ACT["tanh"]:
+                g2 = g2 * (1.0 - y2 * y2)
+            elif act == ACT["relu"]:
+                g2 = g2 * (y2 > 0).to(g2.dtype)
+        w1p, w2p = weights[0], weights[1]
+        grads = [None] * nw
+        grads[1] = wgrad_nhwc(y1, g2, 3).permute(0, 3, 1, 2)
+        if ub2 is not None:
+            g1 = wino_conv(g2, ub2, cout, act=act, epilogue=EPI_DACT, dsrc=y1)
         else:
-            g2 = dy
-        wi = len(weights)
-        for b in range(nb - 1, -1, -1):
-            cin, cout, stride, has_ds = blocks[b]
-            wi -= 3 if has_ds else 2
-            w1p, w2p = weights[wi], weights[wi + 1]
-            x, y1 = acts[2 * b], acts[2 * b + 1]
-            first = b == 0                                 # x0 is the pooled stem output: its act' belongs to the stem
-            grads[wi + 1] = wgrad_nhwc(y1, g2, 3).permute(0, 3, 1, 2)
-            ub1, ub2 = ubwd[2 * b], ubwd[2 * b + 1]
-            if ub2 is not None:
-                g1 = wino_conv(g2, ub2, cout, act=act, epilogue=EPI_DACT, dsrc=y1)
-            else:
-                g1 = conv_nhwc(g2, weight_storage(w2p), act=act, epilogue=EPI_DACT, dsrc=y1, transposed=True)
-            grads[wi] = wgrad_nhwc(x, g1, 3, stride=stride).permute(0, 3, 1, 2)
-            if not has_ds:
+            g1 = conv_nhwc(g2, weight_storage(w2p), act=act, epilogue=EPI_DACT, dsrc=y1, transposed=True)
+        grads[0] = wgrad_nhwc(x, g1, 3, stride=stride).permute(0, 3, 1, 2)
+        gx = None
+        if not has_ds:
+            if ctx.needs_input_grad[0]:
                 epi = EPI_ADD if first else (EPI_ADD | EPI_DACT)
                 if ub1 is not None:
-                    g2 = wino_conv(g1, ub1, cin, act=act, epilogue=epi, add=g2, dsrc=None if first else x)
+                    gx = wino_conv(g1, ub1, cin, act=act, epilogue=epi, add=g2, dsrc=None if first else x)
                 else:
-                    g2 = conv_nhwc(g1, weight_storage(w1p), act=act, epilogue=epi, add=g2, dsrc=None if first else x, transposed=True)
-            else:
-                wdp = weights[wi + 2]
-                grads[wi + 2] = wgrad_nhwc(x, g2, 1, stride=stride).permute(0, 3, 1, 2)
+                    gx = conv_nhwc(g1, weight_storage(w1p), act=act, epilogue=epi, add=g2, dsrc=None if first else x, transposed=True)
+        else:
+            grads[2] = wgrad_nhwc(x, g2, 1, stride=stride).permute(0, 3, 1, 2)
+            if ctx.needs_input_grad[0]:
                 # down-sampling branch on the grid, then one pass per stride phase of the 3x3 layer with it and act'(x) fused
-                dxb = dgrad_strided(g2, weight_storage(wdp), stride, dense=True)
+                dxb = dgrad_strided(g2, weight_storage(weights[2]), stride, dense=True)
                 epi = EPI_ADD_GRID if first else (EPI_ADD_GRID | EPI_DACT)
-                g2 = dgrad_strided(g1, weight_storage(w1p), stride, act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)
-        return (g2, None, None, *grads)
+                gx = dgrad_strided(g1, weight_storage(w1p), stride, act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)
+        if BACKWARD_TRACE is not None:
+            BACKWARD_TRACE.append(("block", cin, cout, stride))
+        return (gx, None, None, None, None, *grads)
+
+
+def ring_trunk(x0, act, blocks, weights):
+    """layer1..layer4 of the pose CNN: x0 ``[N,H,W,C0]`` channels-last fp32, already activated (the pooled stem output); blocks =
+    tuple of (cin, cout, stride, has_downsample); weights in block order (conv1, conv2[, downsample]).  Returns the last
+    feature map ``[N,H',W',C']``.  Stride-1 3x3 layers run as fused Winograd F(2x2,3x3) when ``USE_WINOGRAD`` and the shape
+    tiles, the strided and 1x1 layers on the direct kernel."""
+    x, wi = x0, 0
+    for b, cfg in enumerate(blocks):
+        nw = 3 if cfg[3] else 2
+        x = RingBlock.apply(x, act, cfg, b == 0, b == len(blocks) - 1, *weights[wi:wi + nw])
+        wi += nw
+    return x
+
+
+class RingTrunk:
+    """Round-2 interface kept for callers: ``RingTrunk.apply(x0, act, blocks, *weights)`` = ``ring_trunk``."""
+
+    @staticmethod
+    def apply(x0, act, blocks, *weights):
+        return ring_trunk(x0, act, blocks, list(weights))
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -390,70 +413,116 @@ def supported_h(x_shape, blocks):
     return True
 
 
-class RingTrunkH(torch.autograd.Function):
-    """layer1..layer4 + global average pooling of the pose CNN in half precision.  ``forward(x0, act, blocks, dtype, *weights)``:
-    x0 ``[N,H,W,C0]`` fp32 channels-last, already activated (the pooled stem output); weights = the fp32 parameters in block
-    order (conv1, conv2[, downsample]).  Returns the pooled features ``[N,C']`` in fp32.  Same launch structure as
-    ``RingTrunk`` (2 (+1) convolutions per block forward, 4 (+2) backward, every elementwise tail in an epilogue); in
-    addition one weight-conversion launch per convolution and one cast of x0."""
+class CastToHalf(torch.autograd.Function):
+    """fp32 -> bf16 / fp16 copy of the pooled stem output (one launch); the backward converts the gradient back."""
 
     @staticmethod
-    def forward(ctx, x0, act, blocks, dtype, *weights):
+    def forward(ctx, x, dtype):
         lib = _lib.load()
-        code = DTYPE_CODE[dtype]
+        x = x.contiguous()
+        y = torch.empty(x.shape, dtype=dtype, device=x.device)
+        _lib.check(lib.dl_cast_f32_to_h(_ptr(x), _ptr(y), x.numel(), DTYPE_CODE[dtype], _stream()), "dl_cast_f32_to_h")
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.float(), None
+
+
+class RingBlockH(torch.autograd.Function):
+    """``RingBlock`` in half precision: x / outputs / inter-block gradients in bf16 or fp16, fp32 parameters, fp32 weight
+    gradients (same private gradient convention between blocks, same launch structure; one weight-conversion launch per
+    convolution in addition)."""
+
+    @staticmethod
+    def forward(ctx, x, act, cfg, first, last, *weights):
+        cin, cout, stride, has_ds = cfg
+        dtype = x.dtype
         need_bwd = any(ctx.needs_input_grad)
-        x = torch.empty(x0.shape, dtype=dtype, device=x0.device)
-        _lib.check(lib.dl_cast_f32_to_h(_ptr(x0.contiguous()), _ptr(x), x0.numel(), code, _stream()), "dl_cast_f32_to_h")
-        saved, wbs, wi = [x], [], 0
-        for (cin, cout, stride, has_ds) in blocks:
-            w1f, w1b = weights_h(weights[wi], dtype, want_bwd=need_bwd)
-            w2f, w2b = weights_h(weights[wi + 1], dtype, want_bwd=need_bwd)
-            wdf, wdb = weights_h(weights[wi + 2], dtype, want_bwd=need_bwd) if has_ds else (None, None)
-            wi += 3 if has_ds else 2
-            y1 = conv_nhwc_h(x, w1f, 3, stride=stride, act=act, epilogue=EPI_ACT)
-            shortcut = conv_nhwc_h(x, wdf, 1, stride=stride) if has_ds else x
-            y2 = conv_nhwc_h(y1, w2f, 3, act=act, epilogue=EPI_ADD | EPI_ACT, add=shortcut)
-            wbs += [w1b, w2b] + ([wdb] if has_ds else [])
-            saved += [y1, y2]
-            x = y2
-        N, H, W, C = x.shape
-        feat = torch.empty((N, C), dtype=torch.float32, device=x.device)
-        _lib.check(lib.dl_mean_hw_nhwc_h(_ptr(x), N, H * W, C, code, _ptr(feat), _stream()), "dl_mean_hw_nhwc_h")
-        ctx.act, ctx.blocks, ctx.code = act, blocks, code
-        ctx.n_w = len(weights)
-        ctx.save_for_backward(*saved, *(wbs if need_bwd else []))
+        w1f, w1b = weights_h(weights[0], dtype, want_bwd=need_bwd)
+        w2f, w2b = weights_h(weights[1], dtype, want_bwd=need_bwd)
+        wdf, wdb = weights_h(weights[2], dtype, want_bwd=need_bwd) if has_ds else (None, None)
+        y1 = conv_nhwc_h(x, w1f, 3, stride=stride, act=act, epilogue=EPI_ACT)
+        shortcut = conv_nhwc_h(x, wdf, 1, stride=stride) if has_ds else x
+        y2 = conv_nhwc_h(y1, w2f, 3, act=act, epilogue=EPI_ADD | EPI_ACT, add=shortcut)
+        ctx.act, ctx.cfg, ctx.first, ctx.last = act, cfg, first, last
+        ctx.save_for_backward(x, y1, y2, *([w1b, w2b] + ([wdb] if has_ds else []) if need_bwd else []))
+        return y2
+
+    @staticmethod
+    def backward(ctx, g):
+        lib = _lib.load()
+        act, (cin, cout, stride, has_ds), first = ctx.act, ctx.cfg, ctx.first
+        saved = ctx.saved_tensors
+        x, y1, y2 = saved[:3]
+        wbs = saved[3:]
+        nw = 3 if has_ds else 2
+        g2 = g.contiguous()
+        if ctx.last:                                    # never taken by ring_trunk_h (the pooling Function hands over the
+            if act == ACT["tanh"]:                      # pre-activation gradient); kept for stand-alone use of a block
+                g2 = (g2.float() * (1.0 - y2.float() ** 2)).to(g2.dtype)
+            elif act == ACT["relu"]:
+                g2 = g2 * (y2 > 0).to(g2.dtype)
+        grads = [None] * nw
+        grads[1] = wgrad_nhwc_h(y1, g2, 3).permute(0, 3, 1, 2)
+        g1 = conv_nhwc_h(g2, wbs[1], 3, act=act, epilogue=EPI_DACT, dsrc=y1, transposed=True)
+        grads[0] = wgrad_nhwc_h(x, g1, 3, stride=stride).permute(0, 3, 1, 2)
+        gx = None
+        if not has_ds:
+            if ctx.needs_input_grad[0]:
+                epi = EPI_ADD if first else (EPI_ADD | EPI_DACT)
+                gx = conv_nhwc_h(g1, wbs[0], 3, act=act, epilogue=epi, add=g2, dsrc=None if first else x, transposed=True)
+        else:
+            grads[2] = wgrad_nhwc_h(x, g2, 1, stride=stride).permute(0, 3, 1, 2)
+            if ctx.needs_input_grad[0]:
+                dxb = dgrad_strided_h(g2, wbs[2], 1, stride, dense=True)
+                epi = EPI_ADD_GRID if first else (EPI_ADD_GRID | EPI_DACT)
+                gx = dgrad_strided_h(g1, wbs[0], 3, stride, act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)
+        if BACKWARD_TRACE is not None:
+            BACKWARD_TRACE.append(("block", cin, cout, stride))
+        return (gx, None, None, None, None, *grads)
+
+
+class MeanHWActH(torch.autograd.Function):
+    """Global average pooling of the last half-precision feature map -> fp32 ``[N,C]``; its backward is fused with the activation
+    derivative of the block that produced the map and returns the gradient with respect to that block's PRE-activation (the
+    private convention of ``RingBlockH``)."""
+
+    @staticmethod
+    def forward(ctx, y, act):
+        lib = _lib.load()
+        N, H, W, C = y.shape
+        feat = torch.empty((N, C), dtype=torch.float32, device=y.device)
+        _lib.check(lib.dl_mean_hw_nhwc_h(_ptr(y), N, H * W, C, DTYPE_CODE[y.dtype], _ptr(feat), _stream()), "dl_mean_hw_nhwc_h")
+        ctx.save_for_backward(y)
+        ctx.act = act
         return feat
 
     @staticmethod
     def backward(ctx, gfeat):
         lib = _lib.load()
-        act, blocks, code = ctx.act, ctx.blocks, ctx.code
-        nb = len(blocks)
-        saved = ctx.saved_tensors
-        acts, wbs = saved[:1 + 2 * nb], saved[1 + 2 * nb:]
-        grads = [None] * ctx.n_w
-        y_last = acts[-1]
-        N, H, W, C = y_last.shape
-        # gradient with respect to the pre-activation of the last block's output: pooling backward + act' in one launch
-        g2 = torch.empty_like(y_last)
-        _lib.check(lib.dl_mean_hw_bwd_act_h(_ptr(gfeat.contiguous().float()), _ptr(y_last), N, H * W, C, act, code, _ptr(g2), _stream()),
-                   "dl_mean_hw_bwd_act_h")
-        wi = ctx.n_w
-        for b in range(nb - 1, -1, -1):
-            cin, cout, stride, has_ds = blocks[b]
-            wi -= 3 if has_ds else 2
-            w1b, w2b = wbs[wi], wbs[wi + 1]
-            x, y1 = acts[2 * b], acts[2 * b + 1]
-            first = b == 0                                 # x0 is the pooled stem output: its act' belongs to the stem
-            grads[wi + 1] = wgrad_nhwc_h(y1, g2, 3).permute(0, 3, 1, 2)
-            g1 = conv_nhwc_h(g2, w2b, 3, act=act, epilogue=EPI_DACT, dsrc=y1, transposed=True)
-            grads[wi] = wgrad_nhwc_h(x, g1, 3, stride=stride).permute(0, 3, 1, 2)
-            if not has_ds:
-                epi = EPI_ADD if first else (EPI_ADD | EPI_DACT)
-                g2 = conv_nhwc_h(g1, w1b, 3, act=act, epilogue=epi, add=g2, dsrc=None if first else x, transposed=True)
-            else:
-                grads[wi + 2] = wgrad_nhwc_h(x, g2, 1, stride=stride).permute(0, 3, 1, 2)
-                dxb = dgrad_strided_h(g2, wbs[wi + 2], 1, stride, dense=True)
-                epi = EPI_ADD_GRID if first else (EPI_ADD_GRID | EPI_DACT)
-                g2 = dgrad_strided_h(g1, w1b, 3, stride, act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)
-        return (g2.float(), None, None, None, *grads)
+        (y,) = ctx.saved_tensors
+        N, H, W, C = y.shape
+        g = torch.empty_like(y)
+        _lib.check(lib.dl_mean_hw_bwd_act_h(_ptr(gfeat.contiguous().float()), _ptr(y), N, H * W, C, ctx.act, DTYPE_CODE[y.dtype], _ptr(g),
+                                            _stream()), "dl_mean_hw_bwd_act_h")
+        return g, None
+
+
+def ring_trunk_h(x0, act, blocks, dtype, weights):
+    """layer1..layer4 + global average pooling in half precision: x0 ``[N,H,W,C0]`` fp32 channels-last (the pooled stem output),
+    fp32 parameters in block order; returns the pooled features ``[N,C']`` in fp32."""
+    x, wi = CastToHalf.apply(x0, dtype), 0
+    for b, cfg in enumerate(blocks):
+        nw = 3 if cfg[3] else 2
+        x = RingBlockH.apply(x, act, cfg, b == 0, False, *weights[wi:wi + nw])
+        wi += nw
+    return MeanHWActH.apply(x, act)
+
+
+class RingTrunkH:
+    """``RingTrunkH.apply(x0, act, blocks, dtype, *weights)`` = ``ring_trunk_h`` (interface of the first version, one Function)."""
+
+    @staticmethod
+    def apply(x0, act, blocks, dtype, *weights):
+        return ring_trunk_h(x0, act, blocks, dtype, list(weights))

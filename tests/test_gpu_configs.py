@@ -417,3 +417,53 @@ def test_full_size_step_replays_as_a_hip_graph():
     print("eager", eager, "graph", got)
     util.measured("full-size graph replay: worst relative deviation of the loss from the eager trajectory",
                   float(np.max(np.abs(np.array(got) - np.array(eager[3:6])) / np.abs(np.array(eager[3:6])))), bound=1e-3)
+
+
+def test_ddp_all_reduce_overlaps_the_trunk_backward():
+    """The gradient all-reduce is the path's only exchange.  Every residual block is its own autograd Function, so
+    DistributedDataParallel receives a block's weight gradients when that block's backward has run: the buckets holding layer4 and
+    layer3 (85 % of the 47.5 MB) must be handed to the communication hook BEFORE the backward of layer1 has finished, and what is
+    still outstanding when the last trunk block returns must be less than one 10 MB bucket."""
+    dev = _dev()
+    import torch.distributed as dist
+    from delora_amd.models import ring_conv
+    if dist.is_initialized():
+        pytest.skip("a process group is already initialised in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29536")
+    dist.init_process_group(backend="gloo", rank=0, world_size=1)
+    try:
+        from delora_amd.deploy.trainer import Trainer
+        cfg = util.repo_config(16, 1024, device="cuda:0", unsupervised_at_start=True, inference_only=False, batch_size=2)
+        tr = Trainer(cfg, dataset=util.ListDataset([]))
+        tr.world_size = 2
+        model = Trainer._wrap_ddp(tr, tr.raw_model)
+        trace = []
+
+        def hook(state, bucket):
+            trace.append(("bucket", bucket.index(), bucket.buffer().numel() * 4))
+            fut = torch.futures.Future()
+            fut.set_result(bucket.buffer())
+            return fut
+        model.register_comm_hook(None, hook)
+        ring_conv.BACKWARD_TRACE = trace
+        x = torch.randn((2, 8, 16, 1024), device=dev)
+        for _ in range(2):                                   # DDP rebuilds its buckets in gradient-ready order after the first pass
+            del trace[:]
+            model.zero_grad(set_to_none=True)
+            t, q = model(x)
+            (t.square().sum() + q.sum()).backward()
+            torch.cuda.synchronize()
+    finally:
+        ring_conv.BACKWARD_TRACE = None
+        dist.destroy_process_group()
+    blocks = [i for i, e in enumerate(trace) if e[0] == "block"]
+    assert len(blocks) == 8, trace
+    total = sum(e[2] for e in trace if e[0] == "bucket")
+    after_trunk = sum(e[2] for e in trace[blocks[-1]:] if e[0] == "bucket")
+    # blocks run layer4.1, 4.0, 3.1, 3.0, 2.1, 2.0, 1.1, 1.0; a bucket is launched when the LAST of its parameters is ready
+    early = sum(e[2] for e in trace[:blocks[4]] if e[0] == "bucket")              # before layer2.1's backward has finished
+    util.measured("DDP: gradient bytes handed to the all-reduce only after the last trunk block's backward", after_trunk, bound=10 * 1024 * 1024)
+    util.measured("DDP: share of the gradient bytes already in flight when the backward of layer2 finishes its first block", early / total)
+    assert abs(total - 4 * sum(p.numel() for p in tr.raw_model.parameters())) < 1024
+    assert early / total > 0.6
