@@ -51,6 +51,9 @@ def parse(argv=None):
     ap.add_argument("--rotate", type=int, default=8, help="distinct batches the steps rotate over (HBM resident)")
     ap.add_argument("--long-steps", type=int, default=200, help="extra timed run of this many steps (0 = skip); N=1 only")
     ap.add_argument("--feed-steps", type=int, default=64, help="steps of the host-fed leg (0 = skip); N=1 only")
+    ap.add_argument("--alloc-skew", type=int, default=-1, help="A/B: base-address skew (bytes) of the trunk's activation tensors (-1: library default)")
+    ap.add_argument("--trunk-segments", default="", help="A/B: how the trunk is cut into autograd Functions (mono / layer / block; default: the library's choice)")
+    ap.add_argument("--no-profile", action="store_true", help="no event-carrying launches in the timed steps (no roofline object)")
     ap.add_argument("--conv-table", action="store_true", help="also time every stride-1 layer shape and pass back to back (roofline_cnn)")
     ap.add_argument("--autocast-steps", type=int, default=20, help="timed steps of the extra bf16-autocast leg of the fp32 run (0 = skip); N=1 only")
     ap.add_argument("--amp", default="", help="optional autocast dtype for the CNN (bfloat16/float16); default fp32 = parity mode")
@@ -185,8 +188,27 @@ def autocast_leg(args, device, host_batches, batches, timed_region):
     for _ in range(max(3, args.warmup)):
         step()
     el, ep = timed_region(args.autocast_steps, step)
+    out_graph = None
+    try:
+        from delora_amd.deploy.graph_step import GraphedStep
+        graphed = GraphedStep(trainer, batches[0])
+        if graphed.captured:
+            def gstep():
+                batch = batches[counter["i"] % len(batches)]
+                counter["i"] += 1
+                return graphed(batch)[0]
+            for _ in range(3):
+                gstep()
+            elg, epg = timed_region(args.autocast_steps, gstep)
+            out_graph = {"value": round(args.batch * args.autocast_steps / elg, 3), "ms_per_step": round(1e3 * elg / args.autocast_steps, 3),
+                         "final_loss": float(epg["loss_epoch"]), "eager_fallback_steps": graphed.fallback_steps,
+                         "note": "the same steps replayed as ONE captured HIP graph; the rotating ragged batches go through static buffers "
+                                 "(deploy/graph_step.py, config key hip_graph)"}
+    except Exception as e:                                       # noqa: BLE001 -- the leg is informative
+        out_graph = {"error": f"{type(e).__name__}: {e}"}
     return {"dtype": "bfloat16", "steps": args.autocast_steps, "value": round(args.batch * args.autocast_steps / el, 3), "unit": "scan-pairs/s",
             "ms_per_step": round(1e3 * el / args.autocast_steps, 3), "final_loss": float(ep["loss_epoch"]), "cnn_impl": cnn_impl_in_use(trainer, a2),
+            "hip_graph": out_graph,
             "note": "autocast(bfloat16) around the pose CNN: fp32 stem, layer1-4 on v_mfma_f32_32x32x16_bf16 with bf16 activations, fp32 "
                     "accumulation, fp32 master weights and weight gradients; geometry kernels, loss and Adam unchanged (fp32)"}
 
@@ -511,6 +533,12 @@ def main():
     if args.miopen_benchmark:
         torch.backends.cudnn.benchmark = True
     cfg = build_config(args, device)
+    if args.trunk_segments:
+        from delora_amd.models import ring_conv
+        ring_conv.TRUNK_SEGMENTS = args.trunk_segments
+    if args.alloc_skew >= 0:
+        from delora_amd.models import ring_conv
+        ring_conv.ALLOC_SKEW = args.alloc_skew
     torch.manual_seed(1234)
     host_batches = pin_batches(derived_batches(make_batch(args, rank), max(1, args.rotate), rank))
     batches = [to_device(b, device) for b in host_batches]
@@ -534,12 +562,18 @@ def main():
         from delora_amd.deploy.graph_step import GraphedStep
         graphed = GraphedStep(trainer, batches[0])
         if graphed.captured:
-            run_step = lambda batch=None: graphed()[0]            # noqa: E731  (static shapes: one batch replayed)
+            eager_step = run_step
+
+            def run_step(batch=None):                              # ragged batches through the captured graph's static buffers
+                if batch is None:
+                    batch = batches[counter["i"] % len(batches)]
+                    counter["i"] += 1
+                return graphed(batch)[0]
     # in-situ timing of the streaming loss kernel (k_icp_loss) in every timed step: the launch carries a pair of HIP
     # events that receive the kernel's own begin/end timestamps (dl_icp_loss_partial_timed) on the launch stream
     from delora_amd import geometry as G
     timers = G.LossTimers()
-    if graphed is None or not graphed.captured:            # event-carrying launches cannot be captured into a graph
+    if (graphed is None or not graphed.captured) and not args.no_profile:      # event-carrying launches cannot be captured into a graph
         G.LOSS_TIMER_FACTORY = timers.new
 
     enqueue = {}
@@ -568,7 +602,7 @@ def main():
     from delora_amd import _lib
     conv_prof = None
     dominant = "k_convh" if args.amp else "k_wino_conv"          # the family with the largest share of the step (conv_profile below)
-    if (graphed is None or not graphed.captured) and "hip trunk" in cnn_impl_in_use(trainer, args):
+    if (graphed is None or not graphed.captured) and "hip trunk" in cnn_impl_in_use(trainer, args) and not args.no_profile:
         _lib.profile_begin(int(args.steps) * 64, dominant)         # the headline's timed steps time this family only
         conv_prof = True
     counter["i"] = 0

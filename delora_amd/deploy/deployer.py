@@ -130,12 +130,19 @@ class Deployer(object):
 
     def step(self, preprocessed_dicts, epoch_losses=None, log_images_bool=False):
         cfg = self.config
+        packed = preprocessed_dicts if isinstance(preprocessed_dicts, step_geometry.PackedBatch) else None
         B = len(preprocessed_dicts)
+        if packed is not None:
+            # a batch that already lies concatenated in static device buffers (deploy/graph_step.py): one sensor, no per-sample
+            # host-side preprocessing
+            if (self.training_bool and cfg["random_point_cloud_rotations"]) or cfg["normalization_scaling"]:
+                raise ValueError("a PackedBatch cannot be augmented or range-normalised (config: random_point_cloud_rotations / normalization_scaling)")
+            preprocessed_dicts = [{"dataset": packed.dataset}] * B
         if B != self.batch_size:
             # the reference indexes batch_size transforms against the list and fails on a short last batch
             # (deployer.py:240,290-292); make that explicit
             raise ValueError(f"step() needs exactly batch_size={self.batch_size} samples, got {B} (use drop_last)")
-        for i, d in enumerate(preprocessed_dicts):
+        for i, d in enumerate(preprocessed_dicts if packed is None else []):
             if self.training_bool:
                 d = self.augment_input(preprocessed_data=d)
             if cfg["normalization_scaling"]:
@@ -154,7 +161,8 @@ class Deployer(object):
         for idx in groups.values():
             dataset = preprocessed_dicts[idx[0]]["dataset"]
             sensor = self.img_projection.sensor(dataset)
-            prepared = self.geo.prepare([preprocessed_dicts[i] for i in idx], sensor, self._normal_params(dataset))
+            prepared = self.geo.prepare(packed if packed is not None else [preprocessed_dicts[i] for i in idx], sensor,
+                                        self._normal_params(dataset))
             translations, rotation_representation = self._run_model(prepared["stacked"])
             T_g = self.geometry_handler.get_transformation_matrix_quaternion(
                 translation=translations, quaternion=rotation_representation, device=self.device)

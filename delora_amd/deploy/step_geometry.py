@@ -11,6 +11,19 @@ import torch
 from .. import geometry
 
 
+class PackedBatch:
+    """A batch whose 2B scans already lie concatenated in ONE static device buffer (deploy/graph_step.py): ``pts [C, capacity]``
+    fp32 (C = 3, or 6 with the stored normals as extra rows), CSR ``offs [2B+1]`` int32 on the device in the order b0.scan_1,
+    b0.scan_2, b1.scan_1 ..., ``max_points`` = the per-scan capacity the launch is sized for.  Shapes and addresses never change
+    between steps, only the contents and the offsets -- which is what lets a captured HIP graph run ragged batches."""
+
+    def __init__(self, pts, offs, max_points, batch_size, dataset, with_lists):
+        self.pts, self.offs, self.max_points, self.B, self.dataset, self.with_lists = pts, offs, int(max_points), int(batch_size), dataset, bool(with_lists)
+
+    def __len__(self):
+        return self.B
+
+
 class HipStepGeometry:
     """Default (and only product) backend; raises through delora_amd._lib when libdelora_hip.so is missing."""
 
@@ -35,18 +48,22 @@ class HipStepGeometry:
         Returns dict(stacked [B,8,H,W] network input, images [B,2,4,H,W] view, normals [B,2,3,H,W], their packed twins
         packed / normals_packed [B,2,H,W,4], pix2pt [B,2,H,W])."""
         B = len(samples)
-        with_lists = samples[0].get("normal_list_1") is not None
-        chunks, lengths = [], []
-        for s in samples:
-            for k in ("1", "2"):
-                scan = s["scan_" + k][0]
-                if with_lists:
-                    scan = torch.cat((scan[:3], s["normal_list_" + k][0]), dim=0)
-                chunks.append(scan)
-                lengths.append(scan.shape[1])
-        pts = torch.cat(chunks, dim=1).contiguous().float()
-        offs = self._offsets_for(lengths, pts.device)
-        out = geometry.project(pts, offs, max(lengths), sensor, want_kept=False)
+        if isinstance(samples, PackedBatch):
+            with_lists = samples.with_lists
+            out = geometry.project(samples.pts, samples.offs, samples.max_points, sensor, want_kept=False)
+        else:
+            with_lists = samples[0].get("normal_list_1") is not None
+            chunks, lengths = [], []
+            for s in samples:
+                for k in ("1", "2"):
+                    scan = s["scan_" + k][0]
+                    if with_lists:
+                        scan = torch.cat((scan[:3], s["normal_list_" + k][0]), dim=0)
+                    chunks.append(scan)
+                    lengths.append(scan.shape[1])
+            pts = torch.cat(chunks, dim=1).contiguous().float()
+            offs = self._offsets_for(lengths, pts.device)
+            out = geometry.project(pts, offs, max(lengths), sensor, want_kept=False)
         image4 = out["image4"]
         H, W = sensor.H, sensor.W
         if with_lists:

@@ -54,11 +54,15 @@ class Trainer(deployer.Deployer):
     def _wrap_ddp(self, model):
         """DistributedDataParallel over the process group (backend "nccl" = RCCL over xGMI).  Buckets fill in backward order:
         heads, fc and the four 9.4 MB convolutions of layer4 -- 80 % of the 47.5 MB -- are ready in the first fraction of
-        backward; layer3..conv1 (11 MB) only at its very end.  With 10 MB buckets the last, exposed all-reduce carries ~6 MB
-        instead of the ~21 MB a 25 MB cap leaves for it."""
+        backward, layer3 next; layer2..conv1 (2.7 MB) only at its very end.  With 5 MB buckets the last, exposed all-reduce
+        carries ~4 MB (a 25 MB cap leaves ~21 MB for it)."""
         ids = [self.device.index] if getattr(self.device, "type", "cpu") == "cuda" else None
+        # the HIP trunk as three autograd Functions ([layer1+2] [layer3] [layer4]) instead of one: layer4's and layer3's weight
+        # gradients (89 % of the bytes) reach the reducer while the rest of the backward still runs (tests/test_gpu_configs.py)
+        from ..models import ring_conv
+        ring_conv.TRUNK_SEGMENTS = self.config.get("trunk_segments", "layer")
         return torch.nn.parallel.DistributedDataParallel(model, device_ids=ids, gradient_as_bucket_view=True,
-                                                         bucket_cap_mb=self.config.get("ddp_bucket_cap_mb", 10))
+                                                         bucket_cap_mb=self.config.get("ddp_bucket_cap_mb", 5))
 
     @staticmethod
     def new_epoch_losses():
@@ -80,7 +84,12 @@ class Trainer(deployer.Deployer):
         if show:
             iterator = qqdm.qqdm(iterator, desc=qqdm.format_str("blue", "Epoch " + str(epoch)))
         every = max(1, int(self.config.get("progress_every", 50)))
+        use_graph = (bool(self.config.get("hip_graph", False)) and self.world_size == 1
+                     and getattr(self.device, "type", "cpu") == "cuda")
         for counter, preprocessed_dicts in enumerate(iterator):
+            if use_graph:
+                epoch_losses = self._graphed_step(preprocessed_dicts, epoch_losses)
+                continue
             self.optimizer.zero_grad(set_to_none=True)
             epoch_losses, _ = self.step(preprocessed_dicts=preprocessed_dicts, epoch_losses=epoch_losses,
                                         log_images_bool=False)
@@ -88,6 +97,21 @@ class Trainer(deployer.Deployer):
                 iterator.set_infos({"loss": f'{float(epoch_losses["loss_epoch"]) / (counter + 1):.6f}',
                                     "loss_po2pl": f'{float(epoch_losses["loss_po2pl_epoch"]) / (counter + 1):.6f}',
                                     "loss_pl2pl": f'{float(epoch_losses["loss_pl2pl_epoch"]) / (counter + 1):.6f}'})
+        return epoch_losses
+
+    def _graphed_step(self, preprocessed_dicts, epoch_losses):
+        """config ``hip_graph: true``: the step replayed as one captured HIP graph (deploy/graph_step.py; ragged batches go
+        through static buffers of ``graph_max_points`` points per scan).  Re-captured when the training phase changes."""
+        from .graph_step import GraphedStep
+        phase = bool(self.config["unsupervised_at_start"])
+        g = getattr(self, "_graphed", None)
+        if g is None or self._graphed_phase != phase:
+            g = self._graphed = GraphedStep(self, preprocessed_dicts, max_points=self.config.get("graph_max_points"))
+            self._graphed_phase = phase
+        ep, _ = g(preprocessed_dicts)
+        for k, v in ep.items():                      # the graph's outputs are static tensors: add their VALUES to the epoch sums
+            if torch.is_tensor(v):
+                epoch_losses[k] = epoch_losses[k] + v
         return epoch_losses
 
     def _reduce_metrics(self, epoch_losses):

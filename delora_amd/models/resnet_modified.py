@@ -7,11 +7,11 @@ each side of H, strides (1,2) in the stem/pool/layer2/layer3 and (2,2) in layer4
 
 Two GPU paths compute it (``cnn_impl``; both are compared with each other and with torch-CPU in the tests):
   * fp32 tensors on shapes that tile (the reference's full-size network on 64/128-ring images): three autograd
-    Functions on channels-last activations -- ``ring_conv.RingStem`` (conv1 + activation + max-pooling), one ``RingBlock``
-    per residual block of layer1..layer4 (fused Winograd / direct MFMA convolutions with the wrap-around as addressing and
-    the elementwise tail in their epilogues; per block so that DDP overlaps the gradient all-reduce with the backward) and
-    ``MeanHW`` before ``fc``; inside ``torch.autocast`` the same structure in bf16 / fp16 (``RingBlockH``: csrc/convh.hip,
-    wgradh.hip);
+    Functions on channels-last activations -- ``ring_conv.RingStem`` (conv1 + activation + max-pooling), ``RingSegment``
+    for layer1..layer4 (fused Winograd / direct MFMA convolutions with the wrap-around as addressing and the elementwise tail
+    in their epilogues; one Function in a single process, cut per layer under DDP so that the gradient all-reduce overlaps
+    the backward) and ``MeanHW`` before ``fc``; inside ``torch.autocast`` the same structure in bf16 / fp16
+    (``RingSegmentH``: csrc/convh.hip, wgradh.hip);
   * everything else (narrow test networks, autocast, dropout): the modules below -- library convolutions on inputs that
     travel in wrapped form, with activation (+ residual add) and the wrap-around padding as ONE fused HIP elementwise op
     (``ring_ops.ring_act_pad``) instead of the reference's separate tanh, add and three-copy F.pad per layer, and the

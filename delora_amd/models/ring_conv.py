@@ -37,6 +37,24 @@ def _stream():
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Base-address skew of the activation tensors this module allocates (bytes, cycled per allocation; 0 = off).  Tensors that one
+# kernel streams together (x, y, shortcut, saved activation) otherwise start at addresses a large power of two apart.
+ALLOC_SKEW = 0
+_skew_state = {"i": 0}
+
+
+def _empty(shape, dtype, device):
+    if not ALLOC_SKEW:
+        return torch.empty(shape, dtype=dtype, device=device)
+    n = 1
+    for d in shape:
+        n *= int(d)
+    esz = torch.empty((), dtype=dtype).element_size()
+    _skew_state["i"] = (_skew_state["i"] + 1) % 8
+    off = (_skew_state["i"] * ALLOC_SKEW) // esz
+    return torch.empty((n + (8 * ALLOC_SKEW) // esz,), dtype=dtype, device=device)[off:off + n].view(shape)
+
+
 def weight_storage(w):
     """The parameter ``[K,C,k,k]`` viewed as its channels_last storage ``[K,k,k,C]`` (no copy when it already has that
     memory format -- ``OdometryModel`` converts its convolution weights once)."""
@@ -51,7 +69,7 @@ def conv_nhwc(x, w_krsc, stride=(1, 1), act=0, epilogue=0, add=None, dsrc=None, 
     N, H, W, C = x.shape
     ks = w_krsc.shape[1]
     K = w_krsc.shape[3] if transposed else w_krsc.shape[0]
-    y = torch.empty((N, H // stride[0], W // stride[1], K), dtype=torch.float32, device=x.device)
+    y = _empty((N, H // stride[0], W // stride[1], K), torch.float32, x.device)
     _lib.check(lib.dl_conv2d_nhwc_f32(_ptr(x), _ptr(w_krsc), _ptr(y), _ptr(add), _ptr(dsrc), N, H, W, C, K, ks, stride[0],
                                       stride[1], int(transposed), int(act), int(epilogue), _stream()), "dl_conv2d_nhwc_f32")
     return y
@@ -107,7 +125,7 @@ def wino_conv(x, u, K, act=0, epilogue=0, add=None, dsrc=None):
     output gradient as x: input gradient) -> ``[N,H,W,K]``, epilogue as conv_nhwc."""
     lib = _lib.load()
     N, H, W, C = x.shape
-    y = torch.empty((N, H, W, K), dtype=torch.float32, device=x.device)
+    y = _empty((N, H, W, K), torch.float32, x.device)
     _lib.check(lib.dl_wino_conv3x3_nhwc_f32(_ptr(x), _ptr(u), _ptr(y), _ptr(add), _ptr(dsrc), N, H, W, C, K, int(act),
                                             int(epilogue), _stream()), "dl_wino_conv3x3_nhwc_f32")
     return y
@@ -139,7 +157,7 @@ def dgrad_strided(g, w_krsc, stride, act=0, epilogue=0, add_grid=None, dsrc=None
     N, Ho, Wo, K = g.shape
     ks, C = w_krsc.shape[1], w_krsc.shape[3]
     shape = (N, Ho, Wo, C) if dense else (N, Ho * stride[0], Wo * stride[1], C)
-    dx = torch.empty(shape, dtype=torch.float32, device=g.device)
+    dx = _empty(shape, torch.float32, g.device)
     _lib.check(lib.dl_conv2d_dgrad_strided_nhwc_f32(_ptr(g), _ptr(w_krsc), _ptr(dx), _ptr(add_grid), _ptr(dsrc), N, Ho, Wo, K, C, ks,
                                                     stride[0], stride[1], int(dense), int(act), int(epilogue), _stream()),
                "dl_conv2d_dgrad_strided_nhwc_f32")
@@ -225,110 +243,143 @@ class RingStem(torch.autograd.Function):
         return (gx if want_x else None), dw, None
 
 
-# Order in which the block Functions finished their backward passes in this process (tests: DDP overlap) -- appended to by
-# RingBlock / RingBlockH when it is a list
+# How the trunk is cut into autograd Functions.  Each Function hands its weight gradients to autograd when its backward has run, so
+# the cuts decide what DistributedDataParallel can overlap with the rest of the backward; each Function also costs the host
+# ~0.1 ms per step (apply + saved tensors + backward dispatch), and the eager step is only just GPU-bound:
+#   "mono"   one Function for layer1..layer4 (single process: nothing to overlap)
+#   "layer"  [layer1 + layer2] [layer3] [layer4]: layer4 (71 % of the gradient bytes) and layer3 (18 %) are in flight while the
+#            rest of the backward runs -- what deploy/trainer.py selects under DDP
+#   "block"  one Function per residual block
+TRUNK_SEGMENTS = "mono"
+# Order in which the segment Functions finished their backward passes in this process (tests: DDP overlap) -- appended to when a list
 BACKWARD_TRACE = None
 
 
-class RingBlock(torch.autograd.Function):
-    """One residual block of the pose CNN (reference BasicBlock.forward, src/models/resnet_modified.py:159-177) on channels-last
-    fp32 activations: ``forward(x, act, cfg, first, last, w1, w2[, wd])`` with cfg = (cin, cout, stride, has_downsample); returns the
-    block's activated output ``[N,H',W',cout]``.
+def _segments(blocks, mode):
+    """Index ranges [(b0, b1), ...] of the blocks each autograd Function covers."""
+    nb = len(blocks)
+    if mode == "block":
+        return [(b, b + 1) for b in range(nb)]
+    if mode == "layer":
+        cuts = [b for b in range(1, nb) if blocks[b][3] and blocks[b][0] >= 128]      # first block of layer3 and of layer4
+        edges = [0] + cuts + [nb]
+        return [(edges[i], edges[i + 1]) for i in range(len(edges) - 1)]
+    return [(0, nb)]
 
-    One Function PER BLOCK (round 2 had one for the whole trunk): its weight gradients are handed to autograd as soon as the
-    block's backward has run, so under DistributedDataParallel the all-reduce of layer4 / layer3 (85 % of the gradient bytes)
-    overlaps with the rest of the backward pass instead of waiting for the whole trunk.
 
-    Private gradient convention BETWEEN two RingBlocks (the tensors never leave ``ring_trunk``): the gradient a block receives
-    for its output is already multiplied by ``act'(output)`` -- i.e. it is the gradient with respect to the block's
-    pre-activation -- because the consumer block folds that factor into the epilogue of its input-gradient convolution
-    (``EPI_DACT``): no elementwise kernel runs between two convolutions.  Only the LAST block receives a true ``dL/dy`` (from
-    the pooling) and applies ``act'`` itself; only the FIRST block returns a true ``dL/dx`` (x = the pooled stem output, whose
-    activation derivative belongs to the stem)."""
+class RingSegment(torch.autograd.Function):
+    """A run of residual blocks of the pose CNN (reference BasicBlock.forward, src/models/resnet_modified.py:159-177) on channels-
+    last fp32 activations: ``forward(x, act, blocks, first, last, *weights)`` with blocks = tuple of (cin, cout, stride,
+    has_downsample) and the weights in block order (conv1, conv2[, downsample]); returns the last block's activated output.
+
+    Private gradient convention BETWEEN two segments (the tensors never leave ``ring_trunk``): the gradient a segment receives for
+    its output is already multiplied by ``act'(output)`` -- it is the gradient with respect to the PRE-activation -- because
+    the consumer folds that factor into the epilogue of its input-gradient convolution (``EPI_DACT``): no elementwise kernel
+    runs between two convolutions, across segment boundaries either.  Only the ``last`` segment receives a true ``dL/dy`` (from
+    the pooling) and applies ``act'`` itself; only the ``first`` one returns a true ``dL/dx`` (x = the pooled stem output,
+    whose activation derivative belongs to the stem)."""
 
     @staticmethod
-    def forward(ctx, x, act, cfg, first, last, *weights):
-        cin, cout, stride, has_ds = cfg
-        w1p, w2p = weights[0], weights[1]
-        wd = weight_storage(weights[2]) if has_ds else None
+    def forward(ctx, x0, act, blocks, first, last, *weights):
+        """Stride-1 3x3 layers run as fused Winograd F(2x2,3x3) when ``USE_WINOGRAD`` and the shape tiles (their
+        Winograd-domain weights for the backward pass are produced by the same launch and kept for it); the strided and 1x1
+        layers run the direct kernel."""
+        saved, x, wi = [x0], x0, 0
+        ubwd = []
         need_bwd = any(ctx.needs_input_grad)
-        N, H, W, _ = x.shape
-        if USE_WINOGRAD and stride == (1, 1) and wino_ok(H, W, cin, cout):
-            uf, ub1 = wino_weights(w1p, want_bwd=need_bwd)
-            y1 = wino_conv(x, uf, cout, act=act, epilogue=EPI_ACT)
-        else:
-            ub1 = None
-            y1 = conv_nhwc(x, weight_storage(w1p), stride=stride, act=act, epilogue=EPI_ACT)
-        shortcut = conv_nhwc(x, wd, stride=stride) if has_ds else x
-        Ho, Wo = y1.shape[1], y1.shape[2]
-        if USE_WINOGRAD and wino_ok(Ho, Wo, cout, cout):
-            uf, ub2 = wino_weights(w2p, want_bwd=need_bwd)
-            y2 = wino_conv(y1, uf, cout, act=act, epilogue=EPI_ADD | EPI_ACT, add=shortcut)
-        else:
-            ub2 = None
-            y2 = conv_nhwc(y1, weight_storage(w2p), act=act, epilogue=EPI_ADD | EPI_ACT, add=shortcut)
-        ctx.act, ctx.cfg, ctx.first, ctx.last = act, cfg, first, last
+        for (cin, cout, stride, has_ds) in blocks:
+            w1p, w2p = weights[wi], weights[wi + 1]
+            wd = weight_storage(weights[wi + 2]) if has_ds else None
+            wi += 3 if has_ds else 2
+            N, H, W, _ = x.shape
+            if USE_WINOGRAD and stride == (1, 1) and wino_ok(H, W, cin, cout):
+                uf, ub1 = wino_weights(w1p, want_bwd=need_bwd)
+                y1 = wino_conv(x, uf, cout, act=act, epilogue=EPI_ACT)
+            else:
+                ub1 = None
+                y1 = conv_nhwc(x, weight_storage(w1p), stride=stride, act=act, epilogue=EPI_ACT)
+            shortcut = conv_nhwc(x, wd, stride=stride) if has_ds else x
+            Ho, Wo = y1.shape[1], y1.shape[2]
+            if USE_WINOGRAD and wino_ok(Ho, Wo, cout, cout):
+                uf, ub2 = wino_weights(w2p, want_bwd=need_bwd)
+                y2 = wino_conv(y1, uf, cout, act=act, epilogue=EPI_ADD | EPI_ACT, add=shortcut)
+            else:
+                ub2 = None
+                y2 = conv_nhwc(y1, weight_storage(w2p), act=act, epilogue=EPI_ADD | EPI_ACT, add=shortcut)
+            ubwd += [ub1, ub2]
+            saved += [y1, y2]
+            x = y2
+        ctx.act, ctx.blocks, ctx.first, ctx.last = act, blocks, first, last
         # the Winograd-domain backward weights travel with the saved tensors (released with the graph, covered by autograd's
         # in-place version check like the raw weights); layers on the direct kernel have none
-        ubwd = [ub1, ub2]
         ctx.ubwd_mask = tuple(u is not None for u in ubwd)
-        ctx.save_for_backward(x, y1, y2, *weights, *[u for u in ubwd if u is not None])
-        return y2
+        ctx.save_for_backward(*saved, *weights, *[u for u in ubwd if u is not None])
+        return x
 
     @staticmethod
-    def backward(ctx, g):
-        act, (cin, cout, stride, has_ds), first = ctx.act, ctx.cfg, ctx.first
+    def backward(ctx, dy):
+        act, blocks = ctx.act, ctx.blocks
+        nb = len(blocks)
         saved = ctx.saved_tensors
-        nw = 3 if has_ds else 2
-        x, y1, y2 = saved[:3]
-        weights = saved[3:3 + nw]
-        u_it = iter(saved[3 + nw:])
-        ub1, ub2 = [next(u_it) if has else None for has in ctx.ubwd_mask]
-        g2 = g.contiguous()
-        if ctx.last:                                    # a true dL/dy: apply the activation derivative here
+        nu = sum(ctx.ubwd_mask)
+        acts, weights = saved[:1 + 2 * nb], saved[1 + 2 * nb:len(saved) - nu]
+        u_it = iter(saved[len(saved) - nu:])
+        ubwd = [next(u_it) if has else None for has in ctx.ubwd_mask]
+        grads = [None] * len(weights)
+        g2 = dy.contiguous()
+        if ctx.last:                                        # a true dL/dy: the activation derivative is applied here
+            y_last = acts[-1]
             if act == ACT["tanh"]:
-                g2 = g2 * (1.0 - y2 * y2)
+                g2 = g2 * (1.0 - y_last * y_last)
             elif act == ACT["relu"]:
-                g2 = g2 * (y2 > 0).to(g2.dtype)
-        w1p, w2p = weights[0], weights[1]
-        grads = [None] * nw
-        grads[1] = wgrad_nhwc(y1, g2, 3).permute(0, 3, 1, 2)
-        if ub2 is not None:
-            g1 = wino_conv(g2, ub2, cout, act=act, epilogue=EPI_DACT, dsrc=y1)
-        else:
-            g1 = conv_nhwc(g2, weight_storage(w2p), act=act, epilogue=EPI_DACT, dsrc=y1, transposed=True)
-        grads[0] = wgrad_nhwc(x, g1, 3, stride=stride).permute(0, 3, 1, 2)
-        gx = None
-        if not has_ds:
-            if ctx.needs_input_grad[0]:
+                g2 = g2 * (y_last > 0).to(g2.dtype)
+        wi = len(weights)
+        for b in range(nb - 1, -1, -1):
+            cin, cout, stride, has_ds = blocks[b]
+            wi -= 3 if has_ds else 2
+            w1p, w2p = weights[wi], weights[wi + 1]
+            x, y1 = acts[2 * b], acts[2 * b + 1]
+            first = ctx.first and b == 0                    # x0 is the pooled stem output: its act' belongs to the stem
+            grads[wi + 1] = wgrad_nhwc(y1, g2, 3).permute(0, 3, 1, 2)
+            ub1, ub2 = ubwd[2 * b], ubwd[2 * b + 1]
+            if ub2 is not None:
+                g1 = wino_conv(g2, ub2, cout, act=act, epilogue=EPI_DACT, dsrc=y1)
+            else:
+                g1 = conv_nhwc(g2, weight_storage(w2p), act=act, epilogue=EPI_DACT, dsrc=y1, transposed=True)
+            grads[wi] = wgrad_nhwc(x, g1, 3, stride=stride).permute(0, 3, 1, 2)
+            if not has_ds:
                 epi = EPI_ADD if first else (EPI_ADD | EPI_DACT)
                 if ub1 is not None:
-                    gx = wino_conv(g1, ub1, cin, act=act, epilogue=epi, add=g2, dsrc=None if first else x)
+                    g2 = wino_conv(g1, ub1, cin, act=act, epilogue=epi, add=g2, dsrc=None if first else x)
                 else:
-                    gx = conv_nhwc(g1, weight_storage(w1p), act=act, epilogue=epi, add=g2, dsrc=None if first else x, transposed=True)
-        else:
-            grads[2] = wgrad_nhwc(x, g2, 1, stride=stride).permute(0, 3, 1, 2)
-            if ctx.needs_input_grad[0]:
+                    g2 = conv_nhwc(g1, weight_storage(w1p), act=act, epilogue=epi, add=g2, dsrc=None if first else x, transposed=True)
+            else:
+                wdp = weights[wi + 2]
+                grads[wi + 2] = wgrad_nhwc(x, g2, 1, stride=stride).permute(0, 3, 1, 2)
                 # down-sampling branch on the grid, then one pass per stride phase of the 3x3 layer with it and act'(x) fused
-                dxb = dgrad_strided(g2, weight_storage(weights[2]), stride, dense=True)
+                dxb = dgrad_strided(g2, weight_storage(wdp), stride, dense=True)
                 epi = EPI_ADD_GRID if first else (EPI_ADD_GRID | EPI_DACT)
-                gx = dgrad_strided(g1, weight_storage(w1p), stride, act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)
+                g2 = dgrad_strided(g1, weight_storage(w1p), stride, act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)
         if BACKWARD_TRACE is not None:
-            BACKWARD_TRACE.append(("block", cin, cout, stride))
-        return (gx, None, None, None, None, *grads)
+            BACKWARD_TRACE.append(("segment", blocks[0][0], blocks[-1][1], nb))
+        return (g2, None, None, None, None, *grads)
 
 
-def ring_trunk(x0, act, blocks, weights):
-    """layer1..layer4 of the pose CNN: x0 ``[N,H,W,C0]`` channels-last fp32, already activated (the pooled stem output); blocks =
-    tuple of (cin, cout, stride, has_downsample); weights in block order (conv1, conv2[, downsample]).  Returns the last
-    feature map ``[N,H',W',C']``.  Stride-1 3x3 layers run as fused Winograd F(2x2,3x3) when ``USE_WINOGRAD`` and the shape
-    tiles, the strided and 1x1 layers on the direct kernel."""
-    x, wi = x0, 0
-    for b, cfg in enumerate(blocks):
-        nw = 3 if cfg[3] else 2
-        x = RingBlock.apply(x, act, cfg, b == 0, b == len(blocks) - 1, *weights[wi:wi + nw])
+def _run_segments(fn, x, act, blocks, weights, mode, last_applies_act):
+    segs = _segments(blocks, mode or TRUNK_SEGMENTS)
+    wi = 0
+    for i, (b0, b1) in enumerate(segs):
+        nw = sum(3 if blocks[b][3] else 2 for b in range(b0, b1))
+        x = fn.apply(x, act, tuple(blocks[b0:b1]), i == 0, last_applies_act and i == len(segs) - 1, *weights[wi:wi + nw])
         wi += nw
     return x
+
+
+def ring_trunk(x0, act, blocks, weights, segments=None):
+    """layer1..layer4 of the pose CNN: x0 ``[N,H,W,C0]`` channels-last fp32, already activated (the pooled stem output); blocks =
+    tuple of (cin, cout, stride, has_downsample); weights in block order (conv1, conv2[, downsample]).  Returns the last
+    feature map ``[N,H',W',C']``.  ``segments``: how the trunk is cut into autograd Functions (default ``TRUNK_SEGMENTS``)."""
+    return _run_segments(RingSegment, x0, act, blocks, list(weights), segments, True)
 
 
 class RingTrunk:
@@ -429,64 +480,73 @@ class CastToHalf(torch.autograd.Function):
         return g.float(), None
 
 
-class RingBlockH(torch.autograd.Function):
-    """``RingBlock`` in half precision: x / outputs / inter-block gradients in bf16 or fp16, fp32 parameters, fp32 weight
-    gradients (same private gradient convention between blocks, same launch structure; one weight-conversion launch per
-    convolution in addition)."""
+class RingSegmentH(torch.autograd.Function):
+    """``RingSegment`` in half precision: x / outputs / inter-segment gradients in bf16 or fp16, fp32 parameters, fp32 weight
+    gradients (same private gradient convention, same launch structure; one weight-conversion launch per convolution in
+    addition)."""
 
     @staticmethod
-    def forward(ctx, x, act, cfg, first, last, *weights):
-        cin, cout, stride, has_ds = cfg
-        dtype = x.dtype
+    def forward(ctx, x0, act, blocks, first, last, *weights):
+        dtype = x0.dtype
         need_bwd = any(ctx.needs_input_grad)
-        w1f, w1b = weights_h(weights[0], dtype, want_bwd=need_bwd)
-        w2f, w2b = weights_h(weights[1], dtype, want_bwd=need_bwd)
-        wdf, wdb = weights_h(weights[2], dtype, want_bwd=need_bwd) if has_ds else (None, None)
-        y1 = conv_nhwc_h(x, w1f, 3, stride=stride, act=act, epilogue=EPI_ACT)
-        shortcut = conv_nhwc_h(x, wdf, 1, stride=stride) if has_ds else x
-        y2 = conv_nhwc_h(y1, w2f, 3, act=act, epilogue=EPI_ADD | EPI_ACT, add=shortcut)
-        ctx.act, ctx.cfg, ctx.first, ctx.last = act, cfg, first, last
-        ctx.save_for_backward(x, y1, y2, *([w1b, w2b] + ([wdb] if has_ds else []) if need_bwd else []))
-        return y2
+        saved, wbs, x, wi = [x0], [], x0, 0
+        for (cin, cout, stride, has_ds) in blocks:
+            w1f, w1b = weights_h(weights[wi], dtype, want_bwd=need_bwd)
+            w2f, w2b = weights_h(weights[wi + 1], dtype, want_bwd=need_bwd)
+            wdf, wdb = weights_h(weights[wi + 2], dtype, want_bwd=need_bwd) if has_ds else (None, None)
+            wi += 3 if has_ds else 2
+            y1 = conv_nhwc_h(x, w1f, 3, stride=stride, act=act, epilogue=EPI_ACT)
+            shortcut = conv_nhwc_h(x, wdf, 1, stride=stride) if has_ds else x
+            y2 = conv_nhwc_h(y1, w2f, 3, act=act, epilogue=EPI_ADD | EPI_ACT, add=shortcut)
+            wbs += [w1b, w2b] + ([wdb] if has_ds else [])
+            saved += [y1, y2]
+            x = y2
+        ctx.act, ctx.blocks, ctx.first, ctx.last = act, blocks, first, last
+        ctx.n_w = len(weights)
+        ctx.save_for_backward(*saved, *(wbs if need_bwd else []))
+        return x
 
     @staticmethod
-    def backward(ctx, g):
-        lib = _lib.load()
-        act, (cin, cout, stride, has_ds), first = ctx.act, ctx.cfg, ctx.first
+    def backward(ctx, dy):
+        act, blocks = ctx.act, ctx.blocks
+        nb = len(blocks)
         saved = ctx.saved_tensors
-        x, y1, y2 = saved[:3]
-        wbs = saved[3:]
-        nw = 3 if has_ds else 2
-        g2 = g.contiguous()
-        if ctx.last:                                    # never taken by ring_trunk_h (the pooling Function hands over the
-            if act == ACT["tanh"]:                      # pre-activation gradient); kept for stand-alone use of a block
-                g2 = (g2.float() * (1.0 - y2.float() ** 2)).to(g2.dtype)
+        acts, wbs = saved[:1 + 2 * nb], saved[1 + 2 * nb:]
+        grads = [None] * ctx.n_w
+        g2 = dy.contiguous()
+        if ctx.last:                                    # never taken by ring_trunk_h (the pooling Function hands over the pre-
+            y_last = acts[-1]                           # activation gradient); kept for stand-alone use of a segment
+            if act == ACT["tanh"]:
+                g2 = (g2.float() * (1.0 - y_last.float() ** 2)).to(g2.dtype)
             elif act == ACT["relu"]:
-                g2 = g2 * (y2 > 0).to(g2.dtype)
-        grads = [None] * nw
-        grads[1] = wgrad_nhwc_h(y1, g2, 3).permute(0, 3, 1, 2)
-        g1 = conv_nhwc_h(g2, wbs[1], 3, act=act, epilogue=EPI_DACT, dsrc=y1, transposed=True)
-        grads[0] = wgrad_nhwc_h(x, g1, 3, stride=stride).permute(0, 3, 1, 2)
-        gx = None
-        if not has_ds:
-            if ctx.needs_input_grad[0]:
+                g2 = g2 * (y_last > 0).to(g2.dtype)
+        wi = ctx.n_w
+        for b in range(nb - 1, -1, -1):
+            cin, cout, stride, has_ds = blocks[b]
+            wi -= 3 if has_ds else 2
+            w1b, w2b = wbs[wi], wbs[wi + 1]
+            x, y1 = acts[2 * b], acts[2 * b + 1]
+            first = ctx.first and b == 0
+            grads[wi + 1] = wgrad_nhwc_h(y1, g2, 3).permute(0, 3, 1, 2)
+            g1 = conv_nhwc_h(g2, w2b, 3, act=act, epilogue=EPI_DACT, dsrc=y1, transposed=True)
+            grads[wi] = wgrad_nhwc_h(x, g1, 3, stride=stride).permute(0, 3, 1, 2)
+            if not has_ds:
                 epi = EPI_ADD if first else (EPI_ADD | EPI_DACT)
-                gx = conv_nhwc_h(g1, wbs[0], 3, act=act, epilogue=epi, add=g2, dsrc=None if first else x, transposed=True)
-        else:
-            grads[2] = wgrad_nhwc_h(x, g2, 1, stride=stride).permute(0, 3, 1, 2)
-            if ctx.needs_input_grad[0]:
-                dxb = dgrad_strided_h(g2, wbs[2], 1, stride, dense=True)
+                g2 = conv_nhwc_h(g1, w1b, 3, act=act, epilogue=epi, add=g2, dsrc=None if first else x, transposed=True)
+            else:
+                grads[wi + 2] = wgrad_nhwc_h(x, g2, 1, stride=stride).permute(0, 3, 1, 2)
+                dxb = dgrad_strided_h(g2, wbs[wi + 2], 1, stride, dense=True)
                 epi = EPI_ADD_GRID if first else (EPI_ADD_GRID | EPI_DACT)
-                gx = dgrad_strided_h(g1, wbs[0], 3, stride, act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)
+                g2 = dgrad_strided_h(g1, w1b, 3, stride, act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)
         if BACKWARD_TRACE is not None:
-            BACKWARD_TRACE.append(("block", cin, cout, stride))
-        return (gx, None, None, None, None, *grads)
+            BACKWARD_TRACE.append(("segment", blocks[0][0], blocks[-1][1], nb))
+        return (g2, None, None, None, None, *grads)
 
 
 class MeanHWActH(torch.autograd.Function):
     """Global average pooling of the last half-precision feature map -> fp32 ``[N,C]``; its backward is fused with the activation
     derivative of the block that produced the map and returns the gradient with respect to that block's PRE-activation (the
-    private convention of ``RingBlockH``)."""
+    private convention of ``RingSegmentH``)."""
 
     @staticmethod
     def forward(ctx, y, act):
@@ -509,14 +569,10 @@ class MeanHWActH(torch.autograd.Function):
         return g, None
 
 
-def ring_trunk_h(x0, act, blocks, dtype, weights):
+def ring_trunk_h(x0, act, blocks, dtype, weights, segments=None):
     """layer1..layer4 + global average pooling in half precision: x0 ``[N,H,W,C0]`` fp32 channels-last (the pooled stem output),
     fp32 parameters in block order; returns the pooled features ``[N,C']`` in fp32."""
-    x, wi = CastToHalf.apply(x0, dtype), 0
-    for b, cfg in enumerate(blocks):
-        nw = 3 if cfg[3] else 2
-        x = RingBlockH.apply(x, act, cfg, b == 0, False, *weights[wi:wi + nw])
-        wi += nw
+    x = _run_segments(RingSegmentH, CastToHalf.apply(x0, dtype), act, blocks, list(weights), segments, False)
     return MeanHWActH.apply(x, act)
 
 

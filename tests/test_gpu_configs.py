@@ -390,40 +390,52 @@ def test_ddp_wrapping_uses_small_buckets_and_bucket_views():
         tr.world_size = 2                                    # wrap as a 2-rank job would
         wrapped = Trainer._wrap_ddp(tr, tr.raw_model)
         assert isinstance(wrapped, torch.nn.parallel.DistributedDataParallel)
-        assert wrapped.bucket_bytes_cap == 10 * 1024 * 1024 and wrapped.gradient_as_bucket_view
+        assert wrapped.bucket_bytes_cap == 5 * 1024 * 1024 and wrapped.gradient_as_bucket_view
     finally:
         dist.destroy_process_group()
 
 
 def test_full_size_step_replays_as_a_hip_graph():
-    """The whole bench step (64x2048, B=8, HIP stem + trunk) captured once and replayed: three replays must run (a memset
-    node in the captured graph used to fault on the second replay: the library initialises its buffers with a kernel
-    instead) and follow the eager trajectory."""
+    """The whole bench step (64x2048, B=8, HIP stem + trunk) captured once and replayed over ROTATING RAGGED batches (different scan
+    lengths and contents per step, packed into the graph's static buffers): the replays must run (a memset node in the captured
+    graph used to fault on the second replay: the library initialises its buffers with a kernel instead) and follow the eager
+    trajectory of the same batch sequence."""
     from delora_amd.deploy.graph_step import GraphedStep
     dev = _dev()
-    args, cfg, samples, tr_e = _bench_setup(8, dev)
+    args, cfg, batches, tr_e = _bench_setup(8, dev, rotate=4)
+    lengths = {d[k].shape[2] for b in batches for d in b for k in ("scan_1", "scan_2")}
+    assert len(lengths) > 8, "the rotating batches must be ragged"
+    seq = [0, 0, 0, 1, 2, 3, 0, 1]                       # three warm-up steps on batch 0 (as GraphedStep does), then the rotation
     eager = []
-    for _ in range(6):
-        ep, _ = _one_step(tr_e, samples)
+    for i in seq:
+        ep, _ = _one_step(tr_e, batches[i])
         eager.append(float(ep["loss_epoch"]))
-    args, cfg, samples, tr_g = _bench_setup(8, dev)
-    gs = GraphedStep(tr_g, samples, warmup=3)
+    args, cfg, batches, tr_g = _bench_setup(8, dev, rotate=4)
+    gs = GraphedStep(tr_g, batches[0], warmup=3)
     assert gs.captured
     got = []
-    for _ in range(3):
-        ep, _ = gs()
+    for i in seq[3:]:
+        ep, _ = gs(batches[i])
         torch.cuda.synchronize()
         got.append(float(ep["loss_epoch"]))
+    assert gs.fallback_steps == 0
     print("eager", eager, "graph", got)
-    util.measured("full-size graph replay: worst relative deviation of the loss from the eager trajectory",
-                  float(np.max(np.abs(np.array(got) - np.array(eager[3:6])) / np.abs(np.array(eager[3:6])))), bound=1e-3)
+    util.measured("full-size graph replay over rotating ragged batches: worst relative deviation of the loss from the eager trajectory",
+                  float(np.max(np.abs(np.array(got) - np.array(eager[3:])) / np.abs(np.array(eager[3:])))), bound=1e-3)
+    # a batch that does not fit the static buffers runs eagerly instead of failing
+    long_batch = [dict(d) for d in batches[1]]
+    long_batch[0]["scan_1"] = torch.cat([long_batch[0]["scan_1"]] * 2, dim=2)
+    ep, _ = gs(long_batch)
+    assert gs.fallback_steps == 1 and np.isfinite(float(ep["loss_epoch"]))
 
 
 def test_ddp_all_reduce_overlaps_the_trunk_backward():
-    """The gradient all-reduce is the path's only exchange.  Every residual block is its own autograd Function, so
-    DistributedDataParallel receives a block's weight gradients when that block's backward has run: the buckets holding layer4 and
-    layer3 (85 % of the 47.5 MB) must be handed to the communication hook BEFORE the backward of layer1 has finished, and what is
-    still outstanding when the last trunk block returns must be less than one 10 MB bucket."""
+    """The gradient all-reduce is the path's only exchange.  Under DDP the trunk is cut into three autograd Functions
+    ([layer1+2] [layer3] [layer4]; ``Trainer._wrap_ddp``), so DistributedDataParallel receives layer4's and layer3's weight
+    gradients (89 % of the 47.5 MB) when those segments' backward has run: their buckets must be handed to the communication hook
+    BEFORE the backward of layer1 + layer2 has finished, and what is still outstanding when the last segment returns must be less
+    than one 10 MB bucket.  (One Function per block would overlap more but costs the host 1.7 ms per step -- the eager step is
+    only just GPU-bound; measured with bench.py --trunk-segments.)"""
     dev = _dev()
     import torch.distributed as dist
     from delora_amd.models import ring_conv
@@ -457,13 +469,13 @@ def test_ddp_all_reduce_overlaps_the_trunk_backward():
     finally:
         ring_conv.BACKWARD_TRACE = None
         dist.destroy_process_group()
-    blocks = [i for i, e in enumerate(trace) if e[0] == "block"]
-    assert len(blocks) == 8, trace
+    segs = [i for i, e in enumerate(trace) if e[0] == "segment"]
+    assert len(segs) == 3 and [trace[i][3] for i in segs] == [2, 2, 4], trace          # layer4, layer3, layer1+2 (backward order)
     total = sum(e[2] for e in trace if e[0] == "bucket")
-    after_trunk = sum(e[2] for e in trace[blocks[-1]:] if e[0] == "bucket")
-    # blocks run layer4.1, 4.0, 3.1, 3.0, 2.1, 2.0, 1.1, 1.0; a bucket is launched when the LAST of its parameters is ready
-    early = sum(e[2] for e in trace[:blocks[4]] if e[0] == "bucket")              # before layer2.1's backward has finished
-    util.measured("DDP: gradient bytes handed to the all-reduce only after the last trunk block's backward", after_trunk, bound=10 * 1024 * 1024)
-    util.measured("DDP: share of the gradient bytes already in flight when the backward of layer2 finishes its first block", early / total)
+    after_trunk = sum(e[2] for e in trace[segs[-1]:] if e[0] == "bucket")
+    # a bucket is launched when the LAST of its parameters is ready, i.e. when the segment holding it has returned
+    early = sum(e[2] for e in trace[:segs[-1]] if e[0] == "bucket")               # before the backward of layer1 + layer2 has finished
+    util.measured("DDP: gradient bytes handed to the all-reduce only after the last trunk segment's backward", after_trunk, bound=10 * 1024 * 1024)
+    util.measured("DDP: share of the gradient bytes already in flight while layer1 + layer2 still run their backward", early / total)
     assert abs(total - 4 * sum(p.numel() for p in tr.raw_model.parameters())) < 1024
     assert early / total > 0.6
