@@ -67,6 +67,8 @@ SIGNATURES = {
     "dl_wino_wgrad3x3_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dl_pool3x3s12_nhwc_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "dl_pool3x3s12_nhwc_bwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "dl_stem_wgrad_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "dl_stem_wgrad_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "dl_quat_to_T_fwd": (_i32, [_vp, _vp, _i32, ctypes.c_float, _vp, _vp]),
     "dl_quat_to_T_bwd": (_i32, [_vp, _vp, _i32, ctypes.c_float, _vp, _vp, _vp]),
     "dl_mean_hw_nhwc_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),

@@ -51,40 +51,42 @@ __global__ __launch_bounds__(DL_BLOCK) void k_pool_nhwc_fwd(const float* __restr
   *reinterpret_cast<uint32_t*>(win + (size_t)i * 4) = (uint32_t)k0 | ((uint32_t)k1 << 8) | ((uint32_t)k2 << 16) | ((uint32_t)k3 << 24);
 }
 
-__global__ __launch_bounds__(DL_BLOCK) void k_pool_nhwc_bwd(const float* __restrict__ g, const float* __restrict__ a,
-                                                            const int8_t* __restrict__ win, int H, int Wc, int C4, int act,
-                                                            uint32_t total, float* __restrict__ g_conv) {
-  const uint32_t i = blockIdx.x * DL_BLOCK + threadIdx.x;
-  if (i >= total) return;
+// Gradient of pool(act(.)) with respect to the conv1 PRE-activation at conv1-output pixel (row r of image-row index nr, column j),
+// channels 4 c4 .. 4 c4 + 3: act'(a) * sum of g over the pooled windows that selected the element.
+__device__ __forceinline__ f32x4s pool_bwd_value(const float* __restrict__ g, const float* __restrict__ a, const int8_t* __restrict__ win,
+                                                 int H, int Wc, int C4, int act, uint32_t nr, int r, int j, int c4) {
   const int Wp = Wc >> 1;
-  const uint32_t pix = i / (uint32_t)C4;                 // (n, r, j) of the conv1 output
-  const int c4 = (int)(i - pix * (uint32_t)C4);
-  const uint32_t nr = pix / (uint32_t)Wc;
-  const int j = (int)(pix - nr * (uint32_t)Wc);
-  const int r = (int)(nr % (uint32_t)H);
   // windows that contain column j: q = j/2 at window column 1 (j even) or 2 (j odd); for odd j also q+1 (wrapped) at column 0
   const int q0 = j >> 1, col0 = 1 + (j & 1);
   const int q1 = (q0 + 1 == Wp) ? 0 : q0 + 1;
   const bool two = (j & 1) != 0;
-  f32x4s acc = {0.f, 0.f, 0.f, 0.f};
+  // branch-free: all six (window code, gradient) candidates are loaded back to back -- rows outside the image are clamped
+  // and the second window column of an even j re-reads the first -- and disqualified by a code no window position has
+  uint32_t w4[6];
+  f32x4s gv[6];
+  uint32_t code[6];
 #pragma unroll
   for (int d = -1; d <= 1; ++d) {                        // pooled row r + d sees this element at window row 1 - d
-    if (r + d < 0 || r + d >= H) continue;
-    const size_t rowbase = (size_t)(nr + d) * Wp;
+    const bool row_ok = r + d >= 0 && r + d < H;
+    const size_t rowbase = (size_t)(nr + (row_ok ? d : 0)) * Wp;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      if (t == 1 && !two) continue;
-      const size_t e = ((rowbase + (t ? q1 : q0)) * (size_t)C4 + c4) * 4;
-      const uint32_t w4 = *reinterpret_cast<const uint32_t*>(win + e);
-      const uint32_t code = (uint32_t)((1 - d) * 3 + (t ? 0 : col0));
-      const f32x4s gv = *reinterpret_cast<const f32x4s*>(g + e);
-      if ((w4 & 0xffu) == code) acc.x += gv.x;
-      if (((w4 >> 8) & 0xffu) == code) acc.y += gv.y;
-      if (((w4 >> 16) & 0xffu) == code) acc.z += gv.z;
-      if ((w4 >> 24) == code) acc.w += gv.w;
+      const int i = (d + 1) * 2 + t;
+      const size_t e = ((rowbase + ((t && two) ? q1 : q0)) * (size_t)C4 + c4) * 4;
+      w4[i] = *reinterpret_cast<const uint32_t*>(win + e);
+      gv[i] = *reinterpret_cast<const f32x4s*>(g + e);
+      code[i] = (row_ok && (t == 0 || two)) ? (uint32_t)((1 - d) * 3 + (t ? 0 : col0)) : 0xffu;
     }
   }
-  const f32x4s av = *reinterpret_cast<const f32x4s*>(a + (size_t)i * 4);
+  f32x4s acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    acc.x += (w4[i] & 0xffu) == code[i] ? gv[i].x : 0.f;
+    acc.y += ((w4[i] >> 8) & 0xffu) == code[i] ? gv[i].y : 0.f;
+    acc.z += ((w4[i] >> 16) & 0xffu) == code[i] ? gv[i].z : 0.f;
+    acc.w += (w4[i] >> 24) == code[i] ? gv[i].w : 0.f;
+  }
+  const f32x4s av = *reinterpret_cast<const f32x4s*>(a + (((size_t)nr * Wc + j) * C4 + c4) * 4);
   f32x4s out;
   if (act == ST_TANH) {
     out.x = acc.x * (1.f - av.x * av.x); out.y = acc.y * (1.f - av.y * av.y);
@@ -95,7 +97,131 @@ __global__ __launch_bounds__(DL_BLOCK) void k_pool_nhwc_bwd(const float* __restr
   } else {
     out = acc;
   }
-  *reinterpret_cast<f32x4s*>(g_conv + (size_t)i * 4) = out;
+  return out;
+}
+
+__global__ __launch_bounds__(DL_BLOCK) void k_pool_nhwc_bwd(const float* __restrict__ g, const float* __restrict__ a,
+                                                            const int8_t* __restrict__ win, int H, int Wc, int C4, int act,
+                                                            uint32_t total, float* __restrict__ g_conv) {
+  const uint32_t i = blockIdx.x * DL_BLOCK + threadIdx.x;
+  if (i >= total) return;
+  const uint32_t pix = i / (uint32_t)C4;                 // (n, r, j) of the conv1 output
+  const int c4 = (int)(i - pix * (uint32_t)C4);
+  const uint32_t nr = pix / (uint32_t)Wc;
+  const int j = (int)(pix - nr * (uint32_t)Wc);
+  const int r = (int)(nr % (uint32_t)H);
+  *reinterpret_cast<f32x4s*>(g_conv + (size_t)i * 4) = pool_bwd_value(g, a, win, H, Wc, C4, act, nr, r, j, c4);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient of conv1 (3x3, stride (1,2), 8 -> 64 channels, wrap-around width; reference src/models/resnet_modified.py:
+// 40-42, :97-98) FUSED with the pooling backward and the activation derivative: the gradient g_c with respect to conv1's
+// pre-activation -- [N][H][Wc][64], 134 MB at batch 8 -- is produced tile by tile in LDS (pool_bwd_value) and consumed as
+// the A operand of dw[k][(tap, c)] = sum_pixels g_c[pixel][k] * x[pixel + tap][c], so it never exists in memory and the
+// library convolution that used to compute this gradient (the last one of the fp32 step) is gone.
+//   M = 64 k (two 32-row subtiles), N = 72 (tap, c) columns in three 32-column subtiles (96, 24 unused), reduction = pixels
+//   on v_mfma_f32_32x32x2_f32.  A workgroup walks a slab of 64-pixel chunks of one image row; per chunk the 256 threads build
+//   the g_c tile and stage the 3 x 130 x 8 input patch, then wave w multiplies pixels 16w .. 16w+15 (48 MFMAs); the four waves'
+//   accumulators are added through LDS at the end and the slab partials summed in a fixed order by k_stem_wgrad_reduce.
+#define SG_PX 64
+#define SG_XCOLS (2 * SG_PX + 2)
+typedef float f32x16s __attribute__((ext_vector_type(16)));
+
+__global__ __launch_bounds__(DL_BLOCK, 2) void k_stem_wgrad(const float* __restrict__ g, const float* __restrict__ a,
+                                                            const int8_t* __restrict__ win, const float* __restrict__ x8, int N, int H,
+                                                            int Wc, int act, int chunks_per_slab, float* __restrict__ part) {
+  constexpr int K = 64, C4 = 16;
+  __shared__ __attribute__((aligned(16))) float gc[SG_PX * K];                 // [pixel][k]; reused for the final wave reduction
+  __shared__ __attribute__((aligned(16))) float xt[3 * SG_XCOLS * 8];          // [row][col][c]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, half = lane >> 5;
+  const int W = 2 * Wc;
+  const int cpr = Wc / SG_PX;                                                  // chunks per image row
+  const int total = N * H * cpr;
+  const int ch_begin = blockIdx.x * chunks_per_slab, ch_end = min(ch_begin + chunks_per_slab, total);
+  f32x16s acc[2][3];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  // B-operand columns of this lane: j = li + 32 ns -> (tap = j / 8 = (r, s), c = j % 8); columns 72..95 read a valid address, unused
+  int b_off[3];
+#pragma unroll
+  for (int ns = 0; ns < 3; ++ns) {
+    const int j = min(li + 32 * ns, 71), tap = j >> 3, c = j & 7;
+    b_off[ns] = ((tap / 3) * SG_XCOLS + (tap % 3)) * 8 + c;
+  }
+  for (int ch = ch_begin; ch < ch_end; ++ch) {
+    const int cb = ch % cpr;
+    const uint32_t nr = (uint32_t)(ch / cpr);                                  // n * H + h
+    const int h = (int)(nr % (uint32_t)H), wc0 = cb * SG_PX;
+    __syncthreads();                                                           // the previous chunk's fragments have been read
+#pragma unroll
+    for (int it = 0; it < SG_PX * C4 / DL_BLOCK; ++it) {
+      const int q = tid + it * DL_BLOCK, pl = q / C4, c4 = q % C4;
+      *reinterpret_cast<f32x4s*>(gc + pl * K + c4 * 4) = pool_bwd_value(g, a, win, H, Wc, C4, act, nr, h, wc0 + pl, c4);
+    }
+    for (int q = tid; q < 3 * SG_XCOLS * 2; q += DL_BLOCK) {                    // 16-byte items: (row, col, half pixel)
+      const int hp = q & 1, col = (q >> 1) % SG_XCOLS, row = (q >> 1) / SG_XCOLS;
+      const int hh = h + row - 1;
+      int w = 2 * wc0 - 1 + col;
+      w = w < 0 ? w + W : (w >= W ? w - W : w);
+      f32x4s v = {0.f, 0.f, 0.f, 0.f};
+      if (hh >= 0 && hh < H) v = *reinterpret_cast<const f32x4s*>(x8 + (((size_t)(nr + row - 1)) * W + w) * 8 + hp * 4);
+      *reinterpret_cast<f32x4s*>(xt + (row * SG_XCOLS + col) * 8 + hp * 4) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const int pl = wave * 16 + ks * 2 + half;                                // this lane's pixel of the reduction pair
+      const float a0 = gc[pl * K + li], a1 = gc[pl * K + 32 + li];
+      float b[3];
+#pragma unroll
+      for (int ns = 0; ns < 3; ++ns) b[ns] = xt[b_off[ns] + 2 * pl * 8];
+#pragma unroll
+      for (int ns = 0; ns < 3; ++ns) {
+        acc[0][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b[ns], acc[0][ns], 0, 0, 0);
+        acc[1][ns] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b[ns], acc[1][ns], 0, 0, 0);
+      }
+    }
+  }
+  // sum of the four waves' accumulators in a fixed order (0 + 1 + 2 + 3) through LDS, one accumulator at a time (3 x 4 KiB), then the
+  // slab's partial [64][72]
+  __syncthreads();
+  float* red = gc;
+#pragma unroll
+  for (int ms = 0; ms < 2; ++ms)
+#pragma unroll
+    for (int ns = 0; ns < 3; ++ns) {
+      if (wave > 0)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(wave - 1) * 1024 + r * 64 + lane] = acc[ms][ns][r];
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[ms][ns][r] = ((acc[ms][ns][r] + red[r * 64 + lane]) + red[1024 + r * 64 + lane]) + red[2048 + r * 64 + lane];
+        const int j = ns * 32 + li;
+        if (j < 72)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int k = ms * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            part[((size_t)blockIdx.x * K + k) * 72 + j] = acc[ms][ns][r];
+          }
+      }
+      __syncthreads();
+    }
+}
+
+// dw [64][8][3][3] (the parameter's default layout) = sum over slabs of part[slab][k][(r*3+s)*8 + c], slabs in order
+__global__ __launch_bounds__(DL_BLOCK) void k_stem_wgrad_reduce(const float* __restrict__ part, int nslabs, float* __restrict__ dw) {
+  const int i = blockIdx.x * DL_BLOCK + threadIdx.x;                           // (k, j) with j = tap * 8 + c
+  if (i >= 64 * 72) return;
+  float s = 0.f;
+  for (int sl = 0; sl < nslabs; ++sl) s += part[(size_t)sl * 64 * 72 + i];
+  const int k = i / 72, j = i % 72, tap = j >> 3, c = j & 7;
+  dw[(k * 8 + c) * 9 + tap] = s;
 }
 
 // Global average pooling of the last feature map, channels-last: x [N][P][C] -> y [N][C] (reference resnet_modified.py:
@@ -157,4 +283,28 @@ extern "C" int dl_pool3x3s12_nhwc_bwd(const float* g, const float* a, const int8
   hipLaunchKernelGGL(k_pool_nhwc_bwd, dim3((total + DL_BLOCK - 1) / DL_BLOCK), dim3(DL_BLOCK), 0, (hipStream_t)stream, g, a, win,
                      H, W, C / 4, act, total, g_conv);
   return dl_check_launch("dl_pool3x3s12_nhwc_bwd");
+}
+
+static int stem_wgrad_slabs(int total_chunks) { return total_chunks < 1024 ? total_chunks : 1024; }
+
+/* see include/delora_hip.h */
+extern "C" size_t dl_stem_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t W) {
+  if (N <= 0 || H <= 0 || W <= 0 || W % (2 * SG_PX)) return 0;
+  return (size_t)stem_wgrad_slabs(N * H * (W / 2 / SG_PX)) * 64 * 72 * sizeof(float);
+}
+
+extern "C" int dl_stem_wgrad_f32(const float* g_pooled, const float* a, const int8_t* win, const float* x8, int32_t N, int32_t H,
+                                 int32_t W, int32_t act, void* workspace, float* dw, dl_stream stream) {
+  if (!g_pooled || !a || !win || !x8 || !workspace || !dw || N <= 0 || H <= 0 || W <= 0 || act < 0 || act > 2)
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_stem_wgrad_f32: bad argument");
+  if (W % (2 * SG_PX) || (size_t)N * H * W * 32 >= ((size_t)1 << 32))
+    return dl_fail(DL_ERR_UNSUPPORTED, "dl_stem_wgrad_f32: N=%d H=%d W=%d not supported (W %% %d, conv1 output below 2^32 elements)", N, H, W, 2 * SG_PX);
+  const int Wc = W / 2, total = N * H * (Wc / SG_PX), nslabs = stem_wgrad_slabs(total);
+  const int cps = (total + nslabs - 1) / nslabs, grid = (total + cps - 1) / cps;
+  hipStream_t st = (hipStream_t)stream;
+  const DlProfTag tag{"k_stem_wgrad", "wgrad", N, H, W, 8, 64, 2.0 * N * H * Wc * 64.0 * 72.0,
+                      4.0 * ((double)N * H * Wc * 64 * 1.5 + (double)N * H * W * 8) + (double)N * H * (Wc / 2) * 64};
+  DL_LAUNCH(tag, k_stem_wgrad, dim3(grid), dim3(DL_BLOCK), st, g_pooled, a, win, x8, N, H, Wc, act, cps, (float*)workspace);
+  hipLaunchKernelGGL(k_stem_wgrad_reduce, dim3((64 * 72 + DL_BLOCK - 1) / DL_BLOCK), dim3(DL_BLOCK), 0, st, (const float*)workspace, grid, dw);
+  return dl_check_launch("dl_stem_wgrad_f32");
 }

@@ -214,9 +214,10 @@ class RingStem(torch.autograd.Function):
     """conv1 (3x3, stride (1,2), wrap-around width) + activation + the 3x3 / stride (1,2) max-pooling of the stem on
     channels-last tensors (reference resnet_modified.py:97-102): ``[N,8,H,W]`` planar input -> ``[N,H,W/4,64]``.  Forward:
     one transposing copy of the 8-channel input, the direct MFMA convolution with the activation in its epilogue, the
-    pooling kernel.  Backward: pooling + activation derivative in one gather kernel, then the weight gradient (8 input
-    channels are below the tile of dl_conv2d_wgrad_nhwc_f32: the library's channels-last kernel on views, no layout
-    conversion).  The 134 MB pre-pooling map is kept for the backward (the pooled output is not: the trunk saves it)."""
+    pooling kernel.  Backward: pooling backward + activation derivative + conv1's weight gradient in ONE kernel
+    (``dl_stem_wgrad_f32``); only when the gradient with respect to the INPUT image is wanted (never in training: the range image
+    is data) the three steps run separately with the library's convolution backward.  The 134 MB pre-pooling map is kept for
+    the backward (the pooled output is not: the trunk saves it)."""
 
     @staticmethod
     def forward(ctx, x, w1, act):
@@ -230,9 +231,20 @@ class RingStem(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x8, a, win, w1 = ctx.saved_tensors
+        want_x = ctx.needs_input_grad[0]
+        lib = _lib.load()
+        N, H, W, _ = x8.shape
+        nbytes = 0 if want_x or a.shape[3] != 64 or x8.shape[3] != 8 else lib.dl_stem_wgrad_workspace_bytes(N, H, W)
+        if nbytes:
+            # the usual case (the range image is data): pooling backward + act' + conv1's weight gradient in ONE kernel, the
+            # gradient with respect to conv1's pre-activation (134 MB at batch 8) is never written (csrc/stem.hip: k_stem_wgrad)
+            ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x8.device)
+            dw = torch.empty((64, 8, 3, 3), dtype=torch.float32, device=x8.device)
+            _lib.check(lib.dl_stem_wgrad_f32(_ptr(g.contiguous()), _ptr(a), _ptr(win), _ptr(x8), N, H, W, int(ctx.act), _ptr(ws), _ptr(dw),
+                                             _stream()), "dl_stem_wgrad_f32")
+            return None, dw, None
         gc = pool_bwd(g.contiguous(), a, win, ctx.act)
         xp = torch.cat((x8[:, :, -1:], x8, x8[:, :, :1]), dim=2).permute(0, 3, 1, 2)       # wrapped, channels_last strides
-        want_x = ctx.needs_input_grad[0]
         gx, dw, _ = torch.ops.aten.convolution_backward(gc.permute(0, 3, 1, 2), xp, w1, None, (1, 2), (1, 0), (1, 1), False,
                                                         (0, 0), 1, (want_x, True, False))
         if want_x:                                     # fold the two wrap columns back

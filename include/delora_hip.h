@@ -358,6 +358,15 @@ int dl_pool3x3s12_nhwc_fwd(const float* a, int32_t N, int32_t H, int32_t W, int3
 int dl_pool3x3s12_nhwc_bwd(const float* g, const float* a, const int8_t* win, int32_t N, int32_t H, int32_t W, int32_t C,
                            int32_t act, float* g_conv, dl_stream stream);
 
+/* Weight gradient of conv1 (3x3, stride (1,2), 8 -> 64 channels; reference src/models/resnet_modified.py:40-42, :97-98) fused with
+ * the pooling backward and the activation derivative: g_pooled [N][H][W/4][64] (gradient of the pooled map), a [N][H][W/2][64] and
+ * win (forward outputs of conv1 + activation and of dl_pool3x3s12_nhwc_fwd), x8 [N][H][W][8] (the channels-last network input)
+ * -> dw [64][8][3][3] (the parameter's default layout).  The 134 MB gradient with respect to conv1's pre-activation is built
+ * tile by tile in LDS and never written.  W % 128 == 0; workspace bytes from the first function (0 = not supported). */
+size_t dl_stem_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t W);
+int dl_stem_wgrad_f32(const float* g_pooled, const float* a, const int8_t* win, const float* x8, int32_t N, int32_t H, int32_t W,
+                      int32_t act, void* workspace, float* dw, dl_stream stream);
+
 /* Quaternion (x,y,z,w) + translation -> T [B][4][4] = [[R, t], [0, 1]] and its backward (reference src/models/model_parts.py:
  * 24-44; R = kornia 0.3.0 quaternion_to_rotation_matrix: normalise with eps, then the element-wise formula):
  *   dl_quat_to_T_fwd: translation [B][3], quaternion [B][4] -> T
