@@ -369,7 +369,7 @@ extern "C" int dl_wino_weights_f32(const float* w, float* u_fwd, float* u_bwd, i
 // DMA brought in) and one column of A g A^T (16 scalar loads of g, coalesced over the 64 channels of a wave), written as
 // 16-byte rows [xi][channel][4 tiles]: lane (i, half) reads tiles 4 half .. 4 half+3 of its row, MFMA j reduces over tiles
 // {j, 4 + j}.  Addressing validated by tools/exp/wino_wgrad_emulate.py; tools/exp/wino_wgrad.hip is the stand-alone check.
-// Measured (B=8): layer2 306 us (direct kernel 335), layer3 572 (607), layer4 574 (608); 64-channel layers stay direct.
+// Measured (B=8, slab sum and G^T . G kernels included): layer2 259 us (direct kernel 335), layer3 463 (607), layer4 464 (608); 64-channel layers stay direct.
 #define WW_THREADS 512
 #define WW_PLANE 528                     // floats per plane: 64 rows x 8 tiles + 16 of padding
 #define WW_BUF (2 * 16 * WW_PLANE)       // one (Gh, Dh) pair
@@ -383,11 +383,22 @@ struct WWArgs {
   int N, H, W, C, K, chunks_per_slab, nslabs;
 };
 
+// Pipeline (round 3; the first version ran the transforms in a phase of their own between two barriers while the matrix pipe
+// idled: 557 us on layer3, this one 463): the transforms of chunk ch+1 are sliced into small pieces placed behind the individual
+// MFMAs of chunk ch (as k_wino_conv does), branch-free, with the LDS reads of a piece issued one slot ahead of their use.
+// Per iteration:
+//   first half   MFMAs of planes 0..3 of chunk ch  ||  Dh(ch+1) = B^T d B from the raw input patch (landed by DMA during the
+//                previous iteration) and Gh(ch+1) = A g A^T from the gradient values held in registers -> buf[nxt]
+//   barrier M    every thread has read the raw patch and consumed its gradient registers
+//   second half  the DMA of the raw patch and the 16 gradient loads of chunk ch+2 are issued at once (they have the whole half to
+//                land);  MFMAs of planes 4..7
+//   wait + barrier E
+// Chunk indices beyond the slab are clamped (a harmless repeat of the last chunk: no branch in the loop body).
 __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
   static_assert((2 * WW_BUF + WW_RAW) * 4 <= 163840, "LDS budget");
   __shared__ __attribute__((aligned(16))) float lds[2 * WW_BUF + WW_RAW];
   float* raw = lds + 2 * WW_BUF;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, half = lane >> 5;
   const int mb = wave & 1, nb = (wave >> 1) & 1, xh = wave >> 2;
   const int CT = a.C / 64;
@@ -400,86 +411,86 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
   const int total_chunks = a.N * th * tw8;
   const int ch_begin = slab * a.chunks_per_slab;
   const int ch_end = min(ch_begin + a.chunks_per_slab, total_chunks);
+  if (ch_begin >= ch_end) return;                                                   // (never: every slab holds a chunk)
 
-  // transform role: channel r of the block (c for Dh, k for Gh), tile quad tq, column bcol of the 4x4 domain
-  const int r = tid & 63, tq = (tid >> 6) & 1, bcol = tid >> 7;
+  // transform role: channel r of the block (c for Dh, k for Gh), tile quad tq, column bcol of the 4x4 domain (wave-uniform tq, bcol)
+  const int r = lane, tq = wave & 1, bcol = wave >> 1;
   const int j0 = bcol == 0 ? 0 : 1, j1 = bcol == 3 ? 3 : 2;                       // (d B)[.][bcol] = sg0 d[.][j0] + sg1 d[.][j1]
   const float sg0 = bcol == 2 ? -1.f : 1.f, sg1 = (bcol == 0 || bcol == 3) ? -1.f : 1.f;
   const int w_off = r * 8 + ((tq ^ ((r >> 3) & 1)) * 4);                           // 16-byte slot of (row r, tiles 4tq..4tq+3)
+  float gr[4][2][2];                                                               // output-gradient values of the chunk to transform next
 
-  float gr[4][2][2];                                                               // output-gradient values of the chunk in flight
-  unsigned rowmask[4];
-
-  // raw x patch of a chunk -> LDS by DMA (global_load_lds, 16 bytes per lane, no registers): 18 pieces of 4 pixels x 64 channels
-  // (1 KiB, linear in the lane id as the instruction requires); wave w brings pieces w, w+8, w+16 (clamped: a harmless
-  // re-write of piece 17).  Rows outside the image read row 0 / H-1 and are masked when the patch is consumed.
-  auto load_raw = [&](int ch) {
+  auto chunk_pos = [&](int ch, int& n, int& ta, int& b8) {
     int u = ch;
-    const int b8 = u % tw8; u /= tw8;
-    const int ta = u % th;
-    const int n = u / th;
-    const float* xn = a.x + ((size_t)n * a.H * a.W) * a.C + c0;
-    const float* gn = a.g + ((size_t)n * a.H * a.W) * a.K + k0 + r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int row = 2 * ta - 1 + i;
-      rowmask[i] = (row >= 0 && row < a.H) ? 0xffffffffu : 0u;
-    }
-#pragma unroll
-    for (int it = 0; it < 3; ++it) {
-      const int piece = min(wave + 8 * it, WW_RAWPIX / 4 - 1);
-      const int pix = piece * 4 + (lane >> 4);
-      const int pi = pix / 18, pj = pix % 18;
-      int row = 2 * ta - 1 + pi;
-      row = row < 0 ? 0 : (row >= a.H ? a.H - 1 : row);
-      int col = 16 * b8 - 1 + pj;
-      col = col < 0 ? col + a.W : (col >= a.W ? col - a.W : col);
-      const float* src = xn + ((size_t)row * a.W + col) * a.C + (lane & 15) * 4;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(raw + __builtin_amdgcn_readfirstlane(piece * 256)), 16, 0, 0);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int tb = b8 * 8 + tq * 4 + e;
-#pragma unroll
-      for (int p = 0; p < 2; ++p)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) gr[e][p][q] = gn[((size_t)(2 * ta + p) * a.W + (2 * tb + q)) * a.K];
-    }
+    b8 = u % tw8; u /= tw8;
+    ta = u % th;
+    n = u / th;
   };
-
-  auto transform_write = [&](float* buf) {
-    float* gh = buf + w_off;                       // planes 0..15: Gh
-    float* dh = buf + 16 * WW_PLANE + w_off;       // planes 16..31: Dh
-    f32x4 v[4];
-    // Dh = B^T d B, column bcol, for the four tiles
+  // chunk-invariant lane roles of the three DMA pieces of this wave (pixel (pi, pj) of the 4 x 18 patch, 16-byte channel quad)
+  int dma_pi[3], dma_pj[3], dma_l[3];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float tt[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const float d0 = __uint_as_float(__float_as_uint(raw[(i * 18 + 2 * (4 * tq + e) + j0) * 64 + r]) & rowmask[i]);
-        const float d1 = __uint_as_float(__float_as_uint(raw[(i * 18 + 2 * (4 * tq + e) + j1) * 64 + r]) & rowmask[i]);
-        tt[i] = sg0 * d0 + sg1 * d1;
-      }
-      v[0][e] = tt[0] - tt[2]; v[1][e] = tt[1] + tt[2]; v[2][e] = tt[2] - tt[1]; v[3][e] = tt[1] - tt[3];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dh + (i * 4 + bcol) * WW_PLANE) = v[i];
-    // Gh = A g A^T, column bcol:  (g A^T)[p][bcol] then A .
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float h[2];
-#pragma unroll
-      for (int p = 0; p < 2; ++p) {
-        const float g0 = gr[e][p][0], g1 = gr[e][p][1];
-        h[p] = bcol == 0 ? g0 : (bcol == 1 ? g0 + g1 : (bcol == 2 ? g0 - g1 : -g1));
-      }
-      v[0][e] = h[0]; v[1][e] = h[0] + h[1]; v[2][e] = h[0] - h[1]; v[3][e] = -h[1];
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(gh + (i * 4 + bcol) * WW_PLANE) = v[i];
-  };
+  for (int it = 0; it < 3; ++it) {
+    const int piece = min(wave + 8 * it, WW_RAWPIX / 4 - 1);
+    const int pix = piece * 4 + (lane >> 4);
+    dma_pi[it] = pix / 18; dma_pj[it] = pix % 18;
+    dma_l[it] = piece * 256;
+  }
+  const int x_lane = c0 + (lane & 15) * 4;
+#define WW2_DMA(CH)                                                                                                       \
+  {                                                                                                                       \
+    int n_, ta_, b8_;                                                                                                     \
+    chunk_pos((CH), n_, ta_, b8_);                                                                                        \
+    const float* xn_ = a.x + ((size_t)n_ * a.H * a.W) * a.C + x_lane;                                                     \
+    _Pragma("unroll") for (int it = 0; it < 3; ++it) {                                                                    \
+      int row = 2 * ta_ - 1 + dma_pi[it];                                                                                 \
+      row = row < 0 ? 0 : (row >= a.H ? a.H - 1 : row);                                                                   \
+      int col = 16 * b8_ - 1 + dma_pj[it];                                                                                \
+      col = col < 0 ? col + a.W : (col >= a.W ? col - a.W : col);                                                         \
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xn_ + (row * a.W + col) * a.C),    \
+                                       (__attribute__((address_space(3))) void*)(raw + dma_l[it]), 16, 0, 0);             \
+    }                                                                                                                     \
+  }
+  // the 16 gradient values of this thread's four tiles: one base pointer per chunk, offsets p * W K + (2 e + q) K
+  const int g_row = a.W * a.K;
+#define WW2_GLOAD(CH)                                                                                                     \
+  {                                                                                                                       \
+    int n_, ta_, b8_;                                                                                                     \
+    chunk_pos((CH), n_, ta_, b8_);                                                                                        \
+    const float* gn_ = a.g + (((size_t)n_ * a.H + 2 * ta_) * a.W + 2 * (b8_ * 8 + tq * 4)) * a.K + k0 + r;                \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                         \
+      _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                       \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) gr[e][p][q] = gn_[p * g_row + (2 * e + q) * a.K];                   \
+  }
+  // Dh = B^T d B, column bcol, tile E of this thread's four: 8 LDS reads of the raw patch (issued one slot ahead of their use),
+  // rows outside the image masked
+  const float* rb0 = raw + (2 * 4 * tq + j0) * 64 + r;
+  const float* rb1 = raw + (2 * 4 * tq + j1) * 64 + r;
+#define WW2_TDL(E)                                                                                                        \
+  {                                                                                                                       \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                       \
+      dd[(E) & 1][2 * i] = rb0[(i * 18 + 2 * (E)) * 64];                                                                  \
+      dd[(E) & 1][2 * i + 1] = rb1[(i * 18 + 2 * (E)) * 64];                                                              \
+    }                                                                                                                     \
+  }
+#define WW2_TD(E)                                                                                                         \
+  {                                                                                                                       \
+    float tt_[4];                                                                                                         \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                       \
+      const unsigned m_ = i == 0 ? mask_top : (i == 3 ? mask_bot : 0xffffffffu);                                          \
+      const float d0 = __uint_as_float(__float_as_uint(dd[(E) & 1][2 * i]) & m_);                                         \
+      const float d1 = __uint_as_float(__float_as_uint(dd[(E) & 1][2 * i + 1]) & m_);                                     \
+      tt_[i] = sg0 * d0 + sg1 * d1;                                                                                       \
+    }                                                                                                                     \
+    vv[0][E] = tt_[0] - tt_[2]; vv[1][E] = tt_[1] + tt_[2]; vv[2][E] = tt_[2] - tt_[1]; vv[3][E] = tt_[1] - tt_[3];       \
+  }
+#define WW2_WRITE(BASE, V) { _Pragma("unroll") for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>((BASE) + (i * 4 + bcol) * WW_PLANE) = V[i]; }
+  // Gh = A g A^T, column bcol, tile E:  (g A^T)[p][bcol] = ca g[p][0] + cb g[p][1]  (branch-free: wave-uniform coefficients), then A .
+  const float ca = bcol == 3 ? 0.f : 1.f, cb = bcol == 0 ? 0.f : (bcol == 1 ? 1.f : -1.f);
+#define WW2_TG(E)                                                                                                         \
+  {                                                                                                                       \
+    const float h0_ = ca * gr[E][0][0] + cb * gr[E][0][1], h1_ = ca * gr[E][1][0] + cb * gr[E][1][1];                     \
+    vg[0][E] = h0_; vg[1][E] = h0_ + h1_; vg[2][E] = h0_ - h1_; vg[3][E] = -h1_;                                          \
+  }
 
   f32x16 acc[8];
 #pragma unroll
@@ -489,34 +500,72 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
   const int arow = mb * 32 + li, brow = nb * 32 + li;
   const int a_off = arow * 8 + ((half ^ ((arow >> 3) & 1)) * 4);
   const int b_off = 16 * WW_PLANE + brow * 8 + ((half ^ ((brow >> 3) & 1)) * 4);
+  f32x4 vv[4], vg[4];
+  float dd[2][8];
+  unsigned mask_top, mask_bot;
+#define WW2_MASKS(CH) { int n_, ta_, b8_; chunk_pos((CH), n_, ta_, b8_); mask_top = ta_ > 0 ? 0xffffffffu : 0u; mask_bot = ta_ < th - 1 ? 0xffffffffu : 0u; }
 
-  // Pipeline: operands of chunk ch in buf[ch & 1]; the raw patch / gradient values of chunk ch+1 travel during the MFMAs of
-  // chunk ch; barrier A: every wave's DMA pieces have landed; transforms into buf[(ch+1) & 1]; barrier B: operands visible,
-  // raw buffer free again.
-  if (ch_begin < ch_end) {
-    load_raw(ch_begin);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    transform_write(lds);
-  }
+  // prologue: operands of the first chunk, then the raw patch / gradient values of the second
+  WW2_DMA(ch_begin)
+  WW2_GLOAD(ch_begin)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  WW2_MASKS(ch_begin)
+  WW2_TDL(0) WW2_TD(0) WW2_TDL(1) WW2_TD(1) WW2_TDL(2) WW2_TD(2) WW2_TDL(3) WW2_TD(3)
+  WW2_WRITE(lds + 16 * WW_PLANE + w_off, vv)
+  WW2_TG(0) WW2_TG(1) WW2_TG(2) WW2_TG(3)
+  WW2_WRITE(lds + w_off, vg)
+  __syncthreads();
+  {
+    const int c1 = min(ch_begin + 1, ch_end - 1);
+    WW2_DMA(c1)
+    WW2_GLOAD(c1)
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+#define WW2_FR(XL)                                                                                                        \
+  {                                                                                                                       \
+    av[(XL) & 1] = *reinterpret_cast<const f32x4*>(cur + (xh * 8 + (XL)) * WW_PLANE + a_off);                             \
+    bv[(XL) & 1] = *reinterpret_cast<const f32x4*>(cur + (xh * 8 + (XL)) * WW_PLANE + b_off);                             \
+  }
+#define WW2_M(XL, J, ...)                                                                                                 \
+  {                                                                                                                       \
+    acc[XL] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(XL) & 1][J], bv[(XL) & 1][J], acc[XL], 0, 0, 0);                   \
+    __VA_ARGS__                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+  }
+  f32x4 av[2], bv[2];
   for (int ch = ch_begin; ch < ch_end; ++ch) {
     const float* cur = lds + ((ch - ch_begin) & 1) * WW_BUF;
     float* nxt = lds + ((ch - ch_begin + 1) & 1) * WW_BUF;
-    const bool more = ch + 1 < ch_end;
-    if (more) load_raw(ch + 1);
-#pragma unroll
-    for (int xl = 0; xl < 8; ++xl) {
-      const f32x4 av = *reinterpret_cast<const f32x4*>(cur + (xh * 8 + xl) * WW_PLANE + a_off);
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(cur + (xh * 8 + xl) * WW_PLANE + b_off);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[xl] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], bv[j], acc[xl], 0, 0, 0);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();                               // A
-    if (more) transform_write(nxt);
-    __syncthreads();                               // B
+    const int c1 = min(ch + 1, ch_end - 1), c2 = min(ch + 2, ch_end - 1);
+    WW2_MASKS(c1)
+    WW2_FR(0)
+    WW2_M(0, 0, WW2_FR(1) WW2_TDL(0)) WW2_M(0, 1, WW2_TDL(1)) WW2_M(0, 2, WW2_TD(0)) WW2_M(0, 3, WW2_TDL(2))
+    WW2_M(1, 0, WW2_FR(2) WW2_TD(1)) WW2_M(1, 1, WW2_TDL(3)) WW2_M(1, 2, WW2_TD(2)) WW2_M(1, 3, WW2_TG(0))
+    WW2_M(2, 0, WW2_FR(3) WW2_TD(3)) WW2_M(2, 1, WW2_WRITE(nxt + 16 * WW_PLANE + w_off, vv)) WW2_M(2, 2, WW2_TG(1)) WW2_M(2, 3, WW2_TG(2))
+    WW2_M(3, 0, WW2_FR(4)) WW2_M(3, 1, WW2_TG(3)) WW2_M(3, 2, WW2_WRITE(nxt + w_off, vg)) WW2_M(3, 3, )
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                                    // M: the raw patch has been read by everybody
+    __builtin_amdgcn_sched_barrier(0);
+    WW2_M(4, 0, WW2_FR(5) WW2_DMA(c2)) WW2_M(4, 1, WW2_GLOAD(c2)) WW2_M(4, 2, ) WW2_M(4, 3, )
+    WW2_M(5, 0, WW2_FR(6)) WW2_M(5, 1, ) WW2_M(5, 2, ) WW2_M(5, 3, )
+    WW2_M(6, 0, WW2_FR(7)) WW2_M(6, 1, ) WW2_M(6, 2, ) WW2_M(6, 3, )
+    WW2_M(7, 0, ) WW2_M(7, 1, ) WW2_M(7, 2, ) WW2_M(7, 3, )
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                                    // E: operands of chunk ch+1 visible, raw patch landed
+    __builtin_amdgcn_sched_barrier(0);
   }
+#undef WW2_DMA
+#undef WW2_GLOAD
+#undef WW2_TD
+#undef WW2_TDL
+#undef WW2_TG
+#undef WW2_WRITE
+#undef WW2_MASKS
+#undef WW2_FR
+#undef WW2_M
   // partial of this slab: ws[slab][xi][k0 + m][c0 + n]; accumulator register q of lane (li, half) is
   // row m = mb*32 + 8*(q/4) + 4*half + q%4, column n = nb*32 + li
   float* wp = a.ws + ((size_t)slab * 16) * a.K * a.C;

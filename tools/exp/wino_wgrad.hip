@@ -1,6 +1,6 @@
-// DRAFT v1 (end of round 2; `wino_wgrad check` passes on MI355X: 2-3e-7 relative; `time`: layer1 215 us, layer2 306, layer3 572,
-// layer4 574 = 90 / 126 / 135 / 135 TFLOP/s direct-equivalent against 204 / 335 / 607 / 608 us of k_wgrad_f32 -- not used by the
-// library yet; next: transforms sliced behind the MFMAs, one barrier per chunk):
+// Stand-alone check / timing of k_wino_wgrad (csrc/wino.hip).  Round 2 (transforms in their own phase): layer1 215 us, layer2 306,
+// layer3 572, layer4 574; round 3 (transforms sliced behind the MFMAs): 192 / 259 / 463 / 464 us = 101 / 149 / 167 / 167 TFLOP/s
+// direct-equivalent (k_wgrad_f32: 204 / 335 / 607 / 608 us):
 // weight gradient of a stride-1 3x3 layer in the Winograd domain, DESIGN.md section 8 "blueprint of next step (1)".
 //
 //   dw_tile = G^T [ (A g A^T) .* (B^T d B) ] G        g: 2x2 tile of the output gradient, d: 4x4 input patch around it
@@ -61,11 +61,12 @@ static void host_wgrad(const std::vector<float>& x, const std::vector<float>& g,
 int main(int argc, char** argv) {
   const bool timing = argc > 1 && !strcmp(argv[1], "time");
   struct S { const char* name; int N, H, W, C, K; };
-  const S small[] = {{"1x4x32 64->64", 1, 4, 32, 64, 64}, {"2x8x64 128->64", 2, 8, 64, 128, 64}, {"1x6x48 64->128", 1, 6, 48, 64, 128}};
+  const S small[] = {{"1x4x32 64->64", 1, 4, 32, 64, 64}, {"2x8x64 128->64", 2, 8, 64, 128, 64}, {"1x6x48 64->128", 1, 6, 48, 64, 128},
+                     {"2x16x64 256->256", 2, 16, 64, 256, 256}, {"2x16x128 128->128", 2, 16, 128, 128, 128}, {"2x8x32 512->512", 2, 8, 32, 512, 512}};
   const S big[] = {{"layer1", 8, 64, 512, 64, 64}, {"layer2", 8, 64, 256, 128, 128}, {"layer3", 8, 64, 128, 256, 256}, {"layer4", 8, 32, 64, 512, 512}};
   std::mt19937 rng(3);
   std::normal_distribution<float> nd(0.f, 1.f);
-  for (const S& s : (timing ? std::vector<S>(big, big + 4) : std::vector<S>(small, small + 3))) {
+  for (const S& s : (timing ? std::vector<S>(big, big + 4) : std::vector<S>(small, small + 6))) {
     const size_t nx = (size_t)s.N * s.H * s.W * s.C, ng = (size_t)s.N * s.H * s.W * s.K, nw = (size_t)s.K * 9 * s.C;
     std::vector<float> hx(nx), hg(ng), hw(nw);
     for (auto& v : hx) v = nd(rng);
