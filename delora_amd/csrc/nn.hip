@@ -57,12 +57,21 @@ struct NNWorkspace {
   NNHard* hard;                // [B*HW]: tile-walk queries with one wave each from the front, scanned queries from the end
   NNHard* mid;                 // [B*HW]: tile-walk queries with one 16-lane group each (counter[2])
   float4* tiles;               // [B][ceil(H/4)][ceil(W/16)] bounding sphere (cx,cy,cz,radius) of every target tile; radius < 0: empty
+  float4* super;               // [B][ceil(ntr/4)][ceil(ntc/8)] bounding sphere of every 4 x 8 block of tiles (16 x 128 pixels)
 };
+
+#define NN_SR 4                 // super tile: 4 x 8 tiles = 32 child spheres (half a wave)
+#define NN_SC 8
+#define NN_SUPER_TRIPS 4        // the hierarchical walk keeps the super tiles' lower bounds in registers: images up to 256 super tiles
 
 #define NN_VIS0 64             // counter[0]: number of hard queries; counter[NN_VIS0 + 32 b + k]: visible-pixel sub-counters
 static inline size_t nn_header_bytes(int B) { return (((size_t)(NN_VIS0 + 32 * B) * sizeof(int32_t)) + 255) / 256 * 256; }
 
 static inline size_t nn_tiles(int H, int W) { return (size_t)((H + NN_TR - 1) / NN_TR) * ((W + NN_TC - 1) / NN_TC); }
+static inline size_t nn_supers(int H, int W) {
+  const size_t ntr = (H + NN_TR - 1) / NN_TR, ntc = (W + NN_TC - 1) / NN_TC;
+  return ((ntr + NN_SR - 1) / NN_SR) * ((ntc + NN_SC - 1) / NN_SC);
+}
 
 static inline NNWorkspace carve_nn(void* ws, int B, int H, int W) {
   NNWorkspace w;
@@ -71,11 +80,12 @@ static inline NNWorkspace carve_nn(void* ws, int B, int H, int W) {
   w.hard = (NNHard*)((char*)ws + nn_header_bytes(B));
   w.mid = w.hard + (size_t)B * H * W;
   w.tiles = (float4*)((char*)w.mid + (size_t)B * H * W * sizeof(NNHard));
+  w.super = w.tiles + (size_t)B * nn_tiles(H, W);
   return w;
 }
 
 extern "C" size_t dl_nn_workspace_bytes(int32_t B, int32_t H, int32_t W) {
-  return nn_header_bytes(B) + 2 * (size_t)B * H * W * sizeof(NNHard) + (size_t)B * nn_tiles(H, W) * sizeof(float4);
+  return nn_header_bytes(B) + 2 * (size_t)B * H * W * sizeof(NNHard) + (size_t)B * (nn_tiles(H, W) + nn_supers(H, W)) * sizeof(float4);
 }
 
 // Angular description of a query in fp32.  The image is only a spatial index here: these values pick WHICH pixels
@@ -426,6 +436,163 @@ __device__ __forceinline__ void scan_tiles(const Window& w, const float4* __rest
   if (lidx >= 0 && (lbest < best || (lbest == best && (bidx < 0 || lidx < bidx)))) { best = lbest; bidx = lidx; }
 }
 
+// Second level of the pyramid: one wave per super tile (4 x 8 tiles, lanes 0..31 = children): a sphere that encloses the
+// children's spheres (centre = middle of the box around them, radius = largest |c_child - centre| + r_child, rounded up).
+__global__ __launch_bounds__(DL_BLOCK) void k_nn_supers(const float4* __restrict__ tiles, int H, int W, int nb, float4* __restrict__ super) {
+  const int lane = threadIdx.x & (DL_WAVE - 1);
+  const int ntr = (H + NN_TR - 1) / NN_TR, ntc = (W + NN_TC - 1) / NN_TC;
+  const int nsr = (ntr + NN_SR - 1) / NN_SR, nsc = (ntc + NN_SC - 1) / NN_SC;
+  const int t = (blockIdx.x * DL_BLOCK + threadIdx.x) / DL_WAVE;
+  if (t >= nb * nsr * nsc) return;
+  const int b = t / (nsr * nsc), r = t - b * nsr * nsc;
+  const int sr = r / nsc, sc = r - sr * nsc;
+  const int tr = sr * NN_SR + (lane >> 3), tc = sc * NN_SC + (lane & 7);
+  float4 c = make_float4(0.f, 0.f, 0.f, -1.f);
+  if (lane < NN_SR * NN_SC && tr < ntr && tc < ntc) c = tiles[(size_t)b * ntr * ntc + tr * ntc + tc];
+  const bool occ = c.w >= 0.f;
+  const float big = 3.0e38f;
+  const float xmin = wave_min_sf(occ ? c.x - c.w : big), xmax = wave_max_f(occ ? c.x + c.w : -big);
+  const float ymin = wave_min_sf(occ ? c.y - c.w : big), ymax = wave_max_f(occ ? c.y + c.w : -big);
+  const float zmin = wave_min_sf(occ ? c.z - c.w : big), zmax = wave_max_f(occ ? c.z + c.w : -big);
+  float4 out = make_float4(0.f, 0.f, 0.f, -1.f);
+  if (xmax >= xmin) {
+    const float cx = 0.5f * (xmin + xmax), cy = 0.5f * (ymin + ymax), cz = 0.5f * (zmin + zmax);
+    const float dx = c.x - cx, dy = c.y - cy, dz = c.z - cz;
+    const float rr = wave_max_f(occ ? sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx))) * (1.0f + 2e-6f) + c.w : 0.f);
+    out = make_float4(cx, cy, cz, rr * (1.0f + 2e-6f) + 1e-7f);
+  }
+  if (lane == 0) super[t] = out;
+}
+
+// Exact search of the WHOLE image for one query (wave-uniform arguments) through the two-level sphere pyramid, best first.
+// Used when pass A has no usable bound (an untrained network's random pose: q is nowhere near its pixel's surface): the bound
+// window is most of the image and walking its 2048 tiles in raster order costs 32 trips of sphere tests before the cull
+// distance means anything.  Here: (1) all super spheres are tested at once (one per lane): lower bound dist - R, upper bound
+// dist + R (a non-empty sphere holds a point at most that far away) -- the smallest upper bound is a rigorous cull distance
+// before a single pixel has been read; (2) super tiles are visited in order of their lower bound until the next lower bound
+// exceeds the cull distance; (3) a visited super tile tests its 32 child spheres (again tightening the cull distance by
+// their upper bounds) and scans the surviving tiles, one pixel per lane, four tiles per round trip.
+__device__ __forceinline__ void pyramid_walk(const float4* __restrict__ super_b, const float4* __restrict__ tiles_b,
+                                             const float4* __restrict__ tp, int H, int W, float qx, float qy, float qz, int lane,
+                                             double& best, int& bidx) {
+  const int ntr = (H + NN_TR - 1) / NN_TR, ntc = (W + NN_TC - 1) / NN_TC;
+  const int nsr = (ntr + NN_SR - 1) / NN_SR, nsc = (ntc + NN_SC - 1) / NN_SC, nsuper = nsr * nsc;
+  double lbest = best;
+  int lidx = -1;
+  float thr = best < 1e30 ? (float)best * (1.0f + 1e-5f) : 3.0e38f;            // fp32 screen of squared distances
+  float dcur = best < 1e30 ? sqrtf((float)best) * (1.0f + 1e-6f) : 3.0e38f;    // wave-uniform cull distance (an upper bound of the answer)
+  float lb2[NN_SUPER_TRIPS];
+#pragma unroll
+  for (int k = 0; k < NN_SUPER_TRIPS; ++k) {
+    const int sidx = k * DL_WAVE + lane;
+    lb2[k] = 3.0e38f;
+    float ub = 3.0e38f;
+    if (sidx < nsuper) {
+      const float4 s4 = super_b[sidx];
+      if (s4.w >= 0.f) {
+        const float dx = qx - s4.x, dy = qy - s4.y, dz = qz - s4.z;
+        const float dist = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+        lb2[k] = (dist - s4.w) - 4e-6f * (dist + s4.w) - 1e-7f;
+        ub = (dist + s4.w) * (1.0f + 4e-6f) + 1e-7f;
+      }
+    }
+    dcur = fminf(dcur, wave_min_f(ub));
+  }
+  bool first = true;
+  for (;;) {
+    // Two super tiles per trip (lanes 0..31 test the children of the first, lanes 32..63 of the second).  The first trip takes
+    // the super tile with the smallest lower bound alone -- it almost always holds the neighbour or a point nearly as close,
+    // which makes the cull distance tight -- later trips take any two unvisited ones that can still hold a closer point.
+    int sA = -1, sB = -1;
+    if (first) {
+      float mine = lb2[0];
+      int mk = 0;
+#pragma unroll
+      for (int k = 1; k < NN_SUPER_TRIPS; ++k)
+        if (lb2[k] < mine) { mine = lb2[k]; mk = k; }
+      // lower bounds can be slightly negative (q inside a sphere): order by value through a monotone integer key
+      const unsigned key = __float_as_uint(mine) ^ ((__float_as_uint(mine) >> 31) ? 0xffffffffu : 0x80000000u);
+      const unsigned kmin = wave_min_u(key);
+      const float lbmin = __uint_as_float(kmin ^ ((kmin >> 31) ? 0x80000000u : 0xffffffffu));
+      if (!(lbmin <= dcur) || lbmin >= 3.0e38f) break;           // nothing that can hold a closer point (or nothing at all)
+      const int wl = __builtin_ctzll(__ballot(key == kmin));
+      sA = __builtin_amdgcn_readlane(mk, wl) * DL_WAVE + wl;
+      first = false;
+    } else {
+#pragma unroll
+      for (int k = 0; k < NN_SUPER_TRIPS; ++k) {
+        unsigned long long m = __ballot(lb2[k] <= dcur && lb2[k] < 3.0e38f);
+        if (m && sA < 0) { sA = k * DL_WAVE + __builtin_ctzll(m); m &= m - 1; }
+        if (m && sB < 0) sB = k * DL_WAVE + __builtin_ctzll(m);
+      }
+      if (sA < 0) break;
+    }
+#pragma unroll
+    for (int k = 0; k < NN_SUPER_TRIPS; ++k)
+      if (k * DL_WAVE + lane == sA || k * DL_WAVE + lane == sB) lb2[k] = 3.0e38f;      // visited
+    // their children
+    const int sidx = (lane < NN_SR * NN_SC) ? sA : sB;
+    const int sr = sidx / nsc, sc = sidx - sr * nsc;
+    const int cl = lane & (NN_SR * NN_SC - 1);
+    const int tr = sr * NN_SR + (cl >> 3), tc = sc * NN_SC + (cl & 7);
+    bool survive = false;
+    float ub = 3.0e38f, lb1 = 3.0e38f;
+    if (sidx >= 0 && tr < ntr && tc < ntc) {
+      const float4 s4 = tiles_b[tr * ntc + tc];
+      if (s4.w >= 0.f) {
+        const float dx = qx - s4.x, dy = qy - s4.y, dz = qz - s4.z;
+        const float dist = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+        lb1 = (dist - s4.w) - 4e-6f * (dist + s4.w) - 1e-7f;
+        ub = (dist + s4.w) * (1.0f + 4e-6f) + 1e-7f;
+        survive = true;
+      }
+    }
+    dcur = fminf(dcur, wave_min_f(ub));
+    survive = survive && lb1 <= dcur;
+    unsigned long long mask = __ballot(survive);
+    while (mask) {
+      float4 c4[4];
+      int pp[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        pp[u] = -1;
+        c4[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (mask) {
+          const int i = __builtin_ctzll(mask);
+          mask &= mask - 1;
+          const int row = __builtin_amdgcn_readlane(tr, i) * NN_TR + lane / NN_TC;
+          const int col = __builtin_amdgcn_readlane(tc, i) * NN_TC + lane % NN_TC;
+          if (row < H && col < W) {
+            pp[u] = row * W + col;
+            c4[u] = tp[pp[u]];
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int p = pp[u];
+        const float dx = qx - c4[u].x, dy = qy - c4[u].y, dz = qz - c4[u].z;
+        const float d2f = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        if (p >= 0 && !(c4[u].x == 0.f && c4[u].y == 0.f && c4[u].z == 0.f) && d2f <= thr) {
+          const double d2 = dist2(qx, qy, qz, c4[u].x, c4[u].y, c4[u].z);
+          if (d2 < lbest || (d2 == lbest && lidx >= 0 && p < lidx)) {
+            lbest = d2; lidx = p;
+            thr = (float)lbest * (1.0f + 1e-5f);
+          }
+        }
+      }
+      // tiles not yet read of this super tile may now be out of reach
+      const float tmin = wave_min_f(thr);
+      thr = fminf(thr, tmin * (1.0f + 1e-5f));
+      if (tmin < 3.0e38f) dcur = fminf(dcur, sqrtf(tmin) * (1.0f + 1e-6f));
+      mask &= __ballot(lb1 <= dcur);
+    }
+  }
+  if (lidx < 0) lbest = 1e300;
+  wave_argmin(lbest, lidx);
+  if (lidx >= 0 && (lbest < best || (lbest == best && (bidx < 0 || lidx < bidx)))) { best = lbest; bidx = lidx; }
+}
+
 // Row reductions (16 lanes = one DPP row): every lane of a row ends up with the row's minimum.
 __device__ __forceinline__ unsigned row_min_u(unsigned v) {
   v = min(v, dpp_u<0xB1>(v));
@@ -644,6 +811,7 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float4* __restrict__
     visible[threadIdx.x] = sum;
   }
   const int ntiles_img = nn_tiles_dev(H, W);
+  const int nsuper_img = ((((H + NN_TR - 1) / NN_TR) + NN_SR - 1) / NN_SR) * ((((W + NN_TC - 1) / NN_TC) + NN_SC - 1) / NN_SC);
   for (int h = wave; h < count; h += nwaves) {
 #ifdef NN_PROFILE
     const long long t0_ = clock64();
@@ -657,24 +825,15 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float4* __restrict__
     int bidx = rec.idx;
     const float4* tp = tgt + (size_t)b * tgt_ss4;
     const float4* tiles_b = ws.tiles + (size_t)b * ntiles_img;
-    if ((w.r1 - w.r0 + 1) * w.nc > NN_SEED_MIN) {
-      // A window this large means pass A found nothing near q's pixel (an empty neighbourhood, q outside the field of view)
-      // or only a far candidate.  Walking it from its top-left corner spends the first trips on far tiles with a useless cull
-      // distance -- a whole-image walk took ~90k cycles, 36 % of this kernel at the bench's motion.  So first SEED: scan the
-      // 13 x 49 pixel neighbourhood of q's pixel (a dozen tiles), then replace the window by the rigorous bound of the distance
-      // found (bound_window is exact for any upper bound of the true distance).  The result is the same; only the order and
-      // the size of the final walk change.
-      const QueryF q = make_query(rec.qx, rec.qy, rec.qz, sen);
-      int v0 = (int)rintf(q.vq);
-      v0 = v0 < 0 ? 0 : (v0 > H - 1 ? H - 1 : v0);
-      const int u0 = wrap_col((int)rintf(q.uq), W);
-      Window s;
-      s.r0 = max(v0 - 6, 0); s.r1 = min(v0 + 6, H - 1);
-      s.c0 = wrap_col(u0 - 24, W); s.nc = min(49, W);
-      scan_tiles(s, tiles_b, tp, H, W, rec.qx, rec.qy, rec.qz, lane, best, bidx);
-      if (bidx >= 0) w = bound_window(q, (float)sqrt(best) * NN_UP, sen);
+    if ((w.r1 - w.r0 + 1) * w.nc > NN_SEED_MIN && nsuper_img <= NN_SUPER_TRIPS * DL_WAVE) {
+      // A window this large means pass A found nothing near q's pixel (an empty neighbourhood, q outside the field of view) or
+      // only a far candidate -- for an untrained network's random pose that is EVERY query.  The bound window is useless then:
+      // search the whole image through the two-level sphere pyramid, best first (pyramid_walk).  Round 2 walked the window's
+      // tiles in raster order after a seed scan around q's pixel: 9.6 ms per batch for random poses.
+      pyramid_walk(ws.super + (size_t)b * nsuper_img, tiles_b, tp, H, W, rec.qx, rec.qy, rec.qz, lane, best, bidx);
+    } else {
+      scan_tiles(w, tiles_b, tp, H, W, rec.qx, rec.qy, rec.qz, lane, best, bidx);
     }
-    scan_tiles(w, tiles_b, tp, H, W, rec.qx, rec.qy, rec.qz, lane, best, bidx);
     // the result: lanes 0-2 fetch and store the matched point's coordinates, lanes 3-5 the normal's
     if (lane == 0) nn_pix[rec.slot] = bidx;
     if (match && lane < 6) {
@@ -718,6 +877,11 @@ extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const f
     const int waves = (int)(B * nn_tiles(sen.H, sen.W));
     hipLaunchKernelGGL(k_nn_tiles, dim3((waves * DL_WAVE + DL_BLOCK - 1) / DL_BLOCK), dim3(DL_BLOCK), 0, st,
                        (const float4*)tgt_packed, tgt_ss / 4, sen.H, sen.W, B, ws.tiles);
+  }
+  {
+    const int waves = (int)(B * nn_supers(sen.H, sen.W));
+    hipLaunchKernelGGL(k_nn_supers, dim3((waves * DL_WAVE + DL_BLOCK - 1) / DL_BLOCK), dim3(DL_BLOCK), 0, st, (const float4*)ws.tiles, sen.H, sen.W,
+                       B, ws.super);
   }
   hipLaunchKernelGGL(k_nn_window, dim3((sen.HW + DL_BLOCK - 1) / DL_BLOCK, B), dim3(DL_BLOCK), 0, st,
                      src_image4, src_ss, src_normals, srcn_ss, (const float4*)tgt_packed, tgt_ss / 4,
