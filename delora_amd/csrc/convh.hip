@@ -388,7 +388,10 @@ static int dispatch_convh(const ConvHArgs& a, hipStream_t st) {
       default: break;
     }
 #endif
-    // 512 x 128 tiles while they still give every CU a workgroup; 256-pixel tiles for the small late layers
+    // Tile choice (tools/convh_harness tune, batch 8): up to 128 reduction channels the layer is as much an HBM stream as a GEMM
+    // -- 256 pixels x 64 channels, 8 waves, two workgroups per CU (layer1 31 us against 40 with 512 x 64, layer2 46 / 48); from
+    // 256 channels on 512 x 128 while that still gives every CU a workgroup (layer3), else 256 x 128 (layer4).
+    if (a.C <= 128 && !launch_convh<F16, 256, 64, 4, 2, 64, G, NG>(a, st)) return 0;
     if (a.K % 128 == 0 && pixels / 512 * (a.K / 128) >= 256 && !launch_convh<F16, 512, 128, 4, 2, 64, G, NG>(a, st)) return 0;
     if (a.K % 128 == 0 && !launch_convh<F16, 256, 128, 4, 2, 64, G, NG>(a, st)) return 0;
     if (pixels / 512 >= 256 && !launch_convh<F16, 512, 64, 8, 1, 64, G, NG>(a, st)) return 0;

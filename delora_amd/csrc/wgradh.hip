@@ -149,15 +149,37 @@ __global__ __launch_bounds__(64 * (BMK / 32) * 2, 2) void k_wgradh(WgradHArgs a)
         const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(gb + g_lane + gpix * PG));
         const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(gb + g_lane + (gpix + 4) * PG));
         const s16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+        if constexpr (SW == 1 && KS == 3) {
+          // the three taps of a row read the windows [s, s + 8) of the same pixel run: three transposing reads (12 pixels per lane,
+          // two per register) serve all of them -- s = 0 and s = 2 are register subsets, s = 1 is four 16-bit funnel shifts
+          // (9 LDS reads per 9 taps instead of 18: the kernel is LDS-read bound)
 #pragma unroll
-        for (int tp = 0; tp < TAPS; ++tp) {
-          const int r = tp / KS, s = tp % KS;
-          const int cs = s / SW, phase = s % SW;
-          const int xpix = ((pr * SH + r) * SW + phase) * RWXP + i0;
-          const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xb + x_lane[cs] + xpix * PX));
-          const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xb + x_lane[cs] + (xpix + 4) * PX));
-          const s16x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-          acc[tp] = ch_mfma<F16>(af, bf, acc[tp]);
+          for (int r = 0; r < 3; ++r) {
+            const int xpix = (pr * SH + r) * RWXP + i0;
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            u32x2 w01 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xb + x_lane[0] + xpix * PX)));
+            u32x2 w23 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xb + x_lane[0] + (xpix + 4) * PX)));
+            u32x2 w45 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xb + x_lane[0] + (xpix + 8) * PX)));
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 f0 = {w01[0], w01[1], w23[0], w23[1]};
+            const u32x4 f2 = {w01[1], w23[0], w23[1], w45[0]};
+            const u32x4 f1 = {__builtin_amdgcn_alignbit(w01[1], w01[0], 16), __builtin_amdgcn_alignbit(w23[0], w01[1], 16),
+                              __builtin_amdgcn_alignbit(w23[1], w23[0], 16), __builtin_amdgcn_alignbit(w45[0], w23[1], 16)};
+            acc[r * 3 + 0] = ch_mfma<F16>(af, __builtin_bit_cast(s16x8, f0), acc[r * 3 + 0]);
+            acc[r * 3 + 1] = ch_mfma<F16>(af, __builtin_bit_cast(s16x8, f1), acc[r * 3 + 1]);
+            acc[r * 3 + 2] = ch_mfma<F16>(af, __builtin_bit_cast(s16x8, f2), acc[r * 3 + 2]);
+          }
+        } else {
+#pragma unroll
+          for (int tp = 0; tp < TAPS; ++tp) {
+            const int r = tp / KS, s = tp % KS;
+            const int cs = s / SW, phase = s % SW;
+            const int xpix = ((pr * SH + r) * SW + phase) * RWXP + i0;
+            const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xb + x_lane[cs] + xpix * PX));
+            const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xb + x_lane[cs] + (xpix + 4) * PX));
+            const s16x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+            acc[tp] = ch_mfma<F16>(af, bf, acc[tp]);
+          }
         }
       }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
