@@ -74,7 +74,7 @@ void dl_prof_events(const DlProfTag& tag, hipEvent_t* e0, hipEvent_t* e1) {
   if (!g_prof.only.empty() && g_prof.only != tag.kernel) return;
   if (2 * g_prof.used + 1 >= (int)g_prof.ev.size()) { ++g_prof.skipped; return; }
   char name[96];
-  snprintf(name, sizeof(name), "%s %s N%d %dx%d C%d K%d", tag.kernel, tag.pass, tag.N, tag.H, tag.W, tag.C, tag.K);
+  snprintf(name, sizeof(name), "%s %s N%d %dx%d C%d K%d %dx%d s(%d,%d)", tag.kernel, tag.pass, tag.N, tag.H, tag.W, tag.C, tag.K, tag.ks, tag.ks, tag.sh, tag.sw);
   ProfAgg& a = g_prof.rows[name];
   a.launches++; a.flop += tag.flop; a.bytes += tag.bytes; a.ev.push_back(g_prof.used);
   *e0 = g_prof.ev[2 * g_prof.used]; *e1 = g_prof.ev[2 * g_prof.used + 1];

@@ -91,6 +91,7 @@ struct DlProfTag {
   const char* kernel;     // kernel family, e.g. "k_wino_conv"
   const char* pass;       // "fwd", "dgrad", "wgrad", ...
   int N, H, W, C, K;      // shape of the launch (input image, channels)
+  int ks, sh, sw;         // kernel size and stride of the layer
   double flop;            // floating-point operations the algorithm issues on the matrix cores (2 per multiply-add)
   double bytes;           // compulsory HBM bytes (operands read once + result written once)
 };

@@ -487,7 +487,8 @@ static int launch_conv(const ConvArgs& a, hipStream_t st) {
   if (a.Wo % TW || a.Ho % TH || a.K % BN || a.C % CK) return 1;
   const int ntiles = a.N * (a.Ho / TH) * (a.Wo / TW) * (a.K / BN);
   const double px_ = (double)a.N * a.Ho * a.Wo;
-  const DlProfTag tag{"k_conv_f32", BT ? "dgrad" : "fwd", a.N, a.H, a.W, a.C, a.K, 2.0 * px_ * a.K * a.C * G::NT,
+  constexpr int ks_ = G::WTAPS == 9 ? 3 : 1;
+  const DlProfTag tag{"k_conv_f32", BT ? "dgrad" : "fwd", a.N, a.H, a.W, a.C, a.K, ks_, BT ? G::OSH : G::ISH, BT ? G::OSW : G::ISW, 2.0 * px_ * a.K * a.C * G::NT,
                       4.0 * ((double)a.N * a.H * a.W * a.C + px_ * a.K + (double)G::WTAPS * a.K * a.C)};
   DL_LAUNCH(tag, (k_conv_f32<BM, BN, CK, TW, G, BT, WGN>), dim3(ntiles), dim3(CV_THREADS), st, a);
   return 0;
@@ -673,7 +674,7 @@ static int launch_wgrad(const float* x, const float* g, float* dw, float* ws, in
   const int total_chunks = N * Ho * (Wo / WG_PK);
   const int nslabs = wgrad_slabs(total_chunks, tiles);
   const int chunks_per_slab = (total_chunks + nslabs - 1) / nslabs;
-  const DlProfTag tag{"k_wgrad_f32", "wgrad", N, H, W, C, K, 2.0 * N * Ho * Wo * (double)K * C * KS * KS,
+  const DlProfTag tag{"k_wgrad_f32", "wgrad", N, H, W, C, K, KS, SH, SW, 2.0 * N * Ho * Wo * (double)K * C * KS * KS,
                       4.0 * ((double)N * H * W * C + (double)N * Ho * Wo * K + (double)K * KS * KS * C)};
   DL_LAUNCH(tag, (k_wgrad_f32<BMK, BNC, WG_PK, SH, SW, KS>), dim3(tiles * nslabs), dim3(CV_THREADS), st, x, g, ws, N,
             H, W, C, K, Ho, Wo, chunks_per_slab, nslabs);

@@ -358,7 +358,7 @@ static int launch_convh(const ConvHArgs& a, hipStream_t st) {
   const int ntiles = a.N * (a.Ho / TH) * (a.Wo / TW) * (a.K / BN);
   const double px_ = (double)a.N * a.Ho * a.Wo;
   const DlProfTag tag{"k_convh", std::is_same<G, GeomConv<3, 1, 1>>::value ? "fwd" : (G::ISH * G::ISW > 1 || G::WTAPS == 1 ? "fwd-strided" : "dgrad"),
-                      a.N, a.H, a.W, a.C, a.K, 2.0 * px_ * a.K * a.C * G::NT, 2.0 * ((double)a.N * a.H * a.W * a.C + px_ * a.K + (double)G::NT * a.K * a.C)};
+                      a.N, a.H, a.W, a.C, a.K, G::WTAPS == 9 ? 3 : 1, G::ISH * G::OSH, G::ISW * G::OSW, 2.0 * px_ * a.K * a.C * G::NT, 2.0 * ((double)a.N * a.H * a.W * a.C + px_ * a.K + (double)G::NT * a.K * a.C)};
   DL_LAUNCH(tag, (k_convh<F16, BM, BN, WGM, WGN, TW, G, NG>), dim3(ntiles), dim3(64 * WGM * WGN), st, a);
   return 0;
 }

@@ -302,7 +302,7 @@ extern "C" int dl_stem_wgrad_f32(const float* g_pooled, const float* a, const in
   const int Wc = W / 2, total = N * H * (Wc / SG_PX), nslabs = stem_wgrad_slabs(total);
   const int cps = (total + nslabs - 1) / nslabs, grid = (total + cps - 1) / cps;
   hipStream_t st = (hipStream_t)stream;
-  const DlProfTag tag{"k_stem_wgrad", "wgrad", N, H, W, 8, 64, 2.0 * N * H * Wc * 64.0 * 72.0,
+  const DlProfTag tag{"k_stem_wgrad", "wgrad", N, H, W, 8, 64, 3, 1, 2, 2.0 * N * H * Wc * 64.0 * 72.0,
                       4.0 * ((double)N * H * Wc * 64 * 1.5 + (double)N * H * W * 8) + (double)N * H * (Wc / 2) * 64};
   DL_LAUNCH(tag, k_stem_wgrad, dim3(grid), dim3(DL_BLOCK), st, g_pooled, a, win, x8, N, H, Wc, act, cps, (float*)workspace);
   hipLaunchKernelGGL(k_stem_wgrad_reduce, dim3((64 * 72 + DL_BLOCK - 1) / DL_BLOCK), dim3(DL_BLOCK), 0, st, (const float*)workspace, grid, dw);

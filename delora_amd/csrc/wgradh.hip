@@ -257,7 +257,7 @@ extern "C" size_t dl_conv2d_wgrad_h_workspace_bytes(int32_t N, int32_t H, int32_
 
 template <bool F16, int BMK, int PK, int SH, int SW, int KS>
 static void launch_wgradh(const WgradHArgs& a, const WgradHPlan& p, hipStream_t st) {
-  const DlProfTag tag{"k_wgradh", "wgrad", a.N, a.H, a.W, a.C, a.K, 2.0 * a.N * a.Ho * a.Wo * (double)a.K * a.C * KS * KS,
+  const DlProfTag tag{"k_wgradh", "wgrad", a.N, a.H, a.W, a.C, a.K, KS, SH, SW, 2.0 * a.N * a.Ho * a.Wo * (double)a.K * a.C * KS * KS,
                       2.0 * ((double)a.N * a.H * a.W * a.C + (double)a.N * a.Ho * a.Wo * a.K) + 4.0 * a.K * KS * KS * a.C};
   DL_LAUNCH(tag, (k_wgradh<F16, BMK, PK, 2, SH, SW, KS>), dim3(p.tiles * p.nslabs), dim3(64 * (BMK / 32) * 2), st, a);
 }

@@ -645,7 +645,7 @@ extern "C" int dl_wino_wgrad3x3_nhwc_f32(const float* x, const float* g, float* 
   const int total_chunks = N * (H / 2) * ((W / 2) / 8);
   const int nslabs = ww_slabs(total_chunks, tiles);
   WWArgs a{x, g, ws, N, H, W, C, K, (total_chunks + nslabs - 1) / nslabs, nslabs};
-  const DlProfTag tag{"k_wino_wgrad", "wgrad", N, H, W, C, K, 2.0 * 16.0 * (double)N * (H / 2) * (W / 2) * (double)C * K,
+  const DlProfTag tag{"k_wino_wgrad", "wgrad", N, H, W, C, K, 3, 1, 1, 2.0 * 16.0 * (double)N * (H / 2) * (W / 2) * (double)C * K,
                       4.0 * ((double)N * H * W * (C + K) + 9.0 * C * K)};
   DL_LAUNCH(tag, k_wino_wgrad, dim3(tiles * nslabs), dim3(WW_THREADS), st, a);
   const size_t count4 = (size_t)16 * K * C / 4;
@@ -670,7 +670,7 @@ extern "C" int dl_wino_conv3x3_nhwc_f32(const float* x, const float* u, float* y
   if (!((tw % 32 == 0 && th % 2 == 0) || (tw % 16 == 0 && th % 4 == 0)))
     return dl_fail(DL_ERR_UNSUPPORTED, "dl_wino_conv3x3_nhwc_f32: image %dx%d does not tile (W/2 %% 16, rows)", H, W);
   // what the algorithm asks of the matrix cores: 16 multiply-adds per 2x2 output tile and (c, k) pair (a direct convolution: 36)
-  const DlProfTag tag{"k_wino_conv", "conv", N, H, W, C, K, 2.0 * 16.0 * (double)N * th * tw * (double)C * K,
+  const DlProfTag tag{"k_wino_conv", "conv", N, H, W, C, K, 3, 1, 1, 2.0 * 16.0 * (double)N * th * tw * (double)C * K,
                       4.0 * ((double)N * H * W * (C + K) + 16.0 * C * K)};
   if (tw % 32 == 0 && th % 2 == 0) {
     const dim3 grid(N * (th / 2) * (tw / 32) * (K / WN_KB));

@@ -14,13 +14,33 @@ def last_json(path):
     return json.loads(open(path).read().strip().splitlines()[-1])
 
 
-for a, b in [("bench.json", f"{R}_bench.json"), ("bench_profiled.json", f"{R}_bench_profiled.json")]:
-    json.dump(last_json(os.path.join(src, a)), open(os.path.join(dst, b), "w"), indent=1)
-shutil.copy(os.path.join(src, "bench_trace", "bench_kernel_stats.csv"), os.path.join(dst, f"{R}_bench_kernel_stats.csv"))
-shutil.copy(os.path.join(src, "geo_trace", "geo_kernel_stats.csv"), os.path.join(dst, f"{R}_geometry_kernel_stats.csv"))
-for name in ("loss_warm.txt", "ring_bench.txt", "conv_harness.txt", "conv_pmc.txt", "conv_hbm_pmc.json", "scatter_probe.txt", "step_breakdown.txt", "miopen_layers.txt"):
-    if os.path.exists(os.path.join(src, name)):
-        shutil.copy(os.path.join(src, name), os.path.join(dst, f"{R}_{name}"))
+NEW = os.path.exists(os.path.join(src, "step_breakdown_f32.txt"))          # bundle layout since round 3 (tools/prof_round.sh)
+if NEW:
+    for a in ("bench.json", "bench_bf16.json", "bench_profiled_f32.json", "bench_profiled_bf16.json"):
+        if os.path.exists(os.path.join(src, a)):
+            json.dump(last_json(os.path.join(src, a)), open(os.path.join(dst, f"{R}_{a}"), "w"), indent=1)
+    for name in ("bench_kernel_stats_f32.csv", "bench_kernel_stats_bf16.csv", "step_breakdown_f32.txt", "step_breakdown_bf16.txt",
+                 "geometry_kernel_stats.csv", "loss_calibration.txt", "loss_warm.txt", "conv_harness.txt", "convh_harness.txt",
+                 "conv_layers_float32.txt", "conv_layers_bfloat16.txt", "conv_pmc.txt", "convh_pmc.txt", "scatter_probe.txt"):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, f"{R}_{name}"))
+    merged = {"launches": {}}
+    for m in ("float32", "bfloat16"):
+        f = os.path.join(src, f"conv_hbm_pmc_{m}.json")
+        if os.path.exists(f) and os.path.getsize(f):
+            d = json.load(open(f))
+            merged.setdefault("workload", []).append(d["workload"])
+            merged["correction"] = d["correction"]
+            merged["launches"].update(d["launches"])
+    json.dump(merged, open(os.path.join(dst, f"{R}_conv_hbm_pmc.json"), "w"), indent=1)
+else:
+    for a, b in [("bench.json", f"{R}_bench.json"), ("bench_profiled.json", f"{R}_bench_profiled.json")]:
+        json.dump(last_json(os.path.join(src, a)), open(os.path.join(dst, b), "w"), indent=1)
+    shutil.copy(os.path.join(src, "bench_trace", "bench_kernel_stats.csv"), os.path.join(dst, f"{R}_bench_kernel_stats.csv"))
+    shutil.copy(os.path.join(src, "geo_trace", "geo_kernel_stats.csv"), os.path.join(dst, f"{R}_geometry_kernel_stats.csv"))
+    for name in ("loss_warm.txt", "ring_bench.txt", "conv_harness.txt", "conv_pmc.txt", "conv_hbm_pmc.json", "scatter_probe.txt", "step_breakdown.txt", "miopen_layers.txt"):
+        if os.path.exists(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(dst, f"{R}_{name}"))
 
 
 def counter(path, name):
@@ -48,14 +68,15 @@ for k in OWN:
         pmc["kernels"][k] = {"FETCH_SIZE_KB_raw": fetch[k], "WRITE_SIZE_KB_raw": write[k], "read_bytes_corrected_x2": rd, "write_bytes": wr,
                              "hbm_bytes_per_launch": rd + wr}
 json.dump(pmc, open(os.path.join(dst, f"{R}_geometry_pmc.json"), "w"), indent=1)
-trace = os.path.join(src, "bench_trace", "bench_kernel_trace.csv")
-if os.path.exists(trace):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_breakdown.py"), trace, "20", "40"], capture_output=True, text=True)
-    open(os.path.join(dst, f"{R}_step_breakdown.txt"), "w").write(out.stdout)
-elif os.path.exists(os.path.join(src, "step_breakdown.txt")):      # computed on the GPU box (the raw trace is too large to travel)
-    shutil.copy(os.path.join(src, "step_breakdown.txt"), os.path.join(dst, f"{R}_step_breakdown.txt"))
-geo = os.path.join(src, "geo_trace", "geo_kernel_trace.csv")
-if os.path.exists(geo):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "loss_calibration.py"), geo, "30"], capture_output=True, text=True)
-    open(os.path.join(dst, f"{R}_loss_calibration.txt"), "w").write(out.stdout)
+if not NEW:
+    trace = os.path.join(src, "bench_trace", "bench_kernel_trace.csv")
+    if os.path.exists(trace):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "step_breakdown.py"), trace, "20", "40"], capture_output=True, text=True)
+        open(os.path.join(dst, f"{R}_step_breakdown.txt"), "w").write(out.stdout)
+    elif os.path.exists(os.path.join(src, "step_breakdown.txt")):      # computed on the GPU box (the raw trace is too large to travel)
+        shutil.copy(os.path.join(src, "step_breakdown.txt"), os.path.join(dst, f"{R}_step_breakdown.txt"))
+    geo = os.path.join(src, "geo_trace", "geo_kernel_trace.csv")
+    if os.path.exists(geo):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "loss_calibration.py"), geo, "30"], capture_output=True, text=True)
+        open(os.path.join(dst, f"{R}_loss_calibration.txt"), "w").write(out.stdout)
 print("k_icp_loss PMC bytes/launch:", pmc["kernels"].get("k_icp_loss", {}).get("hbm_bytes_per_launch"))

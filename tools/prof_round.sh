@@ -1,28 +1,46 @@
 #!/bin/bash
-# Round profile bundle (run on the GPU box through gpurun): kernel trace of the bench command, kernel trace of the
-# geometry micro-benchmark, and the two PMC passes (FETCH_SIZE, WRITE_SIZE) for the geometry kernels.
-# Counters are collected in their own runs, with --kernel-trace only (never together with sys/hip/hsa tracing).
+# Round profile bundle (run on the GPU box through gpurun, ROUND=r03): bench lines, kernel traces of the fp32 and the autocast
+# step with per-step breakdowns, the geometry micro-benchmark with its PMC passes, and the convolution kernels: per-layer
+# launch table + FETCH_SIZE / WRITE_SIZE per layer (tools/conv_layers.py), matrix-core counters of the Winograd and the
+# half-precision kernels.  Counters are collected in their own runs, with --kernel-trace only.
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-R=${ROUND:-r01}
+R=${ROUND:-r03}
 out=gpurun_out/profiles_$R; rm -rf $out; mkdir -p $out
-python bench.py > $out/bench.json 2> $out/bench.err; tail -1 $out/bench.json | cut -c1-400
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/bench_trace -o bench -- python bench.py --no-cpu-baseline > $out/bench_profiled.json 2>/dev/null
-python tools/step_breakdown.py $(find $out/bench_trace -name "*kernel_trace.csv" | head -1) 20 45 > $out/step_breakdown.txt 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/geo_trace -o geo -- python tools/geo_bench.py 30 0.4 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/geo_fetch -o geo -- python tools/geo_bench.py 5 0.4 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/geo_write -o geo -- python tools/geo_bench.py 5 0.4 > /dev/null 2>&1
+T=/tmp/prof_$R; rm -rf $T; mkdir -p $T
+python bench.py > $out/bench.json 2> $out/bench.err; tail -1 $out/bench.json | cut -c1-300
+python bench.py --amp bfloat16 --no-cpu-baseline --feed-steps 0 --long-steps 0 > $out/bench_bf16.json 2>/dev/null
+for m in f32 bf16; do
+  fl=""; [ $m = bf16 ] && fl="--amp bfloat16"
+  rocprofv3 --kernel-trace --stats --output-format csv -d $T/bench_$m -o bench -- python bench.py $fl --no-cpu-baseline --no-profile --long-steps 0 --feed-steps 0 --autocast-steps 0 --kernel-reps 2 > $out/bench_profiled_$m.json 2>/dev/null
+  python tools/step_breakdown.py $(find $T/bench_$m -name "*kernel_trace.csv" | head -1) 20 200 > $out/step_breakdown_$m.txt 2>&1
+  cp $(find $T/bench_$m -name "*kernel_stats.csv" | head -1) $out/bench_kernel_stats_$m.csv
+done
+# geometry kernels alone + their HBM counters
+rocprofv3 --kernel-trace --stats --output-format csv -d $T/geo_trace -o geo -- python tools/geo_bench.py 30 0.4 > /dev/null 2>&1
+cp $(find $T/geo_trace -name "*kernel_stats.csv" | head -1) $out/geometry_kernel_stats.csv
+python tools/loss_calibration.py $(find $T/geo_trace -name "*kernel_trace.csv" | head -1) 30 > $out/loss_calibration.txt 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $T/geo_fetch -o geo -- python tools/geo_bench.py 5 0.4 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $T/geo_write -o geo -- python tools/geo_bench.py 5 0.4 > /dev/null 2>&1
+mkdir -p $out/geo_fetch $out/geo_write
+cp $(find $T/geo_fetch -name "*counter_collection.csv" | head -1) $out/geo_fetch/geo_counter_collection.csv
+cp $(find $T/geo_write -name "*counter_collection.csv" | head -1) $out/geo_write/geo_counter_collection.csv
 python tools/loss_warm.py 50 > $out/loss_warm.txt 2>/dev/null
-PYTHONPATH=. python tools/ring_bench.py 20 > $out/ring_bench.txt 2>/dev/null
-# convolution kernels: host-checked correctness, per-layer times, sustained MFMA peak, Winograd; matrix-core counters
-(tools/bin/conv_harness peak; tools/bin/conv_harness all 10; tools/bin/conv_harness wino 10) > $out/conv_harness.txt 2>&1
-rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d $out/conv_pmc -o conv -- tools/bin/conv_harness wino 2 > /dev/null 2>&1
-python tools/exp/conv_pmc.py $(find $out/conv_pmc -name "*counter_collection.csv" | head -1) > $out/conv_pmc.txt 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $out/conv_fetch -o conv -- tools/bin/conv_harness wino 2 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $out/conv_write -o conv -- tools/bin/conv_harness wino 2 > /dev/null 2>&1
-python tools/exp/conv_hbm.py $(find $out/conv_fetch -name "*counter_collection.csv" | head -1) $(find $out/conv_write -name "*counter_collection.csv" | head -1) > $out/conv_hbm_pmc.json 2>$out/conv_hbm.err
+# convolution kernels: stand-alone harnesses (host-checked correctness + per-layer times)
+(tools/bin/conv_harness all 10; tools/bin/conv_harness wino 10; tools/bin/wino_wgrad check; tools/bin/wino_wgrad time 10) > $out/conv_harness.txt 2>&1
+(tools/bin/convh_harness check; tools/bin/convh_harness time 10; tools/bin/convh_harness check f16 | tail -3; tools/bin/hw_probe | tail -3) > $out/convh_harness.txt 2>&1
+# per-layer launch table and HBM traffic of every convolution of a step (fp32 and bf16)
+for m in float32 bfloat16; do
+  python tools/conv_layers.py $m $out/conv_layers_$m.json > $out/conv_layers_$m.txt 2>/dev/null
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $T/cl_fetch_$m -o c -- python tools/conv_layers.py $m > /dev/null 2>&1
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $T/cl_write_$m -o c -- python tools/conv_layers.py $m > /dev/null 2>&1
+  python tools/conv_layers_pmc.py $out/conv_layers_$m.json $(find $T/cl_fetch_$m -name "*counter_collection.csv" | head -1) $(find $T/cl_write_$m -name "*counter_collection.csv" | head -1) > $out/conv_hbm_pmc_$m.json 2> $out/conv_hbm_$m.err
+done
+# matrix-core counters: fp32 Winograd kernels (conv_harness wino + wino_wgrad), half-precision kernels (convh_harness time)
+PMC="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE"
+rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $T/conv_pmc -o conv -- tools/bin/conv_harness wino 2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $T/ww_pmc -o conv -- tools/bin/wino_wgrad time 2 > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $T/convh_pmc -o conv -- tools/bin/convh_harness time 2 > /dev/null 2>&1
+(python tools/exp/conv_pmc.py $(find $T/conv_pmc -name "*counter_collection.csv" | head -1); python tools/exp/conv_pmc.py $(find $T/ww_pmc -name "*counter_collection.csv" | head -1) k_wino_wgrad) > $out/conv_pmc.txt 2>&1
+python tools/exp/convh_pmc.py $(find $T/convh_pmc -name "*counter_collection.csv" | head -1) > $out/convh_pmc.txt 2>&1
 (tools/bin/scatter_probe 20; echo "-- points in raster order"; tools/bin/scatter_probe 20 1) > $out/scatter_probe.txt 2>&1
-python tools/miopen_layers.py 10 2>/dev/null | grep miopen > $out/miopen_layers.txt
-find $out -name "*.csv" | head -30
-# keep only summaries (the raw traces are large)
-find $out -name "*kernel_trace.csv" -size +20M -delete
-du -sh $out
+du -sh $out; ls $out
