@@ -566,3 +566,18 @@ def test_loss_weight_matrix_and_epoch_accumulation():
     ep2 = {"a": 3.0, "b": 0.0}                                                                       # a non-zero python start
     Deployer._accumulate(ep2, ["a", "b"], [torch.tensor(1.0), torch.tensor(1.0)])
     assert float(ep2["a"]) == 4.0 and float(ep2["b"]) == 1.0
+
+
+def test_hip_trunk_shape_gate_decides_the_weight_layout():
+    """`ResNetModified.hip_path_takes` is the shape test the Deployer uses before it stores the trunk's weights channels-last
+    (the layout the HIP kernels read in place): the reference's default KITTI image (64 x 720, config/deployment_options.yaml)
+    does not tile and must keep the module path with NCHW weights; BASELINE.json's image sizes take the HIP path."""
+    from delora_amd.models.model import OdometryModel
+    cfg = util.repo_config(64, 2048)
+    model = OdometryModel(cfg)
+    takes = model.resnet.hip_path_takes
+    assert takes(64, 2048) and takes(64, 1024) and takes(128, 2048)
+    assert not takes(64, 720) and not takes(64, 722)
+    cfg_m = util.repo_config(64, 2048)
+    cfg_m["cnn_impl"] = "modules"
+    assert not OdometryModel(cfg_m).resnet.hip_path_takes(64, 2048)

@@ -16,7 +16,7 @@ def last_json(path):
 
 NEW = os.path.exists(os.path.join(src, "step_breakdown_f32.txt"))          # bundle layout since round 3 (tools/prof_round.sh)
 if NEW:
-    for a in ("bench.json", "bench_bf16.json", "bench_profiled_f32.json", "bench_profiled_bf16.json"):
+    for a in ("bench.json", "bench_bf16.json", "bench_graph.json", "bench_profiled_f32.json", "bench_profiled_bf16.json"):
         if os.path.exists(os.path.join(src, a)):
             json.dump(last_json(os.path.join(src, a)), open(os.path.join(dst, f"{R}_{a}"), "w"), indent=1)
     for name in ("bench_kernel_stats_f32.csv", "bench_kernel_stats_bf16.csv", "step_breakdown_f32.txt", "step_breakdown_bf16.txt",

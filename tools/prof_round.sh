@@ -9,6 +9,7 @@ out=gpurun_out/profiles_$R; rm -rf $out; mkdir -p $out
 T=/tmp/prof_$R; rm -rf $T; mkdir -p $T
 python bench.py > $out/bench.json 2> $out/bench.err; tail -1 $out/bench.json | cut -c1-300
 python bench.py --amp bfloat16 --no-cpu-baseline --feed-steps 0 --long-steps 0 > $out/bench_bf16.json 2>/dev/null
+python bench.py --graph --no-cpu-baseline --feed-steps 0 --long-steps 0 --autocast-steps 0 --kernel-reps 2 > $out/bench_graph.json 2>/dev/null
 for m in f32 bf16; do
   fl=""; [ $m = bf16 ] && fl="--amp bfloat16"
   rocprofv3 --kernel-trace --stats --output-format csv -d $T/bench_$m -o bench -- python bench.py $fl --no-cpu-baseline --no-profile --long-steps 0 --feed-steps 0 --autocast-steps 0 --kernel-reps 2 > $out/bench_profiled_$m.json 2>/dev/null
