@@ -53,6 +53,7 @@ def parse(argv=None):
     ap.add_argument("--feed-steps", type=int, default=64, help="steps of the host-fed leg (0 = skip); N=1 only")
     ap.add_argument("--alloc-skew", type=int, default=-1, help="A/B: base-address skew (bytes) of the trunk's activation tensors (-1: library default)")
     ap.add_argument("--trunk-segments", default="", help="A/B: how the trunk is cut into autograd Functions (mono / layer / block; default: the library's choice)")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not run the rocprofv3 --pmc child passes (roofline.traffic then comes from the committed bundle)")
     ap.add_argument("--no-profile", action="store_true", help="no event-carrying launches in the timed steps (no roofline object)")
     ap.add_argument("--conv-table", action="store_true", help="also time every stride-1 layer shape and pass back to back (roofline_cnn)")
     ap.add_argument("--autocast-steps", type=int, default=20, help="timed steps of the extra bf16-autocast leg of the fp32 run (0 = skip); N=1 only")
@@ -294,8 +295,9 @@ def conv_roofline(rows, args, step_ms):
             "note": "achieved = flop the algorithm issues on the matrix cores (Winograd: 16 multiply-adds per 2x2 output tile and (c,k) pair = a direct "
                     "convolution's / 2.25; direct kernels: 36) / kernel time; begin/end timestamps on HIP events attached to every launch "
                     "(hipExtLaunchKernelGGL) of the K timed steps, summed per layer shape; peak = dense MFMA peak of the arithmetic type "
-                    "(MI355X_MICROARCH.md: 157.3 TFLOP/s fp32, 2500 bf16/fp16); traffic = HBM bytes per launch (launch-weighted mean of the "
-                    "layer rows) from the committed rocprofv3 FETCH_SIZE (x2: gfx950 correction) / WRITE_SIZE passes, profiles/r*_conv_hbm_pmc.json"}
+                    "(MI355X_MICROARCH.md: 157.3 TFLOP/s fp32, 2500 bf16/fp16); traffic = bytes beyond the L2 per launch (launch-weighted mean of the "
+                    "layer rows) from rocprofv3 --pmc FETCH_SIZE (x2: gfx950 correction) and --pmc WRITE_SIZE passes, see traffic_source",
+            "traffic_source": LIVE_PMC["source"]}
     if dom == "k_wino_conv":
         roof["achieved_direct_equivalent"] = round(2.25 * tf, 1)
     prof = [{"launch": r["name"], "launches_per_step": round(r["launches"] / args.steps, 2), "ms_per_step": round(r["ms"] / args.steps, 4),
@@ -304,10 +306,49 @@ def conv_roofline(rows, args, step_ms):
     return roof, {"families_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}, "rows": prof}
 
 
+LIVE_PMC = {"rows": None, "source": None}      # filled once by live_pmc_traffic()
+
+
+def live_pmc_traffic(mode, timeout_s=240):
+    """HBM-side bytes per convolution launch MEASURED BY THIS RUN: two rocprofv3 child processes (`--kernel-trace --pmc FETCH_SIZE`
+    and `--pmc WRITE_SIZE`, separate passes as MI355X_MICROARCH.md prescribes; no other trace domain) over tools/conv_layers.py,
+    which launches every (kernel, pass, layer shape) of the trunk once at the bench's batch size; the dispatches are mapped back to
+    the launch-profile row names by tools/conv_layers_pmc.py (x2 read correction of gfx950).  Returns {row: bytes per launch} or
+    None (no rocprofv3, nested under a profiler, child failure) -- the caller then falls back to the committed bundle."""
+    import glob, importlib.util, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    order = os.path.join(tmp, "order.json")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "-o", "c", "--",
+                   sys.executable, os.path.join(ROOT, "tools", "conv_layers.py"), mode, order]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+            if r.returncode != 0:
+                return None
+        csvs = [glob.glob(os.path.join(tmp, c, "**", "*counter_collection.csv"), recursive=True) for c in ("FETCH_SIZE", "WRITE_SIZE")]
+        if not (csvs[0] and csvs[1] and os.path.exists(order)):
+            return None
+        spec = importlib.util.spec_from_file_location("conv_layers_pmc", os.path.join(ROOT, "tools", "conv_layers_pmc.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        rows = mod.traffic_rows(json.load(open(order)), csvs[0][0], csvs[1][0])
+        return {name: int(v["hbm_bytes_per_launch"]) for name, v in rows.items() if v["hbm_bytes_per_launch"] > 0}
+    except (OSError, subprocess.SubprocessError, ValueError, KeyError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def pmc_layer_traffic(family):
-    """HBM bytes per launch by profile-row name from the newest committed PMC bundle (profiles/r*_conv_hbm_pmc.json:
-    {"launches": {row name: {"hbm_bytes_per_launch": ...}}}); {} when absent."""
+    """HBM bytes per launch by profile-row name: measured by this run (live_pmc_traffic) when available, else from the newest
+    committed PMC bundle (profiles/r*_conv_hbm_pmc.json: {"launches": {row name: {"hbm_bytes_per_launch": ...}}}); {} when absent."""
     import glob
+    if LIVE_PMC["rows"]:
+        return {k: v for k, v in LIVE_PMC["rows"].items() if k.startswith(family + " ")}
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_conv_hbm_pmc.json")))
     out = {}
     for f in files[-1:]:
@@ -315,6 +356,7 @@ def pmc_layer_traffic(family):
             for name, v in json.load(open(f)).get("launches", {}).items():
                 if name.startswith(family + " "):
                     out[name] = int(v["hbm_bytes_per_launch"])
+            LIVE_PMC["source"] = "committed " + os.path.relpath(f, ROOT) + " (rocprofv3 --pmc passes of tools/prof_round.sh; not measured by this run)"
         except (ValueError, KeyError, TypeError):
             pass
     return out
@@ -659,6 +701,11 @@ def main():
                     "of unrelated writes (operands come from HBM); 52 B x source points with a correspondence, vs the 8 TB/s HBM peak"}
         result["network_pose_after_timed_steps"] = counts["network_pose"]
         if conv_prof:
+            if world == 1 and not args.no_live_pmc:
+                LIVE_PMC["rows"] = live_pmc_traffic(args.amp or "float32")
+                if LIVE_PMC["rows"]:
+                    LIVE_PMC["source"] = ("measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes over "
+                                          "tools/conv_layers.py (one launch per kernel / pass / layer shape at the bench's batch size)")
             result["roofline"], _ = conv_roofline(conv_prof, args, result["ms_per_step"])
             # every instrumented convolution launch, in a second run of the same K steps (untimed for the headline)
             _lib.profile_begin(int(args.steps) * 200)

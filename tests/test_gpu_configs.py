@@ -288,13 +288,36 @@ def test_bench_final_loss_reproduces():
     mine = float(ep["loss_epoch"])
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "0", "--no-cpu-baseline",
-                        "--kernel-reps", "2", "--feed-steps", "0", "--long-steps", "0"], capture_output=True, text=True, timeout=900)
+                        "--kernel-reps", "2", "--feed-steps", "0", "--long-steps", "0", "--no-live-pmc"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
     j = json.loads(line)
     util.measured("bench.py final_loss vs the same 3 steps in-process (relative)", abs(j["final_loss"] - mine) / abs(mine), bound=REL)
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["dtype"] == "f32" and j["config"]["global_batch"] == 8
     assert j["roofline"]["bound"] and 0 < j["roofline"]["frac"] < 1.5
+
+
+def test_bench_measures_the_convolution_traffic_itself():
+    """`bench.py`'s roofline.traffic is measured by the run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes over one launch per
+    convolution kernel and layer shape.  Every Winograd row must come back, at or above the bytes the launch cannot avoid
+    (input + output; the counters include L2 misses served by the Infinity Cache) and below 8x of them."""
+    _dev()
+    import shutil
+    if not (shutil.which("rocprofv3") or os.path.exists("/opt/rocm/bin/rocprofv3")):
+        pytest.skip("no rocprofv3 on this box")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    rows = bench.live_pmc_traffic("float32")
+    assert rows, "the rocprofv3 child passes returned nothing"
+    wino = {k: v for k, v in rows.items() if k.startswith("k_wino_conv ")}
+    assert len(wino) == 4, sorted(rows)
+    for name, b in wino.items():
+        n, hw, c, k = name.split(" ")[2:6]
+        h, w = (int(v) for v in hw.split("x"))
+        compulsory = int(n[1:]) * h * w * (int(c[1:]) + int(k[1:])) * 4
+        util.measured(f"live PMC traffic / (input + output bytes): {name}", b / compulsory, bound=8.0)
+        assert b >= 0.9 * compulsory, (name, b, compulsory)
 
 
 # ------------------------------------------------------------------------------------------------------------ config 3

@@ -27,34 +27,48 @@ def dispatches(path, counter):
     return out
 
 
-order = json.load(open(sys.argv[1]))
-fetch, write = dispatches(sys.argv[2], "FETCH_SIZE"), dispatches(sys.argv[3], "WRITE_SIZE")
-res = {}
-pf = pw = 0
-for o in order["order"]:
-    fam, n = family_of(o["row"]), o["launches"]
-    vals = []
-    for seq, pos in ((fetch, "f"), (write, "w")):
-        p = pf if pos == "f" else pw
-        # two runs of the op (warm-up, measured): skip the first n dispatches of the family, take the next n
-        got, skipped, taken = [], 0, 0
-        while p < len(seq) and taken < n:
-            if seq[p][0] == fam:
-                if skipped < n:
-                    skipped += 1
-                else:
-                    got.append(seq[p][1]); taken += 1
-            p += 1
-        if pos == "f":
-            pf = p
+def traffic_rows(order, fetch_csv, write_csv):
+    """{profile-row name: {...bytes per launch...}} for the rows of `order` (the dict tools/conv_layers.py writes)."""
+    fetch, write = dispatches(fetch_csv, "FETCH_SIZE"), dispatches(write_csv, "WRITE_SIZE")
+    res = {}
+    pf = pw = 0
+    for o in order["order"]:
+        fam, n = family_of(o["row"]), o["launches"]
+        vals = []
+        for seq, pos in ((fetch, "f"), (write, "w")):
+            p = pf if pos == "f" else pw
+            # two runs of the op (warm-up, measured): skip the first n dispatches of the family, take the next n
+            got, skipped, taken = [], 0, 0
+            while p < len(seq) and taken < n:
+                if seq[p][0] == fam:
+                    if skipped < n:
+                        skipped += 1
+                    else:
+                        got.append(seq[p][1]); taken += 1
+                p += 1
+            if pos == "f":
+                pf = p
+            else:
+                pw = p
+            vals.append(sum(got))
+        rd, wr = vals[0] * 1024 * 2, vals[1] * 1024
+        prev = res.get(o["row"])
+        if prev is not None:
+            # the same kernel on the same shape in two passes (e.g. Winograd forward and input gradient): launch-weighted mean
+            rd, wr, n = rd + prev["read_bytes_corrected_x2"], wr + prev["write_bytes"], n + prev["kernel_launches"]
+            op, comp = prev["op"] + " + " + o["op"], prev["compulsory_bytes_per_op"] + int(o["compulsory_bytes"])
         else:
-            pw = p
-        vals.append(sum(got))
-    rd, wr = vals[0] * 1024 * 2, vals[1] * 1024
-    res[o["row"]] = {"op": o["op"], "kernel_launches": n, "read_bytes_corrected_x2": int(rd), "write_bytes": int(wr),
-                     "hbm_bytes_per_launch": int((rd + wr) / max(n, 1)), "hbm_bytes_per_op": int(rd + wr),
-                     "compulsory_bytes_per_op": int(o["compulsory_bytes"])}
-print(json.dumps({"workload": order["workload"] + "; rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/conv_layers.py",
-                  "correction": "gfx950: read bytes = FETCH_SIZE x 1024 x 2 (64 B counted per 128-B request); WRITE_SIZE x 1024; Infinity-Cache hits are "
-                                "counted by these counters (fabric-side requests), so this is traffic beyond the L2, not only HBM",
-                  "launches": res}, indent=1))
+            op, comp = o["op"], int(o["compulsory_bytes"])
+        res[o["row"]] = {"op": op, "kernel_launches": n, "read_bytes_corrected_x2": int(rd), "write_bytes": int(wr),
+                         "hbm_bytes_per_launch": int((rd + wr) / max(n, 1)), "hbm_bytes_per_op": int(rd + wr),
+                         "compulsory_bytes_per_op": comp}
+    return res
+
+
+CORRECTION = ("gfx950: read bytes = FETCH_SIZE x 1024 x 2 (64 B counted per 128-B request); WRITE_SIZE x 1024; Infinity-Cache hits are "
+              "counted by these counters (fabric-side requests), so this is traffic beyond the L2, not only HBM")
+
+if __name__ == "__main__":
+    order = json.load(open(sys.argv[1]))
+    print(json.dumps({"workload": order["workload"] + "; rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/conv_layers.py",
+                      "correction": CORRECTION, "launches": traffic_rows(order, sys.argv[2], sys.argv[3])}, indent=1))

@@ -12,7 +12,7 @@ python bench.py --amp bfloat16 --no-cpu-baseline --feed-steps 0 --long-steps 0 >
 python bench.py --graph --no-cpu-baseline --feed-steps 0 --long-steps 0 --autocast-steps 0 --kernel-reps 2 > $out/bench_graph.json 2>/dev/null
 for m in f32 bf16; do
   fl=""; [ $m = bf16 ] && fl="--amp bfloat16"
-  rocprofv3 --kernel-trace --stats --output-format csv -d $T/bench_$m -o bench -- python bench.py $fl --no-cpu-baseline --no-profile --long-steps 0 --feed-steps 0 --autocast-steps 0 --kernel-reps 2 > $out/bench_profiled_$m.json 2>/dev/null
+  rocprofv3 --kernel-trace --stats --output-format csv -d $T/bench_$m -o bench -- python bench.py $fl --no-cpu-baseline --no-profile --no-live-pmc --long-steps 0 --feed-steps 0 --autocast-steps 0 --kernel-reps 2 > $out/bench_profiled_$m.json 2>/dev/null
   python tools/step_breakdown.py $(find $T/bench_$m -name "*kernel_trace.csv" | head -1) 20 200 > $out/step_breakdown_$m.txt 2>&1
   cp $(find $T/bench_$m -name "*kernel_stats.csv" | head -1) $out/bench_kernel_stats_$m.csv
 done
