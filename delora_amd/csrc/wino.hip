@@ -23,6 +23,7 @@
 // Numerics: fp32 throughout; Winograd F(2x2,3x3) adds/subtracts before and after the products, error ~1e-6 relative to the
 // layer's output scale (tests/test_gpu_conv.py bounds it against torch's direct convolution at 1e-4).
 #include "common.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -124,6 +125,12 @@ __global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ 
 // sinking every piece to its first use.  (Fetching the raw pieces straight into registers -- 8 scattered 16-byte loads
 // per thread and chunk, each 32-byte pixel slice requested by ~4 threads -- measured 15 % slower: the vector-memory
 // path, not the matrix pipe, became the limit.)
+#ifdef CV_TUNE
+__device__ unsigned long long g_wn_t[8 * 8192];       // phase time stamps per group (tools/conv_harness wino-phases)
+#define WN_T(I) { if (tid == 0 && grp < 8192) g_wn_t[grp * 8 + (I)] = clock64(); }
+#else
+#define WN_T(I)
+#endif
 template <int TC>
 __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   constexpr int TR = WN_TILES / TC;
@@ -136,6 +143,9 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   static_assert((2 * BUF + 2 * RAWBUF) * 4 <= 163840, "LDS budget");
   __shared__ __attribute__((aligned(16))) float lds[2 * BUF + 2 * RAWBUF];
   float* rawbase = lds + 2 * BUF;
+  // chunk ch lives in buffer (ch + 1) & 1: chunk 0 of the NEXT group can then be fetched into the upper buffer while the epilogue of
+  // the current group uses the lower 74 KB as its exchange / transposition space
+#define WN_BUFOF(CH) (lds + (((CH) + 1) & 1) * BUF)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, half = lane >> 5;
@@ -143,14 +153,7 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   const int KT = a.K / WN_KB;
   const int tiles_w = (a.W / 2) / TC, tiles_h = (a.H / 2) / TR;
   const int ngroups = a.N * tiles_h * tiles_w * KT;
-  int t = wn_xcd_swizzle(blockIdx.x, ngroups);
-  const int kt = t % KT; t /= KT;
-  const int gw = t % tiles_w; t /= tiles_w;
-  const int gh = t % tiles_h;
-  const int n = t / tiles_h;
-  const int k0 = kt * WN_KB;
-  const int h_base = gh * TR * 2 - 1, w_base = gw * TC * 2 - 1;     // image position of raw(0,0)
-  const float* xn = a.x + (size_t)n * a.H * a.W * a.C;
+  const int nchunks = a.C / WN_CK;
 
   // transform role of this thread: tile, channel quad, column b of the 4x4 domain
   const int tb = tid & 3, tc4 = (tid >> 2) & 1, ttile = tid >> 3;
@@ -159,58 +162,71 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   const float sg0 = tb == 2 ? -1.f : 1.f, sg1 = (tb == 0 || tb == 3) ? -1.f : 1.f;   // T[.][b] = sg0*d[.][j0] + sg1*d[.][j1]
   const int t_wr = tb * WN_PLANE + ttile * 8 + ((tc4 ^ ((ttile >> 3) & 1)) * 4);
   const int t_rd = ((2 * ttr) * RW + 2 * ttc) * 8 + tc4 * 4;        // raw(row 0, col 0) of this tile's window
-  int rowmask[4];                                                     // zero rows above / below the image
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int h = h_base + 2 * ttr + i;
-    rowmask[i] = (h >= 0 && h < a.H) ? -1 : 0;
-  }
   // DMA pieces of this wave: raw pixels r*32 + lane/2, channel quad lane & 1 (ids beyond the patch re-read its last
   // pixel; rows outside the image read row 0 / H-1 and are masked by the transform)
-  int raw_g[NR_IT], raw_l[NR_IT];
+  int raw_l[NR_IT];
 #pragma unroll
-  for (int it = 0; it < NR_IT; ++it) {
-    const int r = min(wave + it * 8, NRI - 1);
-    const int p = min(r * 32 + (lane >> 1), NPIX - 1);
-    const int row = p / RW, col = p % RW;
-    int h = h_base + row;
-    h = h < 0 ? 0 : (h >= a.H ? a.H - 1 : h);
-    int w = w_base + col;
-    w = w < 0 ? w + a.W : (w >= a.W ? w - a.W : w);
-    raw_g[it] = (h * a.W + w) * a.C + (lane & 1) * 4;
-    raw_l[it] = r * 256;
-  }
+  for (int it = 0; it < NR_IT; ++it) raw_l[it] = min(wave + it * 8, NRI - 1) * 256;
   // U: wave w copies the half-planes 4w .. 4w+3 (plane = id >> 1, rows 32 * (id & 1) ..); a lane's LDS slot is linear in
   // the lane id as the instruction requires, so the 16-byte XOR swizzle is applied to the SOURCE address instead
-  int u_g[NU_IT], u_l[NU_IT];
+  // (32-bit UNSIGNED per-lane offsets next to wave-uniform 64-bit bases: the DMA then takes its address as scalar base + vector
+  // offset and no per-lane 64-bit address has to live in registers across the chunk loop)
+  unsigned u_g[NU_IT];
+  int u_l[NU_IT];
 #pragma unroll
   for (int it = 0; it < NU_IT; ++it) {
     const int id = wave * NU_IT + it, xi = id >> 1, kk = (id & 1) * 32 + (lane >> 1), slot = lane & 1;
-    u_g[it] = (xi * a.K + k0 + kk) * 8 + ((slot ^ ((kk >> 3) & 1)) * 4);     // + chunk * 16 * K * 8
+    u_g[it] = (unsigned)((xi * a.K + kk) * 8 + ((slot ^ ((kk >> 3) & 1)) * 4));          // + k0 * 8 + chunk * 16 * K * 8
     u_l[it] = 16 * WN_PLANE + xi * WN_PLANE + (id & 1) * 256;                // wave-uniform base (floats)
   }
-
-  f32x16 acc[8];
-#pragma unroll
-  for (int i = 0; i < 8; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
-
   const int arow = mb * 32 + li, brow = nb * 32 + li;
   const int a_off = arow * 8 + ((half ^ ((arow >> 3) & 1)) * 4);
   const int b_off = 16 * WN_PLANE + brow * 8 + ((half ^ ((brow >> 3) & 1)) * 4);
 
+  // (tile group, channel block) of the group in hand: persistent workgroups -- the grid is capped at the number of CUs (one
+  // 512-thread workgroup fits a CU) and every workgroup walks its share of the groups, fetching the first operands of its NEXT
+  // group while the epilogue of the current one runs
+  int n, k0, gh, gw;
+  const float* xn;
+  int rowmask[4];                                                     // zero rows above / below the image
+  unsigned raw_g[NR_IT];
+#define WN_SETUP(G, LN)                                                                                                   \
+  {                                                                                                                       \
+    int t_ = wn_xcd_swizzle((G), ngroups);                                                                                \
+    const int kt_ = t_ % KT; t_ /= KT;                                                                                    \
+    gw = t_ % tiles_w; t_ /= tiles_w;                                                                                     \
+    gh = t_ % tiles_h;                                                                                                    \
+    n = t_ / tiles_h;                                                                                                     \
+    k0 = kt_ * WN_KB;                                                                                                     \
+    const int h_base_ = gh * TR * 2 - 1, w_base_ = gw * TC * 2 - 1;          /* image position of raw(0,0) */             \
+    xn = a.x + (size_t)n * a.H * a.W * a.C;                                                                               \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                       \
+      const int h_ = h_base_ + 2 * ttr + i;                                                                               \
+      rowmask[i] = (h_ >= 0 && h_ < a.H) ? -1 : 0;                                                                        \
+    }                                                                                                                     \
+    _Pragma("unroll") for (int it = 0; it < NR_IT; ++it) {                                                                \
+      const int p_ = min(min(wave + it * 8, NRI - 1) * 32 + ((LN) >> 1), NPIX - 1);        /* recomputed: registers are scarce */ \
+      int h_ = h_base_ + p_ / RW;                                                                                         \
+      h_ = h_ < 0 ? 0 : (h_ >= a.H ? a.H - 1 : h_);                                                                       \
+      int w_ = w_base_ + p_ % RW;                                                                                         \
+      w_ = w_ < 0 ? w_ + a.W : (w_ >= a.W ? w_ - a.W : w_);                                                               \
+      raw_g[it] = (unsigned)((h_ * a.W + w_) * a.C + ((LN) & 1) * 4);                                                     \
+    }                                                                                                                     \
+  }
+
 #define WN_GLDS(GPTR, LPTR)                                                                                               \
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(GPTR),                                 \
                                    (__attribute__((address_space(3))) void*)(LPTR), 16, 0, 0);
-#define WN_U_PIECE(IT, CH, BUFP) WN_GLDS(a.u + (size_t)(CH) * 16 * a.K * 8 + u_g[IT], (BUFP) + __builtin_amdgcn_readfirstlane(u_l[IT]))
+#define WN_U_PIECE_X(UG, IT, CH, BUFP) \
+  WN_GLDS((a.u + ((size_t)(CH) * 16 * a.K * 8 + k0 * 8)) + (size_t)(UG)[IT], (BUFP) + __builtin_amdgcn_readfirstlane(u_l[IT]))
+#define WN_U_PIECE(IT, CH, BUFP) WN_U_PIECE_X(u_g, IT, CH, BUFP)
 #define WN_RAW_PIECE(IT, CH) \
-  WN_GLDS(xn + raw_g[IT] + (CH) * WN_CK, rawbase + ((CH) & 1) * RAWBUF + __builtin_amdgcn_readfirstlane(raw_l[IT]))
+  WN_GLDS((xn + (CH) * WN_CK) + (size_t)raw_g[IT], rawbase + ((CH) & 1) * RAWBUF + __builtin_amdgcn_readfirstlane(raw_l[IT]))
 #define WN_RAW_ALL(CH) { _Pragma("unroll") for (int it = 0; it < NR_IT; ++it) WN_RAW_PIECE(it, CH) }
 #define WN_U_ALL(CH, BUFP) { _Pragma("unroll") for (int it = 0; it < NU_IT; ++it) WN_U_PIECE(it, CH, BUFP) }
-  // row I of T = d B for this thread's column: two 16-byte reads of the raw patch (issued one slice ahead of their use: a read and
-  // its use in the same slice stalls the wave for an LDS round trip while its partner on the SIMD is in the same phase), masked for
-  // rows outside the image
+  // row I of T = d B for this thread's column: two 16-byte reads of the raw patch (issued ahead of their use: a read and its use in
+  // the same slice stalls the wave for an LDS round trip while its partner on the SIMD is in the same phase), masked for rows
+  // outside the image
 #define WN_TROW_LD(I, RB)                                                                                                 \
   {                                                                                                                       \
     dd[(I) & 1][0] = *reinterpret_cast<const i32x4*>((RB) + t_rd + ((I) * RW + j0) * 8);                                  \
@@ -221,6 +237,19 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
     tt[I] = sg0 * __builtin_bit_cast(f32x4, dd[(I) & 1][0] & rowmask[I]) + sg1 * __builtin_bit_cast(f32x4, dd[(I) & 1][1] & rowmask[I]); \
   }
 #define WN_TROW(I, RB) WN_TROW_LD(I, RB) WN_TROW_FIN(I)
+  // V(0) of the group in hand from its raw(0): the one transform that is not hidden behind MFMAs
+#define WN_V0()                                                                                                           \
+  {                                                                                                                       \
+    f32x4 tt[4];                                                                                                          \
+    i32x4 dd[2][2];                                                                                                       \
+    const float* rb_ = rawbase;                                                                                           \
+    float* vb_ = WN_BUFOF(0) + t_wr;                                                                                      \
+    WN_TROW(0, rb_) WN_TROW(1, rb_) WN_TROW(2, rb_) WN_TROW(3, rb_)                                                       \
+    *reinterpret_cast<f32x4*>(vb_ + 0 * 4 * WN_PLANE) = tt[0] - tt[2];                                                    \
+    *reinterpret_cast<f32x4*>(vb_ + 1 * 4 * WN_PLANE) = tt[1] + tt[2];                                                    \
+    *reinterpret_cast<f32x4*>(vb_ + 2 * 4 * WN_PLANE) = tt[2] - tt[1];                                                    \
+    *reinterpret_cast<f32x4*>(vb_ + 3 * 4 * WN_PLANE) = tt[1] - tt[3];                                                    \
+  }
 #define WN_LOAD_FRAGS_FROM(XL, BP)                                                                                        \
   {                                                                                                                       \
     av[(XL) & 1] = *reinterpret_cast<const f32x4*>((BP) + (xh * 8 + (XL)) * WN_PLANE + a_off);                            \
@@ -234,154 +263,212 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
     __builtin_amdgcn_sched_barrier(0);                                                                                    \
   }
 
-  const int nchunks = a.C / WN_CK;
-  f32x4 av[2], bv[2], tt[4];
-  i32x4 dd[2][2];
-  // prologue: raw(0), raw(1), U(0) -> LDS; V(0) from raw(0)
+  int grp = blockIdx.x;                              // the launcher guarantees gridDim.x <= ngroups
+  WN_SETUP(grp, lane)
+  // prologue of the first group: raw(0), raw(1), U(0) -> LDS; V(0) from raw(0)
   WN_RAW_ALL(0)
   WN_RAW_ALL(min(1, nchunks - 1))
-  WN_U_ALL(0, lds)
+  WN_U_ALL(0, WN_BUFOF(0))
   __syncthreads();
-  {
-    const float* rb = rawbase;
-    float* vb = lds + t_wr;
-    WN_TROW(0, rb) WN_TROW(1, rb) WN_TROW(2, rb) WN_TROW(3, rb)
-    *reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = tt[0] - tt[2];
-    *reinterpret_cast<f32x4*>(vb + 1 * 4 * WN_PLANE) = tt[1] + tt[2];
-    *reinterpret_cast<f32x4*>(vb + 2 * 4 * WN_PLANE) = tt[2] - tt[1];
-    *reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = tt[1] - tt[3];
+  WN_V0()
+  for (;;) {
+    __syncthreads();
+    WN_T(0)
+    f32x4 av[2], bv[2], tt[4];                       // (declared per group: nothing of them is carried from one group to the next)
+    i32x4 dd[2][2];
+    f32x16 acc[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    {
+      float* cur = WN_BUFOF(0);
+      WN_LOAD_FRAGS(0)
+    }
+    // Pipeline (one barrier per chunk).  LDS holds two (V, U) buffers and two raw-patch buffers.  While the waves multiply chunk c:
+    //   * the LDS DMA (global_load_lds, no registers) brings U of chunk c+1 into the other (V, U) buffer and the raw input patch of
+    //     chunk c+2 -- (2TR+2) x (2TC+2) pixels x 8 channels, wrap-around columns by addressing -- into raw[c & 1]; both have the
+    //     whole chunk to land;
+    //   * every thread turns the raw patch of chunk c+1 (raw[(c+1) & 1], landed during chunk c-1) into its column b of
+    //     V = B^T d B for its (tile, channel quad): 8 x 16-byte LDS reads, a few adds, 4 x 16-byte LDS writes.
+    // All of that is sliced into small pieces placed behind individual MFMAs: in-order issue means a wave's next MFMA on the same
+    // accumulator cannot issue for 64 cycles anyway, and a piece runs in that shadow.  The fences keep hipcc from sinking every
+    // piece to its first use.  The barrier of a chunk sits in front of its LAST plane: every wave holds that plane's fragments in
+    // registers by then, so its four MFMAs run behind the barrier and cover the fetch of the next chunk's first fragments.
+    // (Fetching the raw pieces straight into registers -- 8 scattered 16-byte loads per thread and chunk, each 32-byte pixel slice
+    // requested by ~4 threads -- measured 15 % slower: the vector-memory path, not the matrix pipe, became the limit.)
+    for (int ch = 0; ch + 1 < nchunks; ++ch) {
+      float* cur = WN_BUFOF(ch);
+      float* nxt = WN_BUFOF(ch + 1);
+      const float* rb = rawbase + ((ch + 1) & 1) * RAWBUF;
+      float* vb = nxt + t_wr;
+      WN_M(0, 0, WN_LOAD_FRAGS(1)) WN_M(0, 1, WN_U_PIECE(0, ch + 1, nxt) WN_U_PIECE(1, ch + 1, nxt))
+      WN_M(0, 2, WN_U_PIECE(2, ch + 1, nxt) WN_U_PIECE(3, ch + 1, nxt))
+      // raw(ch+2) overwrites raw(ch), which every wave finished reading before the last barrier
+      WN_M(0, 3, if (ch + 2 < nchunks) WN_RAW_ALL(ch + 2))
+      // LDS traffic only in the first two slices of a plane, arithmetic in the last two: the compiler waits for ALL outstanding LDS
+      // operations (lgkmcnt(0)) in front of a plane's first MFMA, and with this layout everything it waits for is two slices old
+      WN_M(1, 0, WN_LOAD_FRAGS(2)) WN_M(1, 1, WN_TROW_LD(0, rb) WN_TROW_LD(1, rb)) WN_M(1, 2, ) WN_M(1, 3, WN_TROW_FIN(0) WN_TROW_FIN(1))
+      WN_M(2, 0, WN_LOAD_FRAGS(3)) WN_M(2, 1, WN_TROW_LD(2, rb) WN_TROW_LD(3, rb)) WN_M(2, 2, ) WN_M(2, 3, WN_TROW_FIN(2) WN_TROW_FIN(3))
+      WN_M(3, 0, WN_LOAD_FRAGS(4) *reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = tt[0] - tt[2];)
+      WN_M(3, 1, *reinterpret_cast<f32x4*>(vb + 1 * 4 * WN_PLANE) = tt[1] + tt[2];) WN_M(3, 2, ) WN_M(3, 3, )
+      WN_M(4, 0, WN_LOAD_FRAGS(5) *reinterpret_cast<f32x4*>(vb + 2 * 4 * WN_PLANE) = tt[2] - tt[1];)
+      WN_M(4, 1, *reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = tt[1] - tt[3];) WN_M(4, 2, ) WN_M(4, 3, )
+      WN_M(5, 0, WN_LOAD_FRAGS(6)) WN_M(5, 1, ) WN_M(5, 2, ) WN_M(5, 3, )
+      WN_M(6, 0, WN_LOAD_FRAGS(7)) WN_M(6, 1, ) WN_M(6, 2, ) WN_M(6, 3, )
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      WN_M(7, 0, WN_LOAD_FRAGS_FROM(0, nxt)) WN_M(7, 1, ) WN_M(7, 2, ) WN_M(7, 3, )
+    }
+    {
+      float* cur = WN_BUFOF(nchunks - 1);
+      WN_M(0, 0, WN_LOAD_FRAGS(1)) WN_M(0, 1, ) WN_M(0, 2, ) WN_M(0, 3, )
+      WN_M(1, 0, WN_LOAD_FRAGS(2)) WN_M(1, 1, ) WN_M(1, 2, ) WN_M(1, 3, )
+      WN_M(2, 0, WN_LOAD_FRAGS(3)) WN_M(2, 1, ) WN_M(2, 2, ) WN_M(2, 3, )
+      WN_M(3, 0, WN_LOAD_FRAGS(4)) WN_M(3, 1, ) WN_M(3, 2, ) WN_M(3, 3, )
+      WN_M(4, 0, WN_LOAD_FRAGS(5)) WN_M(4, 1, ) WN_M(4, 2, ) WN_M(4, 3, )
+      WN_M(5, 0, WN_LOAD_FRAGS(6)) WN_M(5, 1, ) WN_M(5, 2, ) WN_M(5, 3, )
+      WN_M(6, 0, WN_LOAD_FRAGS(7)) WN_M(6, 1, ) WN_M(6, 2, ) WN_M(6, 3, )
+      WN_M(7, 0, ) WN_M(7, 1, ) WN_M(7, 2, ) WN_M(7, 3, )
+    }
+    __syncthreads();                                 // every wave is done with the staging buffers
+    WN_T(1)
+
+    // Everything the epilogue derives from the lane id is derived from an opaque copy of it: hoisted out of the persistent loop those
+    // values would have to live -- or be spilled -- across the chunk loop, where every register is taken
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int li_e = lane_e & 31, half_e = lane_e >> 5;
+    // Output offsets of this lane's eight epilogue items (item i = lane + 64 it: row = i >> 3 = tile_in_block * 2 + q, channel
+    // quad i & 7), taken before the group variables move on
+    unsigned ooff[8];                                // (element offsets fit 31 bits: checked by the entry point)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int i = lane_e + it * 64, row = i >> 3, c4 = i & 7;
+      const int tile = mb * 32 + (row >> 1), q = row & 1;
+      const int tr = tile / TC, tc = tile % TC;
+      const int oh = (gh * TR + tr) * 2 + xh, ow = (gw * TC + tc) * 2 + q;
+      ooff[it] = (unsigned)(((n * a.H + oh) * a.W + ow) * a.K + k0 + nb * 32 + c4 * 4);
+    }
+    // The first operands of the NEXT group are requested now: raw(0), raw(1) into the raw buffers, U(0) into the upper (V, U) buffer --
+    // none of them is touched by the epilogue below, whose duration covers their latency.
+    const int nextg = grp + gridDim.x;
+    const bool more = nextg < ngroups;
+    if (more) {
+      WN_SETUP(nextg, lane_e)
+      WN_RAW_ALL(0)
+      WN_RAW_ALL(min(1, nchunks - 1))
+      unsigned u_gn[NU_IT];
+#pragma unroll
+      for (int it = 0; it < NU_IT; ++it) {
+        const int id = wave * NU_IT + it, xi = id >> 1, kk = (id & 1) * 32 + (lane_e >> 1), slot = lane_e & 1;
+        u_gn[it] = (unsigned)((xi * a.K + kk) * 8 + ((slot ^ ((kk >> 3) & 1)) * 4));
+      }
+#pragma unroll
+      for (int it = 0; it < NU_IT; ++it) WN_U_PIECE_X(u_gn, it, 0, WN_BUFOF(0))
+    }
+
+    // The contribution to the partner's row goes to LDS as soon as it exists (exchange region per (block, direction): 2 x 16 x 64
+    // floats in the lower staging buffer, which is free): the accumulators, both halves of the result and the loop-carried
+    // addressing state of the persistent loop do not fit the register file together.
+    f32x16 keep[2];
+    float* xch = lds;
+    const int blk = wave & 3;                          // (mb, nb) block; partner = wave ^ 4
+    {
+      float* dst = xch + ((blk * 2 + xh) * 32) * 64 + lane_e;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        f32x16 p0, p1;                                  // P[2xh][q], P[2xh+1][q]
+        if (q == 0) { p0 = acc[0] + acc[1] + acc[2]; p1 = acc[4] + acc[5] + acc[6]; }
+        else        { p0 = acc[1] - acc[2] - acc[3]; p1 = acc[5] - acc[6] - acc[7]; }
+        f32x16 snd;
+        if (xh == 0) { keep[q] = p0 + p1; snd = p1; }              // rows 0,1: Y0 += P0 + P1, Y1 += P1
+        else         { keep[q] = -p0 - p1; snd = p0; }             // rows 2,3: Y0 += P2,      Y1 += -P2 - P3
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[(q * 16 + r) * 64] = snd[r];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    const bool f_add = a.epi & WN_EPI_ADD, f_act = a.epi & WN_EPI_ACT, f_dact = a.epi & WN_EPI_DACT;
+    __syncthreads();
+    {
+      const float* src = xch + ((blk * 2 + (xh ^ 1)) * 32) * 64 + lane_e;
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keep[q][r] += src[(q * 16 + r) * 64];
+    }
+    __syncthreads();
+    WN_T(2)
+    // keep[q][r] = output pixel (row 2*tr + xh, col 2*tc + q) of tile (r & 3) + 8 * (r >> 2) + 4 * half of this block, channel li.
+    // Transposed through LDS per wave (32 tiles x 2 pixels x 32 channels; all of it inside the lower staging buffer) so that a lane
+    // owns four consecutive channels: float4 epilogue arithmetic and 16-byte stores of 128-byte channel rows.
+    constexpr int ES = 32;
+    static_assert(8 * 64 * ES <= BUF, "the transposition space must stay inside the lower (V, U) buffer");
+    float* ep = lds + wave * (64 * ES);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) ep[(((r & 3) + 8 * (r >> 2) + 4 * half_e) * 2 + q) * ES + li_e] = keep[q][r];
+    // Epilogue operand of this lane's eight output rows (the saved activation of an input-gradient pass, else the shortcut),
+    // requested in one batch as soon as the registers of the result are free: its latency runs under the wait for the next group's
+    // operands instead of in front of every store (the compiler cannot batch the loads itself: y may alias them as far as it
+    // knows).  A pass with both operands fetches the shortcut in the store loop.
+    f32x4 opv[8];
+    {
+      // (unconditional: without an operand every lane re-reads the first 16 bytes of the weights -- cheaper than what the register
+      // allocator does with conditionally defined values in this loop)
+      const bool has_op = f_dact || f_add;
+      const float* op = f_dact ? a.dsrc : (f_add ? a.add : a.u);
+#pragma unroll
+      for (int it = 0; it < 8; ++it) opv[it] = *reinterpret_cast<const f32x4*>(op + (has_op ? ooff[it] : 0u));
+    }
+    if (more) {
+      // the next group's operands have landed (the stores of this group are issued AFTER this wait, so they are never waited
+      // for); V(0) of the next group goes into the upper buffer, which the epilogue does not touch
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      WN_V0()
+    }
+    WN_T(3)
+    const bool tanh_act = a.act == 1;
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int i = lane_e + it * 64, row = i >> 3, c4 = i & 7;
+      f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * ES + c4 * 4);
+      if (f_add) v += f_dact ? *reinterpret_cast<const f32x4*>(a.add + ooff[it]) : opv[it];
+      if (f_act) {
+        if (tanh_act) { v[0] = dl_tanh(v[0]); v[1] = dl_tanh(v[1]); v[2] = dl_tanh(v[2]); v[3] = dl_tanh(v[3]); }
+        else { v[0] = wn_act(v[0], a.act); v[1] = wn_act(v[1], a.act); v[2] = wn_act(v[2], a.act); v[3] = wn_act(v[3], a.act); }
+      }
+      if (f_dact) {
+        const f32x4 sv = opv[it];
+        if (tanh_act) v *= 1.f - sv * sv;
+        else { v[0] *= wn_dact(sv[0], a.act); v[1] *= wn_dact(sv[1], a.act); v[2] *= wn_dact(sv[2], a.act); v[3] *= wn_dact(sv[3], a.act); }
+      }
+      *reinterpret_cast<f32x4*>(a.y + ooff[it]) = v;
+    }
+    WN_T(4)
+    if (!more) break;
+    grp = nextg;
   }
-  __syncthreads();
-  {
-    float* cur = lds;
-    WN_LOAD_FRAGS(0)
-  }
-  // The barrier of a chunk sits in front of its LAST plane: every wave holds that plane's fragments in registers by then, so its
-  // four MFMAs run behind the barrier and cover the fetch of the next chunk's first fragments.
-  for (int ch = 0; ch + 1 < nchunks; ++ch) {
-    float* cur = lds + (ch & 1) * BUF;
-    float* nxt = lds + ((ch + 1) & 1) * BUF;
-    const float* rb = rawbase + ((ch + 1) & 1) * RAWBUF;
-    float* vb = nxt + t_wr;
-    WN_M(0, 0, WN_LOAD_FRAGS(1)) WN_M(0, 1, WN_U_PIECE(0, ch + 1, nxt) WN_U_PIECE(1, ch + 1, nxt))
-    WN_M(0, 2, WN_U_PIECE(2, ch + 1, nxt) WN_U_PIECE(3, ch + 1, nxt))
-    // raw(ch+2) overwrites raw(ch), which every wave finished reading before the last barrier
-    WN_M(0, 3, if (ch + 2 < nchunks) WN_RAW_ALL(ch + 2))
-    WN_M(1, 0, WN_LOAD_FRAGS(2)) WN_M(1, 1, WN_TROW_LD(0, rb)) WN_M(1, 2, WN_TROW_LD(1, rb)) WN_M(1, 3, WN_TROW_FIN(0))
-    WN_M(2, 0, WN_LOAD_FRAGS(3)) WN_M(2, 1, WN_TROW_LD(2, rb)) WN_M(2, 2, WN_TROW_FIN(1) WN_TROW_LD(3, rb)) WN_M(2, 3, WN_TROW_FIN(2))
-    WN_M(3, 0, WN_LOAD_FRAGS(4)) WN_M(3, 1, WN_TROW_FIN(3)) WN_M(3, 2, *reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = tt[0] - tt[2];) WN_M(3, 3, )
-    WN_M(4, 0, WN_LOAD_FRAGS(5)) WN_M(4, 1, ) WN_M(4, 2, *reinterpret_cast<f32x4*>(vb + 1 * 4 * WN_PLANE) = tt[1] + tt[2];) WN_M(4, 3, )
-    WN_M(5, 0, WN_LOAD_FRAGS(6)) WN_M(5, 1, *reinterpret_cast<f32x4*>(vb + 2 * 4 * WN_PLANE) = tt[2] - tt[1];) WN_M(5, 2, *reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = tt[1] - tt[3];) WN_M(5, 3, )
-    WN_M(6, 0, WN_LOAD_FRAGS(7)) WN_M(6, 1, ) WN_M(6, 2, ) WN_M(6, 3, )
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    WN_M(7, 0, WN_LOAD_FRAGS_FROM(0, nxt)) WN_M(7, 1, ) WN_M(7, 2, ) WN_M(7, 3, )
-  }
-  {
-    float* cur = lds + ((nchunks - 1) & 1) * BUF;
-    WN_M(0, 0, WN_LOAD_FRAGS(1)) WN_M(0, 1, ) WN_M(0, 2, ) WN_M(0, 3, )
-    WN_M(1, 0, WN_LOAD_FRAGS(2)) WN_M(1, 1, ) WN_M(1, 2, ) WN_M(1, 3, )
-    WN_M(2, 0, WN_LOAD_FRAGS(3)) WN_M(2, 1, ) WN_M(2, 2, ) WN_M(2, 3, )
-    WN_M(3, 0, WN_LOAD_FRAGS(4)) WN_M(3, 1, ) WN_M(3, 2, ) WN_M(3, 3, )
-    WN_M(4, 0, WN_LOAD_FRAGS(5)) WN_M(4, 1, ) WN_M(4, 2, ) WN_M(4, 3, )
-    WN_M(5, 0, WN_LOAD_FRAGS(6)) WN_M(5, 1, ) WN_M(5, 2, ) WN_M(5, 3, )
-    WN_M(6, 0, WN_LOAD_FRAGS(7)) WN_M(6, 1, ) WN_M(6, 2, ) WN_M(6, 3, )
-    WN_M(7, 0, ) WN_M(7, 1, ) WN_M(7, 2, ) WN_M(7, 3, )
-  }
-  __syncthreads();
+#undef WN_BUFOF
+#undef WN_SETUP
 #undef WN_GLDS
 #undef WN_U_PIECE
+#undef WN_U_PIECE_X
 #undef WN_RAW_PIECE
 #undef WN_RAW_ALL
 #undef WN_U_ALL
 #undef WN_TROW
 #undef WN_TROW_LD
 #undef WN_TROW_FIN
+#undef WN_V0
 #undef WN_LOAD_FRAGS
 #undef WN_LOAD_FRAGS_FROM
 #undef WN_M
-
-  // Output transform.  This wave holds M[a][b] for a = 2xh, 2xh+1 (acc[(a - 2xh) * 4 + b]).  Column pass (over b):
-  //   P[a][0] = M[a][0] + M[a][1] + M[a][2],  P[a][1] = M[a][1] - M[a][2] - M[a][3]
-  // Row pass: Y[0][q] = P[0][q] + P[1][q] + P[2][q],  Y[1][q] = P[1][q] - P[2][q] - P[3][q].  Wave xh finalises output row xh
-  // of its tiles: it keeps its own contribution to that row and sends its contribution to the other row to its partner.
-  f32x16 keep[2], send[2];
-#pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    f32x16 p0, p1;                                  // P[2xh][q], P[2xh+1][q]
-    if (q == 0) { p0 = acc[0] + acc[1] + acc[2]; p1 = acc[4] + acc[5] + acc[6]; }
-    else        { p0 = acc[1] - acc[2] - acc[3]; p1 = acc[5] - acc[6] - acc[7]; }
-    if (xh == 0) { keep[q] = p0 + p1; send[q] = p1; }          // rows 0,1: Y0 += P0 + P1, Y1 += P1
-    else         { keep[q] = -p0 - p1; send[q] = p0; }         // rows 2,3: Y0 += P2,      Y1 += -P2 - P3
-  }
-  // exchange through LDS (the staging buffers are free): region per (block, direction): 2 x 16 x 64 floats
-  float* xch = lds;
-  const int blk = wave & 3;                          // (mb, nb) block; partner = wave ^ 4
-  {
-    float* dst = xch + ((blk * 2 + xh) * 32) * 64 + lane;
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) dst[(q * 16 + r) * 64] = send[q][r];
-  }
-  // Epilogue operands (shortcut / saved activation) of this lane's eight output rows: requested HERE, so that their HBM latency
-  // runs under the exchange and the transposition below instead of in front of every store (the compiler cannot hoist them
-  // itself: y may alias them as far as it knows).  Item i = lane + 64 it: row = i >> 3 (tile_in_block * 2 + q), channel quad i & 7.
-  const bool f_add = a.epi & WN_EPI_ADD, f_act = a.epi & WN_EPI_ACT, f_dact = a.epi & WN_EPI_DACT;
-  size_t ooff[8];
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int i = lane + it * 64, row = i >> 3, c4 = i & 7;
-    const int tile = mb * 32 + (row >> 1), q = row & 1;
-    const int tr = tile / TC, tc = tile % TC;
-    const int oh = (gh * TR + tr) * 2 + xh, ow = (gw * TC + tc) * 2 + q;
-    ooff[it] = (((size_t)n * a.H + oh) * a.W + ow) * a.K + k0 + nb * 32 + c4 * 4;
-  }
-  f32x4 addv[8], dsv[8];
-  if (f_add) {
-#pragma unroll
-    for (int it = 0; it < 8; ++it) addv[it] = *reinterpret_cast<const f32x4*>(a.add + ooff[it]);
-  }
-  if (f_dact) {
-#pragma unroll
-    for (int it = 0; it < 8; ++it) dsv[it] = *reinterpret_cast<const f32x4*>(a.dsrc + ooff[it]);
-  }
-  __syncthreads();
-  {
-    const float* src = xch + ((blk * 2 + (xh ^ 1)) * 32) * 64 + lane;
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) keep[q][r] += src[(q * 16 + r) * 64];
-  }
-  __syncthreads();
-  // Epilogue: keep[q][r] = output pixel (row 2*tr + xh, col 2*tc + q) of tile (r & 3) + 8 * (r >> 2) + 4 * half of this
-  // block, channel li.  Transposed through LDS per wave (32 tiles x 2 pixels x 32 channels) so that a lane owns four
-  // consecutive channels: float4 epilogue arithmetic and 16-byte stores of 128-byte channel rows.
-  constexpr int ES = 32 + 4;
-  float* ep = lds + wave * (64 * ES);
-#pragma unroll
-  for (int q = 0; q < 2; ++q)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) ep[(((r & 3) + 8 * (r >> 2) + 4 * half) * 2 + q) * ES + li] = keep[q][r];
-  const bool tanh_act = a.act == 1;
-#pragma unroll
-  for (int it = 0; it < 8; ++it) {
-    const int i = lane + it * 64, row = i >> 3, c4 = i & 7;
-    f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * ES + c4 * 4);
-    if (f_add) v += addv[it];
-    if (f_act) {
-      if (tanh_act) { v[0] = dl_tanh(v[0]); v[1] = dl_tanh(v[1]); v[2] = dl_tanh(v[2]); v[3] = dl_tanh(v[3]); }
-      else { v[0] = wn_act(v[0], a.act); v[1] = wn_act(v[1], a.act); v[2] = wn_act(v[2], a.act); v[3] = wn_act(v[3], a.act); }
-    }
-    if (f_dact) {
-      const f32x4 sv = dsv[it];
-      if (tanh_act) v *= 1.f - sv * sv;
-      else { v[0] *= wn_dact(sv[0], a.act); v[1] *= wn_dact(sv[1], a.act); v[2] *= wn_dact(sv[2], a.act); v[3] *= wn_dact(sv[3], a.act); }
-    }
-    *reinterpret_cast<f32x4*>(a.y + ooff[it]) = v;
-  }
 }
 
 extern "C" size_t dl_wino_weights_floats(int32_t K, int32_t C) { return (size_t)16 * K * C; }
@@ -568,6 +655,7 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
 #define WW2_M(XL, J, ...)                                                                                                 \
   {                                                                                                                       \
     acc[XL] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(XL) & 1][J], bv[(XL) & 1][J], acc[XL], 0, 0, 0);                   \
+    asm volatile("" : "+v"(acc[XL]) :: "memory");          /* pins the MFMA in front of its slice's memory operations */     \
     __VA_ARGS__                                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                                    \
   }
@@ -584,13 +672,15 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
     float* nxt = lds + ((ch - ch_begin + 1) & 1) * WW_BUF;
     const int c1 = min(ch + 1, ch_end - 1), c2 = min(ch + 2, ch_end - 1);
     WW2_MASKS(c1)
-    WW2_M(0, 0, WW2_FR(1) WW2_TDL(0)) WW2_M(0, 1, WW2_TDL(1)) WW2_M(0, 2, WW2_TD(0)) WW2_M(0, 3, WW2_TDL(2))
-    WW2_M(1, 0, WW2_FR(2) WW2_TD(1)) WW2_M(1, 1, WW2_TDL(3)) WW2_M(1, 2, WW2_TD(2)) WW2_M(1, 3, WW2_TD(3))
+    // (the gradient registers are consumed -- TG -- BEFORE the DMA of this iteration is issued: the compiler guards their first use
+    // with vmcnt(0), which would otherwise wait for the DMA it has just started)
+    WW2_M(0, 0, WW2_FR(1) WW2_TDL(0)) WW2_M(0, 1, WW2_TDL(1)) WW2_M(0, 2, WW2_TD(0) WW2_TG(0)) WW2_M(0, 3, WW2_TDL(2))
+    WW2_M(1, 0, WW2_FR(2) WW2_TD(1)) WW2_M(1, 1, WW2_TDL(3)) WW2_M(1, 2, WW2_TD(2) WW2_TG(1) WW2_TG(2)) WW2_M(1, 3, WW2_TD(3) WW2_TG(3))
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                                                    // M: the raw patch has been read by everybody
     __builtin_amdgcn_sched_barrier(0);
-    WW2_M(2, 0, WW2_FR(3) WW2_DMA(c2)) WW2_M(2, 1, WW2_WRITE(nxt + 16 * WW_PLANE + w_off, vv)) WW2_M(2, 2, WW2_TG(0) WW2_TG(1)) WW2_M(2, 3, WW2_TG(2) WW2_TG(3))
-    WW2_M(3, 0, WW2_FR(4)) WW2_M(3, 1, WW2_WRITE(nxt + w_off, vg)) WW2_M(3, 2, WW2_GLOAD(c2)) WW2_M(3, 3, )
+    WW2_M(2, 0, WW2_FR(3) WW2_DMA(c2)) WW2_M(2, 1, WW2_WRITE(nxt + 16 * WW_PLANE + w_off, vv)) WW2_M(2, 2, WW2_WRITE(nxt + w_off, vg)) WW2_M(2, 3, WW2_GLOAD(c2))
+    WW2_M(3, 0, WW2_FR(4)) WW2_M(3, 1, ) WW2_M(3, 2, ) WW2_M(3, 3, )
     WW2_M(4, 0, WW2_FR(5)) WW2_M(4, 1, ) WW2_M(4, 2, ) WW2_M(4, 3, )
     WW2_M(5, 0, WW2_FR(6)) WW2_M(5, 1, ) WW2_M(5, 2, ) WW2_M(5, 3, )
     WW2_M(6, 0, WW2_FR(7)) WW2_M(6, 1, ) WW2_M(6, 2, ) WW2_M(6, 3, )
@@ -715,11 +805,23 @@ extern "C" int dl_wino_conv3x3_nhwc_f32(const float* x, const float* u, float* y
   // what the algorithm asks of the matrix cores: 16 multiply-adds per 2x2 output tile and (c, k) pair (a direct convolution: 36)
   const DlProfTag tag{"k_wino_conv", "conv", N, H, W, C, K, 3, 1, 1, 2.0 * 16.0 * (double)N * th * tw * (double)C * K,
                       4.0 * ((double)N * H * W * (C + K) + 16.0 * C * K)};
+  // persistent workgroups: one per CU (a 512-thread workgroup with 162 KB of LDS fills a CU); the CU count is read once
+  static int cap = -1;
+  if (cap < 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    cap = cus;
+#ifdef CV_TUNE
+    if (const char* e = getenv("DL_WN_GRID")) cap = atoi(e);
+#endif
+  }
   if (tw % 32 == 0 && th % 2 == 0) {
-    const dim3 grid(N * (th / 2) * (tw / 32) * (K / WN_KB));
+    int groups = N * (th / 2) * (tw / 32) * (K / WN_KB);
+    const dim3 grid(cap > 0 && groups > cap ? cap : groups);
     DL_LAUNCH(tag, k_wino_conv<32>, grid, dim3(WN_THREADS), st, a);
   } else {
-    const dim3 grid(N * (th / 4) * (tw / 16) * (K / WN_KB));
+    int groups = N * (th / 4) * (tw / 16) * (K / WN_KB);
+    const dim3 grid(cap > 0 && groups > cap ? cap : groups);
     DL_LAUNCH(tag, k_wino_conv<16>, grid, dim3(WN_THREADS), st, a);
   }
   return dl_check_launch("dl_wino_conv3x3_nhwc_f32");

@@ -441,6 +441,36 @@ int main(int argc, char** argv) {
     const Shape layers[] = {{"layer1 3x3 64->64", B, 64, 512, 64, 64, 3, 1, 1}, {"layer2 3x3 128->128", B, 64, 256, 128, 128, 3, 1, 1},
                             {"layer3 3x3 256->256", B, 64, 128, 256, 256, 3, 1, 1}, {"layer4 3x3 512->512", B, 32, 64, 512, 512, 3, 1, 1}};
     for (const auto& s : layers) time_wino(s, reps, gen);
+    if (argc >= 4 && !strcmp(argv[3], "phases")) {
+      // phase time stamps of the persistent Winograd kernel (clock64 at: group start, end of the chunk loop, end of the exchange,
+      // after the next group's V(0), after the stores were issued), averaged over the groups of one launch
+      for (const auto& s : layers) {
+        const size_t nx = (size_t)s.N * s.H * s.W * s.C, ny = (size_t)s.N * s.H * s.W * s.K, nw = (size_t)s.K * 9 * s.C;
+        auto x = rnd(nx, gen, 1.f), w = rnd(nw, gen, 0.05f);
+        float *dx = dev(x), *dw = dev(w), *dy, *uf, *ub;
+        CK(hipMalloc(&dy, ny * sizeof(float)));
+        CK(hipMalloc(&uf, 16 * nw / 9 * sizeof(float))); CK(hipMalloc(&ub, 16 * nw / 9 * sizeof(float)));
+        dl_wino_weights_f32(dw, uf, ub, s.K, s.C, nullptr);
+        for (int mode = 0; mode < 2; ++mode) {
+          for (int i = 0; i < 3; ++i) dl_wino_conv3x3_nhwc_f32(dx, uf, dy, nullptr, mode ? dx : nullptr, s.N, s.H, s.W, s.C, s.K, 1, mode ? 4 : 2, nullptr);
+          CK(hipDeviceSynchronize());
+          std::vector<unsigned long long> t(8 * 8192);
+          CK(hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_wn_t), t.size() * sizeof(unsigned long long)));
+          const int groups = s.N * (s.H / 2) * (s.W / 2) / 64 * (s.K / 64);
+          double d[4] = {0, 0, 0, 0};
+          int cnt = 0;
+          for (int g = 0; g < groups && g < 8192; ++g) {
+            const unsigned long long* q = &t[g * 8];
+            if (!q[0] || q[4] < q[0]) continue;
+            for (int k = 0; k < 4; ++k) d[k] += (double)(q[k + 1] - q[k]);
+            ++cnt;
+          }
+          printf("%-22s %s  groups %d: chunk loop %8.0f  transform+exchange %6.0f  wait+V0(next) %6.0f  act+stores %6.0f  cycles (clock64)\n",
+                 s.name, mode ? "dgrad" : "fwd  ", cnt, d[0] / cnt, d[1] / cnt, d[2] / cnt, d[3] / cnt);
+        }
+        CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dy)); CK(hipFree(uf)); CK(hipFree(ub));
+      }
+    }
     return bad ? 1 : 0;
   }
   if (argc >= 2 && !strcmp(argv[1], "tune")) {
