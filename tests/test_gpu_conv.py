@@ -253,3 +253,32 @@ def test_winograd_domain_weight_gradient_against_the_direct_kernel_and_torch(sha
     util.measured(f"{tag}: vs torch autograd (relative)", _rel(dw_wino.permute(0, 3, 1, 2), w.grad), bound=REL)
     util.measured(f"{tag}: vs the direct MFMA kernel (relative)", _rel(dw_wino, dw_direct), bound=REL)
     assert not torch.equal(dw_wino, dw_direct)          # the two paths really are different kernels
+
+
+def test_epilogue_tanh_is_within_two_ulp_of_float64():
+    """The activation of the convolution epilogues (csrc/common.h: dl_tanh -- branch-free, exp2 / rcp above |x| = 0.625, an odd
+    polynomial below) measured in isolation: a 1x1 convolution with the identity as its weight reproduces its input exactly (one
+    product with 1 and sums with exact zeros on the fp32 matrix cores), so y = tanh(x) as the kernels compute it.  Bound: 2.5 ulp of
+    the float32 result against numpy's float64 tanh over [-12, 12] and down to 1e-30; NaN propagates."""
+    dev = _dev()
+    from delora_amd.models import ring_conv as rc
+    C = 64
+    g = torch.Generator(device="cpu").manual_seed(9)
+    H, W = 16, 256
+    x = (torch.rand((1, H, W, C), generator=g) * 24.0 - 12.0)
+    x[0, 0] = torch.linspace(-0.7, 0.7, W * C).view(W, C)                       # dense around the switch point of the two formulas
+    x[0, 1] = torch.logspace(-30, 0, W * C).view(W, C) * torch.where(torch.rand((W, C), generator=g) < 0.5, -1.0, 1.0)
+    x[0, 2, 0, 0] = 0.0
+    x[0, 2, 0, 1] = -0.0                            # (reaches the activation as +0: the sum with the other channels' +0 products)
+    x[0, 2, 2, :] = float("nan")                    # a whole pixel: NaN x 0 in the identity GEMM spreads over the pixel's channels
+    w = torch.eye(C).view(C, 1, 1, C).contiguous()
+    y = rc.conv_nhwc(x.to(dev), w.to(dev), stride=(1, 2), act=rc.ACT["tanh"], epilogue=rc.EPI_ACT).cpu()
+    xs = x[:, :, ::2, :]
+    ref = np.tanh(xs.double().numpy())
+    got = y.double().numpy()
+    nan = np.isnan(ref)
+    assert np.isnan(got[nan]).all() and not np.isnan(got[~nan]).any()
+    ulp = np.spacing(np.abs(ref[~nan]).astype(np.float32)).astype(np.float64)
+    err = np.abs(got[~nan] - ref[~nan]) / ulp
+    util.measured("epilogue tanh vs float64 (ulp of the float32 result)", float(err.max()), bound=2.5)
+    assert got[0, 2, 0, 0] == 0.0 and got[0, 2, 0, 1] == 0.0
