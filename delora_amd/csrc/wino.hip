@@ -497,6 +497,7 @@ extern "C" int dl_wino_weights_f32(const float* w, float* u_fwd, float* u_bwd, i
 #define WW_BUF (2 * 16 * WW_PLANE)       // one (Gh, Dh) pair
 #define WW_RAWPIX 72                     // raw input patch of a chunk: 4 rows x 18 columns (8 tiles), 64 channels each
 #define WW_RAW (WW_RAWPIX * 64)          // floats
+#define WW_GRAW (2 * 16 * 64)            // floats: the 2 x 16 output-gradient pixels of a chunk, 64 channels each
 
 struct WWArgs {
   const float* x;    // [N][H][W][C]
@@ -509,17 +510,17 @@ struct WWArgs {
 // idled: 557 us on layer3, this one 463): the transforms of chunk ch+1 are sliced into small pieces placed behind the individual
 // MFMAs of chunk ch (as k_wino_conv does), branch-free, with the LDS reads of a piece issued one slot ahead of their use.
 // Per iteration:
-//   planes 0..1   || the raw input patch of chunk ch+1 (landed by DMA during the previous iteration) is read and turned into the
-//                    thread's columns of Dh(ch+1) = B^T d B
-//   barrier M     every thread has read the raw patch
-//   planes 2..6   || DMA of the raw patch of chunk ch+2; Dh(ch+1) -> buf[nxt]; Gh(ch+1) = A g A^T from the gradient values held in
-//                    registers -> buf[nxt]; the 16 gradient loads of chunk ch+2
+//   planes 0..2   || the raw input patch and the output-gradient patch of chunk ch+1 (both landed by DMA during the previous
+//                    iteration) are read and turned into the thread's columns of Dh(ch+1) = B^T d B and Gh(ch+1) = A g A^T
+//   barrier M     every thread has read the raw patches
+//   planes 3..6   || DMA of the patches of chunk ch+2; Dh(ch+1), Gh(ch+1) -> buf[nxt]
 //   wait + barrier E, then plane 7 || first fragments of chunk ch+1
 // Chunk indices beyond the slab are clamped (a harmless repeat of the last chunk: no branch in the loop body).
 __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
-  static_assert((2 * WW_BUF + WW_RAW) * 4 <= 163840, "LDS budget");
-  __shared__ __attribute__((aligned(16))) float lds[2 * WW_BUF + WW_RAW];
+  static_assert((2 * WW_BUF + WW_RAW + WW_GRAW) * 4 <= 163840, "LDS budget");
+  __shared__ __attribute__((aligned(16))) float lds[2 * WW_BUF + WW_RAW + WW_GRAW];
   float* raw = lds + 2 * WW_BUF;
+  float* graw = raw + WW_RAW;                    // output-gradient patch of a chunk: [2 rows][16 pixels][64 k]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, half = lane >> 5;
   const int mb = wave & 1, nb = (wave >> 1) & 1, xh = wave >> 2;
@@ -540,7 +541,6 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
   const int j0 = bcol == 0 ? 0 : 1, j1 = bcol == 3 ? 3 : 2;                       // (d B)[.][bcol] = sg0 d[.][j0] + sg1 d[.][j1]
   const float sg0 = bcol == 2 ? -1.f : 1.f, sg1 = (bcol == 0 || bcol == 3) ? -1.f : 1.f;
   const int w_off = r * 8 + ((tq ^ ((r >> 3) & 1)) * 4);                           // 16-byte slot of (row r, tiles 4tq..4tq+3)
-  float gr[4][2][2];                                                               // output-gradient values of the chunk to transform next
 
   auto chunk_pos = [&](int ch, int& n, int& ta, int& b8) {
     int u = ch;
@@ -571,17 +571,18 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xn_ + (row * a.W + col) * a.C),    \
                                        (__attribute__((address_space(3))) void*)(raw + dma_l[it]), 16, 0, 0);             \
     }                                                                                                                     \
+    /* the output-gradient patch: wave w brings pixels 4w .. 4w+3 of the 2 x 16 (one 1 KiB piece; lane = pixel, channel quad) */ \
+    const float* gn_ = a.g + (((size_t)n_ * a.H + 2 * ta_ + g_p) * a.W + 16 * b8_ + g_px) * a.K + k0 + (lane & 15) * 4;   \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gn_,                                  \
+                                     (__attribute__((address_space(3))) void*)(graw + wave * 256), 16, 0, 0);             \
   }
-  // the 16 gradient values of this thread's four tiles: one base pointer per chunk, offsets p * W K + (2 e + q) K
-  const int g_row = a.W * a.K;
-#define WW2_GLOAD(CH)                                                                                                     \
+  // the four gradient values of tile E of this thread's four: g[p][2 (4 tq + E) + q][k = r], two LDS reads of two rows each
+  const int g_p = (wave * 4 + (lane >> 4)) >> 4, g_px = (wave * 4 + (lane >> 4)) & 15;     // DMA role: pixel of the 2 x 16 patch
+  const float* gb = graw + (8 * tq) * 64 + r;
+#define WW2_TGL(E)                                                                                                        \
   {                                                                                                                       \
-    int n_, ta_, b8_;                                                                                                     \
-    chunk_pos((CH), n_, ta_, b8_);                                                                                        \
-    const float* gn_ = a.g + (((size_t)n_ * a.H + 2 * ta_) * a.W + 2 * (b8_ * 8 + tq * 4)) * a.K + k0 + r;                \
-    _Pragma("unroll") for (int e = 0; e < 4; ++e)                                                                         \
-      _Pragma("unroll") for (int p = 0; p < 2; ++p)                                                                       \
-        _Pragma("unroll") for (int q = 0; q < 2; ++q) gr[e][p][q] = gn_[p * g_row + (2 * e + q) * a.K];                   \
+    _Pragma("unroll") for (int q = 0; q < 2; ++q)                                                                         \
+      _Pragma("unroll") for (int p = 0; p < 2; ++p) gq[E][p][q] = gb[(p * 16 + 2 * (E) + q) * 64];                        \
   }
   // Dh = B^T d B, column bcol, tile E of this thread's four: 8 LDS reads of the raw patch (issued one slot ahead of their use),
   // rows outside the image masked
@@ -590,8 +591,8 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
 #define WW2_TDL(E)                                                                                                        \
   {                                                                                                                       \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                       \
-      dd[(E) & 1][2 * i] = rb0[(i * 18 + 2 * (E)) * 64];                                                                  \
-      dd[(E) & 1][2 * i + 1] = rb1[(i * 18 + 2 * (E)) * 64];                                                              \
+      dd[E][2 * i] = rb0[(i * 18 + 2 * (E)) * 64];                                                                        \
+      dd[E][2 * i + 1] = rb1[(i * 18 + 2 * (E)) * 64];                                                                    \
     }                                                                                                                     \
   }
 #define WW2_TD(E)                                                                                                         \
@@ -599,8 +600,8 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
     float tt_[4];                                                                                                         \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                       \
       const unsigned m_ = i == 0 ? mask_top : (i == 3 ? mask_bot : 0xffffffffu);                                          \
-      const float d0 = __uint_as_float(__float_as_uint(dd[(E) & 1][2 * i]) & m_);                                         \
-      const float d1 = __uint_as_float(__float_as_uint(dd[(E) & 1][2 * i + 1]) & m_);                                     \
+      const float d0 = __uint_as_float(__float_as_uint(dd[E][2 * i]) & m_);                                               \
+      const float d1 = __uint_as_float(__float_as_uint(dd[E][2 * i + 1]) & m_);                                           \
       tt_[i] = sg0 * d0 + sg1 * d1;                                                                                       \
     }                                                                                                                     \
     vv[0][E] = tt_[0] - tt_[2]; vv[1][E] = tt_[1] + tt_[2]; vv[2][E] = tt_[2] - tt_[1]; vv[3][E] = tt_[1] - tt_[3];       \
@@ -610,7 +611,7 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
   const float ca = bcol == 3 ? 0.f : 1.f, cb = bcol == 0 ? 0.f : (bcol == 1 ? 1.f : -1.f);
 #define WW2_TG(E)                                                                                                         \
   {                                                                                                                       \
-    const float h0_ = ca * gr[E][0][0] + cb * gr[E][0][1], h1_ = ca * gr[E][1][0] + cb * gr[E][1][1];                     \
+    const float h0_ = ca * gq[E][0][0] + cb * gq[E][0][1], h1_ = ca * gq[E][1][0] + cb * gq[E][1][1];                     \
     vg[0][E] = h0_; vg[1][E] = h0_ + h1_; vg[2][E] = h0_ - h1_; vg[3][E] = -h1_;                                          \
   }
 
@@ -623,25 +624,23 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
   const int a_off = arow * 8 + ((half ^ ((arow >> 3) & 1)) * 4);
   const int b_off = 16 * WW_PLANE + brow * 8 + ((half ^ ((brow >> 3) & 1)) * 4);
   f32x4 vv[4], vg[4];
-  float dd[2][8];
+  float dd[4][8], gq[4][2][2];
   unsigned mask_top, mask_bot;
 #define WW2_MASKS(CH) { int n_, ta_, b8_; chunk_pos((CH), n_, ta_, b8_); mask_top = ta_ > 0 ? 0xffffffffu : 0u; mask_bot = ta_ < th - 1 ? 0xffffffffu : 0u; }
 
   // prologue: operands of the first chunk, then the raw patch / gradient values of the second
   WW2_DMA(ch_begin)
-  WW2_GLOAD(ch_begin)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   WW2_MASKS(ch_begin)
   WW2_TDL(0) WW2_TD(0) WW2_TDL(1) WW2_TD(1) WW2_TDL(2) WW2_TD(2) WW2_TDL(3) WW2_TD(3)
   WW2_WRITE(lds + 16 * WW_PLANE + w_off, vv)
-  WW2_TG(0) WW2_TG(1) WW2_TG(2) WW2_TG(3)
+  WW2_TGL(0) WW2_TG(0) WW2_TGL(1) WW2_TG(1) WW2_TGL(2) WW2_TG(2) WW2_TGL(3) WW2_TG(3)
   WW2_WRITE(lds + w_off, vg)
   __syncthreads();
   {
     const int c1 = min(ch_begin + 1, ch_end - 1);
     WW2_DMA(c1)
-    WW2_GLOAD(c1)
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -655,7 +654,8 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
 #define WW2_M(XL, J, ...)                                                                                                 \
   {                                                                                                                       \
     acc[XL] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(XL) & 1][J], bv[(XL) & 1][J], acc[XL], 0, 0, 0);                   \
-    asm volatile("" : "+v"(acc[XL]) :: "memory");          /* pins the MFMA in front of its slice's memory operations */     \
+    asm volatile("" : "+v"(acc[XL]) :: "memory");          /* pins the MFMA in front of its slice ... */                     \
+    __builtin_amdgcn_sched_barrier(0);                     /* ... and the slice's arithmetic behind it */                    \
     __VA_ARGS__                                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                                    \
   }
@@ -672,15 +672,15 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
     float* nxt = lds + ((ch - ch_begin + 1) & 1) * WW_BUF;
     const int c1 = min(ch + 1, ch_end - 1), c2 = min(ch + 2, ch_end - 1);
     WW2_MASKS(c1)
-    // (the gradient registers are consumed -- TG -- BEFORE the DMA of this iteration is issued: the compiler guards their first use
-    // with vmcnt(0), which would otherwise wait for the DMA it has just started)
-    WW2_M(0, 0, WW2_FR(1) WW2_TDL(0)) WW2_M(0, 1, WW2_TDL(1)) WW2_M(0, 2, WW2_TD(0) WW2_TG(0)) WW2_M(0, 3, WW2_TDL(2))
-    WW2_M(1, 0, WW2_FR(2) WW2_TD(1)) WW2_M(1, 1, WW2_TDL(3)) WW2_M(1, 2, WW2_TD(2) WW2_TG(1) WW2_TG(2)) WW2_M(1, 3, WW2_TD(3) WW2_TG(3))
+    // LDS reads in the first two slices of a plane, arithmetic two slices later: the compiler guards the first use of an LDS result
+    // with a wait for ALL outstanding LDS operations, and with this layout everything it waits for is at least two slices old
+    WW2_M(0, 0, WW2_FR(1) WW2_TDL(0) WW2_TDL(1)) WW2_M(0, 1, WW2_TGL(0) WW2_TGL(1)) WW2_M(0, 2, ) WW2_M(0, 3, WW2_TD(0) WW2_TG(0))
+    WW2_M(1, 0, WW2_FR(2) WW2_TDL(2) WW2_TDL(3)) WW2_M(1, 1, WW2_TGL(2) WW2_TGL(3)) WW2_M(1, 2, WW2_TD(1) WW2_TG(1)) WW2_M(1, 3, WW2_TD(2) WW2_TG(2))
+    WW2_M(2, 0, WW2_FR(3)) WW2_M(2, 1, ) WW2_M(2, 2, WW2_TD(3) WW2_TG(3)) WW2_M(2, 3, )
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                                    // M: the raw patch has been read by everybody
+    __builtin_amdgcn_s_barrier();                                                    // M: the raw patches have been read by everybody
     __builtin_amdgcn_sched_barrier(0);
-    WW2_M(2, 0, WW2_FR(3) WW2_DMA(c2)) WW2_M(2, 1, WW2_WRITE(nxt + 16 * WW_PLANE + w_off, vv)) WW2_M(2, 2, WW2_WRITE(nxt + w_off, vg)) WW2_M(2, 3, WW2_GLOAD(c2))
-    WW2_M(3, 0, WW2_FR(4)) WW2_M(3, 1, ) WW2_M(3, 2, ) WW2_M(3, 3, )
+    WW2_M(3, 0, WW2_FR(4) WW2_DMA(c2)) WW2_M(3, 1, WW2_WRITE(nxt + 16 * WW_PLANE + w_off, vv)) WW2_M(3, 2, WW2_WRITE(nxt + w_off, vg)) WW2_M(3, 3, )
     WW2_M(4, 0, WW2_FR(5)) WW2_M(4, 1, ) WW2_M(4, 2, ) WW2_M(4, 3, )
     WW2_M(5, 0, WW2_FR(6)) WW2_M(5, 1, ) WW2_M(5, 2, ) WW2_M(5, 3, )
     WW2_M(6, 0, WW2_FR(7)) WW2_M(6, 1, ) WW2_M(6, 2, ) WW2_M(6, 3, )
@@ -690,7 +690,7 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
     WW2_M(7, 0, WW2_FR_FROM(0, nxt)) WW2_M(7, 1, ) WW2_M(7, 2, ) WW2_M(7, 3, )
   }
 #undef WW2_DMA
-#undef WW2_GLOAD
+#undef WW2_TGL
 #undef WW2_TD
 #undef WW2_TDL
 #undef WW2_TG
