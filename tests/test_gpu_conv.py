@@ -10,7 +10,8 @@ import torch.nn.functional as F
 from tests import util
 
 pytestmark = pytest.mark.gpu
-REL = 1e-4
+REL = 1e-4          # the contract of north_star
+TIGHT = 1e-5        # what the operator-level comparisons assert: ~10x the largest deviation measured on MI355X (<= 1e-6)
 
 
 def _dev():
@@ -53,7 +54,7 @@ def test_conv_forward_and_both_gradients_against_torch(shape):
     tag = f"conv {ks}x{ks} s{stride} {N}x{H}x{W} {C}->{K}"
     # forward, plain and with the fused tail  act(conv + shortcut)
     y = rc.conv_nhwc(x_nhwc, w_krsc, stride=stride)
-    util.measured(f"{tag}: forward vs torch (relative)", _rel(y.permute(0, 3, 1, 2), y_ref.detach()), bound=REL)
+    util.measured(f"{tag}: forward vs torch (relative)", _rel(y.permute(0, 3, 1, 2), y_ref.detach()), bound=TIGHT)
     sc = torch.randn(y.shape, generator=g).to(dev)
     y2 = rc.conv_nhwc(x_nhwc, w_krsc, stride=stride, act=rc.ACT["tanh"], epilogue=rc.EPI_ADD | rc.EPI_ACT, add=sc)
     ref2 = torch.tanh(y_ref.detach() + sc.permute(0, 3, 1, 2))
@@ -61,16 +62,16 @@ def test_conv_forward_and_both_gradients_against_torch(shape):
     # weight gradient
     gy_nhwc = gy.permute(0, 2, 3, 1).contiguous()
     dw = rc.wgrad_nhwc(x_nhwc, gy_nhwc, ks, stride=stride)
-    util.measured(f"{tag}: weight gradient vs torch autograd (relative)", _rel(dw.permute(0, 3, 1, 2), wr.grad), bound=REL)
+    util.measured(f"{tag}: weight gradient vs torch autograd (relative)", _rel(dw.permute(0, 3, 1, 2), wr.grad), bound=TIGHT)
     # input gradient (stride-1 3x3: the transposed kernel, with the activation derivative and shortcut gradient fused)
     if ks == 3 and stride == (1, 1) and C % 64 == 0:
         dx = rc.conv_nhwc(gy_nhwc, w_krsc, transposed=True)
-        util.measured(f"{tag}: input gradient vs torch autograd (relative)", _rel(dx.permute(0, 3, 1, 2), xr.grad), bound=REL)
+        util.measured(f"{tag}: input gradient vs torch autograd (relative)", _rel(dx.permute(0, 3, 1, 2), xr.grad), bound=TIGHT)
         ysave = torch.tanh(torch.randn(x_nhwc.shape, generator=g)).to(dev)
         extra = torch.randn(x_nhwc.shape, generator=g).to(dev)
         dx2 = rc.conv_nhwc(gy_nhwc, w_krsc, act=rc.ACT["tanh"], epilogue=rc.EPI_ADD | rc.EPI_DACT, add=extra, dsrc=ysave, transposed=True)
         ref = (xr.grad.permute(0, 2, 3, 1) + extra) * (1 - ysave * ysave)
-        util.measured(f"{tag}: fused (dgrad + g) * tanh' vs torch (relative)", _rel(dx2, ref), bound=REL)
+        util.measured(f"{tag}: fused (dgrad + g) * tanh' vs torch (relative)", _rel(dx2, ref), bound=TIGHT)
 
 
 @pytest.mark.parametrize("shape", [(2, 8, 128, 64, 64), (1, 4, 64, 128, 128), (2, 8, 32, 64, 128), (1, 8, 256, 64, 64), (1, 32, 64, 512, 512)])
@@ -92,19 +93,19 @@ def test_winograd_forward_and_input_gradient_against_torch(shape):
     x_nhwc, gy_nhwc = x.permute(0, 2, 3, 1).contiguous(), gy.permute(0, 2, 3, 1).contiguous()
     tag = f"winograd {N}x{H}x{W} {C}->{K}"
     y = rc.wino_conv(x_nhwc, uf, K)
-    util.measured(f"{tag}: forward vs torch direct convolution (relative)", _rel(y.permute(0, 3, 1, 2), y_ref.detach()), bound=REL)
+    util.measured(f"{tag}: forward vs torch direct convolution (relative)", _rel(y.permute(0, 3, 1, 2), y_ref.detach()), bound=TIGHT)
     sc = torch.randn(y.shape, generator=g).to(dev)
     y2 = rc.wino_conv(x_nhwc, uf, K, act=rc.ACT["tanh"], epilogue=rc.EPI_ADD | rc.EPI_ACT, add=sc)
     util.measured(f"{tag}: forward + shortcut + tanh vs torch (absolute)",
                   float((y2.permute(0, 3, 1, 2) - torch.tanh(y_ref.detach() + sc.permute(0, 3, 1, 2))).abs().max()), bound=2e-5)
     dx = rc.wino_conv(gy_nhwc, ub, C)
-    util.measured(f"{tag}: input gradient vs torch autograd (relative)", _rel(dx.permute(0, 3, 1, 2), xr.grad), bound=REL)
+    util.measured(f"{tag}: input gradient vs torch autograd (relative)", _rel(dx.permute(0, 3, 1, 2), xr.grad), bound=TIGHT)
     ysave = torch.tanh(torch.randn(x_nhwc.shape, generator=g)).to(dev)
     dx2 = rc.wino_conv(gy_nhwc, ub, C, act=rc.ACT["tanh"], epilogue=rc.EPI_DACT, dsrc=ysave)
-    util.measured(f"{tag}: fused dgrad * tanh' vs torch (relative)", _rel(dx2, xr.grad.permute(0, 2, 3, 1) * (1 - ysave * ysave)), bound=REL)
+    util.measured(f"{tag}: fused dgrad * tanh' vs torch (relative)", _rel(dx2, xr.grad.permute(0, 2, 3, 1) * (1 - ysave * ysave)), bound=TIGHT)
     # and against this library's own direct kernel (same layout, same epilogue)
     y_direct = rc.conv_nhwc(x_nhwc, rc.weight_storage(w))
-    util.measured(f"{tag}: Winograd vs the direct MFMA kernel (relative)", _rel(y, y_direct), bound=REL)
+    util.measured(f"{tag}: Winograd vs the direct MFMA kernel (relative)", _rel(y, y_direct), bound=TIGHT)
 
 
 def test_conv_rejects_shapes_that_do_not_tile():
@@ -146,7 +147,7 @@ def test_hip_trunk_matches_module_path(act, wino, monkeypatch):
         e = float((p.grad - p2.grad).norm() / p2.grad.norm().clamp_min(1e-30))
         if e > worst:
             worst, name = e, k
-    util.measured(f"trunk[{act}{',winograd' if wino else ',direct'}]: worst relative parameter-gradient difference hip vs modules ({name})", worst, bound=(5e-5 if act == "tanh" else 1e-3))   # measured 4-7e-6 (tanh), 9e-7 (relu; a relu mask may flip where a pre-activation is within rounding of 0: 1e-3)
+    util.measured(f"trunk[{act}{',winograd' if wino else ',direct'}]: worst relative parameter-gradient difference hip vs modules ({name})", worst, bound=(5e-5 if act == "tanh" else 1e-5))   # measured 4-7e-6 (tanh), 8e-7 (relu: no mask flips on this seeded input; one flipped mask would show as ~1e-4)
     assert m_hip.resnet.layer1[0].conv1.weight.grad.stride() == m_hip.resnet.layer1[0].conv1.weight.stride()
 
 
@@ -208,11 +209,11 @@ def test_stem_function_against_torch(act):
     y_ref = _ref_stem(xr, w1, act)
     y_ref.backward(gy.permute(0, 3, 1, 2))
     util.measured(f"stem[{act}]: pooled output vs torch (absolute)", float((y.permute(0, 3, 1, 2) - y_ref.detach()).abs().max()), bound=2e-5)
-    util.measured(f"stem[{act}]: conv1 weight gradient vs torch autograd (relative)", _rel(dw, w1.grad), bound=(REL if act == "tanh" else 1e-2))
+    util.measured(f"stem[{act}]: conv1 weight gradient vs torch autograd (relative)", _rel(dw, w1.grad), bound=TIGHT)     # measured 3-8e-7 (relu: no mask flips on this seeded input)
     # and the input gradient (not needed by the training step: the image carries none)
     x2 = x.clone().requires_grad_(True)
     rc.RingStem.apply(x2, w1, rc.ACT[act]).backward(gy)
-    util.measured(f"stem[{act}]: input gradient vs torch autograd (relative)", _rel(x2.grad, xr.grad), bound=(REL if act == "tanh" else 1e-2))
+    util.measured(f"stem[{act}]: input gradient vs torch autograd (relative)", _rel(x2.grad, xr.grad), bound=TIGHT)     # measured 3-8e-7 (relu: no mask flips on this seeded input)
 
 
 def test_mean_hw_kernel_against_torch():
@@ -250,8 +251,8 @@ def test_winograd_domain_weight_gradient_against_the_direct_kernel_and_torch(sha
     monkeypatch.setattr(rc, "USE_WINOGRAD_WGRAD", False)
     dw_direct = rc.wgrad_nhwc(x_nhwc, gy_nhwc, 3)
     tag = f"winograd-domain wgrad {N}x{H}x{W} {C}->{K}"
-    util.measured(f"{tag}: vs torch autograd (relative)", _rel(dw_wino.permute(0, 3, 1, 2), w.grad), bound=REL)
-    util.measured(f"{tag}: vs the direct MFMA kernel (relative)", _rel(dw_wino, dw_direct), bound=REL)
+    util.measured(f"{tag}: vs torch autograd (relative)", _rel(dw_wino.permute(0, 3, 1, 2), w.grad), bound=TIGHT)
+    util.measured(f"{tag}: vs the direct MFMA kernel (relative)", _rel(dw_wino, dw_direct), bound=TIGHT)
     assert not torch.equal(dw_wino, dw_direct)          # the two paths really are different kernels
 
 
