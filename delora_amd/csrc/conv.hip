@@ -331,7 +331,7 @@ __global__ __launch_bounds__(CV_THREADS, CV_MINWAVES) void k_conv_f32(ConvArgs a
 // fragments are ds_read_b32 with lanes along k / c (consecutive addresses, conflict-free) -- one read per MFMA operand,
 // which the 64-cycle fp32 MFMA hides easily.
 template <int BMK, int BNC, int PK, int SH, int SW, int KS>
-__global__ __launch_bounds__(CV_THREADS, (SW == 2 && KS == 3) ? 1 : 2) void k_wgrad_f32(const float* __restrict__ x, const float* __restrict__ g,
+__global__ __launch_bounds__(CV_THREADS, 2) void k_wgrad_f32(const float* __restrict__ x, const float* __restrict__ g,
                                                              float* __restrict__ part, int N, int H, int W, int C, int K,
                                                              int Ho, int Wo, int chunks_per_slab, int nslabs) {
   // pixel chunk: PK consecutive output columns of one output row; a slab is a run of consecutive chunks
@@ -365,23 +365,15 @@ __global__ __launch_bounds__(CV_THREADS, (SW == 2 && KS == 3) ? 1 : 2) void k_wg
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[tp][j][r] = 0.f;
 
-  // chunk-invariant parts of the staging items (ids beyond the tile are clamped: duplicates of the last item)
-  int x_row[NX_IT], x_col[NX_IT], x_c4[NX_IT], x_l[NX_IT];
-#pragma unroll
-  for (int it = 0; it < NX_IT; ++it) {
-    const int q = min(tid + it * CV_THREADS, NX - 1);
-    x_c4[it] = (q % (BNC / 4)) * 4;
-    const int pc = q / (BNC / 4);
-    x_col[it] = pc % RW; x_row[it] = pc / RW;
-    x_l[it] = pc * BNC + x_c4[it];
-  }
-  int g_p[NG_IT], g_k4[NG_IT];
-#pragma unroll
-  for (int it = 0; it < NG_IT; ++it) {
-    const int q = min(tid + it * CV_THREADS, NG - 1);
-    g_k4[it] = (q % (BMK / 4)) * 4;
-    g_p[it] = q / (BMK / 4);
-  }
+  // staging items (ids beyond the tile are clamped: duplicates of the last item).  Their coordinates are recomputed where they are
+  // used -- four index registers per item (13 items for the stride-2 layers) are what kept those variants at one wave per SIMD
+#define WG_XITEM(IT)                                                                                                      \
+    const int q_ = min(tid + (IT) * CV_THREADS, NX - 1);                                                                  \
+    const int x_c4_ = (q_ % (BNC / 4)) * 4, pc_ = q_ / (BNC / 4);                                                         \
+    const int x_col_ = pc_ % RW, x_row_ = pc_ / RW, x_l_ = pc_ * BNC + x_c4_;
+#define WG_GITEM(IT)                                                                                                      \
+    const int gq_ = min(tid + (IT) * CV_THREADS, NG - 1);                                                                 \
+    const int g_k4_ = (gq_ % (BMK / 4)) * 4, g_p_ = gq_ / (BMK / 4);
   const int chunks_per_row = Wo / PK;
   const int total_chunks = N * Ho * chunks_per_row;
   const int ch_begin = slab * chunks_per_slab;
@@ -393,20 +385,31 @@ __global__ __launch_bounds__(CV_THREADS, (SW == 2 && KS == 3) ? 1 : 2) void k_wg
     const int row_ = (CH) / chunks_per_row, wo0_ = ((CH) % chunks_per_row) * PK;                                          \
     const int n_ = row_ / Ho, ho_ = row_ % Ho;                                                                            \
     _Pragma("unroll") for (int it = 0; it < NX_IT; ++it) {                                                                \
-      const int h = ho_ * SH - PAD + x_row[it];                                                                           \
-      int w = wo0_ * SW - PAD + x_col[it];                                                                                \
+      WG_XITEM(it)                                                                                                        \
+      (void)x_l_;                                                                                                         \
+      const int h = ho_ * SH - PAD + x_row_;                                                                              \
+      int w = wo0_ * SW - PAD + x_col_;                                                                                   \
       w = w < 0 ? w + W : (w >= W ? w - W : w);                                                                           \
       const bool in = h >= 0 && h < H;                                                                                    \
-      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (in ? (((size_t)n_ * H + h) * W + w) * C + c0 + x_c4[it] : 0)); \
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + (in ? (((size_t)n_ * H + h) * W + w) * C + c0 + x_c4_ : 0));    \
       x_r[it] = in ? v : (f32x4){0.f, 0.f, 0.f, 0.f};                                                                     \
     }                                                                                                                     \
-    _Pragma("unroll") for (int it = 0; it < NG_IT; ++it) g_r[it] = *reinterpret_cast<const f32x4*>(                       \
-        g + (((size_t)n_ * Ho + ho_) * Wo + wo0_ + g_p[it]) * K + k0 + g_k4[it]);                                         \
+    _Pragma("unroll") for (int it = 0; it < NG_IT; ++it) {                                                                \
+      WG_GITEM(it)                                                                                                        \
+      g_r[it] = *reinterpret_cast<const f32x4*>(g + (((size_t)n_ * Ho + ho_) * Wo + wo0_ + g_p_) * K + k0 + g_k4_);       \
+    }                                                                                                                     \
   }
 #define WG_STAGE()                                                                                                        \
   {                                                                                                                       \
-    _Pragma("unroll") for (int it = 0; it < NX_IT; ++it) *reinterpret_cast<f32x4*>(x_lds + x_l[it]) = x_r[it];            \
-    _Pragma("unroll") for (int it = 0; it < NG_IT; ++it) *reinterpret_cast<f32x4*>(g_lds + g_p[it] * BMK + g_k4[it]) = g_r[it]; \
+    _Pragma("unroll") for (int it = 0; it < NX_IT; ++it) {                                                                \
+      WG_XITEM(it)                                                                                                        \
+      (void)x_col_; (void)x_row_;                                                                                         \
+      *reinterpret_cast<f32x4*>(x_lds + x_l_) = x_r[it];                                                                  \
+    }                                                                                                                     \
+    _Pragma("unroll") for (int it = 0; it < NG_IT; ++it) {                                                                \
+      WG_GITEM(it)                                                                                                        \
+      *reinterpret_cast<f32x4*>(g_lds + g_p_ * BMK + g_k4_) = g_r[it];                                                    \
+    }                                                                                                                     \
   }
   if (ch_begin < ch_end) {
     WG_FETCH(ch_begin)
@@ -416,25 +419,34 @@ __global__ __launch_bounds__(CV_THREADS, (SW == 2 && KS == 3) ? 1 : 2) void k_wg
   for (int ch = ch_begin; ch < ch_end; ++ch) {
     const bool more = ch + 1 < ch_end;
     if (more) WG_FETCH(ch + 1)
-#pragma unroll 2
-    for (int p = 0; p < PK; p += 2) {
-      // A: g[p + half][k = tile row * 32 + li]; B: x[(p + half) * SW + s][r][c = tile col * 32 + li]
-      float af[TPW], bf[TAPS][TPW];
+    // A: g[p + half][k = tile row * 32 + li]; B: x[(p + half) * SW + s][r][c = tile col * 32 + li].  The fragments of pixel pair
+    // p+2 are read while pair p multiplies (two register sets): read-then-use in one step exposed an LDS round trip per pair
+    float af[2][TPW], bf[2][TAPS][TPW];
+    auto load_frags = [&](int p, int buf) {
 #pragma unroll
       for (int j = 0; j < TPW; ++j) {
         const int tile = wave * TPW + j, tm = tile / TN, tn = tile % TN;
-        af[j] = g_lds[(p + half) * BMK + tm * 32 + li];
+        af[buf][j] = g_lds[(p + half) * BMK + tm * 32 + li];
 #pragma unroll
         for (int tp = 0; tp < TAPS; ++tp) {
           const int r = tp / KS, s = tp % KS;
-          bf[tp][j] = x_lds[(r * RW + (p + half) * SW + s) * BNC + tn * 32 + li];
+          bf[buf][tp][j] = x_lds[(r * RW + (p + half) * SW + s) * BNC + tn * 32 + li];
         }
       }
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int p = 0; p < PK; p += 2) {
+      const int cur = (p >> 1) & 1;
+      if (p + 2 < PK) load_frags(p + 2, cur ^ 1);
 #pragma unroll
       for (int tp = 0; tp < TAPS; ++tp)
 #pragma unroll
         for (int j = 0; j < TPW; ++j)
-          acc[tp][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[j], bf[tp][j], acc[tp][j], 0, 0, 0);
+          acc[tp][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][j], bf[cur][tp][j], acc[tp][j], 0, 0, 0);
+      // issue order: the next pair's LDS reads first, then this pair's MFMAs (hipcc otherwise sinks the reads to their use)
+      if (p + 2 < PK) __builtin_amdgcn_sched_group_barrier(0x100, (TAPS + 1) * TPW, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, TAPS * TPW, 0);
     }
     __syncthreads();
     if (more) {
@@ -444,6 +456,8 @@ __global__ __launch_bounds__(CV_THREADS, (SW == 2 && KS == 3) ? 1 : 2) void k_wg
   }
 #undef WG_FETCH
 #undef WG_STAGE
+#undef WG_XITEM
+#undef WG_GITEM
   // partial result of this slab: part[slab][k][tap][c]
   float* dst = part + (size_t)slab * K * TAPS * C;
 #pragma unroll
@@ -641,6 +655,9 @@ extern "C" int dl_conv2d_dgrad_strided_nhwc_f32(const float* g, const float* w, 
 #ifndef WG_PK
 #define WG_PK 32
 #endif
+// pixels per chunk: the stride-2 3x3 layers stage twice as many input columns per output pixel -- with 32 pixels their staging
+// registers (13 x 16 bytes per thread) left room for one wave per SIMD only; 16 pixels keep two workgroups on a CU
+static constexpr int wg_pk(int sw, int ks) { return (sw == 2 && ks == 3) ? 16 : WG_PK; }
 
 #ifdef CV_TUNE
 int g_wg_want = 512;
@@ -662,21 +679,22 @@ extern "C" size_t dl_conv2d_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t 
   if (stride_h < 1 || stride_w < 1 || ksize < 1 || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return 0;
   const int Ho = H / stride_h, Wo = W / stride_w;
   const int tiles = (K / 64 > 0 ? K / 64 : 1) * (C / 64 > 0 ? C / 64 : 1);
-  return (size_t)wgrad_slabs(N * Ho * (Wo / WG_PK > 0 ? Wo / WG_PK : 1), tiles) * K * ksize * ksize * C * sizeof(float);
+  const int pk = wg_pk(stride_w, ksize);
+  return (size_t)wgrad_slabs(N * Ho * (Wo / pk > 0 ? Wo / pk : 1), tiles) * K * ksize * ksize * C * sizeof(float);
 }
 
 template <int SH, int SW, int KS>
 static int launch_wgrad(const float* x, const float* g, float* dw, float* ws, int N, int H, int W, int C, int K, hipStream_t st) {
-  constexpr int BMK = 64, BNC = 64;
+  constexpr int BMK = 64, BNC = 64, PK = wg_pk(SW, KS);
   const int Ho = H / SH, Wo = W / SW;
-  if (K % BMK || C % BNC || Wo % WG_PK) return 1;
+  if (K % BMK || C % BNC || Wo % PK) return 1;
   const int tiles = (K / BMK) * (C / BNC);
-  const int total_chunks = N * Ho * (Wo / WG_PK);
+  const int total_chunks = N * Ho * (Wo / PK);
   const int nslabs = wgrad_slabs(total_chunks, tiles);
   const int chunks_per_slab = (total_chunks + nslabs - 1) / nslabs;
   const DlProfTag tag{"k_wgrad_f32", "wgrad", N, H, W, C, K, KS, SH, SW, 2.0 * N * Ho * Wo * (double)K * C * KS * KS,
                       4.0 * ((double)N * H * W * C + (double)N * Ho * Wo * K + (double)K * KS * KS * C)};
-  DL_LAUNCH(tag, (k_wgrad_f32<BMK, BNC, WG_PK, SH, SW, KS>), dim3(tiles * nslabs), dim3(CV_THREADS), st, x, g, ws, N,
+  DL_LAUNCH(tag, (k_wgrad_f32<BMK, BNC, PK, SH, SW, KS>), dim3(tiles * nslabs), dim3(CV_THREADS), st, x, g, ws, N,
             H, W, C, K, Ho, Wo, chunks_per_slab, nslabs);
   const size_t count = (size_t)K * KS * KS * C;
   hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((count / 4 + CV_THREADS - 1) / CV_THREADS)), dim3(CV_THREADS), 0, st,
