@@ -468,7 +468,7 @@ def kernel_table(trainer, batch, reps):
     row("dl_icp_loss_fwd", timed(lambda: G.icp_loss(T_small, img[:, 1], nrm[:, 1], match, nn, flags)), 52 * M, "hbm",
         f"both launches (stream + reduce); {M} source points with a correspondence, {K} pairs; 52 B/point")
     # cold: the loss kernel alone right after 1 GiB of unrelated writes has gone through the 256 MiB infinity cache
-    timers = G.LossTimers()
+    timers = G.LossTimers(reserve=16)
     flush = torch.empty((256 * 1024 * 1024,), dtype=torch.float32, device=trainer.device)
     G.LOSS_TIMER_FACTORY = timers.new
     try:
@@ -614,9 +614,8 @@ def main():
     # in-situ timing of the streaming loss kernel (k_icp_loss) in every timed step: the launch carries a pair of HIP
     # events that receive the kernel's own begin/end timestamps (dl_icp_loss_partial_timed) on the launch stream
     from delora_amd import geometry as G
-    timers = G.LossTimers()
-    if (graphed is None or not graphed.captured) and not args.no_profile:      # event-carrying launches cannot be captured into a graph
-        G.LOSS_TIMER_FACTORY = timers.new
+    timers = G.LossTimers(reserve=args.steps + 8)
+    loss_timed = (graphed is None or not graphed.captured) and not args.no_profile      # event-carrying launches cannot be captured into a graph
 
     enqueue = {}
 
@@ -644,14 +643,29 @@ def main():
     from delora_amd import _lib
     conv_prof = None
     dominant = "k_convh" if args.amp else "k_wino_conv"          # the family with the largest share of the step (conv_profile below)
-    if (graphed is None or not graphed.captured) and "hip trunk" in cnn_impl_in_use(trainer, args) and not args.no_profile:
+    can_profile = (graphed is None or not graphed.captured) and "hip trunk" in cnn_impl_in_use(trainer, args) and not args.no_profile
+    # An event-carrying launch (hipExtLaunchKernelGGL with start/stop events) keeps the HOST from running ahead of the GPU: 0.2-4 ms
+    # of enqueue time per such launch.  The fp32 step on one GPU has that slack (11 ms of enqueue against 14.7 ms of kernels: same
+    # value with and without, --no-profile); the 5 ms autocast step (4 ms of enqueue) and a DDP rank do not -- there the K timed
+    # steps carry no events at all and the rooflines are read in a second pass of the same steps.
+    in_timed = not args.amp and world == 1
+    if in_timed and loss_timed:
+        G.LOSS_TIMER_FACTORY = timers.new
+    if in_timed and can_profile:
         _lib.profile_begin(int(args.steps) * 64, dominant)         # the headline's timed steps time this family only
-        conv_prof = True
     counter["i"] = 0
     elapsed, ep = timed_region(args.steps, run_step)
-    G.LOSS_TIMER_FACTORY = None
     host_enqueue_ms = enqueue["ms_per_step"]
-    if conv_prof:
+    roofline_pass = "the K timed steps"
+    if not in_timed and (can_profile or loss_timed):
+        if loss_timed:
+            G.LOSS_TIMER_FACTORY = timers.new
+        if can_profile:
+            _lib.profile_begin(int(args.steps) * 64, dominant)
+        timed_region(args.steps, run_step)
+        roofline_pass = "a second pass of the same K steps (the timed steps carry no events: see bench.py)"
+    G.LOSS_TIMER_FACTORY = None
+    if can_profile:
         conv_prof, untimed = _lib.profile_end()
         assert untimed == 0, f"{untimed} launches were not timed: raise the profile capacity"
     final_loss = float(ep["loss_epoch"])
@@ -674,7 +688,7 @@ def main():
     }
     if rank == 0:
         rows, counts = kernel_table(trainer, batches[0], args.kernel_reps)
-        if not timers.handles:                                 # graph mode: measure the same launch right after the timed region
+        if timers.used == 0:                                   # graph mode: measure the same launch right after the timed region
             G.LOSS_TIMER_FACTORY = timers.new
             for _ in range(5):
                 trainer.optimizer.zero_grad(set_to_none=True)
@@ -707,6 +721,7 @@ def main():
                     LIVE_PMC["source"] = ("measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes over "
                                           "tools/conv_layers.py (one launch per kernel / pass / layer shape at the bench's batch size)")
             result["roofline"], _ = conv_roofline(conv_prof, args, result["ms_per_step"])
+            result["roofline"]["measured_in"] = roofline_pass
             # every instrumented convolution launch, in a second run of the same K steps (untimed for the headline)
             _lib.profile_begin(int(args.steps) * 200)
             timed_region(args.steps, run_step)

@@ -149,19 +149,29 @@ LOSS_TIMER_FACTORY = None
 class LossTimers:
     """A pool of dl_timer handles; ``new()`` hands one to each launch, ``elapsed_ms()`` reads them all back."""
 
-    def __init__(self):
+    def __init__(self, reserve=0):
+        """``reserve`` timers are created up front: creating the HIP events of a timer while the stream is busy costs the host
+        milliseconds (measured: a 5 ms autocast step became a 10.6 ms step with one timer created per step)."""
         self.lib = _lib.load()
         self.handles = []
+        self.used = 0
+        for _ in range(int(reserve)):
+            self._create()
 
-    def new(self):
+    def _create(self):
         h = ctypes.c_void_p()
         _lib.check(self.lib.dl_timer_create(ctypes.byref(h)), "dl_timer_create")
         self.handles.append(h)
-        return h
+
+    def new(self):
+        if self.used == len(self.handles):
+            self._create()
+        self.used += 1
+        return self.handles[self.used - 1]
 
     def elapsed_ms(self):
         out = []
-        for h in self.handles:
+        for h in self.handles[:self.used]:
             ms = ctypes.c_float()
             _lib.check(self.lib.dl_timer_elapsed_ms(h, ctypes.byref(ms)), "dl_timer_elapsed_ms")
             out.append(ms.value)
@@ -171,6 +181,7 @@ class LossTimers:
         for h in self.handles:
             self.lib.dl_timer_destroy(h)
         self.handles = []
+        self.used = 0
 
 
 class _IcpLoss(torch.autograd.Function):
