@@ -256,11 +256,12 @@ def conv_table(args, device, reps=10):
             "layers": rows}
 
 
-def conv_roofline(rows, args, step_ms):
+def conv_roofline(rows, args, step_ms, prof_steps=None):
     """The `roofline` object of the JSON line from the launch profile of the timed steps (delora_amd/_lib.py: profile_end): the
     kernel family with the largest share of the step, its algorithmic flop / its summed kernel time against the dense MFMA peak
     of its arithmetic type, one row per layer shape with the HBM traffic of the committed PMC passes next to the compulsory
     bytes.  Also returns the whole profile (every instrumented kernel) as per-step rows."""
+    nsteps = prof_steps or args.steps
     fam = {}
     for r in rows:
         k = r["name"].split(" ")[0]
@@ -274,7 +275,7 @@ def conv_roofline(rows, args, step_ms):
     for r in sorted((r for r in rows if r["name"].startswith(dom + " ")), key=lambda r: -r["ms"]):
         per = r["ms"] / r["launches"]
         t = traffic.get(r["name"])
-        layers.append({"launch": r["name"], "launches_per_step": round(r["launches"] / args.steps, 2), "ms_per_launch": round(per, 5),
+        layers.append({"launch": r["name"], "launches_per_step": round(r["launches"] / nsteps, 2), "ms_per_launch": round(per, 5),
                        "TFLOPs": round(r["flop"] / r["ms"] * 1e-9, 1), "frac": round(r["flop"] / r["ms"] * 1e-9 / peak, 4),
                        "compulsory_MB_per_launch": round(r["bytes"] / r["launches"] / 1e6, 2),
                        "traffic_MB_per_launch": None if t is None else round(t / 1e6, 2)})
@@ -289,8 +290,8 @@ def conv_roofline(rows, args, step_ms):
     roof = {"kernel": f"{dom} ({what}; the largest share of the step)", "bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s",
             "frac": round(tf / peak, 4),
             "traffic": None if not known else int(1e6 * sum(t * n for t, n in known) / sum(n for _, n in known)),
-            "launches_per_step": round(d["launches"] / args.steps, 2), "ms_per_launch": round(d["ms"] / d["launches"], 5),
-            "ms_per_step": round(d["ms"] / args.steps, 4), "share_of_step": round(d["ms"] / args.steps / step_ms, 3),
+            "launches_per_step": round(d["launches"] / nsteps, 2), "ms_per_launch": round(d["ms"] / d["launches"], 5),
+            "ms_per_step": round(d["ms"] / nsteps, 4), "share_of_step": round(d["ms"] / nsteps / step_ms, 3),
             "algorithmic_flop_per_launch": round(d["flop"] / d["launches"]), "layers": layers,
             "note": "achieved = flop the algorithm issues on the matrix cores (Winograd: 16 multiply-adds per 2x2 output tile and (c,k) pair = a direct "
                     "convolution's / 2.25; direct kernels: 36) / kernel time; begin/end timestamps on HIP events attached to every launch "
@@ -300,10 +301,10 @@ def conv_roofline(rows, args, step_ms):
             "traffic_source": LIVE_PMC["source"]}
     if dom == "k_wino_conv":
         roof["achieved_direct_equivalent"] = round(2.25 * tf, 1)
-    prof = [{"launch": r["name"], "launches_per_step": round(r["launches"] / args.steps, 2), "ms_per_step": round(r["ms"] / args.steps, 4),
+    prof = [{"launch": r["name"], "launches_per_step": round(r["launches"] / nsteps, 2), "ms_per_step": round(r["ms"] / nsteps, 4),
              "TFLOPs": round(r["flop"] / r["ms"] * 1e-9, 1), "compulsory_GB_s": round(r["bytes"] / r["ms"] * 1e-6, 0)}
             for r in sorted(rows, key=lambda r: -r["ms"])]
-    return roof, {"families_ms_per_step": {k: round(v["ms"] / args.steps, 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}, "rows": prof}
+    return roof, {"families_ms_per_step": {k: round(v["ms"] / nsteps, 4) for k, v in sorted(fam.items(), key=lambda kv: -kv[1]["ms"])}, "rows": prof}
 
 
 LIVE_PMC = {"rows": None, "source": None}      # filled once by live_pmc_traffic()
@@ -644,26 +645,34 @@ def main():
     conv_prof = None
     dominant = "k_convh" if args.amp else "k_wino_conv"          # the family with the largest share of the step (conv_profile below)
     can_profile = (graphed is None or not graphed.captured) and "hip trunk" in cnn_impl_in_use(trainer, args) and not args.no_profile
-    # An event-carrying launch (hipExtLaunchKernelGGL with start/stop events) keeps the HOST from running ahead of the GPU: 0.2-4 ms
-    # of enqueue time per such launch.  The fp32 step on one GPU has that slack (11 ms of enqueue against 14.7 ms of kernels: same
-    # value with and without, --no-profile); the 5 ms autocast step (4 ms of enqueue) and a DDP rank do not -- there the K timed
-    # steps carry no events at all and the rooflines are read in a second pass of the same steps.
+    # An event-carrying launch (hipExtLaunchKernelGGL with start/stop events) costs the HOST ~0.25 ms, and it keeps the host from
+    # running ahead of the GPU.  With the 26 + 1 such launches in EVERY timed step the 14.7 ms fp32 step of a fresh box was host-bound
+    # (492 pairs/s against 545 with --no-profile, same box, back to back).  The timed region therefore carries events in every
+    # EVENT_EVERY-th step only (dl_profile_pause in between): 5 of the default 20 steps, 130 Winograd launches.  The 5 ms autocast
+    # step and a DDP rank have no slack at all: there the K timed steps carry no events and the rooflines come from a second pass.
+    EVENT_EVERY = 4
     in_timed = not args.amp and world == 1
-    if in_timed and loss_timed:
-        G.LOSS_TIMER_FACTORY = timers.new
-    if in_timed and can_profile:
-        _lib.profile_begin(int(args.steps) * 64, dominant)         # the headline's timed steps time this family only
-    counter["i"] = 0
-    elapsed, ep = timed_region(args.steps, run_step)
-    host_enqueue_ms = enqueue["ms_per_step"]
-    roofline_pass = "the K timed steps"
-    if not in_timed and (can_profile or loss_timed):
-        if loss_timed:
-            G.LOSS_TIMER_FACTORY = timers.new
+    evented = {"steps": 0}
+
+    def run_step_sampled():
+        on = counter["i"] % EVENT_EVERY == 0
         if can_profile:
-            _lib.profile_begin(int(args.steps) * 64, dominant)
-        timed_region(args.steps, run_step)
-        roofline_pass = "a second pass of the same K steps (the timed steps carry no events: see bench.py)"
+            _lib.profile_pause(not on)
+        G.LOSS_TIMER_FACTORY = timers.new if (on and loss_timed) else None
+        evented["steps"] += int(on)
+        return run_step()
+    if can_profile:
+        _lib.profile_begin(int(args.steps) * 64, dominant)         # the steps time this kernel family only
+        _lib.profile_pause(True)
+    counter["i"] = 0
+    elapsed, ep = timed_region(args.steps, run_step_sampled if in_timed and (can_profile or loss_timed) else run_step)
+    host_enqueue_ms = enqueue["ms_per_step"]
+    roofline_pass = f"every {EVENT_EVERY}th of the K timed steps ({evented['steps']} steps)"
+    if not in_timed and (can_profile or loss_timed):
+        counter["i"] = 0
+        timed_region(args.steps, run_step_sampled)
+        roofline_pass = (f"every {EVENT_EVERY}th step of a second pass over the same K steps ({evented['steps']} steps; the timed steps of this "
+                         f"mode carry no events: see bench.py)")
     G.LOSS_TIMER_FACTORY = None
     if can_profile:
         conv_prof, untimed = _lib.profile_end()
@@ -720,15 +729,17 @@ def main():
                 if LIVE_PMC["rows"]:
                     LIVE_PMC["source"] = ("measured by this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE child passes over "
                                           "tools/conv_layers.py (one launch per kernel / pass / layer shape at the bench's batch size)")
-            result["roofline"], _ = conv_roofline(conv_prof, args, result["ms_per_step"])
+            result["roofline"], _ = conv_roofline(conv_prof, args, result["ms_per_step"], prof_steps=max(1, evented["steps"]))
             result["roofline"]["measured_in"] = roofline_pass
-            # every instrumented convolution launch, in a second run of the same K steps (untimed for the headline)
-            _lib.profile_begin(int(args.steps) * 200)
-            timed_region(args.steps, run_step)
-            rows_all, untimed = _lib.profile_end(1024)
-            _, result["conv_profile"] = conv_roofline(rows_all, args, result["ms_per_step"])
-            result["conv_profile"]["note"] = ("kernel begin/end timestamps of every convolution launch in a second run of the same steps; "
-                                              "the headline's timed steps instrument the dominant family only")
+            if world == 1:
+                # every instrumented convolution launch, in a few more steps (single process only: under DDP a step is collective)
+                PROFILE_STEPS = 4
+                _lib.profile_begin(PROFILE_STEPS * 200)
+                timed_region(PROFILE_STEPS, run_step)
+                rows_all, untimed = _lib.profile_end(1024)
+                _, result["conv_profile"] = conv_roofline(rows_all, args, result["ms_per_step"], prof_steps=PROFILE_STEPS)
+                result["conv_profile"]["note"] = (f"kernel begin/end timestamps of every convolution launch in {PROFILE_STEPS} further steps; "
+                                                  "the timed steps instrument the dominant family only, in every fourth step")
         else:
             result["roofline"] = result["roofline_loss"]
         result["kernels"] = rows

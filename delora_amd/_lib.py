@@ -83,6 +83,7 @@ SIGNATURES = {
     "dl_conv2d_wgrad_nhwc_h": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dl_profile_begin": (_i32, [_i32, ctypes.c_char_p]),
     "dl_profile_end": (_i32, [_vp, _i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
+    "dl_profile_pause": (_i32, [_i32]),
 }
 
 
@@ -95,6 +96,11 @@ class ProfileRow(ctypes.Structure):
 def profile_begin(max_launches, only_kernel=None):
     """Open the launch profile; ``only_kernel`` restricts it to one kernel family (e.g. "k_wino_conv")."""
     check(load().dl_profile_begin(int(max_launches), only_kernel.encode() if only_kernel else None), "dl_profile_begin")
+
+
+def profile_pause(paused):
+    """Launches pass untimed while the open profile is paused."""
+    check(load().dl_profile_pause(1 if paused else 0), "dl_profile_pause")
 
 
 def profile_end(capacity=512):

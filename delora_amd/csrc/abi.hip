@@ -58,6 +58,7 @@ struct ProfAgg { int launches = 0; double flop = 0, bytes = 0; std::vector<int> 
 struct Profiler {
   std::mutex mu;
   std::atomic<bool> open{false};
+  std::atomic<bool> paused{false};             // dl_profile_pause: launches pass untimed while set
   std::vector<hipEvent_t> ev;                 // start, stop, start, stop ...
   int used = 0, skipped = 0;
   std::string only;                           // kernel family filter ("" = every instrumented launch)
@@ -66,11 +67,11 @@ struct Profiler {
 Profiler g_prof;
 }  // namespace
 
-bool dl_prof_is_open() { return g_prof.open.load(std::memory_order_relaxed); }
+bool dl_prof_is_open() { return g_prof.open.load(std::memory_order_relaxed) && !g_prof.paused.load(std::memory_order_relaxed); }
 
 void dl_prof_events(const DlProfTag& tag, hipEvent_t* e0, hipEvent_t* e1) {
   std::lock_guard<std::mutex> lock(g_prof.mu);
-  if (!g_prof.open.load(std::memory_order_relaxed)) return;
+  if (!g_prof.open.load(std::memory_order_relaxed) || g_prof.paused.load(std::memory_order_relaxed)) return;
   if (!g_prof.only.empty() && g_prof.only != tag.kernel) return;
   if (2 * g_prof.used + 1 >= (int)g_prof.ev.size()) { ++g_prof.skipped; return; }
   char name[96];
@@ -91,7 +92,14 @@ extern "C" int dl_profile_begin(int32_t max_launches, const char* only_kernel) {
   g_prof.used = g_prof.skipped = 0;
   g_prof.rows.clear();
   g_prof.only = only_kernel ? only_kernel : "";
+  g_prof.paused.store(false);
   g_prof.open.store(true);
+  return DL_OK;
+}
+
+/* see include/delora_hip.h */
+extern "C" int dl_profile_pause(int32_t paused) {
+  g_prof.paused.store(paused != 0, std::memory_order_relaxed);
   return DL_OK;
 }
 

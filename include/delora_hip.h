@@ -395,6 +395,9 @@ typedef struct {
   double ms, flop, bytes;
 } dl_profile_row;
 int dl_profile_begin(int32_t max_launches, const char* only_kernel /* NULL: all; else one kernel family, e.g. "k_wino_conv" */);
+/* While paused (paused != 0) launches pass without events and are not counted: bench.py times every fourth step of its timed
+ * region only -- an event-carrying launch costs the host ~0.25 ms, and 26 of them per step made a fresh box host-bound. */
+int dl_profile_pause(int32_t paused);
 int dl_profile_end(dl_profile_row* rows, int32_t capacity, int32_t* count, int32_t* untimed);
 
 #ifdef __cplusplus

@@ -382,7 +382,7 @@ def test_bench_two_ranks_on_one_gpu_through_torchrun():
     env = dict(os.environ, DELORA_BENCH_SHARE_GPU="1", DELORA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2",
-           "--rotate", "2", "--width", "512", "--kernel-reps", "2"]
+           "--rotate", "2", "--kernel-reps", "2", "--no-live-pmc"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
@@ -391,6 +391,8 @@ def test_bench_two_ranks_on_one_gpu_through_torchrun():
     assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["config"]["global_batch"] == 4 and j["config"]["parallelism"] == "dp2"
     assert j["scaling"] == "weak" and j["steps"] == 3 and np.isfinite(j["final_loss"]) and j["value"] > 0
     assert "cpu_baseline" not in j and "feed" not in j          # single-GPU legs only
+    # the full-width image: the ranks run the HIP trunk, and rank 0 must not start collective steps of its own after the timed region
+    assert "hip trunk" in j["config"]["cnn_impl"] and j["roofline"]["bound"] == "mfma" and "second pass" in j["roofline"]["measured_in"]
 
 
 def test_ddp_wrapping_uses_small_buckets_and_bucket_views():
