@@ -598,6 +598,17 @@ def main():
         ep, T = trainer.step(preprocessed_dicts=[dict(s) for s in batch], epoch_losses=ep)
         return ep
 
+    # Priming (set-up, not warm-up): one step on each of the distinct ragged batches, so that torch's caching allocator has seen every
+    # tensor size of the rotation before the W warm-up steps -- a first visit of a batch costs hipMalloc calls (host stalls, device
+    # synchronisation): with W = 5 < 8 batches the first timed steps were such visits (autocast step: 11 ms instead of 5 ms of enqueue)
+    for b in batches:
+        run_step(b)
+    # As Trainer.train does after its set-up: everything alive now (batches, datasets, module trees) moves to the collector's permanent
+    # generation.  A generation-2 pass over that heap stalled the host for ~0.1 s at random steps -- invisible behind a 14.6 ms GPU-bound
+    # step, 5 ms per step of a 20-step autocast region (1500 pairs/s read as 750).
+    import gc
+    gc.collect()
+    gc.freeze()
     for _ in range(args.warmup):
         run_step()
     graphed = None
@@ -621,13 +632,21 @@ def main():
     enqueue = {}
 
     def timed_region(steps, step_fn):
+        return _timed_region(steps, step_fn)
+
+    def _timed_region(steps, step_fn):
         torch.cuda.synchronize()
         if world > 1:
             torch.distributed.barrier()
         t0 = time.perf_counter()
         ep = None
+        per_step = []
         for _ in range(steps):
+            t1 = time.perf_counter()
             ep = step_fn()
+            per_step.append(round(1e3 * (time.perf_counter() - t1), 1))
+        if os.environ.get("DELORA_BENCH_STEP_TIMES"):
+            print("host ms per step:", per_step, file=sys.stderr)
         enqueue["ms_per_step"] = 1e3 * (time.perf_counter() - t0) / steps      # host time to enqueue the steps (no sync yet)
         torch.cuda.synchronize()
         if world > 1:
@@ -691,7 +710,7 @@ def main():
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "cnn": "fp32" if not args.amp else "autocast " + args.amp,
                    "cnn_impl": cnn_impl_in_use(trainer, args),
                    "channels_last": bool(args.channels_last), "hip_graph": bool(graphed is not None and graphed.captured),
-                   "distinct_batches": len(batches)},
+                   "distinct_batches": len(batches), "priming_steps": len(batches)},
         "final_loss": final_loss, "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
         "rccl_ranks": ranks_seen, "collective_backend": (backend if world > 1 else None),
     }
