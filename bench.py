@@ -188,6 +188,9 @@ def autocast_leg(args, device, host_batches, batches, timed_region):
         return ep
     for _ in range(max(3, args.warmup)):
         step()
+    import gc
+    gc.collect()
+    gc.freeze()                                                  # as Trainer.train does after its set-up (see main)
     el, ep = timed_region(args.autocast_steps, step)
     out_graph = None
     try:
