@@ -1,0 +1,71 @@
+"""Host-side logic of bench.py and of the PMC tooling it drives (no GPU): the roofline object built from launch-profile rows, and the
+mapping of rocprofv3 counter dispatches back to profile rows."""
+import csv
+import importlib.util
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_roofline_object_from_profile_rows():
+    """conv_roofline: dominant family by summed time, algorithmic flop / kernel time against the dense peak of its arithmetic type, per-shape
+    rows, launches per step taken over the steps that actually carried events."""
+    import bench
+    args = bench.parse(["--steps", "20"])
+    rows = [  # 5 evented steps: 6 launches of a 256-channel shape per step, 8 of a 64-channel shape, one direct launch
+        {"name": "k_wino_conv conv N8 64x128 C256 K256 3x3 s(1,1)", "launches": 30, "ms": 30 * 0.335, "flop": 30 * 34.36e9, "bytes": 30 * 138e6},
+        {"name": "k_wino_conv conv N8 64x512 C64 K64 3x3 s(1,1)", "launches": 40, "ms": 40 * 0.107, "flop": 40 * 8.59e9, "bytes": 40 * 134e6},
+        {"name": "k_conv_f32 fwd N8 64x512 C64 K128 3x3 s(1,2)", "launches": 5, "ms": 5 * 0.23, "flop": 5 * 19.3e9, "bytes": 5 * 100e6},
+    ]
+    bench.LIVE_PMC["rows"] = {rows[0]["name"]: 312_000_000, rows[1]["name"]: 193_000_000}
+    try:
+        roof, prof = bench.conv_roofline(rows, args, step_ms=14.6, prof_steps=5)
+    finally:
+        bench.LIVE_PMC["rows"] = None
+    assert roof["kernel"].startswith("k_wino_conv") and roof["bound"] == "mfma" and roof["peak"] == bench.MFMA_F32_PEAK_TFLOPS
+    tf = (30 * 34.36e9 + 40 * 8.59e9) / (30 * 0.335 + 40 * 0.107) * 1e-9
+    assert roof["achieved"] == pytest.approx(tf, rel=1e-3) and roof["frac"] == pytest.approx(tf / 157.3, abs=2e-4)
+    assert roof["launches_per_step"] == 14.0 and roof["ms_per_step"] == pytest.approx((30 * 0.335 + 40 * 0.107) / 5, rel=1e-3)
+    by = {l["launch"]: l for l in roof["layers"]}
+    assert by[rows[0]["name"]]["launches_per_step"] == 6.0 and by[rows[0]["name"]]["traffic_MB_per_launch"] == 312.0
+    assert by[rows[1]["name"]]["frac"] == pytest.approx(8.59e9 / 0.107e-3 * 1e-12 / 157.3, abs=2e-4)
+    assert roof["traffic"] == int(1e6 * (312.0 * 6 + 193.0 * 8) / 14)          # launch-weighted mean of the layer rows
+    assert prof["families_ms_per_step"]["k_conv_f32"] == pytest.approx(0.23, rel=1e-3)
+
+
+def test_counter_dispatches_map_back_to_profile_rows(tmp_path):
+    """tools/conv_layers_pmc.traffic_rows: every op runs twice (warm-up + measured) -- the measured dispatches of a family are taken in
+    order; the same kernel on the same shape in two passes (Winograd forward / input gradient) is a launch-weighted mean; gfx950 x2 on reads."""
+    m = _load(os.path.join(ROOT, "tools", "conv_layers_pmc.py"), "conv_layers_pmc")
+
+    def table(path, counter, seq):
+        with open(path, "w") as f:
+            w = csv.DictWriter(f, fieldnames=["Dispatch_Id", "Kernel_Name", "Counter_Name", "Counter_Value"])
+            w.writeheader()
+            for i, (k, v) in enumerate(seq):
+                w.writerow({"Dispatch_Id": i, "Kernel_Name": k, "Counter_Name": counter, "Counter_Value": v})
+    wino, conv = "void k_wino_conv<32>(WinoArgs)", "void k_conv_f32<128, 64, 8, 128, GeomConv<3, 1, 2>, false, 2>(ConvArgs)"
+    seq = [(wino, 1), (wino, 100), ("at::native::fill", 7), (wino, 2), (wino, 200), (conv, 3), (conv, 4), (conv, 30), (conv, 40)]
+    table(tmp_path / "f.csv", "FETCH_SIZE", seq)
+    table(tmp_path / "w.csv", "WRITE_SIZE", [(k, v / 2) for k, v in seq])
+    order = {"workload": "x", "order": [
+        {"op": "fwd", "row": "k_wino_conv conv A", "launches": 1, "compulsory_bytes": 10},
+        {"op": "dgrad", "row": "k_wino_conv conv A", "launches": 1, "compulsory_bytes": 10},
+        {"op": "phases", "row": "k_conv_f32 dgrad B", "launches": 2, "compulsory_bytes": 5}]}
+    rows = m.traffic_rows(order, str(tmp_path / "f.csv"), str(tmp_path / "w.csv"))
+    a = rows["k_wino_conv conv A"]
+    assert a["kernel_launches"] == 2 and a["read_bytes_corrected_x2"] == (100 + 200) * 1024 * 2 and a["write_bytes"] == (50 + 100) * 1024
+    assert a["hbm_bytes_per_launch"] == ((100 + 200) * 2048 + 150 * 1024) // 2
+    b = rows["k_conv_f32 dgrad B"]
+    assert b["kernel_launches"] == 2 and b["read_bytes_corrected_x2"] == (30 + 40) * 2048 and b["hbm_bytes_per_launch"] == ((30 + 40) * 2048 + 35 * 1024) // 2
