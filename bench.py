@@ -166,8 +166,8 @@ def cnn_impl_in_use(trainer, args):
 
 
 def autocast_leg(args, device, host_batches, batches, timed_region):
-    """The same training step with the CNN in half precision (config key amp_dtype = torch.autocast around the model, as a
-    mixed-precision run of the reference would; BASELINE.json configs[4]): a second trainer on the same batches, the trunk on
+    """The same training step with the CNN in half precision (config key amp_dtype = torch.autocast around the model call: the
+    mixed-precision mode BASELINE.json configs[4] names; the reference itself trains in fp32 only): a second trainer on the same batches, the trunk on
     the bf16 MFMA kernels (csrc/convh.hip, wgradh.hip).  Reported next to the fp32 headline, never as it."""
     import argparse
     from delora_amd.deploy.trainer import Trainer
