@@ -199,7 +199,7 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
   }
   if (visible) {
     // one atomic per workgroup, spread over 32 sub-counters per sample (2048 same-address atomics per sample
-    // serialise for ~80 us at the end of the kernel); k_nn_hard folds the sub-counters into visible[b]
+    // serialise for ~80 us at the end of the kernel); nn_hard (k_nn_pass_b) folds the sub-counters into visible[b]
     __shared__ int s_vis;
     if (threadIdx.x == 0) s_vis = 0;
     __syncthreads();
@@ -266,13 +266,13 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
     }
   } else {
     // two lists in one array: windows of at most NN_SCAN_MAX pixels (most of them: a few hundred) grow from the end
-    // and are scanned exhaustively by 16-lane groups (k_nn_scan16); larger ones grow from the front (k_nn_hard: tile walk)
+    // and are scanned exhaustively by 16-lane groups (nn_scan16); larger ones grow from the front (nn_hard: tile walk) -- all three lists are served by k_nn_pass_b
     const int wpx = (w.r1 - w.r0 + 1) * w.nc;
     NNHard* list = ws.hard;
     int pos;
     if (wpx <= NN_SCAN_MAX) pos = ws.capacity - 1 - atomicAdd(ws.counter + 1, 1);
-    else if (wpx <= NN_SEED_MIN) { list = ws.mid; pos = atomicAdd(ws.counter + 2, 1); }   // tile walk, 16 lanes (k_nn_hard16)
-    else pos = atomicAdd(ws.counter, 1);                                                   // tile walk, one wave (k_nn_hard)
+    else if (wpx <= NN_SEED_MIN) { list = ws.mid; pos = atomicAdd(ws.counter + 2, 1); }   // tile walk, 16 lanes (nn_hard16)
+    else pos = atomicAdd(ws.counter, 1);                                                   // tile walk, one wave (nn_hard)
     NNHard h;
     h.d2 = best; h.slot = b * HW + px; h.idx = bidx; h.qx = fx; h.qy = fy; h.qz = fz; h.b = b;
     h.rows = (uint32_t)w.r0 | ((uint32_t)w.r1 << 16);
@@ -616,12 +616,12 @@ __device__ __forceinline__ void row_argmin(double& d2, int& idx) {
 // 256-byte contiguous piece of a packed image row per load -- screens in fp32, refines in fp64, and reduces with DPP row
 // operations; no tile tests, no wave-wide synchronisation, four independent dependency chains per wave.  (One wave per
 // query spent ~9k cycles on each of these, almost all of it memory latency of five dependent round trips.)
-__global__ __launch_bounds__(DL_BLOCK) void k_nn_scan16(const float4* __restrict__ tgt, int64_t tgt_ss4,
-                                                        const float4* __restrict__ tgtn, int64_t tgtn_ss4, SensorK sen,
-                                                        int32_t* __restrict__ nn_pix, float* __restrict__ match, NNWorkspace ws) {
+__device__ __forceinline__ void nn_scan16(const int vblock, const int vgrid, const float4* __restrict__ tgt, int64_t tgt_ss4,
+                                          const float4* __restrict__ tgtn, int64_t tgtn_ss4, const SensorK& sen,
+                                          int32_t* __restrict__ nn_pix, float* __restrict__ match, const NNWorkspace& ws) {
   const int lane = threadIdx.x & (DL_WAVE - 1), l16 = lane & 15;
-  const int group = (blockIdx.x * DL_BLOCK + threadIdx.x) >> 4;
-  const int ngroups = gridDim.x * DL_BLOCK / 16;
+  const int group = (vblock * DL_BLOCK + threadIdx.x) >> 4;
+  const int ngroups = vgrid * DL_BLOCK / 16;
   const int count = ws.counter[1];
   const int HW = sen.HW, W = sen.W;
   for (int h = group; h < count; h += ngroups) {
@@ -682,18 +682,18 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_scan16(const float4* __restrict
 }
 
 // Pass B for the medium bound windows (a few hundred to a few thousand pixels: 4 to 128 tiles): the tile walk of
-// k_nn_hard with FOUR queries per wave, one per 16-lane row.  A row tests 16 tile spheres per trip (one per lane), its
+// nn_hard with FOUR queries per wave, one per 16-lane row.  A row tests 16 tile spheres per trip (one per lane), its
 // surviving tiles are scanned one 16-pixel tile row per lane step (four contiguous 256-byte loads per tile, issued
 // together), cull distance and result are reduced with DPP row operations.  The dependent chain of one query (record ->
 // spheres -> pixels -> result gather, ~5 us of memory latency) is the same as with a whole wave per query -- but four of
 // them run side by side, which is what a latency-bound kernel needs.  Everything per query is per-lane state here (no
 // wave-uniform control flow): rows whose query is finished idle until the slowest row of the wave is done.
-__global__ __launch_bounds__(DL_BLOCK) void k_nn_hard16(const float4* __restrict__ tgt, int64_t tgt_ss4,
-                                                        const float4* __restrict__ tgtn, int64_t tgtn_ss4, SensorK sen,
-                                                        int32_t* __restrict__ nn_pix, float* __restrict__ match, NNWorkspace ws) {
+__device__ __forceinline__ void nn_hard16(const int vblock, const int vgrid, const float4* __restrict__ tgt, int64_t tgt_ss4,
+                                          const float4* __restrict__ tgtn, int64_t tgtn_ss4, const SensorK& sen,
+                                          int32_t* __restrict__ nn_pix, float* __restrict__ match, const NNWorkspace& ws) {
   const int lane = threadIdx.x & (DL_WAVE - 1), l16 = lane & 15, rowbase = lane & 48;
-  const int group = (blockIdx.x * DL_BLOCK + threadIdx.x) >> 4;
-  const int ngroups = gridDim.x * DL_BLOCK / 16;
+  const int group = (vblock * DL_BLOCK + threadIdx.x) >> 4;
+  const int ngroups = vgrid * DL_BLOCK / 16;
   const int count = ws.counter[2];
   const int HW = sen.HW, H = sen.H, W = sen.W;
   const int ntc_all = (W + NN_TC - 1) / NN_TC;
@@ -796,16 +796,16 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_hard16(const float4* __restrict
 // (Measured and rejected, see the history in DESIGN.md: several queries per wave with per-lane arithmetic -- 4 per wave
 // 1.38 ms, 16 per wave 1.96 ms against 1.29 ms for the whole search; pixel-scanned boxes growing around q's pixel before
 // the tile walk; pinning each sample to one XCD, 2.0 -> 5.5 ms; 16 instead of 4 candidate loads in flight.)
-__global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float4* __restrict__ tgt, int64_t tgt_ss4,
-                                                      const float4* __restrict__ tgtn, int64_t tgtn_ss4, SensorK sen,
-                                                      int32_t* __restrict__ nn_pix, float* __restrict__ match,
-                                                      int32_t* __restrict__ visible, int nb, NNWorkspace ws) {
+__device__ __forceinline__ void nn_hard(const int vblock, const int vgrid, const float4* __restrict__ tgt, int64_t tgt_ss4,
+                                        const float4* __restrict__ tgtn, int64_t tgtn_ss4, const SensorK& sen,
+                                        int32_t* __restrict__ nn_pix, float* __restrict__ match,
+                                        int32_t* __restrict__ visible, int nb, const NNWorkspace& ws) {
   const int lane = threadIdx.x & (DL_WAVE - 1);
-  const int wave = __builtin_amdgcn_readfirstlane((blockIdx.x * DL_BLOCK + threadIdx.x) / DL_WAVE);
-  const int nwaves = gridDim.x * DL_BLOCK / DL_WAVE;
+  const int wave = __builtin_amdgcn_readfirstlane((vblock * DL_BLOCK + threadIdx.x) / DL_WAVE);
+  const int nwaves = vgrid * DL_BLOCK / DL_WAVE;
   const int count = ws.counter[0];
   const int HW = sen.HW, H = sen.H, W = sen.W;
-  if (visible && blockIdx.x == 0 && (int)threadIdx.x < nb) {      // fold the visible-pixel sub-counters of pass A
+  if (visible && vblock == 0 && (int)threadIdx.x < nb) {      // fold the visible-pixel sub-counters of pass A
     int sum = 0;
     for (int i = 0; i < 32; ++i) sum += ws.counter[NN_VIS0 + threadIdx.x * 32 + i];
     visible[threadIdx.x] = sum;
@@ -854,6 +854,19 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_hard(const float4* __restrict__
   }
 }
 
+// Pass B in ONE launch: the three work lists are served by three ranges of workgroups (tile walk with 16 lanes per query first, then
+// the one-wave-per-query walk, the short window scans last).  As three launches every list ended in a tail of a few long queries
+// with most of the chip idle; in one grid the next range's workgroups move in as the previous range drains.
+__global__ __launch_bounds__(DL_BLOCK) void k_nn_pass_b(const float4* __restrict__ tgt, int64_t tgt_ss4,
+                                                        const float4* __restrict__ tgtn, int64_t tgtn_ss4, SensorK sen,
+                                                        int32_t* __restrict__ nn_pix, float* __restrict__ match,
+                                                        int32_t* __restrict__ visible, int nb, NNWorkspace ws, int part) {
+  const int blk = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+  if (blk < part) nn_hard16(blk, part, tgt, tgt_ss4, tgtn, tgtn_ss4, sen, nn_pix, match, ws);
+  else if (blk < 2 * part) nn_hard(blk - part, part, tgt, tgt_ss4, tgtn, tgtn_ss4, sen, nn_pix, match, visible, nb, ws);
+  else nn_scan16(blk - 2 * part, part, tgt, tgt_ss4, tgtn, tgtn_ss4, sen, nn_pix, match, ws);
+}
+
 extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const float* src_normals,
                                 int64_t srcn_ss, const float* tgt_packed, int64_t tgt_ss,
                                 const float* tgt_normals_packed, int64_t tgtn_ss, const float* T, int32_t B,
@@ -887,12 +900,8 @@ extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const f
                      src_image4, src_ss, src_normals, srcn_ss, (const float4*)tgt_packed, tgt_ss / 4,
                      (const float4*)tgt_normals_packed, tgtn_ss / 4, T, sen, need_without_normals, nn_pix, match, visible,
                      ws);
-  hipLaunchKernelGGL(k_nn_scan16, dim3(2048), dim3(DL_BLOCK), 0, st, (const float4*)tgt_packed, tgt_ss / 4,
-                     (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, ws);
-  hipLaunchKernelGGL(k_nn_hard16, dim3(2048), dim3(DL_BLOCK), 0, st, (const float4*)tgt_packed, tgt_ss / 4,
-                     (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, ws);
-  hipLaunchKernelGGL(k_nn_hard, dim3(2048), dim3(DL_BLOCK), 0, st, (const float4*)tgt_packed, tgt_ss / 4,
-                     (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, visible, B, ws);
+  hipLaunchKernelGGL(k_nn_pass_b, dim3(3 * 2048), dim3(DL_BLOCK), 0, st, (const float4*)tgt_packed, tgt_ss / 4,
+                     (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, visible, B, ws, 2048);
   return dl_check_launch("dl_nn_correspond");
 }
 

@@ -6,7 +6,7 @@ import csv, json, os, shutil, statistics, subprocess, sys
 R = sys.argv[1] if len(sys.argv) > 1 else "r01"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(ROOT, "gpurun_out", f"profiles_{R}"), os.path.join(ROOT, "profiles")
-OWN = ["k_project_scatter", "k_project_resolve", "k_normals", "k_nn_tiles", "k_nn_window", "k_nn_scan16", "k_nn_hard16", "k_nn_hard(",
+OWN = ["k_project_scatter", "k_project_resolve", "k_normals", "k_nn_tiles", "k_nn_window", "k_nn_scan16", "k_nn_hard16", "k_nn_hard(", "k_nn_pass_b",
        "k_icp_loss", "k_icp_reduce", "k_probe_read"]
 
 
