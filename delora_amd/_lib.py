@@ -62,6 +62,7 @@ SIGNATURES = {
     "dl_conv2d_wgrad_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dl_wino_weights_floats": (_sz, [_i32, _i32]),
     "dl_wino_weights_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    "dl_wino_weights_batch_f32": (_i32, [_vp, _i32, _vp]),
     "dl_wino_conv3x3_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _u32, _vp]),
     "dl_wino_wgrad_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "dl_wino_wgrad3x3_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -85,6 +86,14 @@ SIGNATURES = {
     "dl_profile_end": (_i32, [_vp, _i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "dl_profile_pause": (_i32, [_i32]),
 }
+
+
+class WinoLayer(ctypes.Structure):
+    """``dl_wino_layer`` of include/delora_hip.h."""
+    _fields_ = [("w", ctypes.c_void_p), ("u_fwd", ctypes.c_void_p), ("u_bwd", ctypes.c_void_p), ("K", ctypes.c_int32), ("C", ctypes.c_int32)]
+
+
+WINO_BATCH = 16
 
 
 class ProfileRow(ctypes.Structure):

@@ -471,6 +471,67 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
 #undef WN_M
 }
 
+// The same transform for up to DL_WINO_BATCH layers in ONE launch (the 13 stride-1 layers of the trunk took 13 launches of
+// 4-24 us, most of it launch latency and the ramp of a small grid): the layer table travels in the kernel arguments.
+struct WinoBatchArgs {
+  const float* w[DL_WINO_BATCH];
+  float* u_fwd[DL_WINO_BATCH];
+  float* u_bwd[DL_WINO_BATCH];
+  int K[DL_WINO_BATCH], C[DL_WINO_BATCH];
+  int first_block[DL_WINO_BATCH + 1];          // prefix sums of the layers' block counts
+  int n;
+};
+__global__ __launch_bounds__(256) void k_wino_weights_batch(WinoBatchArgs a) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < DL_WINO_BATCH; ++i)
+    if (i < a.n && (int)blockIdx.x >= a.first_block[i]) l = i;
+  const int K = a.K[l], C = a.C[l];
+  const int i = ((int)blockIdx.x - a.first_block[l]) * 256 + threadIdx.x;
+  if (i >= K * C) return;
+  const float* __restrict__ w = a.w[l];
+  float* __restrict__ u_fwd = a.u_fwd[l];
+  float* __restrict__ u_bwd = a.u_bwd[l];
+  const int c = i % C, k = i / C;
+  float g[3][3], gf[3][3], u[4][4];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s2 = 0; s2 < 3; ++s2) {
+      g[r][s2] = w[((size_t)(k * 3 + r) * 3 + s2) * C + c];
+      gf[2 - r][2 - s2] = g[r][s2];
+    }
+  if (u_fwd) {
+    wn_weight_transform(g, u);
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) u_fwd[(((size_t)(c / 8) * 16 + xi) * K + k) * 8 + (c % 8)] = u[xi / 4][xi % 4];
+  }
+  if (u_bwd) {
+    wn_weight_transform(gf, u);
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi) u_bwd[(((size_t)(k / 8) * 16 + xi) * C + c) * 8 + (k % 8)] = u[xi / 4][xi % 4];
+  }
+}
+
+/* see include/delora_hip.h */
+extern "C" int dl_wino_weights_batch_f32(const dl_wino_layer* layers, int32_t n, dl_stream stream) {
+  if (!layers || n <= 0 || n > DL_WINO_BATCH) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wino_weights_batch_f32: 1..%d layers per call", DL_WINO_BATCH);
+  WinoBatchArgs a{};
+  a.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const dl_wino_layer& L = layers[i];
+    if (!L.w || (!L.u_fwd && !L.u_bwd) || L.K <= 0 || L.C <= 0 || L.K % 8 || L.C % 8)
+      return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wino_weights_batch_f32: bad layer %d (K, C multiples of 8)", i);
+    a.w[i] = L.w; a.u_fwd[i] = L.u_fwd; a.u_bwd[i] = L.u_bwd; a.K[i] = L.K; a.C[i] = L.C;
+    a.first_block[i] = blocks;
+    blocks += (L.K * L.C + 255) / 256;
+  }
+  a.first_block[n] = blocks;
+  hipLaunchKernelGGL(k_wino_weights_batch, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return dl_check_launch("dl_wino_weights_batch_f32");
+}
+
 extern "C" size_t dl_wino_weights_floats(int32_t K, int32_t C) { return (size_t)16 * K * C; }
 
 extern "C" int dl_wino_weights_f32(const float* w, float* u_fwd, float* u_bwd, int32_t K, int32_t C, dl_stream stream) {

@@ -120,6 +120,34 @@ def wino_weights(w_param, want_fwd=True, want_bwd=True):
     return uf, ub
 
 
+def wino_weights_batch(w_params, want_bwd=True):
+    """Winograd-domain weights of several 3x3 layers in ONE launch (``dl_wino_weights_batch_f32``): a list of (u_fwd, u_bwd) in the
+    order of ``w_params``; the outputs of all layers are views of two allocations."""
+    lib = _lib.load()
+    ws = [weight_storage(w) for w in w_params]
+    out = []
+    if not ws:
+        return out
+    sizes = [int(lib.dl_wino_weights_floats(w.shape[0], w.shape[3])) for w in ws]
+    dev = ws[0].device
+    uf_all = torch.empty((sum(sizes),), dtype=torch.float32, device=dev)
+    ub_all = torch.empty((sum(sizes),), dtype=torch.float32, device=dev) if want_bwd else None
+    off = 0
+    for n in sizes:
+        out.append((uf_all[off:off + n], ub_all[off:off + n] if want_bwd else None))
+        off += n
+    for i0 in range(0, len(ws), _lib.WINO_BATCH):
+        part = list(range(i0, min(i0 + _lib.WINO_BATCH, len(ws))))
+        arr = (_lib.WinoLayer * len(part))()
+        for j, i in enumerate(part):
+            arr[j].w = ws[i].data_ptr()
+            arr[j].u_fwd = out[i][0].data_ptr()
+            arr[j].u_bwd = out[i][1].data_ptr() if want_bwd else None
+            arr[j].K, arr[j].C = ws[i].shape[0], ws[i].shape[3]
+        _lib.check(lib.dl_wino_weights_batch_f32(ctypes.cast(arr, ctypes.c_void_p), len(part), _stream()), "dl_wino_weights_batch_f32")
+    return out
+
+
 def wino_conv(x, u, K, act=0, epilogue=0, add=None, dsrc=None):
     """Stride-1 3x3 convolution of x ``[N,H,W,C]`` with Winograd-domain weights ``u`` (u_fwd: forward; u_bwd with the
     output gradient as x: input gradient) -> ``[N,H,W,K]``, epilogue as conv_nhwc."""
@@ -299,21 +327,34 @@ class RingSegment(torch.autograd.Function):
         saved, x, wi = [x0], x0, 0
         ubwd = []
         need_bwd = any(ctx.needs_input_grad)
+        # which layers of this segment run as Winograd (shape walk), and their transformed weights in ONE launch
+        plan, (N, H, W) = [], x0.shape[:3]
         for (cin, cout, stride, has_ds) in blocks:
+            use1 = USE_WINOGRAD and stride == (1, 1) and wino_ok(H, W, cin, cout)
+            H, W = H // stride[0], W // stride[1]
+            use2 = USE_WINOGRAD and wino_ok(H, W, cout, cout)
+            plan.append((use1, use2))
+        wlist, wj = [], 0
+        for (cin, cout, stride, has_ds), (use1, use2) in zip(blocks, plan):
+            if use1:
+                wlist.append(weights[wj])
+            if use2:
+                wlist.append(weights[wj + 1])
+            wj += 3 if has_ds else 2
+        us = iter(wino_weights_batch(wlist, want_bwd=need_bwd))
+        for (cin, cout, stride, has_ds), (use1, use2) in zip(blocks, plan):
             w1p, w2p = weights[wi], weights[wi + 1]
             wd = weight_storage(weights[wi + 2]) if has_ds else None
             wi += 3 if has_ds else 2
-            N, H, W, _ = x.shape
-            if USE_WINOGRAD and stride == (1, 1) and wino_ok(H, W, cin, cout):
-                uf, ub1 = wino_weights(w1p, want_bwd=need_bwd)
+            if use1:
+                uf, ub1 = next(us)
                 y1 = wino_conv(x, uf, cout, act=act, epilogue=EPI_ACT)
             else:
                 ub1 = None
                 y1 = conv_nhwc(x, weight_storage(w1p), stride=stride, act=act, epilogue=EPI_ACT)
             shortcut = conv_nhwc(x, wd, stride=stride) if has_ds else x
-            Ho, Wo = y1.shape[1], y1.shape[2]
-            if USE_WINOGRAD and wino_ok(Ho, Wo, cout, cout):
-                uf, ub2 = wino_weights(w2p, want_bwd=need_bwd)
+            if use2:
+                uf, ub2 = next(us)
                 y2 = wino_conv(y1, uf, cout, act=act, epilogue=EPI_ADD | EPI_ACT, add=shortcut)
             else:
                 ub2 = None

@@ -296,6 +296,16 @@ int dl_conv2d_wgrad_nhwc_f32(const float* x, const float* g, float* dw, void* wo
  */
 size_t dl_wino_weights_floats(int32_t K, int32_t C);
 int dl_wino_weights_f32(const float* w, float* u_fwd, float* u_bwd, int32_t K, int32_t C, dl_stream stream);
+/* The same transform for up to DL_WINO_BATCH layers in one launch (the trunk's 13 stride-1 layers: one launch per autograd segment
+ * instead of one per layer).  A layer's u_fwd or u_bwd may be null. */
+#define DL_WINO_BATCH 16
+typedef struct {
+  const float* w;      /* [K][3][3][C] */
+  float* u_fwd;        /* [C/8][16][K][8] or null */
+  float* u_bwd;        /* [K/8][16][C][8] or null */
+  int32_t K, C;
+} dl_wino_layer;
+int dl_wino_weights_batch_f32(const dl_wino_layer* layers, int32_t n, dl_stream stream);
 int dl_wino_conv3x3_nhwc_f32(const float* x, const float* u, float* y, const float* add, const float* dsrc, int32_t N,
                              int32_t H, int32_t W, int32_t C, int32_t K, int32_t act, uint32_t epilogue, dl_stream stream);
 
