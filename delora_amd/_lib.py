@@ -74,6 +74,7 @@ SIGNATURES = {
     "dl_quat_to_T_bwd": (_i32, [_vp, _vp, _i32, ctypes.c_float, _vp, _vp, _vp]),
     "dl_mean_hw_nhwc_f32": (_i32, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "dl_conv_weights_h": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "dl_conv_weights_batch_h": (_i32, [_vp, _i32, _i32, _vp]),
     "dl_conv2d_nhwc_h": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _u32, _vp]),
     "dl_conv2d_dgrad_strided_nhwc_h": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                               _u32, _vp]),
@@ -94,6 +95,15 @@ class WinoLayer(ctypes.Structure):
 
 
 WINO_BATCH = 16
+
+
+class ConvHLayer(ctypes.Structure):
+    """``dl_convh_layer`` of include/delora_hip.h."""
+    _fields_ = [("w", ctypes.c_void_p), ("w_fwd", ctypes.c_void_p), ("w_bwd", ctypes.c_void_p), ("K", ctypes.c_int32), ("taps", ctypes.c_int32),
+                ("C", ctypes.c_int32)]
+
+
+CONVH_BATCH = 32
 
 
 class ProfileRow(ctypes.Structure):

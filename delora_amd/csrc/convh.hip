@@ -284,6 +284,71 @@ __global__ __launch_bounds__(256) void k_wprep_h(const float* __restrict__ w, u1
   }
 }
 
+// The same conversion for up to DL_CONVH_BATCH layers in ONE launch (19 launches of 3-6 us per autocast step: launch latency and the
+// ramp of small grids): the layer table travels in the kernel arguments, a block finds its layer by its index.
+struct WprepBatchArgs {
+  const float* w[DL_CONVH_BATCH];
+  u16* w_fwd[DL_CONVH_BATCH];
+  u16* w_bwd[DL_CONVH_BATCH];
+  int K[DL_CONVH_BATCH], T[DL_CONVH_BATCH], C[DL_CONVH_BATCH];
+  int first_block[DL_CONVH_BATCH + 1];
+  int n;
+};
+template <bool F16>
+__global__ __launch_bounds__(256) void k_wprep_batch_h(WprepBatchArgs a) {
+  __shared__ float tile[32][33];
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < DL_CONVH_BATCH; ++i)
+    if (i < a.n && (int)blockIdx.x >= a.first_block[i]) l = i;
+  const int K = a.K[l], T = a.T[l], C = a.C[l];
+  const float* __restrict__ w = a.w[l];
+  u16* __restrict__ w_fwd = a.w_fwd[l];
+  u16* __restrict__ w_bwd = a.w_bwd[l];
+  int blk = (int)blockIdx.x - a.first_block[l];
+  const int ct = (C + 31) / 32, kt = (K + 31) / 32;
+  const int c0 = (blk % ct) * 32; blk /= ct;
+  const int k0 = (blk % kt) * 32;
+  const int tp = blk / kt;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 8 rows per pass
+#pragma unroll
+  for (int r = ty; r < 32; r += 8) {
+    const int k = k0 + r, c = c0 + tx;
+    const float v = (k < K && c < C) ? w[((size_t)k * T + tp) * C + c] : 0.f;
+    tile[r][tx] = v;
+    if (w_fwd && k < K && c < C) w_fwd[((size_t)tp * K + k) * C + c] = ch_f2h<F16>(v);
+  }
+  __syncthreads();
+  if (w_bwd) {
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+      const int c = c0 + r, k = k0 + tx;
+      if (k < K && c < C) w_bwd[((size_t)tp * C + c) * K + k] = ch_f2h<F16>(tile[tx][r]);
+    }
+  }
+}
+
+/* see include/delora_hip.h */
+extern "C" int dl_conv_weights_batch_h(const dl_convh_layer* layers, int32_t n, int32_t dtype, dl_stream stream) {
+  if (!layers || n <= 0 || n > DL_CONVH_BATCH) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv_weights_batch_h: 1..%d layers per call", DL_CONVH_BATCH);
+  if (dtype != DL_DTYPE_F16 && dtype != DL_DTYPE_BF16) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv_weights_batch_h: dtype must be DL_DTYPE_F16 / _BF16");
+  WprepBatchArgs a{};
+  a.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const dl_convh_layer& L = layers[i];
+    if (!L.w || (!L.w_fwd && !L.w_bwd) || L.K <= 0 || L.taps <= 0 || L.C <= 0)
+      return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv_weights_batch_h: bad layer %d", i);
+    a.w[i] = L.w; a.w_fwd[i] = (u16*)L.w_fwd; a.w_bwd[i] = (u16*)L.w_bwd; a.K[i] = L.K; a.T[i] = L.taps; a.C[i] = L.C;
+    a.first_block[i] = blocks;
+    blocks += ((L.C + 31) / 32) * ((L.K + 31) / 32) * L.taps;
+  }
+  a.first_block[n] = blocks;
+  if (dtype == DL_DTYPE_F16) hipLaunchKernelGGL(k_wprep_batch_h<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(k_wprep_batch_h<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
+  return dl_check_launch("dl_conv_weights_batch_h");
+}
+
 // fp32 -> half and half -> fp32 copies (network input, head features)
 template <bool F16>
 __global__ __launch_bounds__(256) void k_cast_f2h(const float* __restrict__ src, u16* __restrict__ dst, size_t n8) {

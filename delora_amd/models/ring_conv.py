@@ -462,6 +462,28 @@ def weights_h(w_param, dtype, want_fwd=True, want_bwd=True):
     return wf, wb
 
 
+def weights_batch_h(w_params, dtype, want_bwd=True):
+    """``weights_h`` for a list of parameters in ONE launch (``dl_conv_weights_batch_h``): list of (w_fwd, w_bwd)."""
+    lib = _lib.load()
+    ws = [weight_storage(w) for w in w_params]
+    out = []
+    for w in ws:
+        K, ks, _, C = w.shape
+        out.append((torch.empty((ks * ks, K, C), dtype=dtype, device=w.device),
+                    torch.empty((ks * ks, C, K), dtype=dtype, device=w.device) if want_bwd else None))
+    for i0 in range(0, len(ws), _lib.CONVH_BATCH):
+        part = list(range(i0, min(i0 + _lib.CONVH_BATCH, len(ws))))
+        arr = (_lib.ConvHLayer * len(part))()
+        for j, i in enumerate(part):
+            K, ks, _, C = ws[i].shape
+            arr[j].w = ws[i].data_ptr()
+            arr[j].w_fwd = out[i][0].data_ptr()
+            arr[j].w_bwd = out[i][1].data_ptr() if want_bwd else None
+            arr[j].K, arr[j].taps, arr[j].C = K, ks * ks, C
+        _lib.check(lib.dl_conv_weights_batch_h(ctypes.cast(arr, ctypes.c_void_p), len(part), DTYPE_CODE[dtype], _stream()), "dl_conv_weights_batch_h")
+    return out
+
+
 def conv_nhwc_h(x, w_prepared, ks, stride=(1, 1), act=0, epilogue=0, add=None, dsrc=None, transposed=False):
     """``y = epilogue(conv(x, w))`` on half-precision channels-last tensors; ``w_prepared`` = ``w_fwd`` of the layer, or (``transposed``)
     ``w_bwd`` of the layer whose input gradient is wanted, x then being the output gradient."""
@@ -535,18 +557,17 @@ class CastToHalf(torch.autograd.Function):
 
 class RingSegmentH(torch.autograd.Function):
     """``RingSegment`` in half precision: x / outputs / inter-segment gradients in bf16 or fp16, fp32 parameters, fp32 weight
-    gradients (same private gradient convention, same launch structure; one weight-conversion launch per convolution in
-    addition)."""
+    gradients (same private gradient convention, same launch structure; one weight-conversion launch per segment in addition)."""
 
     @staticmethod
     def forward(ctx, x0, act, blocks, first, last, *weights):
         dtype = x0.dtype
         need_bwd = any(ctx.needs_input_grad)
         saved, wbs, x, wi = [x0], [], x0, 0
+        prepared = weights_batch_h(list(weights), dtype, want_bwd=need_bwd)        # every convolution of the segment: one launch
         for (cin, cout, stride, has_ds) in blocks:
-            w1f, w1b = weights_h(weights[wi], dtype, want_bwd=need_bwd)
-            w2f, w2b = weights_h(weights[wi + 1], dtype, want_bwd=need_bwd)
-            wdf, wdb = weights_h(weights[wi + 2], dtype, want_bwd=need_bwd) if has_ds else (None, None)
+            (w1f, w1b), (w2f, w2b) = prepared[wi], prepared[wi + 1]
+            wdf, wdb = prepared[wi + 2] if has_ds else (None, None)
             wi += 3 if has_ds else 2
             y1 = conv_nhwc_h(x, w1f, 3, stride=stride, act=act, epilogue=EPI_ACT)
             shortcut = conv_nhwc_h(x, wdf, 1, stride=stride) if has_ds else x

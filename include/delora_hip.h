@@ -332,6 +332,15 @@ int dl_wino_wgrad3x3_nhwc_f32(const float* x, const float* g, float* dw, void* w
  *   dl_cast_f32_to_h      n fp32 values -> half precision (n % 8 == 0).
  */
 int dl_conv_weights_h(const float* w, void* w_fwd, void* w_bwd, int32_t K, int32_t taps, int32_t C, int32_t dtype, dl_stream stream);
+/* The same conversion for up to DL_CONVH_BATCH layers in one launch (all convolutions of an autograd segment of the trunk). */
+#define DL_CONVH_BATCH 32
+typedef struct {
+  const float* w;      /* [K][taps][C] fp32 parameter (channels-last storage) */
+  void* w_fwd;         /* [taps][K][C] half precision, or null */
+  void* w_bwd;         /* [taps][C][K] half precision, or null */
+  int32_t K, taps, C;
+} dl_convh_layer;
+int dl_conv_weights_batch_h(const dl_convh_layer* layers, int32_t n, int32_t dtype, dl_stream stream);
 int dl_conv2d_nhwc_h(const void* x, const void* w, void* y, const void* add, const void* dsrc, int32_t N, int32_t H, int32_t W,
                      int32_t C, int32_t K, int32_t ksize, int32_t stride_h, int32_t stride_w, int32_t transposed, int32_t dtype,
                      int32_t act, uint32_t epilogue, dl_stream stream);
