@@ -69,3 +69,34 @@ def test_counter_dispatches_map_back_to_profile_rows(tmp_path):
     assert a["hbm_bytes_per_launch"] == ((100 + 200) * 2048 + 150 * 1024) // 2
     b = rows["k_conv_f32 dgrad B"]
     assert b["kernel_launches"] == 2 and b["read_bytes_corrected_x2"] == (30 + 40) * 2048 and b["hbm_bytes_per_launch"] == ((30 + 40) * 2048 + 35 * 1024) // 2
+
+
+def test_epilogue_tanh_formula_in_float32_emulation():
+    """The constants of csrc/common.h: dl_tanh, read from the source and evaluated with float32 roundings in numpy: odd polynomial below
+    the switch point, 1 - 2 / (2^(2 log2(e) |x|) + 1) above -- both within 2 ulp of float64 tanh (the GPU test measures 1.4 ulp
+    including the hardware's exp2 / rcp)."""
+    import re
+    import numpy as np
+    src = open(os.path.join(ROOT, "delora_amd", "csrc", "common.h")).read()
+    body = src[src.index("float dl_tanh(float x)"):]
+    body = body[:body.index("}")]
+    coef = [np.float32(v) for v in re.findall(r"(-?\d+\.\d+(?:e-?\d+)?)f", body)]
+    # order in the source: p = c4; fma c3, c2, c1, c0; exp2 scale; the constants 1.f / -2.f / 1.f; the switch point
+    c4, c3, c2, c1, c0 = coef[:5]
+    scale = np.float32(2.885390081777927)
+    assert scale in coef and np.float32(0.625) in coef
+    f32 = np.float32
+    x = np.concatenate([np.linspace(0, 0.625, 100001)[:-1], np.linspace(0.625, 12.0, 200001), np.logspace(-30, -3, 2000)]).astype(f32)
+    t = (x * x).astype(f32)
+    p = np.full_like(x, c4)
+    for c in (c3, c2, c1, c0):
+        p = (p.astype(np.float64) * t + np.float64(c)).astype(f32)                         # fmaf: one rounding
+    lo = ((x * t).astype(f32).astype(np.float64) * p + x.astype(np.float64)).astype(f32)
+    e = np.exp2((x * scale).astype(f32).astype(np.float64)).astype(f32)
+    q = (1.0 / (e.astype(np.float64) + 1.0).astype(f32).astype(np.float64)).astype(f32)
+    hi = (q.astype(np.float64) * -2.0 + 1.0).astype(f32)
+    got = np.where(x < f32(0.625), lo, hi).astype(np.float64)
+    ref = np.tanh(x.astype(np.float64))
+    ulp = np.spacing(np.maximum(np.abs(ref), 1e-45).astype(f32)).astype(np.float64)
+    err = np.abs(got - ref) / ulp
+    assert err.max() < 2.0, (float(err.max()), float(x[err.argmax()]))
