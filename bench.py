@@ -556,12 +556,49 @@ def cpu_baseline(args, cfg):
     return stored_leg, online_leg
 
 
+def launch_plan(gpus, environ, device_count, argv, free_port=None):
+    """What a `bench.py --gpus N` invocation has to do before it may measure anything (pure: tested on the CPU).
+
+    Returns ("run", None) when this process is a rank of a correctly sized job (or N = 1), ("spawn", command) when it was
+    started as ONE plain process for N > 1 GPUs -- it then re-executes itself under torch.distributed.run with N ranks, so a
+    `python bench.py --gpus 8` can never print a single-rank number labelled as an 8-GPU run -- and raises SystemExit when the
+    request cannot be honoured (WORLD_SIZE disagrees with --gpus, fewer visible GPUs than ranks without the share-GPU test hook)."""
+    share = environ.get("DELORA_BENCH_SHARE_GPU") == "1"
+    if gpus < 1:
+        raise SystemExit(f"--gpus {gpus}: need at least one GPU")
+    if "WORLD_SIZE" in environ and "RANK" in environ:
+        world = int(environ["WORLD_SIZE"])
+        if world != gpus:
+            raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={world}: launch one rank per GPU (torch.distributed.run --nproc-per-node {gpus})")
+    if device_count < gpus and not share:
+        raise SystemExit(f"--gpus {gpus} but only {device_count} GPU(s) visible: refusing to run several ranks on one device "
+                         f"(DELORA_BENCH_SHARE_GPU=1 is the test hook that allows it)")
+    if gpus == 1 or ("WORLD_SIZE" in environ and "RANK" in environ):
+        return "run", None
+    port = environ.get("MASTER_PORT") or str(free_port() if free_port else 29500)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", port] + list(argv)
+    return "spawn", cmd
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def main():
     args = parse()
+    action, cmd = launch_plan(args.gpus, os.environ, torch.cuda.device_count(), [os.path.abspath(__file__)] + sys.argv[1:], _free_port)
+    if action == "spawn":
+        import subprocess
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        print(f"bench.py: --gpus {args.gpus} started as one process: re-launching as {args.gpus} ranks ({' '.join(cmd[1:8])} ...)", file=sys.stderr)
+        raise SystemExit(subprocess.run(cmd, env=env).returncode)
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     # test hooks (never set in production): run all ranks on one GPU over gloo to exercise the N>1 code path on a 1-GPU box
     if os.environ.get("DELORA_BENCH_SHARE_GPU") == "1":
         local = 0
@@ -657,6 +694,10 @@ def main():
         el = time.perf_counter() - t0
         if world > 1:
             tt = torch.tensor([el], device=device, dtype=torch.float64)
+            every = [torch.zeros_like(tt) for _ in range(world)]
+            torch.distributed.all_gather(every, tt)                    # per-rank wall time of the region (reported min / max)
+            per_rank = [float(t.item()) for t in every]
+            enqueue["rank_ms_per_step"] = [round(1e3 * t / steps, 3) for t in per_rank]
             torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
             el = float(tt.item())
         return el, ep
@@ -689,6 +730,7 @@ def main():
     counter["i"] = 0
     elapsed, ep = timed_region(args.steps, run_step_sampled if in_timed and (can_profile or loss_timed) else run_step)
     host_enqueue_ms = enqueue["ms_per_step"]
+    rank_ms = enqueue.get("rank_ms_per_step")
     roofline_pass = f"every {EVENT_EVERY}th of the K timed steps ({evented['steps']} steps)"
     if not in_timed and (can_profile or loss_timed):
         counter["i"] = 0
@@ -716,6 +758,9 @@ def main():
                    "distinct_batches": len(batches), "priming_steps": len(batches)},
         "final_loss": final_loss, "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
         "rccl_ranks": ranks_seen, "collective_backend": (backend if world > 1 else None),
+        "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 and backend == "nccl" else None),
+        "visible_gpus": torch.cuda.device_count(),
+        "rank_ms_per_step": ({"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms} if rank_ms else None),
     }
     if rank == 0:
         rows, counts = kernel_table(trainer, batches[0], args.kernel_reps)

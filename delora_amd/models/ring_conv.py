@@ -62,6 +62,18 @@ def weight_storage(w):
     return v if v.is_contiguous() else v.contiguous()
 
 
+def grad_for(dw_krsc, w_param):
+    """The weight gradient ``dW [K,k,k,C]`` as the gradient tensor of the parameter ``[K,C,k,k]`` (or of its ``(shape, stride)``
+    pair): the same memory, with the parameter's own strides.  For a 1x1 filter the permuted view has strides (C,1,C,C) while the
+    parameter keeps (C,1,1,1) -- the same layout, but DistributedDataParallel compares strides literally and would copy the
+    gradient into its bucket view on every step ("Grad strides do not match bucket view strides")."""
+    shape, stride = (tuple(w_param.shape), tuple(w_param.stride())) if torch.is_tensor(w_param) else w_param
+    g = dw_krsc.permute(0, 3, 1, 2)
+    if tuple(g.stride()) != stride and shape[2] == 1 and shape[3] == 1 and stride[0] == shape[1] and stride[1] == 1:
+        g = g.as_strided(shape, stride)
+    return g
+
+
 def conv_nhwc(x, w_krsc, stride=(1, 1), act=0, epilogue=0, add=None, dsrc=None, transposed=False):
     """``y = epilogue(conv(x, w))`` on channels-last fp32 tensors.  x ``[N,H,W,C]``; w ``[K,k,k,C]`` (``transposed``: the
     forward weight ``[C,k,k,K]`` of the layer whose input gradient is computed, x then being the output gradient)."""
@@ -393,13 +405,13 @@ class RingSegment(torch.autograd.Function):
             w1p, w2p = weights[wi], weights[wi + 1]
             x, y1 = acts[2 * b], acts[2 * b + 1]
             first = ctx.first and b == 0                    # x0 is the pooled stem output: its act' belongs to the stem
-            grads[wi + 1] = wgrad_nhwc(y1, g2, 3).permute(0, 3, 1, 2)
+            grads[wi + 1] = grad_for(wgrad_nhwc(y1, g2, 3), w2p)
             ub1, ub2 = ubwd[2 * b], ubwd[2 * b + 1]
             if ub2 is not None:
                 g1 = wino_conv(g2, ub2, cout, act=act, epilogue=EPI_DACT, dsrc=y1)
             else:
                 g1 = conv_nhwc(g2, weight_storage(w2p), act=act, epilogue=EPI_DACT, dsrc=y1, transposed=True)
-            grads[wi] = wgrad_nhwc(x, g1, 3, stride=stride).permute(0, 3, 1, 2)
+            grads[wi] = grad_for(wgrad_nhwc(x, g1, 3, stride=stride), w1p)
             if not has_ds:
                 epi = EPI_ADD if first else (EPI_ADD | EPI_DACT)
                 if ub1 is not None:
@@ -408,7 +420,7 @@ class RingSegment(torch.autograd.Function):
                     g2 = conv_nhwc(g1, weight_storage(w1p), act=act, epilogue=epi, add=g2, dsrc=None if first else x, transposed=True)
             else:
                 wdp = weights[wi + 2]
-                grads[wi + 2] = wgrad_nhwc(x, g2, 1, stride=stride).permute(0, 3, 1, 2)
+                grads[wi + 2] = grad_for(wgrad_nhwc(x, g2, 1, stride=stride), wdp)
                 # down-sampling branch on the grid, then one pass per stride phase of the 3x3 layer with it and act'(x) fused
                 dxb = dgrad_strided(g2, weight_storage(wdp), stride, dense=True)
                 epi = EPI_ADD_GRID if first else (EPI_ADD_GRID | EPI_DACT)
@@ -577,6 +589,7 @@ class RingSegmentH(torch.autograd.Function):
             x = y2
         ctx.act, ctx.blocks, ctx.first, ctx.last = act, blocks, first, last
         ctx.n_w = len(weights)
+        ctx.w_meta = [(tuple(w.shape), tuple(w.stride())) for w in weights]
         ctx.save_for_backward(*saved, *(wbs if need_bwd else []))
         return x
 
@@ -601,14 +614,14 @@ class RingSegmentH(torch.autograd.Function):
             w1b, w2b = wbs[wi], wbs[wi + 1]
             x, y1 = acts[2 * b], acts[2 * b + 1]
             first = ctx.first and b == 0
-            grads[wi + 1] = wgrad_nhwc_h(y1, g2, 3).permute(0, 3, 1, 2)
+            grads[wi + 1] = grad_for(wgrad_nhwc_h(y1, g2, 3), ctx.w_meta[wi + 1])
             g1 = conv_nhwc_h(g2, w2b, 3, act=act, epilogue=EPI_DACT, dsrc=y1, transposed=True)
-            grads[wi] = wgrad_nhwc_h(x, g1, 3, stride=stride).permute(0, 3, 1, 2)
+            grads[wi] = grad_for(wgrad_nhwc_h(x, g1, 3, stride=stride), ctx.w_meta[wi])
             if not has_ds:
                 epi = EPI_ADD if first else (EPI_ADD | EPI_DACT)
                 g2 = conv_nhwc_h(g1, w1b, 3, act=act, epilogue=epi, add=g2, dsrc=None if first else x, transposed=True)
             else:
-                grads[wi + 2] = wgrad_nhwc_h(x, g2, 1, stride=stride).permute(0, 3, 1, 2)
+                grads[wi + 2] = grad_for(wgrad_nhwc_h(x, g2, 1, stride=stride), ctx.w_meta[wi + 2])
                 dxb = dgrad_strided_h(g2, wbs[wi + 2], 1, stride, dense=True)
                 epi = EPI_ADD_GRID if first else (EPI_ADD_GRID | EPI_DACT)
                 g2 = dgrad_strided_h(g1, w1b, 3, stride, act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)

@@ -100,3 +100,46 @@ def test_epilogue_tanh_formula_in_float32_emulation():
     ulp = np.spacing(np.maximum(np.abs(ref), 1e-45).astype(f32)).astype(np.float64)
     err = np.abs(got - ref) / ulp
     assert err.max() < 2.0, (float(err.max()), float(x[err.argmax()]))
+
+
+def test_launch_plan_never_lets_a_single_process_pose_as_n_ranks():
+    """`python bench.py --gpus 8` started as ONE plain process must become 8 ranks (re-launch under torch.distributed.run) or stop --
+    never run one rank and print it as an 8-GPU number (bench.py:563 used to fall through)."""
+    import bench
+    argv = ["/x/bench.py", "--gpus", "8", "--steps", "3"]
+    # a plain process, 8 GPUs visible: re-launch with one rank per GPU, rendezvous on 127.0.0.1
+    action, cmd = bench.launch_plan(8, {}, 8, argv, free_port=lambda: 40123)
+    assert action == "spawn"
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "8"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "40123" and cmd[-len(argv):] == argv
+    # a rank of a correctly sized job, and the single-GPU default: just run
+    assert bench.launch_plan(8, {"WORLD_SIZE": "8", "RANK": "3"}, 8, argv) == ("run", None)
+    assert bench.launch_plan(1, {}, 1, argv) == ("run", None)
+    assert bench.launch_plan(1, {}, 8, argv) == ("run", None)
+    # WORLD_SIZE disagrees with --gpus (either direction), too few GPUs for the ranks: refuse
+    for env, gpus, seen in (({"WORLD_SIZE": "2", "RANK": "0"}, 8, 8), ({"WORLD_SIZE": "8", "RANK": "0"}, 1, 8), ({}, 8, 1),
+                            ({"WORLD_SIZE": "8", "RANK": "0"}, 8, 4), ({}, 0, 1)):
+        with pytest.raises(SystemExit):
+            bench.launch_plan(gpus, env, seen, argv)
+    # the share-GPU test hook is the only way to put several ranks on one device
+    action, cmd = bench.launch_plan(2, {"DELORA_BENCH_SHARE_GPU": "1", "MASTER_PORT": "29533"}, 1, argv)
+    assert action == "spawn" and cmd[cmd.index("--master-port") + 1] == "29533"
+    assert bench.launch_plan(2, {"DELORA_BENCH_SHARE_GPU": "1", "WORLD_SIZE": "2", "RANK": "1"}, 1, argv) == ("run", None)
+
+
+def test_weight_gradient_takes_the_parameters_strides():
+    """DistributedDataParallel (gradient_as_bucket_view) compares the strides of a gradient with those of its parameter literally: the
+    1x1 down-sampling weights [512,256,1,1] keep strides (256,1,1,1) in channels_last storage while the permuted kernel output
+    [K,1,1,C] has (256,1,256,256) -- one extra copy per bucket and step (GPUTEST r03 warning)."""
+    import torch
+    from delora_amd.models.ring_conv import grad_for
+    for make in (lambda: torch.empty(512, 256, 1, 1).contiguous(memory_format=torch.channels_last),
+                 lambda: torch.empty(512, 256, 1, 1).to(memory_format=torch.channels_last),
+                 lambda: torch.empty(128, 64, 3, 3).contiguous(memory_format=torch.channels_last)):
+        w = make()
+        K, C, ks = w.shape[0], w.shape[1], w.shape[2]
+        dw = torch.randn(K, ks, ks, C)
+        for ref in (w, (tuple(w.shape), tuple(w.stride()))):
+            g = grad_for(dw, ref)
+            assert g.shape == w.shape and g.stride() == w.stride() and g.data_ptr() == dw.data_ptr()
+            assert torch.equal(g, dw.permute(0, 3, 1, 2))

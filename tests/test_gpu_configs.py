@@ -373,24 +373,38 @@ def test_config4_mixed_sensor_batch_against_oracle(amp):
 
 
 # ------------------------------------------------------------------------------------------- config 2 (multi-GPU readiness)
-def test_bench_two_ranks_on_one_gpu_through_torchrun():
+@pytest.mark.parametrize("launcher", ["torchrun", "plain"])
+def test_bench_two_ranks_on_one_gpu_through_torchrun(launcher):
     """BASELINE config 2's launch path on a 1-GPU box: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`
-    exactly as the driver starts it, both ranks sharing the GPU over gloo (test hooks DELORA_BENCH_SHARE_GPU /
-    DELORA_BENCH_BACKEND).  Checks the JSON contract of a multi-rank run: n_gpus, global batch, ranks seen by the process
-    group, finite loss, weak scaling label.  (RCCL itself is exercised by test_rccl_backend_initialises_and_reduces_on_one_rank;
-    no scaling number can come from one GPU.)"""
+    exactly as the driver starts it ("torchrun"), and the plain `python bench.py --gpus 2` the driver uses for N=1 ("plain": the
+    script must re-launch itself as 2 ranks -- it used to run ONE rank silently), both ranks sharing the GPU over gloo (test hooks
+    DELORA_BENCH_SHARE_GPU / DELORA_BENCH_BACKEND).  Checks the JSON contract of a multi-rank run: n_gpus, global batch, ranks
+    seen by the process group, per-rank step times, finite loss, weak scaling label.  (RCCL itself is exercised by
+    test_rccl_backend_initialises_and_reduces_on_one_rank; no scaling number can come from one GPU.)"""
     _dev()
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DELORA_BENCH_SHARE_GPU="1", DELORA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2",
-           "--rotate", "2", "--kernel-reps", "2", "--no-live-pmc"]
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    bench_args = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--batch", "2",
+                  "--rotate", "2", "--kernel-reps", "2", "--no-live-pmc"]
+    if launcher == "torchrun":
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", "29533"] + bench_args
+    else:
+        cmd = [sys.executable] + bench_args
+        # without the hook the same command must refuse: 2 ranks, 1 visible GPU
+        if torch.cuda.device_count() < 2:
+            refused = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root,
+                                     env={k: v for k, v in env.items() if k != "DELORA_BENCH_SHARE_GPU"})
+            assert refused.returncode != 0 and "GPU(s) visible" in refused.stderr and not [x for x in refused.stdout.splitlines() if x.startswith("{")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=root)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
     assert len(lines) == 1, "rank 0 prints exactly one JSON line"
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["config"]["global_batch"] == 4 and j["config"]["parallelism"] == "dp2"
+    rk = j["rank_ms_per_step"]
+    assert len(rk["per_rank"]) == 2 and 0 < rk["min"] <= rk["max"] <= j["ms_per_step"] * 1.001 + 1e-3
     assert j["scaling"] == "weak" and j["steps"] == 3 and np.isfinite(j["final_loss"]) and j["value"] > 0
     assert "cpu_baseline" not in j and "feed" not in j          # single-GPU legs only
     # the full-width image: the ranks run the HIP trunk, and rank 0 must not start collective steps of its own after the timed region
