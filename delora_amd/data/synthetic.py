@@ -119,3 +119,85 @@ def portable_cloud(seed, n):
     wz = -1.73 + u[5] * 2.4
     pts = np.where(ground[None, :], np.stack([gx, gy, gz]), np.stack([wx, wy, wz]))
     return np.ascontiguousarray(pts.astype(np.float32))
+
+
+def portable_pair(seed, n, yaw_t=0.012, shift=(0.6, -0.05, 0.01)):
+    """A scan pair WITH normal lists, bit-identical on every machine (PCG64 stream, +,-,*,/ and the correctly rounded sqrt only):
+    ``{"scan_1","scan_2","normal_list_1","normal_list_2"}`` as ``[3,n]`` fp32 -- the stored-list form the reference reads from disk
+    (src/data/dataset.py:143-153).  Both scans sample the same surfaces (ground + four walls, ``portable_cloud``'s scene) with
+    different points; scan 2 is seen from a pose moved by ``shift`` and rotated about z by 2 atan(yaw_t) (a rational rotation:
+    c = (1-t^2)/(1+t^2), s = 2t/(1+t^2)).  Normals are the analytic surface normals, perturbed a little, normalised, pointing at the
+    sensor.  Used where a committed reference result must be reproduced from a seed (tests/golden/step_full_*.npz)."""
+    rng = np.random.default_rng(seed)
+    c, s = (1.0 - yaw_t * yaw_t) / (1.0 + yaw_t * yaw_t), 2.0 * yaw_t / (1.0 + yaw_t * yaw_t)
+    R = np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+    t = np.asarray(shift, dtype=np.float64)
+    out = {}
+    for name, moved in (("1", False), ("2", True)):
+        u = rng.random((9, n))
+        ground = u[0] < 0.55
+        gx, gy = (u[1] - 0.5) * 90.0, (u[2] - 0.5) * 90.0
+        gz = -1.73 + (u[3] - 0.5) * 0.04
+        side = u[4]
+        wx = np.where(side < 0.25, 22.0, np.where(side < 0.5, -22.0, (u[1] - 0.5) * 44.0)) + (u[3] - 0.5) * 0.03
+        wy = np.where(side < 0.5, (u[2] - 0.5) * 18.0, np.where(side < 0.75, 9.0, -9.0)) + (u[5] - 0.5) * 0.03
+        wz = -1.73 + u[5] * 2.4
+        pts = np.where(ground[None, :], np.stack([gx, gy, gz]), np.stack([wx, wy, wz]))
+        zero, one = np.zeros(n), np.ones(n)
+        nw = np.where(side[None, :] < 0.25, np.stack([-one, zero, zero]), np.where(side[None, :] < 0.5, np.stack([one, zero, zero]),
+                      np.where(side[None, :] < 0.75, np.stack([zero, -one, zero]), np.stack([zero, one, zero]))))
+        nrm = np.where(ground[None, :], np.stack([zero, zero, one]), nw) + (u[6:9] - 0.5) * 0.06
+        nrm = nrm / np.sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2])[None, :]
+        if moved:                                   # sensor frame 2: p2 = R^T (p1 - t), n2 = R^T n1 (explicit sums: no BLAS, fixed order)
+            d = pts - t[:, None]
+            pts = np.stack([(R[0, i] * d[0] + R[1, i] * d[1]) + R[2, i] * d[2] for i in range(3)])
+            nrm = np.stack([(R[0, i] * nrm[0] + R[1, i] * nrm[1]) + R[2, i] * nrm[2] for i in range(3)])
+        out["scan_" + name] = np.ascontiguousarray(pts.astype(np.float32))
+        out["normal_list_" + name] = np.ascontiguousarray(nrm.astype(np.float32))
+    T = np.eye(4)
+    T[:3, :3], T[:3, 3] = R, t
+    out["T_21"] = T.astype(np.float32)
+    return out
+
+
+def portable_state_dict(seed, shapes, head_scale=0.05):
+    """A state_dict for ``OdometryModel`` from the PCG64 stream with +,-,*,/ only (bit-identical everywhere): ``shapes`` = ordered
+    ``{name: shape}`` of the 30 tensors.  Convolutions: uniform with the standard deviation of the reference's initialisation
+    (kaiming-normal, fan_out, tanh gain 5/3: src/models/resnet_modified.py:64-66); linear layers: uniform(+-1/sqrt(fan_in)); the last
+    layer of each head scaled by ``head_scale`` with the rotation bias at (0,0,0,1), so that the network predicts a small motion."""
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for name, shape in shapes.items():
+        shape = tuple(int(d) for d in shape)
+        count = 1
+        for d in shape:
+            count *= d
+        u = rng.random(count).reshape(shape) - 0.5
+        if len(shape) == 4:
+            fan_out = shape[0] * shape[2] * shape[3]
+            std = (5.0 / 3.0) / np.sqrt(float(fan_out))
+            w = u * (std * 2.0 * np.sqrt(3.0))
+        else:
+            fan_in = shape[-1] if len(shape) == 2 else sd_fan_in(sd, name)
+            w = u * (2.0 / np.sqrt(float(fan_in)))
+        last = name.startswith("fully_connected_") and name.split(".")[1] == "3"
+        if last:
+            w = w * head_scale
+            if name == "fully_connected_rotation.3.bias":
+                w = w + np.array([0.0, 0.0, 0.0, 1.0])
+        sd[name] = np.ascontiguousarray(w.astype(np.float32))
+    return sd
+
+
+def sd_fan_in(sd, bias_name):
+    """fan_in of the linear layer a bias belongs to (its weight precedes it in the state_dict)."""
+    return sd[bias_name[:-len("bias")] + "weight"].shape[1]
+
+
+def digest(arrays):
+    """sha256 over the raw bytes of a sequence of arrays (fixtures store it to prove that regenerated inputs are the committed ones)."""
+    import hashlib
+    h = hashlib.sha256()
+    for a in arrays:
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()

@@ -45,6 +45,13 @@ class Deployer(object):
         self.geo = geometry_backend if geometry_backend is not None else step_geometry.HipStepGeometry()
         self.lossTransformation = torch.nn.MSELoss()
         self.training_bool = False
+        # float16 autocast: the trunk's inter-layer gradients are STORED in fp16 and start at (head gradient) / (H*W/64) -- below
+        # fp16's normal range (6e-5) for O(1e-2) loss gradients -- so the backward runs on a scaled loss (dynamic scale, skipped steps
+        # on overflow: torch's GradScaler, which hands scale and overflow flag to the fused Adam kernel without a host sync).
+        # bfloat16 has fp32's exponent range and needs none.
+        self.grad_scaler = None
+        if config.get("amp_dtype") == "float16" and getattr(self.device, "type", "cpu") == "cuda" and config.get("amp_loss_scaling", True):
+            self.grad_scaler = torch.amp.GradScaler("cuda", init_scale=float(config.get("amp_init_scale", 1024.0)))
         # data-parallel placement of this process' slice inside the global batch (single process: 0 of 1)
         self.rank, self.world_size = 0, 1
         if torch.distributed.is_available() and torch.distributed.is_initialized():
@@ -211,8 +218,13 @@ class Deployer(object):
             loss = losses["loss_pc"]
         if self.training_bool:
             # DDP averages gradients over ranks; the reference's loss is a SUM over the global batch
-            (loss * float(self.world_size)).backward()
-            self.optimizer.step()
+            if self.grad_scaler is not None:
+                self.grad_scaler.scale(loss * float(self.world_size)).backward()
+                self.grad_scaler.step(self.optimizer)
+                self.grad_scaler.update()
+            else:
+                (loss * float(self.world_size)).backward()
+                self.optimizer.step()
         computed_transformations = rescale(computed_transformations)
         if epoch_losses is not None:
             keys = ["loss_epoch", "loss_point_cloud_epoch", "loss_po2po_epoch", "loss_po2pl_epoch", "loss_pl2pl_epoch"]

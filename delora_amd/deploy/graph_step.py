@@ -40,8 +40,11 @@ class GraphedStep:
         self.offs = torch.zeros((2 * self.B + 1,), dtype=torch.int32, device=dev)
         self.packed = step_geometry.PackedBatch(self.pts, self.offs, self.capacity, self.B, self.dataset, self.with_lists)
         cfg = trainer.config
-        if (trainer.world_size != 1 or cfg["normalization_scaling"] or cfg["random_point_cloud_rotations"]
-                or len({d["dataset"] for d in example_batch}) != 1 or self.B != trainer.batch_size):
+        # a PackedBatch cannot be augmented or rescaled (Deployer.step rejects it) and one capture serves one sensor and one rank:
+        # when a requirement does not hold every call runs the eager step on the caller's own list of dicts
+        self.eligible = not (trainer.world_size != 1 or cfg["normalization_scaling"] or cfg["random_point_cloud_rotations"]
+                             or len({d["dataset"] for d in example_batch}) != 1 or self.B != trainer.batch_size)
+        if not self.eligible:
             return
         for group in trainer.optimizer.param_groups:
             group["capturable"] = True
@@ -108,9 +111,12 @@ class GraphedStep:
     def __call__(self, batch=None):
         """One training step on ``batch`` (None: the contents already in the static buffers).  Returns (epoch_losses, T) -- with a
         captured graph these are the graph's static output tensors, overwritten by the next call."""
-        if batch is not None and not self.fits(batch):
+        if batch is not None and (not self.eligible or not self.fits(batch)):
             self.fallback_steps += 1
             return self._step(batch)
+        if not self.eligible:
+            raise ValueError("this configuration cannot run on the packed static buffers (augmentation, range normalisation, mixed "
+                             "sensors or several ranks): pass the batch itself")
         if batch is not None:
             self.pack(batch)
         if self.graph is None:

@@ -455,6 +455,134 @@ def fx_step_normalized(out):
         print(f"  step normalized: loss={e['ep::loss_epoch']:.6f} T_t={t2n(T)[0, :3, 3]}")
 
 
+
+def _write_pairs(tmp, pairs):
+    """The reference's on-disk layout (src/preprocessing/preprocesser.py:64-68): consecutive scans k, k+1 form sample k."""
+    os.makedirs(os.path.join(tmp, "00", "scans")); os.makedirs(os.path.join(tmp, "00", "normals"))
+    i = 0
+    for p in pairs:
+        for name in ("1", "2"):
+            np.save(os.path.join(tmp, "00", "scans", f"{i:06d}.npy"), np.ascontiguousarray(p["scan_" + name].T))
+            np.save(os.path.join(tmp, "00", "normals", f"{i:06d}.npy"), np.ascontiguousarray(p["normal_list_" + name].T))
+            i += 1
+
+
+def _run_reference_step(cfg, state, picks):
+    """One reference Trainer.step on samples ``picks`` of the dataset under cfg; returns (entry dict, oracle pair counts)."""
+    import deploy.trainer as rtrainer
+    trn = rtrainer.Trainer(config=cfg)
+    trn.model.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    dicts = [trn.dataset[i] for i in picks]
+    ep = {k: 0.0 for k in ("loss_epoch", "loss_point_cloud_epoch", "loss_po2po_epoch", "loss_po2pl_epoch", "loss_pl2pl_epoch", "visible_pixels_epoch")}
+    trn.optimizer.zero_grad()
+    ep, T = trn.step(preprocessed_dicts=dicts, epoch_losses=ep, log_images_bool=False)
+    grads = {k: t2n(p.grad).copy() for k, p in trn.model.named_parameters()}
+    state1 = {k: t2n(v).copy() for k, v in trn.model.state_dict().items()}
+    e = dict(T=t2n(T), picks=np.asarray(picks),
+             **{"ep::" + k: float(np.asarray(v).sum()) for k, v in ep.items()},
+             **{"gradnorm::" + k: float(np.linalg.norm(v.astype(np.float64))) for k, v in grads.items()},
+             **{"delta::" + k: (state1[k].astype(np.float64) - state.get(k, state1[k]).astype(np.float64)).sum() for k in state1})
+    # per-sample loss terms and pair counts from the oracle at the reference's own poses -- asserted against the reference's batch sums
+    sen = sensor_of(cfg, cfg["datasets"][0])
+    lists = []
+    for i in picks:
+        d = trn.dataset[i]
+        _, _, l = orc.filter_to_projected(d, sen)
+        lists.append(l)
+    o, per = orc.step_losses(lists, T.detach(), lambda_po2pl=float(cfg["lambda_po2pl"]))
+    B = len(picks)
+    for key, okey in (("loss_point_cloud_epoch", "loss_pc"), ("loss_po2pl_epoch", "loss_po2pl"), ("loss_pl2pl_epoch", "loss_pl2pl")):
+        ref_v, orc_v = e["ep::" + key], float(o[okey])
+        assert abs(ref_v - orc_v) <= 2e-6 * abs(ref_v) + 1e-12, (key, ref_v, orc_v)
+    pairs = []
+    for j, L in enumerate(lists):
+        Tj = T.detach()[j:j + 1]
+        _, aux = orc.icp_losses(orc.transform_points(Tj, L["scan_2"]), orc.rotate_points(Tj, L["normal_list_2"]), L["scan_1"],
+                                L["normal_list_1"], return_aux=True)
+        pairs.append(int(aux["pairs"]))
+    e["pairs"] = np.asarray(pairs, dtype=np.int64)
+    e["terms"] = np.asarray([[float(p["loss_po2po"]), float(p["loss_po2pl"]), float(p["loss_pl2pl"])] for p in per], dtype=np.float64)
+    return e
+
+
+def fx_step_full(out):
+    """The reference's Trainer.step (src/deploy/deployer.py:237-375) at FULL size with the FULL 11.9 M-parameter network: 64x2048 B=1 and
+    B=2, 128x2048 B=1.  Inputs and weights come from the portable generators of delora_amd/data/synthetic.py (bit-identical on every
+    machine; their sha256 is part of the fixture), so the fixture holds only results: poses, loss scalars, per-parameter gradient
+    norms, the Adam update, pair counts."""
+    import models.model as rmodel
+    shapes = None
+    for name, (H, W, vfov_deg, n_pts, seeds) in {
+            "step_full_64_b1": (64, 2048, None, 150000, [7101]),
+            "step_full_64_b2": (64, 2048, None, 150000, [7102, 7103]),
+            "step_full_128_b1": (128, 2048, (-22.5, 22.5), 260000, [7104])}.items():
+        B = len(seeds)
+        with tempfile.TemporaryDirectory() as tmp:
+            cfg = reference_config(H, W, unsupervised_at_start=True, inference_only=False, batch_size=B, store_dataset_in_RAM=False)
+            if vfov_deg is not None:
+                cfg["kitti"]["vertical_field_of_view"] = [vfov_deg[0] * np.pi / 180.0, vfov_deg[1] * np.pi / 180.0]
+            cfg["kitti"]["preprocessed_path"] = tmp
+            cfg["kitti"]["data_identifiers"] = cfg["kitti"]["training_identifiers"] = [0]
+            pairs = [synthetic.portable_pair(sd, n_pts) for sd in seeds]
+            _write_pairs(tmp, pairs)
+            if shapes is None:
+                torch.manual_seed(0)
+                shapes = {k: tuple(v.shape) for k, v in rmodel.OdometryModel(config=cfg).state_dict().items()}
+            state = synthetic.portable_state_dict(9001, shapes)
+            e = _run_reference_step(cfg, state, [2 * j for j in range(B)])
+            e.update(H=H, W=W, n_points=n_pts, seeds=np.asarray(seeds), state_seed=9001,
+                     vfov=np.asarray(cfg["kitti"]["vertical_field_of_view"]),
+                     input_sha=synthetic.digest([p[k] for p in pairs for k in ("scan_1", "normal_list_1", "scan_2", "normal_list_2")]),
+                     state_sha=synthetic.digest([state[k] for k in shapes]),
+                     **{"shape::" + k: np.asarray(v) for k, v in shapes.items()})
+            out[name] = e
+            print(f"  {name}: loss={e['ep::loss_epoch']:.6f} po2pl={e['ep::loss_po2pl_epoch']:.6f} pl2pl={e['ep::loss_pl2pl_epoch']:.6f} "
+                  f"pairs={e['pairs'].tolist()} |t|={np.linalg.norm(e['T'][0, :3, 3]):.4f}")
+
+
+def fx_step_b8_small(out):
+    """Trainer.step with B=8 on the small network (the (B-j)/B weighting over a longer batch, SURVEY.md 8c `step_b8_small`); inputs from
+    the portable generator, weights = the committed model_small state."""
+    gm = dict(np.load(os.path.join(HERE, "model_small.npz")))
+    state = {k[4:]: v for k, v in gm.items() if k.startswith("sd::")}
+    seeds = [7201 + j for j in range(8)]
+    with tempfile.TemporaryDirectory() as tmp:
+        cfg = reference_config(16, 128, factor_fewer_resnet_channels=8, resnet_outputs=64, unsupervised_at_start=True,
+                               inference_only=False, batch_size=8, store_dataset_in_RAM=False)
+        cfg["kitti"]["preprocessed_path"] = tmp
+        cfg["kitti"]["data_identifiers"] = cfg["kitti"]["training_identifiers"] = [0]
+        pairs = [synthetic.portable_pair(sd, 3000) for sd in seeds]
+        _write_pairs(tmp, pairs)
+        e = _run_reference_step(cfg, state, [2 * j for j in range(8)])
+        e.update(H=16, W=128, n_points=3000, seeds=np.asarray(seeds),
+                 input_sha=synthetic.digest([p[k] for p in pairs for k in ("scan_1", "normal_list_1", "scan_2", "normal_list_2")]))
+        out["step_b8_small"] = e
+        print(f"  step_b8_small: loss={e['ep::loss_epoch']:.6f} pairs={e['pairs'].tolist()}")
+
+
+def fx_quat2mat(out):
+    """The reference's OWN quaternion -> rotation matrix (src/ros_utils/odometry_publisher.py:113-126, `quat2mat`, evaluated unbound with
+    rospy & co. stubbed) on 1000 random unit quaternions: the reference-held pin of the kornia boundary (a8)."""
+    for name in ("rospy", "ros_numpy", "tf2_ros", "tf", "tf.transformations", "geometry_msgs", "geometry_msgs.msg", "nav_msgs", "nav_msgs.msg",
+                 "sensor_msgs", "sensor_msgs.msg", "std_msgs", "std_msgs.msg", "tf_conversions"):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            m.__getattr__ = lambda attr, _n=name: type(attr, (), {})      # any imported name resolves to a dummy class
+            sys.modules[name] = m
+    import ros_utils.odometry_publisher as rpub
+    rng = np.random.default_rng(17)
+    q = rng.normal(size=(1000, 4))
+    q = (q / np.linalg.norm(q, axis=1, keepdims=True)).astype(np.float32)
+    q[:4] = np.array([[0, 0, 0, 1.0], [0, 0, 1.0, 0], [1.0, 0, 0, 0], [0.5, 0.5, 0.5, 0.5]], dtype=np.float32)
+    R_ref = t2n(rpub.OdometryPublisher.quat2mat(None, torch.from_numpy(q))).astype(np.float64)
+    R_orc = t2n(orc.quaternion_to_rotation_matrix(torch.from_numpy(q))).astype(np.float64)
+    err = float(np.abs(R_ref - R_orc).max())
+    assert err <= 1e-6, err
+    out["quat2mat"] = dict(q=q, R=R_ref.astype(np.float32), max_abs_diff_to_oracle=err,
+                           note="reference OdometryPublisher.quat2mat (odometry_publisher.py:113-126), x,y,z,w")
+    print(f"  quat2mat: 1000 quaternions, reference vs oracle (kornia 0.3.0 restatement) max |diff| = {err:.2e}")
+
+
 def fx_poses(out):
     """utility.poses.compute_poses / write_poses_to_text_file (src/utility/poses.py:11-74) on a short trajectory."""
     import utility.poses as rposes
@@ -481,7 +609,8 @@ def main():
     torch.set_num_threads(8)
     out = {}
     only = sys.argv[1:]
-    for f in (fx_projection, fx_normals, fx_geometry, fx_loss, fx_loss_alone, fx_model_and_step, fx_model_variants, fx_step_normalized, fx_poses):
+    for f in (fx_projection, fx_normals, fx_geometry, fx_loss, fx_loss_alone, fx_model_and_step, fx_model_variants, fx_step_normalized, fx_poses,
+              fx_step_full, fx_step_b8_small, fx_quat2mat):
         if only and f.__name__ not in only:
             continue
         print(f.__name__)

@@ -520,3 +520,74 @@ def test_ddp_all_reduce_overlaps_the_trunk_backward():
     util.measured("DDP: share of the gradient bytes already in flight while layer1 + layer2 still run their backward", early / total)
     assert abs(total - 4 * sum(p.numel() for p in tr.raw_model.parameters())) < 1024
     assert early / total > 0.6
+
+
+# ------------------------------------------------------- the reference's own Trainer.step at full size (full-size digests)
+@pytest.mark.parametrize("name", ["step_full_64_b1", "step_full_64_b2", "step_full_128_b1", "step_b8_small"])
+def test_step_matches_the_references_own_trainer_step(name):
+    """tests/golden/step_full_*.npz hold what the REFERENCE's `Trainer.step` (src/deploy/deployer.py:237-375) produced at 64x2048
+    (B=1, B=2) and 128x2048 (B=1) with the FULL 11.9 M-parameter network, and at B=8 on the small network: poses, the five loss
+    scalars, the 30 per-parameter gradient norms, the Adam update, pair counts.  Inputs and weights are regenerated here from seeds
+    by the portable generators and sha-checked against the fixture, so the HIP path (stored normal lists through the projection,
+    HIP stem + trunk, search, loss, backward, Adam) is tied to the reference DIRECTLY at full width, not through the narrow module."""
+    from delora_amd.deploy.trainer import Trainer
+    dev = _dev()
+    g = util.load_golden(name)
+    H, W = int(g["H"]), int(g["W"])
+    samples = util.portable_step_inputs(g)
+    B = len(samples)
+    if name == "step_b8_small":
+        gm = util.load_golden("model_small")
+        cfg = util.repo_config(H, W, device="cuda:0", factor_fewer_resnet_channels=int(gm["cfg::factor_fewer_resnet_channels"]),
+                               resnet_outputs=int(gm["cfg::resnet_outputs"]), unsupervised_at_start=True, inference_only=False, batch_size=B)
+        state = {k[4:]: torch.from_numpy(v) for k, v in gm.items() if k.startswith("sd::")}
+    else:
+        cfg = util.repo_config(H, W, device="cuda:0", unsupervised_at_start=True, inference_only=False, batch_size=B)
+        cfg["kitti"]["vertical_field_of_view"] = [float(v) for v in g["vfov"]]
+        state = util.portable_full_state(g)
+    samples = [{k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in s.items()} for s in samples]
+    trainer = Trainer(cfg, dataset=util.ListDataset(samples))
+    trainer.raw_model.load_state_dict({k: v.to(dev) for k, v in state.items()})
+    if name != "step_b8_small":
+        assert trainer.raw_model.resnet.hip_path_takes(H, W, batch=B), "the full-width network must run on the HIP stem + trunk"
+    before = {k: v.detach().clone() for k, v in trainer.raw_model.state_dict().items()}
+    trainer.optimizer.zero_grad()
+    ep, T = trainer.step(preprocessed_dicts=[dict(s) for s in samples], epoch_losses=trainer.new_epoch_losses())
+    torch.cuda.synchronize()
+    T_ref = g["T"]
+    util.measured(f"{name}: poses vs the reference (relative to the largest element)",
+                  float(np.abs(T.detach().cpu().numpy() - T_ref).max() / np.abs(T_ref).max()), bound=REL)
+    for key in ("loss_epoch", "loss_point_cloud_epoch", "loss_po2pl_epoch", "loss_pl2pl_epoch", "loss_po2po_epoch"):
+        ref = float(g["ep::" + key])
+        util.measured(f"{name}: {key} vs the reference (relative)", abs(float(ep[key]) - ref) / max(abs(ref), 1e-12), bound=REL)
+    assert int(ep["visible_pixels_epoch"]) == int(g["ep::visible_pixels_epoch"])
+    counts = trainer.last_step["pair_counts"]
+    if counts is not None:
+        got = counts.detach().cpu().numpy().reshape(B, -1)[:, 0].astype(np.int64)
+        util.measured(f"{name}: pair counts differing from the reference's (pairs, summed over the batch)",
+                      int(np.abs(got - g["pairs"]).sum()), bound=max(2, int(1e-4 * g["pairs"].sum())))
+    terms = trainer.last_step["loss_terms"].detach().cpu().numpy().astype(np.float64)
+    util.measured(f"{name}: per-sample loss terms vs the reference-pinned oracle (relative)",
+                  float((np.abs(terms - g["terms"]) / np.maximum(np.abs(g["terms"]), 1e-12)).max()), bound=REL)
+    worst = 0.0
+    for k, p in trainer.raw_model.named_parameters():
+        ref = float(g["gradnorm::" + k])
+        worst = max(worst, abs(float(p.grad.double().norm()) - ref) / max(ref, 1e-12))
+    util.measured(f"{name}: worst relative error of the 30 per-parameter gradient norms vs the reference", worst, bound=REL)
+    after = trainer.raw_model.state_dict()
+    for k in before:                                        # Adam's first step moves every weight by ~lr*sign(grad)
+        got = float((after[k].double() - before[k].double()).sum())
+        n = before[k].numel()
+        assert abs(got - float(g["delta::" + k])) <= 1e-5 * max(2.0, 0.005 * n), f"Adam update {k}"
+
+
+def test_quaternion_kernel_against_the_references_own_quat2mat():
+    """k_quat_to_T_fwd (csrc/pose.hip) against the reference-held formula `OdometryPublisher.quat2mat`
+    (src/ros_utils/odometry_publisher.py:113-126; 1000 unit quaternions evaluated by the reference in make_golden.py)."""
+    from delora_amd.models.model_parts import GeometryHandler
+    dev = _dev()
+    g = util.load_golden("quat2mat")
+    q = torch.from_numpy(g["q"]).to(dev)
+    T = GeometryHandler.get_transformation_matrix_quaternion(torch.zeros((len(q), 3), device=dev), q, dev)
+    util.measured("quaternion -> T kernel vs the reference's quat2mat (absolute, 1000 unit quaternions)",
+                  float(np.abs(T[:, :3, :3].cpu().numpy() - g["R"]).max()), bound=1e-6)

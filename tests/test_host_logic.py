@@ -581,3 +581,50 @@ def test_hip_trunk_shape_gate_decides_the_weight_layout():
     cfg_m = util.repo_config(64, 2048)
     cfg_m["cnn_impl"] = "modules"
     assert not OdometryModel(cfg_m).resnet.hip_path_takes(64, 2048)
+
+
+@pytest.mark.parametrize("blocker", ["random_point_cloud_rotations", "normalization_scaling", "world_size", "mixed"])
+def test_graphed_step_runs_the_eager_step_when_capture_is_not_possible(blocker):
+    """`hip_graph: true` together with augmentation / range normalisation / several ranks / a mixed-sensor batch: every call must
+    run the eager step on the caller's own list of dicts (advisor r03: it packed the batch and Deployer.step raised ValueError)."""
+    from delora_amd.deploy import step_geometry
+    from delora_amd.deploy.graph_step import GraphedStep
+
+    class FakeTrainer:
+        world_size, batch_size = 1, 2
+        config = {"normalization_scaling": False, "random_point_cloud_rotations": False}
+        seen = []
+
+        class optimizer:
+            param_groups, state = [], {}
+
+            @staticmethod
+            def zero_grad(set_to_none=True):
+                pass
+
+        @staticmethod
+        def new_epoch_losses():
+            return {}
+
+        def step(self, preprocessed_dicts, epoch_losses):
+            self.seen.append(preprocessed_dicts)
+            return epoch_losses, None
+
+    tr = FakeTrainer()
+    tr.config = dict(tr.config)
+    batch = [{"dataset": "kitti", "scan_1": torch.zeros(1, 3, 10), "scan_2": torch.zeros(1, 3, 12), "normal_list_1": None, "normal_list_2": None}
+             for _ in range(2)]
+    if blocker == "world_size":
+        tr.world_size = 2
+    elif blocker == "mixed":
+        batch[1]["dataset"] = "darpa"
+    else:
+        tr.config[blocker] = True
+    g = GraphedStep(tr, batch)
+    assert not g.eligible and not g.captured and tr.seen == []
+    g(batch)
+    g(batch)
+    assert g.fallback_steps == 2 and len(tr.seen) == 2
+    assert all(isinstance(b, list) and not isinstance(b, step_geometry.PackedBatch) for b in tr.seen)
+    with pytest.raises(ValueError):
+        g(None)

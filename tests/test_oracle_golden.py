@@ -137,3 +137,37 @@ def test_losses_po2po_alone():
         assert np.allclose(T.grad.numpy(), g[qname + "_gradT"], rtol=1e-5, atol=1e-7)
     with pytest.raises(UnboundLocalError):
         orc.icp_losses(src, src_n, tgt, tgt_n, po2po_alone=True)
+
+
+@pytest.mark.parametrize("name", ["step_b8_small", "step_full_64_b1"])
+def test_step_losses_from_portable_inputs(name):
+    """Fixtures whose inputs are regenerated from seeds (sha-checked): the reference's Trainer.step at B=8 (weights (B-j)/B over a long
+    batch) and at the FULL image size 64x2048 with the full network -- the oracle, given the reference's poses, reproduces the
+    reference's batch losses, per-sample pair counts and the visible-pixel metric."""
+    g = util.load_golden(name)
+    vfov = [float(v) for v in g["vfov"]] if "vfov" in g else util.kitti_fov()[0]
+    sensor = util.oracle_sensor(g["H"], g["W"], vfov, util.kitti_fov()[1])
+    samples = util.portable_step_inputs(g)
+    lists = [orc.filter_to_projected(s, sensor)[2] for s in samples]
+    T = _t(g["T"])
+    out, per = orc.step_losses(lists, T)
+    assert np.isclose(float(out["loss_pc"]), g["ep::loss_point_cloud_epoch"], rtol=2e-5)
+    assert np.isclose(float(out["loss_po2pl"]), g["ep::loss_po2pl_epoch"], rtol=2e-5)
+    assert np.isclose(float(out["loss_pl2pl"]), g["ep::loss_pl2pl_epoch"], rtol=2e-5)
+    for j, L in enumerate(lists):
+        _, aux = orc.icp_losses(orc.transform_points(T[j:j + 1], L["scan_2"]), orc.rotate_points(T[j:j + 1], L["normal_list_2"]),
+                                L["scan_1"], L["normal_list_1"], return_aux=True)
+        assert aux["pairs"] == int(g["pairs"][j])
+        assert np.allclose([float(per[j][k]) for k in ("loss_po2po", "loss_po2pl", "loss_pl2pl")], g["terms"][j], rtol=1e-6, atol=1e-12)
+    B = len(lists)
+    assert orc.visible_pixels(orc.transform_points(T[B - 1:B], lists[B - 1]["scan_2"]), sensor) == int(g["ep::visible_pixels_epoch"])
+
+
+def test_quaternion_restatement_against_the_references_own_quat2mat():
+    """a8's reference-held pin: `OdometryPublisher.quat2mat` (src/ros_utils/odometry_publisher.py:113-126) evaluated by make_golden.py on
+    1000 random unit quaternions (x,y,z,w) -- the kornia 0.3.0 restatement of the oracle agrees to 1e-6."""
+    g = util.load_golden("quat2mat")
+    R = orc.quaternion_to_rotation_matrix(_t(g["q"])).numpy()
+    assert np.abs(R - g["R"]).max() <= 1e-6
+    T = orc.transformation_matrix(torch.zeros(len(g["q"]), 3), _t(g["q"])).numpy()
+    assert np.abs(T[:, :3, :3] - g["R"]).max() <= 1e-6 and np.all(T[:, 3] == np.array([0, 0, 0, 1.0]))

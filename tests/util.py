@@ -151,3 +151,23 @@ class OracleStepGeometry:
             rows.append(torch.stack([l["loss_po2po"].reshape(()), l["loss_po2pl"].reshape(()), l["loss_pl2pl"].reshape(())]))
             vis.append(orc.visible_pixels(s_t, prepared["sensor"]))
         return torch.stack(rows), None, torch.tensor(vis)
+
+
+def portable_step_inputs(g):
+    """Regenerate the inputs of a `step_full_*` / `step_b8_small` fixture from its seeds (delora_amd.data.synthetic's portable generators)
+    and prove by sha256 that they are the arrays the reference ran on.  Returns the list of sample dicts ([1,3,n] CPU tensors)."""
+    from delora_amd.data import synthetic
+    pairs = [synthetic.portable_pair(int(sd), int(g["n_points"])) for sd in g["seeds"]]
+    got = synthetic.digest([p[k] for p in pairs for k in ("scan_1", "normal_list_1", "scan_2", "normal_list_2")])
+    assert got == str(g["input_sha"]), "the portable generator does not reproduce the fixture's inputs on this machine"
+    return [{**{k: torch.from_numpy(p[k]).unsqueeze(0) for k in ("scan_1", "scan_2", "normal_list_1", "normal_list_2")}, "dataset": "kitti"}
+            for p in pairs]
+
+
+def portable_full_state(g):
+    """The full network's state_dict of a `step_full_*` fixture, regenerated and sha-checked."""
+    from delora_amd.data import synthetic
+    shapes = {k[len("shape::"):]: tuple(int(d) for d in v) for k, v in g.items() if k.startswith("shape::")}
+    state = synthetic.portable_state_dict(int(g["state_seed"]), shapes)
+    assert synthetic.digest([state[k] for k in shapes]) == str(g["state_sha"]), "portable weights differ from the fixture's"
+    return {k: torch.from_numpy(v) for k, v in state.items()}
