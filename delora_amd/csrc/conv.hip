@@ -51,6 +51,8 @@ struct ConvArgs {
   int N, H, W, C, K, Ho, Wo;
   int act;
   unsigned epi;
+  int Hout, Wout;      // dimensions of the tensor y is written into: Ho x Wo, or the full-resolution image a stride phase scatters into
+  int wrap;            // 1: columns outside [0, W) wrap around (the ring); 0: they read zeros (stride phases of an odd-width image)
 };
 
 __device__ __forceinline__ float cv_act(float v, int act) {
@@ -103,7 +105,9 @@ __global__ __launch_bounds__(CV_THREADS, CV_MINWAVES) void k_conv_f32(ConvArgs a
   const int li = lane & 31, half = lane >> 5;
   const int wm = wave / WGN, wn = wave % WGN;
   const int KT = a.K / BN;
-  const int tiles_w = a.Wo / TW, tiles_h = a.Ho / TH;
+  // images that do not tile: the last tile of a row / column hangs over the edge -- its surplus pixels compute on wrapped (valid)
+  // addresses and are not stored
+  const int tiles_w = (a.Wo + TW - 1) / TW, tiles_h = (a.Ho + TH - 1) / TH;
   const int ntiles = a.N * tiles_h * tiles_w * KT;
   const int t = cv_xcd_swizzle(blockIdx.x, ntiles);
   const int kt = t % KT;
@@ -126,9 +130,12 @@ __global__ __launch_bounds__(CV_THREADS, CV_MINWAVES) void k_conv_f32(ConvArgs a
     const int col = pc % RW, row = pc / RW;
     const int h = h_base + row;
     int w = w_base + col;
-    w = w < 0 ? w + a.W : (w >= a.W ? w - a.W : w);
+    const bool col_in = w >= 0 && w < a.W;
+    w %= a.W;                                      // (a full modulo: the surplus columns of an overhanging tile lie beyond 2W)
+    w = w < 0 ? w + a.W : w;
     in_l[it] = pc * S + c4 * 4;
-    in_g[it] = (h >= 0 && h < a.H) ? (h * a.W + w) * a.C + c4 * 4 : -1;     // -1: a zero row above / below the image
+    // -1: a zero row above / below the image (or, without wrap-around, a zero column beside it)
+    in_g[it] = (h >= 0 && h < a.H && (a.wrap || col_in)) ? (h * a.W + w) * a.C + c4 * 4 : -1;
   }
   int w_g[NW_IT], w_l[NW_IT];
 #pragma unroll
@@ -283,7 +290,7 @@ __global__ __launch_bounds__(CV_THREADS, CV_MINWAVES) void k_conv_f32(ConvArgs a
   // activation and 16-byte stores of whole 128/256-byte channel rows.
   __syncthreads();                                       // every wave is done with the last chunk's fragments
   float* ep = lds + wave * (32 * ES);
-  const size_t out_n = (size_t)n * (a.Ho * G::OSH) * (a.Wo * G::OSW), grid_n = (size_t)n * a.Ho * a.Wo;
+  const size_t out_n = (size_t)n * a.Hout * a.Wout, grid_n = (size_t)n * a.Ho * a.Wo;
   const bool f_add = a.epi & CV_EPI_ADD, f_act = a.epi & CV_EPI_ACT, f_dact = a.epi & CV_EPI_DACT;
   const bool f_addg = a.epi & CV_EPI_ADD_GRID;
 #pragma unroll
@@ -298,8 +305,9 @@ __global__ __launch_bounds__(CV_THREADS, CV_MINWAVES) void k_conv_f32(ConvArgs a
       const int row = q / (EPW / 4), c4 = q % (EPW / 4);
       const int p = (wm * WM + mi) * 32 + row;
       const int th = p / TW, tw = p % TW;
-      const size_t o = (out_n + (size_t)((ho0 + th) * G::OSH + G::OPH) * (a.Wo * G::OSW) + ((wo0 + tw) * G::OSW + G::OPW)) * a.K +
-                       k0 + wn * EPW + c4 * 4;
+      const int oh = (ho0 + th) * G::OSH + G::OPH, ow = (wo0 + tw) * G::OSW + G::OPW;
+      if (ho0 + th >= a.Ho || wo0 + tw >= a.Wo || oh >= a.Hout || ow >= a.Wout) continue;      // surplus pixel of an overhanging tile
+      const size_t o = (out_n + (size_t)oh * a.Wout + ow) * a.K + k0 + wn * EPW + c4 * 4;
       float4 v = *reinterpret_cast<const float4*>(ep + row * ES + c4 * 4);
       if (f_addg) {        // an addend that lives on the dense (sub-sampled) grid: the down-sampling branch's gradient
         const float4 t = *reinterpret_cast<const float4*>(a.add + (grid_n + (size_t)(ho0 + th) * a.Wo + (wo0 + tw)) * a.K + k0 + wn * EPW + c4 * 4);
