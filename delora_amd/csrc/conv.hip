@@ -382,7 +382,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void k_wgrad_f32(const float* __rest
 #define WG_GITEM(IT)                                                                                                      \
     const int gq_ = min(tid + (IT) * CV_THREADS, NG - 1);                                                                 \
     const int g_k4_ = (gq_ % (BMK / 4)) * 4, g_p_ = gq_ / (BMK / 4);
-  const int chunks_per_row = Wo / PK;
+  const int chunks_per_row = (Wo + PK - 1) / PK;
   const int total_chunks = N * Ho * chunks_per_row;
   const int ch_begin = slab * chunks_per_slab;
   const int ch_end = min(ch_begin + chunks_per_slab, total_chunks);
@@ -396,15 +396,17 @@ __global__ __launch_bounds__(CV_THREADS, 2) void k_wgrad_f32(const float* __rest
       WG_XITEM(it)                                                                                                        \
       (void)x_l_;                                                                                                         \
       const int h = ho_ * SH - PAD + x_row_;                                                                              \
-      int w = wo0_ * SW - PAD + x_col_;                                                                                   \
-      w = w < 0 ? w + W : (w >= W ? w - W : w);                                                                           \
+      int w = (wo0_ * SW - PAD + x_col_) % W;      /* (full modulo: the last chunk of a row may hang over the edge) */      \
+      w = w < 0 ? w + W : w;                                                                                              \
       const bool in = h >= 0 && h < H;                                                                                    \
       const f32x4 v = *reinterpret_cast<const f32x4*>(x + (in ? (((size_t)n_ * H + h) * W + w) * C + c0 + x_c4_ : 0));    \
       x_r[it] = in ? v : (f32x4){0.f, 0.f, 0.f, 0.f};                                                                     \
     }                                                                                                                     \
     _Pragma("unroll") for (int it = 0; it < NG_IT; ++it) {                                                                \
       WG_GITEM(it)                                                                                                        \
-      g_r[it] = *reinterpret_cast<const f32x4*>(g + (((size_t)n_ * Ho + ho_) * Wo + wo0_ + g_p_) * K + k0 + g_k4_);       \
+      const bool gin = wo0_ + g_p_ < Wo;           /* pixels beyond the row's end contribute nothing */                    \
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(g + (((size_t)n_ * Ho + ho_) * Wo + (gin ? wo0_ + g_p_ : 0)) * K + k0 + g_k4_); \
+      g_r[it] = gin ? gv : (f32x4){0.f, 0.f, 0.f, 0.f};                                                                    \
     }                                                                                                                     \
   }
 #define WG_STAGE()                                                                                                        \
@@ -506,8 +508,8 @@ __global__ __launch_bounds__(CV_THREADS) void k_wgrad_reduce(const float* __rest
 template <int BM, int BN, int CK, int TW, class G, bool BT, int WGN>
 static int launch_conv(const ConvArgs& a, hipStream_t st) {
   constexpr int TH = BM / TW;
-  if (a.Wo % TW || a.Ho % TH || a.K % BN || a.C % CK) return 1;
-  const int ntiles = a.N * (a.Ho / TH) * (a.Wo / TW) * (a.K / BN);
+  if (a.K % BN || a.C % CK) return 1;
+  const int ntiles = a.N * ((a.Ho + TH - 1) / TH) * ((a.Wo + TW - 1) / TW) * (a.K / BN);
   const double px_ = (double)a.N * a.Ho * a.Wo;
   constexpr int ks_ = G::WTAPS == 9 ? 3 : 1;
   const DlProfTag tag{"k_conv_f32", BT ? "dgrad" : "fwd", a.N, a.H, a.W, a.C, a.K, ks_, BT ? G::OSH : G::ISH, BT ? G::OSW : G::ISW, 2.0 * px_ * a.K * a.C * G::NT,
@@ -537,6 +539,31 @@ static int variant_conv(const ConvArgs& a, hipStream_t st) {
 }
 #endif
 
+// Tile width for BM-pixel tiles (TH = BM / TW rows) that wastes the least of an Ho x Wo image: tiles hang over the right / lower
+// edge of images that do not divide (the reference's shipped 64x720 image has feature maps 180, 90, 45 and 23 pixels wide); ties go to
+// the wider tile (longer contiguous rows).
+static int cv_pick_tw(int Ho, int Wo, int bm, int min_tw) {
+  int best = 0;
+  long best_px = 0;
+  for (int tw = 128; tw >= min_tw; tw >>= 1) {
+    const int th = bm / tw;
+    if (th < 1) continue;
+    const long px = (long)((Ho + th - 1) / th) * th * (long)((Wo + tw - 1) / tw) * tw;
+    if (!best || px < best_px) { best = tw; best_px = px; }
+  }
+  return best;
+}
+
+template <class G, bool BT, int CKK>
+static int launch_conv_128(const ConvArgs& a, hipStream_t st) {
+  switch (cv_pick_tw(a.Ho, a.Wo, 128, 16)) {
+    case 128: return launch_conv<128, CV_BN, CKK, 128, G, BT, CV_WGN>(a, st);
+    case 64: return launch_conv<128, CV_BN, CKK, 64, G, BT, CV_WGN>(a, st);
+    case 32: return launch_conv<128, CV_BN, CKK, 32, G, BT, CV_WGN>(a, st);
+    default: return launch_conv<128, CV_BN, CKK, 16, G, BT, CV_WGN>(a, st);
+  }
+}
+
 // G: geometry policy; BIG: a stride-1 3x3 pass (the layer, or its input gradient) that may take the 256-pixel tiles
 template <class G, bool BT, bool BIG>
 static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
@@ -558,32 +585,96 @@ static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
 #endif
   // Tile choice (measured on the layer shapes of the network, tools/conv_harness tune; profiles/): stride-1 3x3 layers take
   // 256 pixels x 64 channels per workgroup (each wave a 64x64 block: one LDS read feeds four MFMAs on both operands), with
-  // 8-channel chunks (3 workgroups per CU) for the shallow layers and 16-channel chunks for C >= 256; strided and 1x1
-  // layers and images that do not tile by 256 pixels take 128-pixel tiles.  Tile width = the widest of 128 / 64 / 32 that
-  // divides the output row; narrow images take several rows per tile.
+  // 8-channel chunks (3 workgroups per CU) for the shallow layers and 16-channel chunks for C >= 256, when the image divides
+  // into such tiles; strided and 1x1 layers and every other image take 128-pixel tiles of the width that wastes the least of
+  // the image (128 / 64 / 32 / 16 columns; narrow images take several rows per tile).
   if constexpr (BIG) {
     if (a.C >= 256) {
-      if (a.Wo % 128 == 0 && !launch_conv<256, 64, 16, 128, G, BT, 1>(a, st)) return 0;
-      if (a.Wo % 64 == 0 && !launch_conv<256, 64, 16, 64, G, BT, 1>(a, st)) return 0;
+      if (a.Wo % 128 == 0 && a.Ho % 2 == 0 && !launch_conv<256, 64, 16, 128, G, BT, 1>(a, st)) return 0;
+      if (a.Wo % 64 == 0 && a.Ho % 4 == 0 && !launch_conv<256, 64, 16, 64, G, BT, 1>(a, st)) return 0;
     } else {
-      if (a.Wo % 128 == 0 && !launch_conv<256, 64, 8, 128, G, BT, 1>(a, st)) return 0;
-      if (a.Wo % 64 == 0 && !launch_conv<256, 64, 8, 64, G, BT, 1>(a, st)) return 0;
+      if (a.Wo % 128 == 0 && a.Ho % 2 == 0 && !launch_conv<256, 64, 8, 128, G, BT, 1>(a, st)) return 0;
+      if (a.Wo % 64 == 0 && a.Ho % 4 == 0 && !launch_conv<256, 64, 8, 64, G, BT, 1>(a, st)) return 0;
     }
   }
   if constexpr (G::WTAPS == 9 && !BIG) {
     // strided 3x3 layers and their input-gradient phases: 8-channel chunks (half the LDS, two workgroups per CU) are
     // 5-9 % faster up to 256 reduction channels (tools/conv_harness time; the 512-channel phases and the 1x1 layers keep
     // 16); the stem (8 input channels) has no other choice
-    if (a.C % CV_CK || a.C <= 256) {
-      if (a.Wo % 128 == 0 && !launch_conv<128, CV_BN, 8, 128, G, BT, CV_WGN>(a, st)) return 0;
-      if (a.Wo % 64 == 0 && !launch_conv<128, CV_BN, 8, 64, G, BT, CV_WGN>(a, st)) return 0;
-      if (a.C % CV_CK) return 1;
+    if (a.C % CV_CK || a.C <= 256) return launch_conv_128<G, BT, 8>(a, st);
+  }
+  return launch_conv_128<G, BT, CV_CK>(a, st);
+}
+
+// Wrap-around terms of a stride-2-in-width layer's input gradient when the image width W is ODD (the reference's 64x720 image:
+// layer4's input is 45 pixels wide).  Column 2 wo + s - 1 of the circularly padded image is column (2 wo + s - 1) mod W; for even W
+// the wrap maps stride phases onto themselves (the phase kernels wrap the gradient grid), for odd W it does not: the phases then read
+// zeros outside the grid, and the two terms that cross the seam are added here,
+//     dx[h][0]     += sum_r sum_k g[ho][Wo-1][k] w[k][r][2][c]        (tap s = 2 of the last output column reads column W = 0)
+//     dx[h][W - 1] += sum_r sum_k g[ho][0][k]    w[k][r][0][c]        (tap s = 0 of the first output column reads column -1 = W-1)
+// with h = SH ho + r - 1, times act'(dsrc) when the phases applied it (the epilogue is linear in the convolution term).
+// One workgroup = FX_ROWS consecutive rows h of one image and one of the two columns; thread = channel c.  ~0.2 GFLOP per launch.
+#define FX_ROWS 16
+#define FX_KC 64
+__global__ __launch_bounds__(CV_THREADS) void k_dgrad_oddw_fix(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ dx,
+                                                               const float* __restrict__ dsrc, int N, int Ho, int Wo, int K, int C, int H,
+                                                               int W, int SH, int act, int f_dact) {
+  constexpr int GROWS = FX_ROWS + 2;                   // grid rows a tile of FX_ROWS image rows can reach (SH = 1), + one row of zeros
+  __shared__ float gs[(GROWS + 1) * FX_KC];            // g[ho_lo + i][the column][k chunk]; row GROWS = zeros
+  const int side = blockIdx.y;                         // 0: image column 0 (tap s = 2, grid column Wo-1); 1: column W-1 (s = 0, grid column 0)
+  const int row_tiles = (H + FX_ROWS - 1) / FX_ROWS;
+  const int n = blockIdx.x / row_tiles, h0 = (blockIdx.x % row_tiles) * FX_ROWS;
+  const int s = side ? 0 : 2, wo = side ? 0 : Wo - 1, col = side ? W - 1 : 0;
+  const int ho_lo = h0 > 0 ? (h0 - 1) / SH : 0;        // first grid row that reaches row h0 (h = SH ho + r - 1 with r <= 2)
+  // LDS row of the grid row that tap r contributes to image row h0 + i from (GROWS: none)
+  int src[FX_ROWS][3];
+#pragma unroll
+  for (int i = 0; i < FX_ROWS; ++i)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int t = h0 + i + 1 - r;                    // = SH * ho
+      const int ho = t / SH;
+      const bool ok = t >= 0 && t % SH == 0 && ho < Ho && ho - ho_lo >= 0 && ho - ho_lo < GROWS;
+      src[i][r] = (ok ? ho - ho_lo : GROWS) * FX_KC;
+    }
+  for (int q = threadIdx.x; q < FX_KC; q += CV_THREADS) gs[GROWS * FX_KC + q] = 0.f;
+  for (int cb = 0; cb < C; cb += CV_THREADS) {
+    const int c = cb + threadIdx.x;
+    const int cc = c < C ? c : C - 1;
+    float acc[FX_ROWS];
+#pragma unroll
+    for (int i = 0; i < FX_ROWS; ++i) acc[i] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += FX_KC) {
+      __syncthreads();
+      for (int q = threadIdx.x; q < GROWS * FX_KC; q += CV_THREADS) {
+        const int i = q / FX_KC, kk = q % FX_KC, ho = ho_lo + i;
+        gs[q] = (ho < Ho && k0 + kk < K) ? g[(((size_t)n * Ho + ho) * Wo + wo) * K + k0 + kk] : 0.f;
+      }
+      __syncthreads();
+      const int kn = K - k0 < FX_KC ? K - k0 : FX_KC;
+      for (int kk = 0; kk < kn; ++kk) {
+        float wv[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) wv[r] = w[(((size_t)(k0 + kk) * 3 + r) * 3 + s) * C + cc];
+#pragma unroll
+        for (int i = 0; i < FX_ROWS; ++i)
+#pragma unroll
+          for (int r = 0; r < 3; ++r) acc[i] = fmaf(gs[src[i][r] + kk], wv[r], acc[i]);
+      }
+    }
+    if (c < C) {
+#pragma unroll
+      for (int i = 0; i < FX_ROWS; ++i) {
+        const int h = h0 + i;
+        if (h < H) {
+          const size_t o = (((size_t)n * H + h) * W + col) * C + c;
+          float v = acc[i];
+          if (f_dact) v *= cv_dact(dsrc[o], act);
+          dx[o] += v;
+        }
+      }
     }
   }
-  if (a.Wo % 128 == 0 && !launch_conv<128, CV_BN, CV_CK, 128, G, BT, CV_WGN>(a, st)) return 0;
-  if (a.Wo % 64 == 0 && !launch_conv<128, CV_BN, CV_CK, 64, G, BT, CV_WGN>(a, st)) return 0;
-  if (a.Wo % 32 == 0 && !launch_conv<128, CV_BN, CV_CK, 32, G, BT, CV_WGN>(a, st)) return 0;
-  return 1;
 }
 
 /* see include/delora_hip.h */
@@ -596,11 +687,12 @@ extern "C" int dl_conv2d_nhwc_f32(const float* x, const float* w, float* y, cons
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_nhwc_f32: epilogue operand missing / bad activation or flag");
   if ((stride_h != 1 && stride_h != 2) || (stride_w != 1 && stride_w != 2) || (ksize != 1 && ksize != 3))
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_nhwc_f32: kernel size must be 1 or 3, strides 1 or 2 (got %d, %d, %d)", ksize, stride_h, stride_w);
-  if (H % stride_h || W % stride_w)
-    return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_f32: image size must be a multiple of the stride");
   if ((size_t)N * H * W * C >= ((size_t)1 << 31) || (size_t)N * H * W * K >= ((size_t)1 << 31))
     return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_f32: tensors beyond 2^31 elements are not supported (split the batch)");
-  ConvArgs a{x, w, y, add, dsrc, N, H, W, C, K, H / stride_h, W / stride_w, act, epilogue};
+  // output size of the reference's padded convolution (circular pad 1 on W, zero pad 1 on H, kernel 3; or kernel 1 unpadded):
+  // floor((X - 1) / stride) + 1 = ceil(X / stride)
+  const int Ho = (H + stride_h - 1) / stride_h, Wo = (W + stride_w - 1) / stride_w;
+  ConvArgs a{x, w, y, add, dsrc, N, H, W, C, K, Ho, Wo, act, epilogue, Ho, Wo, 1};
   hipStream_t st = (hipStream_t)stream;
   int rc = 1;
   if (ksize == 3 && stride_h == 1 && stride_w == 1)
@@ -611,8 +703,8 @@ extern "C" int dl_conv2d_nhwc_f32(const float* x, const float* w, float* y, cons
   else if (ksize == 1 && stride_h == 1 && stride_w == 2) rc = dispatch_conv<GeomConv<1, 1, 2>, false, false>(a, st);
   else if (ksize == 1 && stride_h == 2 && stride_w == 2) rc = dispatch_conv<GeomConv<1, 2, 2>, false, false>(a, st);
   else return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_f32: kernel %d stride (%d,%d) is not built", ksize, stride_h, stride_w);
-  if (rc) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_f32: shape N=%d H=%d W=%d C=%d K=%d does not tile (Wo %% 32, K %% %d, C %% %d)",
-                         N, H, W, C, K, CV_BN, CV_CK);
+  if (rc) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_f32: shape N=%d H=%d W=%d C=%d K=%d does not tile (K %% %d, C %% 8)",
+                         N, H, W, C, K, CV_BN);
   return dl_check_launch("dl_conv2d_nhwc_f32");
 }
 
@@ -628,20 +720,23 @@ static int dgrad_phase(ConvArgs a, bool first_phase, hipStream_t st) {
 
 /* see include/delora_hip.h */
 extern "C" int dl_conv2d_dgrad_strided_nhwc_f32(const float* g, const float* w, float* dx, const float* add_grid, const float* dsrc,
-                                                int32_t N, int32_t Ho, int32_t Wo, int32_t K, int32_t C, int32_t ksize,
+                                                int32_t N, int32_t H, int32_t W, int32_t K, int32_t C, int32_t ksize,
                                                 int32_t stride_h, int32_t stride_w, int32_t dense, int32_t act,
                                                 uint32_t epilogue, dl_stream stream) {
-  if (!g || !w || !dx || N <= 0 || Ho <= 0 || Wo <= 0 || C <= 0 || K <= 0)
+  if (!g || !w || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_dgrad_strided_nhwc_f32: bad argument");
   if (((epilogue & CV_EPI_ADD_GRID) && !add_grid) || ((epilogue & CV_EPI_DACT) && !dsrc) || act < 0 || act > 2 ||
       (epilogue & ~(CV_EPI_ADD_GRID | CV_EPI_DACT)))
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_dgrad_strided_nhwc_f32: epilogue operand missing / unsupported flag");
   if ((stride_h != 1 && stride_h != 2) || (stride_w != 1 && stride_w != 2) || (ksize != 1 && ksize != 3))
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_dgrad_strided_nhwc_f32: kernel size must be 1 or 3, strides 1 or 2 (got %d, %d, %d)", ksize, stride_h, stride_w);
-  if ((size_t)N * Ho * stride_h * Wo * stride_w * C >= ((size_t)1 << 31) || (size_t)N * Ho * Wo * K >= ((size_t)1 << 31))
+  const int Ho = (H + stride_h - 1) / stride_h, Wo = (W + stride_w - 1) / stride_w;      // the layer's output grid (= g)
+  if ((size_t)N * H * W * C >= ((size_t)1 << 31) || (size_t)N * Ho * Wo * K >= ((size_t)1 << 31))
     return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_dgrad_strided_nhwc_f32: tensors beyond 2^31 elements are not supported");
-  // in the kernel's terms: input = g (K channels, the reduction), output channels = C
-  ConvArgs a{g, w, dx, add_grid, dsrc, N, Ho, Wo, K, C, Ho, Wo, act, epilogue};
+  // in the kernel's terms: input = g (K channels, the reduction), output channels = C.  The stride phases of an image whose width is
+  // odd do not close under the wrap-around: they read zeros beside the grid and k_dgrad_oddw_fix adds the two seam terms.
+  const bool odd_w = stride_w == 2 && (W & 1) && ksize == 3;
+  ConvArgs a{g, w, dx, add_grid, dsrc, N, Ho, Wo, K, C, Ho, Wo, act, epilogue, dense ? Ho : H, dense ? Wo : W, odd_w ? 0 : 1};
   hipStream_t st = (hipStream_t)stream;
   int rc = 1;
   if (dense) {                                        // 1x1 layer: only phase (0,0) is non-zero; result kept on the grid
@@ -656,7 +751,12 @@ extern "C" int dl_conv2d_dgrad_strided_nhwc_f32(const float* g, const float* w, 
   } else {
     return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_dgrad_strided_nhwc_f32: kernel %d stride (%d,%d) is not built", ksize, stride_h, stride_w);
   }
-  if (rc) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_dgrad_strided_nhwc_f32: shape N=%d Ho=%d Wo=%d K=%d C=%d does not tile", N, Ho, Wo, K, C);
+  if (rc) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_dgrad_strided_nhwc_f32: shape N=%d H=%d W=%d K=%d C=%d does not tile (K, C %% 64)", N, H, W, K, C);
+  if (odd_w && !dense) {
+    const int row_tiles = (H + FX_ROWS - 1) / FX_ROWS;
+    hipLaunchKernelGGL(k_dgrad_oddw_fix, dim3(N * row_tiles, 2), dim3(CV_THREADS), 0, st, g, w, dx, dsrc, N, Ho, Wo, K, C, H, W, stride_h, act,
+                       (int)((epilogue & CV_EPI_DACT) != 0));
+  }
   return dl_check_launch("dl_conv2d_dgrad_strided_nhwc_f32");
 }
 
@@ -685,19 +785,19 @@ static int wgrad_slabs(int total_chunks, int tiles) {
 extern "C" size_t dl_conv2d_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, int32_t ksize,
                                                   int32_t stride_h, int32_t stride_w) {
   if (stride_h < 1 || stride_w < 1 || ksize < 1 || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0) return 0;
-  const int Ho = H / stride_h, Wo = W / stride_w;
+  const int Ho = (H + stride_h - 1) / stride_h, Wo = (W + stride_w - 1) / stride_w;
   const int tiles = (K / 64 > 0 ? K / 64 : 1) * (C / 64 > 0 ? C / 64 : 1);
   const int pk = wg_pk(stride_w, ksize);
-  return (size_t)wgrad_slabs(N * Ho * (Wo / pk > 0 ? Wo / pk : 1), tiles) * K * ksize * ksize * C * sizeof(float);
+  return (size_t)wgrad_slabs(N * Ho * ((Wo + pk - 1) / pk), tiles) * K * ksize * ksize * C * sizeof(float);
 }
 
 template <int SH, int SW, int KS>
 static int launch_wgrad(const float* x, const float* g, float* dw, float* ws, int N, int H, int W, int C, int K, hipStream_t st) {
   constexpr int BMK = 64, BNC = 64, PK = wg_pk(SW, KS);
-  const int Ho = H / SH, Wo = W / SW;
-  if (K % BMK || C % BNC || Wo % PK) return 1;
+  const int Ho = (H + SH - 1) / SH, Wo = (W + SW - 1) / SW;
+  if (K % BMK || C % BNC) return 1;
   const int tiles = (K / BMK) * (C / BNC);
-  const int total_chunks = N * Ho * (Wo / PK);
+  const int total_chunks = N * Ho * ((Wo + PK - 1) / PK);
   const int nslabs = wgrad_slabs(total_chunks, tiles);
   const int chunks_per_slab = (total_chunks + nslabs - 1) / nslabs;
   const DlProfTag tag{"k_wgrad_f32", "wgrad", N, H, W, C, K, KS, SH, SW, 2.0 * N * Ho * Wo * (double)K * C * KS * KS,
@@ -717,8 +817,6 @@ extern "C" int dl_conv2d_wgrad_nhwc_f32(const float* x, const float* g, float* d
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_wgrad_nhwc_f32: bad argument");
   if ((stride_h != 1 && stride_h != 2) || (stride_w != 1 && stride_w != 2) || (ksize != 1 && ksize != 3))
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_wgrad_nhwc_f32: kernel size must be 1 or 3, strides 1 or 2 (got %d, %d, %d)", ksize, stride_h, stride_w);
-  if (H % stride_h || W % stride_w)
-    return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_wgrad_nhwc_f32: image size must be a multiple of the stride");
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
   int rc = 1;

@@ -136,7 +136,7 @@ __global__ __launch_bounds__(DL_BLOCK, 2) void k_stem_wgrad(const float* __restr
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, half = lane >> 5;
   const int W = 2 * Wc;
-  const int cpr = Wc / SG_PX;                                                  // chunks per image row
+  const int cpr = (Wc + SG_PX - 1) / SG_PX;                                   // chunks per image row (the last may hang over its end)
   const int total = N * H * cpr;
   const int ch_begin = blockIdx.x * chunks_per_slab, ch_end = min(ch_begin + chunks_per_slab, total);
   f32x16s acc[2][3];
@@ -161,13 +161,15 @@ __global__ __launch_bounds__(DL_BLOCK, 2) void k_stem_wgrad(const float* __restr
 #pragma unroll
     for (int it = 0; it < SG_PX * C4 / DL_BLOCK; ++it) {
       const int q = tid + it * DL_BLOCK, pl = q / C4, c4 = q % C4;
-      *reinterpret_cast<f32x4s*>(gc + pl * K + c4 * 4) = pool_bwd_value(g, a, win, H, Wc, C4, act, nr, h, wc0 + pl, c4);
+      f32x4s v = {0.f, 0.f, 0.f, 0.f};                                           // pixels beyond the row's end contribute nothing
+      if (wc0 + pl < Wc) v = pool_bwd_value(g, a, win, H, Wc, C4, act, nr, h, wc0 + pl, c4);
+      *reinterpret_cast<f32x4s*>(gc + pl * K + c4 * 4) = v;
     }
     for (int q = tid; q < 3 * SG_XCOLS * 2; q += DL_BLOCK) {                    // 16-byte items: (row, col, half pixel)
       const int hp = q & 1, col = (q >> 1) % SG_XCOLS, row = (q >> 1) / SG_XCOLS;
       const int hh = h + row - 1;
-      int w = 2 * wc0 - 1 + col;
-      w = w < 0 ? w + W : (w >= W ? w - W : w);
+      int w = (2 * wc0 - 1 + col) % W;
+      w = w < 0 ? w + W : w;
       f32x4s v = {0.f, 0.f, 0.f, 0.f};
       if (hh >= 0 && hh < H) v = *reinterpret_cast<const f32x4s*>(x8 + (((size_t)(nr + row - 1)) * W + w) * 8 + hp * 4);
       *reinterpret_cast<f32x4s*>(xt + (row * SG_XCOLS + col) * 8 + hp * 4) = v;
@@ -305,17 +307,17 @@ static int stem_wgrad_slabs(int total_chunks) { return total_chunks < 512 ? tota
 
 /* see include/delora_hip.h */
 extern "C" size_t dl_stem_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t W) {
-  if (N <= 0 || H <= 0 || W <= 0 || W % (2 * SG_PX)) return 0;
-  return (size_t)stem_wgrad_slabs(N * H * (W / 2 / SG_PX)) * 64 * 72 * sizeof(float);
+  if (N <= 0 || H <= 0 || W <= 0 || W % 4) return 0;
+  return (size_t)stem_wgrad_slabs(N * H * ((W / 2 + SG_PX - 1) / SG_PX)) * 64 * 72 * sizeof(float);
 }
 
 extern "C" int dl_stem_wgrad_f32(const float* g_pooled, const float* a, const int8_t* win, const float* x8, int32_t N, int32_t H,
                                  int32_t W, int32_t act, void* workspace, float* dw, dl_stream stream) {
   if (!g_pooled || !a || !win || !x8 || !workspace || !dw || N <= 0 || H <= 0 || W <= 0 || act < 0 || act > 2)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_stem_wgrad_f32: bad argument");
-  if (W % (2 * SG_PX) || (size_t)N * H * W * 32 >= ((size_t)1 << 32))
-    return dl_fail(DL_ERR_UNSUPPORTED, "dl_stem_wgrad_f32: N=%d H=%d W=%d not supported (W %% %d, conv1 output below 2^32 elements)", N, H, W, 2 * SG_PX);
-  const int Wc = W / 2, total = N * H * (Wc / SG_PX), nslabs = stem_wgrad_slabs(total);
+  if (W % 4 || (size_t)N * H * W * 32 >= ((size_t)1 << 32))
+    return dl_fail(DL_ERR_UNSUPPORTED, "dl_stem_wgrad_f32: N=%d H=%d W=%d not supported (W %% 4, conv1 output below 2^32 elements)", N, H, W);
+  const int Wc = W / 2, total = N * H * ((Wc + SG_PX - 1) / SG_PX), nslabs = stem_wgrad_slabs(total);
   const int cps = (total + nslabs - 1) / nslabs, grid = (total + cps - 1) / cps;
   hipStream_t st = (hipStream_t)stream;
   const DlProfTag tag{"k_stem_wgrad", "wgrad", N, H, W, 8, 64, 3, 1, 2, 2.0 * N * H * Wc * 64.0 * 72.0,

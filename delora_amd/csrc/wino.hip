@@ -131,7 +131,10 @@ __device__ unsigned long long g_wn_t[8 * 8192];       // phase time stamps per g
 #else
 #define WN_T(I)
 #endif
-template <int TC>
+// RAG: the image does not divide into groups of TR x TC tiles (or has an odd width / height): the last group of a row / column
+// hangs over the edge.  Its surplus tiles transform wrapped (valid) addresses and multiply like the others; only the epilogue
+// differs -- surplus output pixels are neither fetched from the epilogue operands nor stored.
+template <int TC, bool RAG>
 __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   constexpr int TR = WN_TILES / TC;
   constexpr int RH = 2 * TR + 2, RW = 2 * TC + 2;
@@ -151,7 +154,8 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   const int li = lane & 31, half = lane >> 5;
   const int mb = wave & 1, nb = (wave >> 1) & 1, xh = wave >> 2;
   const int KT = a.K / WN_KB;
-  const int tiles_w = (a.W / 2) / TC, tiles_h = (a.H / 2) / TR;
+  const int tiles_w = RAG ? ((a.W + 1) / 2 + TC - 1) / TC : (a.W / 2) / TC;
+  const int tiles_h = RAG ? ((a.H + 1) / 2 + TR - 1) / TR : (a.H / 2) / TR;
   const int ngroups = a.N * tiles_h * tiles_w * KT;
   const int nchunks = a.C / WN_CK;
 
@@ -209,7 +213,8 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
       int h_ = h_base_ + p_ / RW;                                                                                         \
       h_ = h_ < 0 ? 0 : (h_ >= a.H ? a.H - 1 : h_);                                                                       \
       int w_ = w_base_ + p_ % RW;                                                                                         \
-      w_ = w_ < 0 ? w_ + a.W : (w_ >= a.W ? w_ - a.W : w_);                                                               \
+      if (RAG) { w_ %= a.W; w_ = w_ < 0 ? w_ + a.W : w_; }       /* surplus columns of an overhanging group lie beyond 2W */ \
+      else w_ = w_ < 0 ? w_ + a.W : (w_ >= a.W ? w_ - a.W : w_);                                                           \
       raw_g[it] = (unsigned)((h_ * a.W + w_) * a.C + ((LN) & 1) * 4);                                                     \
     }                                                                                                                     \
   }
@@ -350,6 +355,7 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
       const int tr = tile / TC, tc = tile % TC;
       const int oh = (gh * TR + tr) * 2 + xh, ow = (gw * TC + tc) * 2 + q;
       ooff[it] = (unsigned)(((n * a.H + oh) * a.W + ow) * a.K + k0 + nb * 32 + c4 * 4);
+      if (RAG && (oh >= a.H || ow >= a.W)) ooff[it] = 0xffffffffu;       // a surplus pixel (offsets are below 2^31)
     }
     // The first operands of the NEXT group are requested now: raw(0), raw(1) into the raw buffers, U(0) into the upper (V, U) buffer --
     // none of them is touched by the epilogue below, whose duration covers their latency.
@@ -422,7 +428,7 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
       const bool has_op = f_dact || f_add;
       const float* op = f_dact ? a.dsrc : (f_add ? a.add : a.u);
 #pragma unroll
-      for (int it = 0; it < 8; ++it) opv[it] = *reinterpret_cast<const f32x4*>(op + (has_op ? ooff[it] : 0u));
+      for (int it = 0; it < 8; ++it) opv[it] = *reinterpret_cast<const f32x4*>(op + ((has_op && (!RAG || ooff[it] != 0xffffffffu)) ? ooff[it] : 0u));
     }
     if (more) {
       // the next group's operands have landed (the stores of this group are issued AFTER this wait, so they are never waited
@@ -437,6 +443,7 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int i = lane_e + it * 64, row = i >> 3, c4 = i & 7;
+      if (RAG && ooff[it] == 0xffffffffu) continue;
       f32x4 v = *reinterpret_cast<const f32x4*>(ep + row * ES + c4 * 4);
       if (f_add) v += f_dact ? *reinterpret_cast<const f32x4*>(a.add + ooff[it]) : opv[it];
       if (f_act) {
@@ -577,6 +584,10 @@ struct WWArgs {
 //   planes 3..6   || DMA of the patches of chunk ch+2; Dh(ch+1), Gh(ch+1) -> buf[nxt]
 //   wait + barrier E, then plane 7 || first fragments of chunk ch+1
 // Chunk indices beyond the slab are clamped (a harmless repeat of the last chunk: no branch in the loop body).
+// RAG: odd image sizes / tile rows that do not divide into chunks of 8 tiles -- the last chunk of a tile row hangs over the edge: the
+// output-gradient values of pixels outside the image are zeroed in the transform (their tiles then contribute nothing, whatever the
+// wrapped input patch holds), and an odd height masks the input row below the image as well.
+template <bool RAG>
 __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
   static_assert((2 * WW_BUF + WW_RAW + WW_GRAW) * 4 <= 163840, "LDS budget");
   __shared__ __attribute__((aligned(16))) float lds[2 * WW_BUF + WW_RAW + WW_GRAW];
@@ -591,7 +602,7 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
   const int ct = t % CT;
   const int kt = t / CT;
   const int k0 = kt * 64, c0 = ct * 64;
-  const int th = a.H / 2, tw8 = (a.W / 2) / 8;
+  const int th = RAG ? (a.H + 1) / 2 : a.H / 2, tw8 = RAG ? ((a.W + 1) / 2 + 7) / 8 : (a.W / 2) / 8;
   const int total_chunks = a.N * th * tw8;
   const int ch_begin = slab * a.chunks_per_slab;
   const int ch_end = min(ch_begin + a.chunks_per_slab, total_chunks);
@@ -628,12 +639,15 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
       int row = 2 * ta_ - 1 + dma_pi[it];                                                                                 \
       row = row < 0 ? 0 : (row >= a.H ? a.H - 1 : row);                                                                   \
       int col = 16 * b8_ - 1 + dma_pj[it];                                                                                \
-      col = col < 0 ? col + a.W : (col >= a.W ? col - a.W : col);                                                         \
+      if (RAG) { col %= a.W; col = col < 0 ? col + a.W : col; }                                                           \
+      else col = col < 0 ? col + a.W : (col >= a.W ? col - a.W : col);                                                    \
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xn_ + (row * a.W + col) * a.C),    \
                                        (__attribute__((address_space(3))) void*)(raw + dma_l[it]), 16, 0, 0);             \
     }                                                                                                                     \
     /* the output-gradient patch: wave w brings pixels 4w .. 4w+3 of the 2 x 16 (one 1 KiB piece; lane = pixel, channel quad) */ \
-    const float* gn_ = a.g + (((size_t)n_ * a.H + 2 * ta_ + g_p) * a.W + 16 * b8_ + g_px) * a.K + k0 + (lane & 15) * 4;   \
+    /* (pixels outside the image: a clamped, valid address -- the transform zeroes them) */                              \
+    const int grow_ = RAG ? min(2 * ta_ + g_p, a.H - 1) : 2 * ta_ + g_p, gcol_ = RAG ? min(16 * b8_ + g_px, a.W - 1) : 16 * b8_ + g_px; \
+    const float* gn_ = a.g + (((size_t)n_ * a.H + grow_) * a.W + gcol_) * a.K + k0 + (lane & 15) * 4;                     \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gn_,                                  \
                                      (__attribute__((address_space(3))) void*)(graw + wave * 256), 16, 0, 0);             \
   }
@@ -660,7 +674,7 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
   {                                                                                                                       \
     float tt_[4];                                                                                                         \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                                       \
-      const unsigned m_ = i == 0 ? mask_top : (i == 3 ? mask_bot : 0xffffffffu);                                          \
+      const unsigned m_ = i == 0 ? mask_top : (i == 3 ? mask_bot : (i == 2 ? mask_r2 : 0xffffffffu));                     \
       const float d0 = __uint_as_float(__float_as_uint(dd[E][2 * i]) & m_);                                               \
       const float d1 = __uint_as_float(__float_as_uint(dd[E][2 * i + 1]) & m_);                                           \
       tt_[i] = sg0 * d0 + sg1 * d1;                                                                                       \
@@ -672,6 +686,11 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
   const float ca = bcol == 3 ? 0.f : 1.f, cb = bcol == 0 ? 0.f : (bcol == 1 ? 1.f : -1.f);
 #define WW2_TG(E)                                                                                                         \
   {                                                                                                                       \
+    if (RAG) {                                   /* zero the gradient of pixels outside the image (wave-uniform conditions) */ \
+      const bool c0_ = (gmask >> (2 * (E))) & 1u, c1_ = (gmask >> (2 * (E) + 1)) & 1u, r1_ = mask_r2 != 0u;               \
+      gq[E][0][0] = c0_ ? gq[E][0][0] : 0.f; gq[E][0][1] = c1_ ? gq[E][0][1] : 0.f;                                       \
+      gq[E][1][0] = (c0_ && r1_) ? gq[E][1][0] : 0.f; gq[E][1][1] = (c1_ && r1_) ? gq[E][1][1] : 0.f;                     \
+    }                                                                                                                     \
     const float h0_ = ca * gq[E][0][0] + cb * gq[E][0][1], h1_ = ca * gq[E][1][0] + cb * gq[E][1][1];                     \
     vg[0][E] = h0_; vg[1][E] = h0_ + h1_; vg[2][E] = h0_ - h1_; vg[3][E] = -h1_;                                          \
   }
@@ -686,8 +705,21 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
   const int b_off = 16 * WW_PLANE + brow * 8 + ((half ^ ((brow >> 3) & 1)) * 4);
   f32x4 vv[4], vg[4];
   float dd[4][8], gq[4][2][2];
-  unsigned mask_top, mask_bot;
-#define WW2_MASKS(CH) { int n_, ta_, b8_; chunk_pos((CH), n_, ta_, b8_); mask_top = ta_ > 0 ? 0xffffffffu : 0u; mask_bot = ta_ < th - 1 ? 0xffffffffu : 0u; }
+  unsigned mask_top, mask_bot, mask_r2 = 0xffffffffu, gmask = 0xffu;
+  // rows 2ta-1 .. 2ta+2 of the input patch: the first may lie above the image, the last (and, for an odd height, the third) below it;
+  // gmask bit 2E+q: column 16 b8 + 2 (4 tq + E) + q of the output gradient lies inside the image
+#define WW2_MASKS(CH)                                                                                                     \
+  {                                                                                                                       \
+    int n_, ta_, b8_;                                                                                                     \
+    chunk_pos((CH), n_, ta_, b8_);                                                                                        \
+    mask_top = ta_ > 0 ? 0xffffffffu : 0u;                                                                                \
+    mask_bot = 2 * ta_ + 2 < a.H ? 0xffffffffu : 0u;                                                                      \
+    if (RAG) {                                                                                                            \
+      mask_r2 = 2 * ta_ + 1 < a.H ? 0xffffffffu : 0u;                                                                     \
+      gmask = 0u;                                                                                                         \
+      _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) gmask |= (16 * b8_ + 8 * tq + e_ < a.W) ? (1u << e_) : 0u;         \
+    }                                                                                                                     \
+  }
 
   // prologue: operands of the first chunk, then the raw patch / gradient values of the second
   WW2_DMA(ch_begin)
@@ -807,6 +839,20 @@ __global__ __launch_bounds__(256) void k_wino_wgrad_out(const float* __restrict_
   }
 }
 
+// CU count of the current device (the persistent grid's size), cached per device id
+#include <atomic>
+static int wn_cu_count() {
+  static std::atomic<int> cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  int cus = cache[dev].load(std::memory_order_relaxed);
+  if (cus <= 0) {
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    cache[dev].store(cus, std::memory_order_relaxed);
+  }
+  return cus;
+}
+
 static int ww_slabs(int total_chunks, int tiles) {
   int want = (256 + tiles - 1) / tiles;              // one 512-thread workgroup per CU
   if (want > total_chunks) want = total_chunks;
@@ -816,32 +862,34 @@ static int ww_slabs(int total_chunks, int tiles) {
 }
 
 static bool ww_supported(int N, int H, int W, int C, int K) {
-  return N > 0 && H > 0 && W > 0 && !(H & 1) && !(W & 1) && ((W / 2) % 8) == 0 && C % 64 == 0 && K % 64 == 0 &&
-         (size_t)N * H * W * (C > K ? C : K) < ((size_t)1 << 31);
+  return N > 0 && H > 0 && W >= 2 && C % 64 == 0 && K % 64 == 0 && (size_t)N * H * W * (C > K ? C : K) < ((size_t)1 << 31);
 }
+static bool ww_exact(int H, int W) { return !(H & 1) && !(W & 1) && ((W / 2) % 8) == 0; }
+static int ww_chunks(int N, int H, int W) { return N * ((H + 1) / 2) * (((W + 1) / 2 + 7) / 8); }
 
 /* see include/delora_hip.h */
 extern "C" size_t dl_wino_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K) {
   if (!ww_supported(N, H, W, C, K)) return 0;
   const int tiles = (K / 64) * (C / 64);
-  return ((size_t)ww_slabs(N * (H / 2) * ((W / 2) / 8), tiles) + 1) * 16 * K * C * sizeof(float);     // slab partials + their sum
+  return ((size_t)ww_slabs(ww_chunks(N, H, W), tiles) + 1) * 16 * K * C * sizeof(float);     // slab partials + their sum
 }
 
 extern "C" int dl_wino_wgrad3x3_nhwc_f32(const float* x, const float* g, float* dw, void* workspace, int32_t N, int32_t H,
                                          int32_t W, int32_t C, int32_t K, dl_stream stream) {
   if (!x || !g || !dw || !workspace) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wino_wgrad3x3_nhwc_f32: null pointer argument");
   if (!ww_supported(N, H, W, C, K))
-    return dl_fail(DL_ERR_UNSUPPORTED, "dl_wino_wgrad3x3_nhwc_f32: shape N=%d H=%d W=%d C=%d K=%d not supported (H even, W/2 %% 8, C, K %% 64)",
+    return dl_fail(DL_ERR_UNSUPPORTED, "dl_wino_wgrad3x3_nhwc_f32: shape N=%d H=%d W=%d C=%d K=%d not supported (C, K %% 64, < 2^31 elements)",
                    N, H, W, C, K);
   hipStream_t st = (hipStream_t)stream;
   float* ws = (float*)workspace;
   const int tiles = (K / 64) * (C / 64);
-  const int total_chunks = N * (H / 2) * ((W / 2) / 8);
+  const int total_chunks = ww_chunks(N, H, W);
   const int nslabs = ww_slabs(total_chunks, tiles);
   WWArgs a{x, g, ws, N, H, W, C, K, (total_chunks + nslabs - 1) / nslabs, nslabs};
-  const DlProfTag tag{"k_wino_wgrad", "wgrad", N, H, W, C, K, 3, 1, 1, 2.0 * 16.0 * (double)N * (H / 2) * (W / 2) * (double)C * K,
+  const DlProfTag tag{"k_wino_wgrad", "wgrad", N, H, W, C, K, 3, 1, 1, 2.0 * 16.0 * (double)N * ((H + 1) / 2) * ((W + 1) / 2) * (double)C * K,
                       4.0 * ((double)N * H * W * (C + K) + 9.0 * C * K)};
-  DL_LAUNCH(tag, k_wino_wgrad, dim3(tiles * nslabs), dim3(WW_THREADS), st, a);
+  if (ww_exact(H, W)) DL_LAUNCH(tag, k_wino_wgrad<false>, dim3(tiles * nslabs), dim3(WW_THREADS), st, a);
+  else DL_LAUNCH(tag, k_wino_wgrad<true>, dim3(tiles * nslabs), dim3(WW_THREADS), st, a);
   const size_t count4 = (size_t)16 * K * C / 4;
   float* usum = ws + (size_t)nslabs * 16 * K * C;
   hipLaunchKernelGGL(k_wino_wgrad_sum, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nslabs, count4, usum);
@@ -856,34 +904,46 @@ extern "C" int dl_wino_conv3x3_nhwc_f32(const float* x, const float* u, float* y
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wino_conv3x3_nhwc_f32: bad argument");
   if (((epilogue & WN_EPI_ADD) && !add) || ((epilogue & WN_EPI_DACT) && !dsrc) || act < 0 || act > 2)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wino_conv3x3_nhwc_f32: epilogue operand missing / bad activation");
-  if (C % WN_CK || K % WN_KB || (H & 1) || (W & 1) || (size_t)N * H * W * (C > K ? C : K) >= ((size_t)1 << 31))
-    return dl_fail(DL_ERR_UNSUPPORTED, "dl_wino_conv3x3_nhwc_f32: shape N=%d H=%d W=%d C=%d K=%d not supported", N, H, W, C, K);
+  if (C % WN_CK || K % WN_KB || (size_t)N * H * W * (C > K ? C : K) >= ((size_t)1 << 31))
+    return dl_fail(DL_ERR_UNSUPPORTED, "dl_wino_conv3x3_nhwc_f32: shape N=%d H=%d W=%d C=%d K=%d not supported (C %% 8, K %% 64, < 2^31 elements)", N, H, W, C, K);
   WinoArgs a{x, u, y, add, dsrc, N, H, W, C, K, act, epilogue};
   hipStream_t st = (hipStream_t)stream;
-  const int tw = W / 2, th = H / 2;
-  if (!((tw % 32 == 0 && th % 2 == 0) || (tw % 16 == 0 && th % 4 == 0)))
-    return dl_fail(DL_ERR_UNSUPPORTED, "dl_wino_conv3x3_nhwc_f32: image %dx%d does not tile (W/2 %% 16, rows)", H, W);
+  const int tw = (W + 1) / 2, th = (H + 1) / 2;                     // 2x2 output tiles (the last one of an odd row / column is partial)
   // what the algorithm asks of the matrix cores: 16 multiply-adds per 2x2 output tile and (c, k) pair (a direct convolution: 36)
   const DlProfTag tag{"k_wino_conv", "conv", N, H, W, C, K, 3, 1, 1, 2.0 * 16.0 * (double)N * th * tw * (double)C * K,
                       4.0 * ((double)N * H * W * (C + K) + 16.0 * C * K)};
-  // persistent workgroups: one per CU (a 512-thread workgroup with 162 KB of LDS fills a CU); the CU count is read once
-  static int cap = -1;
-  if (cap < 0) {
-    int dev = 0, cus = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    cap = cus;
+  // persistent workgroups: one per CU (a 512-thread workgroup with 162 KB of LDS fills a CU); the CU count is read once per device
+  int cap = wn_cu_count();
 #ifdef CV_TUNE
-    if (const char* e = getenv("DL_WN_GRID")) cap = atoi(e);
+  if (const char* e = getenv("DL_WN_GRID")) cap = atoi(e);
 #endif
-  }
-  if (tw % 32 == 0 && th % 2 == 0) {
-    int groups = N * (th / 2) * (tw / 32) * (K / WN_KB);
-    const dim3 grid(cap > 0 && groups > cap ? cap : groups);
-    DL_LAUNCH(tag, k_wino_conv<32>, grid, dim3(WN_THREADS), st, a);
+  // A workgroup takes 64 tiles as TR rows x TC columns.  Images that divide take 2 x 32 or 4 x 16 (the two shapes the network's
+  // BASELINE images need); every other image -- the reference's shipped 64x720 (feature maps 180 / 90 / 45 / 23 wide) and 64x512
+  // (layer4: 32x16) -- takes the shape that wastes the fewest tiles, with overhanging groups at the right / lower edge.
+  const bool even = !(H & 1) && !(W & 1);
+  if (even && tw % 32 == 0 && th % 2 == 0) {
+    const int groups = N * (th / 2) * (tw / 32) * (K / WN_KB);
+    DL_LAUNCH(tag, (k_wino_conv<32, false>), dim3(cap > 0 && groups > cap ? cap : groups), dim3(WN_THREADS), st, a);
+  } else if (even && tw % 16 == 0 && th % 4 == 0) {
+    const int groups = N * (th / 4) * (tw / 16) * (K / WN_KB);
+    DL_LAUNCH(tag, (k_wino_conv<16, false>), dim3(cap > 0 && groups > cap ? cap : groups), dim3(WN_THREADS), st, a);
   } else {
-    int groups = N * (th / 4) * (tw / 16) * (K / WN_KB);
+    int best_tc = 0;
+    long best_tiles = 0;
+    for (int tc = 32; tc >= 4; tc >>= 1) {
+      const int tr = WN_TILES / tc;
+      const long tiles = (long)((tw + tc - 1) / tc) * tc * (long)((th + tr - 1) / tr) * tr;
+      if (!best_tc || tiles < best_tiles) { best_tc = tc; best_tiles = tiles; }
+    }
+    const int tr = WN_TILES / best_tc;
+    const int groups = N * ((th + tr - 1) / tr) * ((tw + best_tc - 1) / best_tc) * (K / WN_KB);
     const dim3 grid(cap > 0 && groups > cap ? cap : groups);
-    DL_LAUNCH(tag, k_wino_conv<16>, grid, dim3(WN_THREADS), st, a);
+    switch (best_tc) {
+      case 32: DL_LAUNCH(tag, (k_wino_conv<32, true>), grid, dim3(WN_THREADS), st, a); break;
+      case 16: DL_LAUNCH(tag, (k_wino_conv<16, true>), grid, dim3(WN_THREADS), st, a); break;
+      case 8: DL_LAUNCH(tag, (k_wino_conv<8, true>), grid, dim3(WN_THREADS), st, a); break;
+      default: DL_LAUNCH(tag, (k_wino_conv<4, true>), grid, dim3(WN_THREADS), st, a); break;
+    }
   }
   return dl_check_launch("dl_wino_conv3x3_nhwc_f32");
 }

@@ -117,10 +117,24 @@ class ResNetModified(torch.nn.Module):
             w.data = w.data.contiguous(memory_format=torch.channels_last)
         return self
 
+    def _note_module_path(self, x):
+        """One line per (shape, dtype, mode) whenever a CUDA input takes the module path (library convolutions + ring ops) instead of
+        the HIP stem + trunk: a 5x slower path must not be taken silently (narrow test networks, dropout, widths not divisible by 4)."""
+        if not x.is_cuda or self.impl == "modules":
+            return
+        key = (tuple(x.shape), x.dtype, torch.is_autocast_enabled(), self.training and self.use_dropout)
+        seen = self.__dict__.setdefault("_module_path_noted", set())
+        if key not in seen:
+            seen.add(key)
+            why = ("dropout is active" if key[3] else "autocast shapes do not tile (csrc/convh.hip)" if key[2]
+                   else "channel counts are not multiples of 64, or the width is not a multiple of 4")
+            print(f"[delora_amd] CNN input {key[0]} {str(x.dtype).replace('torch.', '')} runs on the MODULE path (library convolutions), "
+                  f"not on the HIP stem + trunk: {why}", flush=True)
+
     def hip_path_takes(self, H, W, in_channels=8, batch=1):
         """Whether an ``[N,in_channels,H,W]`` fp32 CUDA input would run on the channels-last HIP stem + trunk (shape test
-        only: the image must tile, see ``ring_conv.supported`` / ``stem_supported``).  The reference's default KITTI image
-        (64 x 720: W/4 = 180 is not a multiple of 32) does NOT -- it takes the module path."""
+        only: ``ring_conv.supported`` / ``stem_supported``: full-width channel counts, a width divisible by 4).  True for BASELINE's
+        images and for the reference's shipped 64 x 720 and 64 x 512 (tiles hang over the edges of maps that do not divide)."""
         if self.impl == "modules" or W % 4:
             return False
         C0 = self.conv1.out_channels
@@ -183,6 +197,7 @@ class ResNetModified(torch.nn.Module):
             return [None, None, None, x4.permute(0, 3, 1, 2), out]
         if self.impl == "hip":
             raise RuntimeError(f"cnn_impl 'hip': the HIP trunk does not support input {tuple(x.shape)} / dtype {x.dtype}")
+        self._note_module_path(x)
         p1 = self.layer1(p)
         p2 = self.layer2(p1)
         p3 = self.dropout_channels(self.layer3(p2))

@@ -74,6 +74,12 @@ def grad_for(dw_krsc, w_param):
     return g
 
 
+def out_size(n, stride):
+    """Output extent of the reference's padded convolutions (3x3 with one pad pixel per side -- circular on the width, zeros on the
+    height -- or 1x1 unpadded; src/models/resnet_modified.py:97-102, :159-177): floor((n - 1) / stride) + 1 = ceil(n / stride)."""
+    return -(-int(n) // int(stride))
+
+
 def conv_nhwc(x, w_krsc, stride=(1, 1), act=0, epilogue=0, add=None, dsrc=None, transposed=False):
     """``y = epilogue(conv(x, w))`` on channels-last fp32 tensors.  x ``[N,H,W,C]``; w ``[K,k,k,C]`` (``transposed``: the
     forward weight ``[C,k,k,K]`` of the layer whose input gradient is computed, x then being the output gradient)."""
@@ -81,7 +87,7 @@ def conv_nhwc(x, w_krsc, stride=(1, 1), act=0, epilogue=0, add=None, dsrc=None, 
     N, H, W, C = x.shape
     ks = w_krsc.shape[1]
     K = w_krsc.shape[3] if transposed else w_krsc.shape[0]
-    y = _empty((N, H // stride[0], W // stride[1], K), torch.float32, x.device)
+    y = _empty((N, out_size(H, stride[0]), out_size(W, stride[1]), K), torch.float32, x.device)
     _lib.check(lib.dl_conv2d_nhwc_f32(_ptr(x), _ptr(w_krsc), _ptr(y), _ptr(add), _ptr(dsrc), N, H, W, C, K, ks, stride[0],
                                       stride[1], int(transposed), int(act), int(epilogue), _stream()), "dl_conv2d_nhwc_f32")
     return y
@@ -113,11 +119,9 @@ def wgrad_nhwc(x, g, ks, stride=(1, 1)):
 
 
 def wino_ok(H, W, C, K):
-    """Whether the fused Winograd F(2x2,3x3) kernel (csrc/wino.hip) takes a stride-1 3x3 layer of this shape."""
-    if H % 2 or W % 2 or C % 8 or K % 64:
-        return False
-    th, tw = H // 2, W // 2
-    return (tw % 32 == 0 and th % 2 == 0) or (tw % 16 == 0 and th % 4 == 0)
+    """Whether the fused Winograd F(2x2,3x3) kernel (csrc/wino.hip) takes a stride-1 3x3 layer of this shape: any image size (groups
+    of 64 tiles hang over the edge of images that do not divide; odd sizes end in partial tiles), channel counts that tile."""
+    return H >= 1 and W >= 1 and C % 8 == 0 and K % 64 == 0
 
 
 def wino_weights(w_param, want_fwd=True, want_bwd=True):
@@ -172,33 +176,31 @@ def wino_conv(x, u, K, act=0, epilogue=0, add=None, dsrc=None):
 
 
 def supported(x_shape, blocks):
-    """Whether the HIP trunk can run these shapes: channel counts multiples of 64, every feature-map width a multiple of
-    32 (and the rows a tile takes must divide the height) -- true for the reference's full-size network on 64/128-ring
-    images of 1024 or 2048 columns (BASELINE.json's configurations).  NOT true for the reference's default KITTI image of
-    720 columns (the pooled map is 180 wide) nor for 512 columns (layer4 would be 16 wide): those, and narrower test
-    networks, use the module path."""
+    """Whether the HIP trunk can run these shapes: channel counts multiples of 64.  The image size is free: tiles hang over the edge
+    of feature maps that do not divide, odd widths / heights included -- the reference's shipped 64x720 image (feature maps 180, 90,
+    45 and 23 pixels wide, config/config_datasets.yaml:21) and 64x512 (layer4: 32x16, :47) run here like BASELINE's 64x2048."""
     N, H, W, C = x_shape
-    if C % 64:
+    if C % 64 or H < 1 or W < 1:
         return False
     for (cin, cout, stride, _) in blocks:
-        if cin % 64 or cout % 64 or H % stride[0] or W % stride[1]:
+        if cin % 64 or cout % 64 or stride[0] not in (1, 2) or stride[1] not in (1, 2) or (stride[0] == 2 and stride[1] == 1):
             return False
-        H, W = H // stride[0], W // stride[1]
-        tw = 128 if W % 128 == 0 else (64 if W % 64 == 0 else (32 if W % 32 == 0 else 0))
-        if not tw or H % max(1, 128 // tw):                 # 128-pixel tiles are the fallback of every layer
-            return False
+        H, W = out_size(H, stride[0]), out_size(W, stride[1])
     return True
 
 
-def dgrad_strided(g, w_krsc, stride, act=0, epilogue=0, add_grid=None, dsrc=None, dense=False):
-    """Input gradient of a strided layer: g ``[N,Ho,Wo,K]`` with the layer's forward weight ``[K,k,k,C]`` ->
-    ``[N,Ho*sh,Wo*sw,C]`` (``dense``: the 1x1 layers' gradient kept on the grid ``[N,Ho,Wo,C]``)."""
+def dgrad_strided(g, w_krsc, stride, in_hw, act=0, epilogue=0, add_grid=None, dsrc=None, dense=False):
+    """Input gradient of a strided layer whose INPUT image is ``in_hw`` = (H, W): g ``[N,Ho,Wo,K]`` (Ho = ceil(H / sh), Wo = ceil(W /
+    sw)) with the layer's forward weight ``[K,k,k,C]`` -> ``[N,H,W,C]`` (``dense``: the 1x1 layers' gradient kept on the grid
+    ``[N,Ho,Wo,C]``)."""
     lib = _lib.load()
     N, Ho, Wo, K = g.shape
+    H, W = int(in_hw[0]), int(in_hw[1])
+    assert Ho == out_size(H, stride[0]) and Wo == out_size(W, stride[1]), (g.shape, in_hw, stride)
     ks, C = w_krsc.shape[1], w_krsc.shape[3]
-    shape = (N, Ho, Wo, C) if dense else (N, Ho * stride[0], Wo * stride[1], C)
+    shape = (N, Ho, Wo, C) if dense else (N, H, W, C)
     dx = _empty(shape, torch.float32, g.device)
-    _lib.check(lib.dl_conv2d_dgrad_strided_nhwc_f32(_ptr(g), _ptr(w_krsc), _ptr(dx), _ptr(add_grid), _ptr(dsrc), N, Ho, Wo, K, C, ks,
+    _lib.check(lib.dl_conv2d_dgrad_strided_nhwc_f32(_ptr(g), _ptr(w_krsc), _ptr(dx), _ptr(add_grid), _ptr(dsrc), N, H, W, K, C, ks,
                                                     stride[0], stride[1], int(dense), int(act), int(epilogue), _stream()),
                "dl_conv2d_dgrad_strided_nhwc_f32")
     return dx
@@ -245,9 +247,9 @@ class MeanHW(torch.autograd.Function):
 
 
 def stem_supported(x_shape, out_channels):
-    """Whether RingStem takes an input ``[N,C,H,W]``: 8 input channels per chunk, 64-channel output tiles, width 4 x 64."""
+    """Whether RingStem takes an input ``[N,C,H,W]``: 8 input channels per chunk, 64-channel output tiles, a width that halves twice."""
     N, C, H, W = x_shape
-    return C % 8 == 0 and C % 16 != 0 and out_channels % 64 == 0 and W % 256 == 0 and H % 2 == 0
+    return C % 8 == 0 and C % 16 != 0 and out_channels % 64 == 0 and W % 4 == 0 and W >= 4 and H >= 1
 
 
 class RingStem(torch.autograd.Function):
@@ -343,7 +345,7 @@ class RingSegment(torch.autograd.Function):
         plan, (N, H, W) = [], x0.shape[:3]
         for (cin, cout, stride, has_ds) in blocks:
             use1 = USE_WINOGRAD and stride == (1, 1) and wino_ok(H, W, cin, cout)
-            H, W = H // stride[0], W // stride[1]
+            H, W = out_size(H, stride[0]), out_size(W, stride[1])
             use2 = USE_WINOGRAD and wino_ok(H, W, cout, cout)
             plan.append((use1, use2))
         wlist, wj = [], 0
@@ -422,9 +424,9 @@ class RingSegment(torch.autograd.Function):
                 wdp = weights[wi + 2]
                 grads[wi + 2] = grad_for(wgrad_nhwc(x, g2, 1, stride=stride), wdp)
                 # down-sampling branch on the grid, then one pass per stride phase of the 3x3 layer with it and act'(x) fused
-                dxb = dgrad_strided(g2, weight_storage(wdp), stride, dense=True)
+                dxb = dgrad_strided(g2, weight_storage(wdp), stride, x.shape[1:3], dense=True)
                 epi = EPI_ADD_GRID if first else (EPI_ADD_GRID | EPI_DACT)
-                g2 = dgrad_strided(g1, weight_storage(w1p), stride, act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)
+                g2 = dgrad_strided(g1, weight_storage(w1p), stride, x.shape[1:3], act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)
         if BACKWARD_TRACE is not None:
             BACKWARD_TRACE.append(("segment", blocks[0][0], blocks[-1][1], nb))
         return (g2, None, None, None, None, *grads)

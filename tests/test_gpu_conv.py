@@ -34,6 +34,11 @@ SHAPES = [  # N, H, W, C, K, ks, stride
     (2, 8, 128, 64, 64, 3, (1, 1)), (1, 4, 64, 128, 128, 3, (1, 1)), (2, 8, 32, 64, 128, 3, (1, 1)),
     (1, 8, 256, 256, 64, 3, (1, 1)), (2, 8, 256, 64, 128, 3, (1, 2)), (1, 8, 128, 64, 64, 3, (2, 2)),
     (2, 8, 128, 64, 128, 1, (1, 2)), (1, 8, 128, 64, 64, 1, (2, 2)),
+    # images that do not divide into tiles (round 4): the feature maps of the reference's shipped 64x720 image are 180, 90, 45 and 23
+    # pixels wide, layer4 of 64x512 is 32x16; odd widths / heights end in partial tiles, strides round the output size up
+    (2, 8, 180, 64, 64, 3, (1, 1)), (1, 6, 90, 64, 128, 3, (1, 1)), (2, 5, 45, 64, 64, 3, (1, 1)), (1, 7, 23, 128, 64, 3, (1, 1)),
+    (2, 8, 180, 64, 128, 3, (1, 2)), (1, 8, 90, 128, 64, 3, (1, 2)), (2, 8, 45, 64, 128, 3, (2, 2)), (1, 7, 45, 64, 64, 3, (1, 2)),
+    (2, 8, 45, 64, 128, 1, (2, 2)), (1, 5, 90, 64, 64, 1, (1, 2)), (1, 16, 16, 64, 64, 3, (1, 1)), (1, 3, 24, 64, 64, 3, (2, 2)),
 ]
 
 
@@ -72,9 +77,29 @@ def test_conv_forward_and_both_gradients_against_torch(shape):
         dx2 = rc.conv_nhwc(gy_nhwc, w_krsc, act=rc.ACT["tanh"], epilogue=rc.EPI_ADD | rc.EPI_DACT, add=extra, dsrc=ysave, transposed=True)
         ref = (xr.grad.permute(0, 2, 3, 1) + extra) * (1 - ysave * ysave)
         util.measured(f"{tag}: fused (dgrad + g) * tanh' vs torch (relative)", _rel(dx2, ref), bound=TIGHT)
+    if stride != (1, 1):
+        # strided layers: one pass per stride phase (and, for an odd width, the two seam terms), plain and with the 1x1 branch's
+        # gradient added on the grid and the activation derivative fused
+        dense = ks == 1
+        dx = rc.dgrad_strided(gy_nhwc, w_krsc, stride, (H, W), dense=dense)
+        ref_dx = xr.grad.permute(0, 2, 3, 1)
+        if dense:
+            ref_dx = ref_dx[:, ::stride[0], ::stride[1]]
+        util.measured(f"{tag}: strided input gradient vs torch autograd (relative)", _rel(dx, ref_dx), bound=TIGHT)
+        if not dense:
+            addg = torch.randn((N, y.shape[1], y.shape[2], C), generator=g).to(dev)
+            ysave = torch.tanh(torch.randn(x_nhwc.shape, generator=g)).to(dev)
+            dx2 = rc.dgrad_strided(gy_nhwc, w_krsc, stride, (H, W), act=rc.ACT["tanh"], epilogue=rc.EPI_ADD_GRID | rc.EPI_DACT, add_grid=addg, dsrc=ysave)
+            full = torch.zeros_like(ref_dx)
+            full[:, ::stride[0], ::stride[1]] = addg
+            util.measured(f"{tag}: fused (strided dgrad + grid gradient) * tanh' vs torch (relative)",
+                          _rel(dx2, (ref_dx + full) * (1 - ysave * ysave)), bound=TIGHT)
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 128, 64, 64), (1, 4, 64, 128, 128), (2, 8, 32, 64, 128), (1, 8, 256, 64, 64), (1, 32, 64, 512, 512)])
+@pytest.mark.parametrize("shape", [(2, 8, 128, 64, 64), (1, 4, 64, 128, 128), (2, 8, 32, 64, 128), (1, 8, 256, 64, 64), (1, 32, 64, 512, 512),
+                                   # overhanging tile groups and partial tiles (64x720: 180 / 90 / 45 / 23 wide; 64x512: layer4 32x16)
+                                   (2, 64, 180, 64, 64), (1, 64, 90, 128, 128), (2, 64, 45, 64, 64), (1, 32, 23, 128, 64), (1, 32, 16, 64, 64),
+                                   (1, 7, 5, 64, 64), (1, 1, 2, 64, 64)])
 def test_winograd_forward_and_input_gradient_against_torch(shape):
     """Fused Winograd F(2x2,3x3) (csrc/wino.hip) against torch's direct convolution of the wrapped image: forward with the
     fused shortcut + tanh, input gradient with the fused activation derivative; all three tile layouts."""
@@ -108,46 +133,57 @@ def test_winograd_forward_and_input_gradient_against_torch(shape):
     util.measured(f"{tag}: Winograd vs the direct MFMA kernel (relative)", _rel(y, y_direct), bound=TIGHT)
 
 
-def test_conv_rejects_shapes_that_do_not_tile():
+def test_conv_rejects_channel_counts_that_do_not_tile():
+    """Image sizes are free since round 4 (tiles hang over the edges); channel counts must still be multiples of the 64-channel
+    output block / 8-channel reduction chunk -- narrower test networks take the module path."""
     from delora_amd import _lib
     from delora_amd.models import ring_conv as rc
     dev = _dev()
-    x = torch.zeros((1, 4, 24, 64), device=dev)          # width 24: no 32-pixel tile
-    w = torch.zeros((64, 3, 3, 64), device=dev)
+    x = torch.zeros((1, 4, 24, 64), device=dev)
     with pytest.raises(_lib.DeloraHipError):
-        rc.conv_nhwc(x, w)
-    assert not rc.supported((1, 4, 24, 64), ((64, 64, (1, 1), False),))
+        rc.conv_nhwc(x, torch.zeros((48, 3, 3, 64), device=dev))          # 48 output channels
+    with pytest.raises(_lib.DeloraHipError):
+        rc.conv_nhwc(torch.zeros((1, 4, 24, 60), device=dev), torch.zeros((64, 3, 3, 60), device=dev))
+    assert rc.supported((1, 4, 24, 64), ((64, 64, (1, 1), False),)) and rc.supported((8, 64, 180, 64), ((64, 128, (1, 2), True),))
+    assert not rc.supported((1, 4, 24, 32), ((32, 32, (1, 1), False),))
 
 
-@pytest.mark.parametrize("act,wino", [("tanh", True), ("tanh", False), ("relu", True)])
-def test_hip_trunk_matches_module_path(act, wino, monkeypatch):
-    """The full-width network (64..512 channels) on a 16x1024 pair: the channels-last HIP trunk against the module path
-    (library convolutions + ring ops) with the same weights -- poses, and the gradient of EVERY parameter."""
+@pytest.mark.parametrize("act,wino,size", [("tanh", True, (16, 1024)), ("tanh", False, (16, 1024)), ("relu", True, (16, 1024)),
+                                           # the reference's shipped image sizes (config/config_datasets.yaml:21, :47) and odd ones
+                                           ("tanh", True, (64, 720)), ("tanh", False, (64, 720)), ("tanh", True, (64, 512)),
+                                           ("relu", True, (18, 360)), ("tanh", True, (7, 100))])
+def test_hip_trunk_matches_module_path(act, wino, size, monkeypatch):
+    """The full-width network (64..512 channels) on a 16x1024 pair -- and on the reference's shipped 64x720 / 64x512 images, whose
+    feature maps do not divide into tiles (720: 180, 90, 45, 23 wide: odd widths, a stride-2 layer on an odd width) -- : the
+    channels-last HIP stem + trunk against the module path (library convolutions + ring ops) with the same weights: poses, and the
+    gradient of EVERY parameter."""
     from delora_amd.models import ring_conv
     from delora_amd.models.model import OdometryModel
     dev = _dev()
     monkeypatch.setattr(ring_conv, "USE_WINOGRAD", wino)
-    cfg = util.repo_config(16, 1024, device="cuda:0", activation_fct=act)
+    cfg = util.repo_config(size[0], size[1], device="cuda:0", activation_fct=act)
     torch.manual_seed(5)
     m_hip = OdometryModel(dict(cfg, cnn_impl="hip")).to(dev)
+    assert m_hip.resnet.hip_path_takes(size[0], size[1], batch=2)
     m_hip.resnet.trunk_weights_channels_last()
     m_mod = OdometryModel(dict(cfg, cnn_impl="modules")).to(dev)
     m_mod.load_state_dict(m_hip.state_dict())
-    x = torch.randn((2, 8, 16, 1024), device=dev)
+    x = torch.randn((2, 8, size[0], size[1]), device=dev)
     out = []
     for m in (m_hip, m_mod):
         t, q = m(x)
         (t.square().sum() + (q * torch.arange(1, 5, device=dev)).sum()).backward()
         out.append((t.detach(), q.detach()))
-    util.measured(f"trunk[{act}{',winograd' if wino else ',direct'}]: translation hip vs modules (relative)", _rel(out[0][0], out[1][0]), bound=1e-5)       # measured 4-8e-7
-    util.measured(f"trunk[{act}{',winograd' if wino else ',direct'}]: quaternion hip vs modules (relative)", _rel(out[0][1], out[1][1]), bound=1e-5)
+    tagn = f"trunk[{act}{',winograd' if wino else ',direct'}{'' if size == (16, 1024) else ',%dx%d' % size}]"
+    util.measured(f"{tagn}: translation hip vs modules (relative)", _rel(out[0][0], out[1][0]), bound=1e-5)       # measured 4-8e-7
+    util.measured(f"{tagn}: quaternion hip vs modules (relative)", _rel(out[0][1], out[1][1]), bound=1e-5)
     worst, name = 0.0, ""
     for (k, p), (_, p2) in zip(m_hip.named_parameters(), m_mod.named_parameters()):
         assert p.grad is not None and p.grad.shape == p.shape, k
         e = float((p.grad - p2.grad).norm() / p2.grad.norm().clamp_min(1e-30))
         if e > worst:
             worst, name = e, k
-    util.measured(f"trunk[{act}{',winograd' if wino else ',direct'}]: worst relative parameter-gradient difference hip vs modules ({name})", worst, bound=(5e-5 if act == "tanh" else 1e-5))   # measured 4-7e-6 (tanh), 8e-7 (relu: no mask flips on this seeded input; one flipped mask would show as ~1e-4)
+    util.measured(f"{tagn}: worst relative parameter-gradient difference hip vs modules ({name})", worst, bound=(5e-5 if act == "tanh" else 1e-5))   # measured 4-7e-6 (tanh), 8e-7 (relu: no mask flips on this seeded input; one flipped mask would show as ~1e-4)
     assert m_hip.resnet.layer1[0].conv1.weight.grad.stride() == m_hip.resnet.layer1[0].conv1.weight.stride()
 
 
@@ -190,14 +226,14 @@ def test_stem_pooling_kernels_against_torch(act):
                   float((gc.permute(0, 3, 1, 2) - pre.grad).abs().max()), bound=2e-6)
 
 
-@pytest.mark.parametrize("act", ["tanh", "relu"])
-def test_stem_function_against_torch(act):
+@pytest.mark.parametrize("act,size", [("tanh", (16, 1024)), ("relu", (16, 1024)), ("tanh", (16, 720)), ("relu", (9, 100))])
+def test_stem_function_against_torch(act, size):
     """RingStem (transposing copy + MFMA conv1 with the activation in the epilogue + pooling; backward: pooling gather +
     weight gradient) against F.pad(circular) + conv2d + act + F.pad(circular) + max_pool2d under torch autograd."""
     from delora_amd.models import ring_conv as rc
     dev = _dev()
     g = torch.Generator(device="cpu").manual_seed(9)
-    x = (torch.randn((2, 8, 16, 1024), generator=g) * 3.0).to(dev)
+    x = (torch.randn((2, 8, size[0], size[1]), generator=g) * 3.0).to(dev)
     w1 = (torch.randn((64, 8, 3, 3), generator=g) * 0.05).to(dev).requires_grad_(True)
     assert rc.stem_supported(tuple(x.shape), 64)
     y = rc.RingStem.apply(x, w1, rc.ACT[act])                                            # [N,H,W/4,64]
@@ -208,12 +244,12 @@ def test_stem_function_against_torch(act):
     xr = x.clone().requires_grad_(True)
     y_ref = _ref_stem(xr, w1, act)
     y_ref.backward(gy.permute(0, 3, 1, 2))
-    util.measured(f"stem[{act}]: pooled output vs torch (absolute)", float((y.permute(0, 3, 1, 2) - y_ref.detach()).abs().max()), bound=2e-5)
-    util.measured(f"stem[{act}]: conv1 weight gradient vs torch autograd (relative)", _rel(dw, w1.grad), bound=TIGHT)     # measured 3-8e-7 (relu: no mask flips on this seeded input)
+    util.measured(f"stem[{act},{size[0]}x{size[1]}]: pooled output vs torch (absolute)", float((y.permute(0, 3, 1, 2) - y_ref.detach()).abs().max()), bound=2e-5)
+    util.measured(f"stem[{act},{size[0]}x{size[1]}]: conv1 weight gradient vs torch autograd (relative)", _rel(dw, w1.grad), bound=TIGHT)     # measured 3-8e-7 (relu: no mask flips on this seeded input)
     # and the input gradient (not needed by the training step: the image carries none)
     x2 = x.clone().requires_grad_(True)
     rc.RingStem.apply(x2, w1, rc.ACT[act]).backward(gy)
-    util.measured(f"stem[{act}]: input gradient vs torch autograd (relative)", _rel(x2.grad, xr.grad), bound=TIGHT)     # measured 3-8e-7 (relu: no mask flips on this seeded input)
+    util.measured(f"stem[{act},{size[0]}x{size[1]}]: input gradient vs torch autograd (relative)", _rel(x2.grad, xr.grad), bound=TIGHT)     # measured 3-8e-7 (relu: no mask flips on this seeded input)
 
 
 def test_mean_hw_kernel_against_torch():
@@ -232,7 +268,7 @@ def test_mean_hw_kernel_against_torch():
     assert torch.allclose(gx, x.grad, rtol=0, atol=1e-9)
 
 
-@pytest.mark.parametrize("shape", [(2, 8, 64, 128, 128), (1, 4, 32, 256, 64)])
+@pytest.mark.parametrize("shape", [(2, 8, 64, 128, 128), (1, 4, 32, 256, 64), (2, 8, 90, 128, 128), (1, 7, 45, 128, 64), (1, 32, 23, 128, 128), (1, 3, 16, 128, 64)])
 def test_winograd_domain_weight_gradient_against_the_direct_kernel_and_torch(shape, monkeypatch):
     """dl_wino_wgrad3x3_nhwc_f32 (weight gradient accumulated in the Winograd domain, csrc/wino.hip) against this library's direct
     kernel and torch autograd on the same data, incl. image rows at the zero-padded border and the wrap-around columns."""

@@ -570,14 +570,17 @@ def test_loss_weight_matrix_and_epoch_accumulation():
 
 def test_hip_trunk_shape_gate_decides_the_weight_layout():
     """`ResNetModified.hip_path_takes` is the shape test the Deployer uses before it stores the trunk's weights channels-last
-    (the layout the HIP kernels read in place): the reference's default KITTI image (64 x 720, config/deployment_options.yaml)
-    does not tile and must keep the module path with NCHW weights; BASELINE.json's image sizes take the HIP path."""
+    (the layout the HIP kernels read in place).  Since round 4 the image size is free (tiles hang over the edges of feature maps
+    that do not divide): BASELINE.json's sizes AND the reference's shipped 64 x 720 / 64 x 512 (config/config_datasets.yaml:21, :47)
+    take the HIP path; only a width that does not halve twice (the stem's two stride-2 stages) and narrow networks do not."""
     from delora_amd.models.model import OdometryModel
     cfg = util.repo_config(64, 2048)
     model = OdometryModel(cfg)
     takes = model.resnet.hip_path_takes
     assert takes(64, 2048) and takes(64, 1024) and takes(128, 2048)
-    assert not takes(64, 720) and not takes(64, 722)
+    assert takes(64, 720) and takes(64, 512) and takes(16, 100) and not takes(64, 722) and not takes(64, 721)
+    narrow = OdometryModel(util.repo_config(64, 720, factor_fewer_resnet_channels=8, resnet_outputs=64))
+    assert not narrow.resnet.hip_path_takes(64, 720)
     cfg_m = util.repo_config(64, 2048)
     cfg_m["cnn_impl"] = "modules"
     assert not OdometryModel(cfg_m).resnet.hip_path_takes(64, 2048)

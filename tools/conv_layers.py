@@ -51,8 +51,8 @@ for name, h, w, c, k, st in layers:
             ws, wd = rc.weight_storage(wt), (torch.randn((k, 1, 1, c), device=dev) * 0.05)
             run(name + " forward 3x3", lambda: rc.conv_nhwc(x, ws, stride=st, act=1, epilogue=rc.EPI_ACT))
             run(name + " forward 1x1", lambda: rc.conv_nhwc(x, wd, stride=st))
-            run(name + " input gradient 1x1", lambda: rc.dgrad_strided(g, wd, st, dense=True))
-            run(name + " input gradient 3x3", lambda: rc.dgrad_strided(g, ws, st, act=1, epilogue=rc.EPI_DACT, dsrc=gi))
+            run(name + " input gradient 1x1", lambda: rc.dgrad_strided(g, wd, st, (h, w), dense=True))
+            run(name + " input gradient 3x3", lambda: rc.dgrad_strided(g, ws, st, (h, w), act=1, epilogue=rc.EPI_DACT, dsrc=gi))
             run(name + " weight gradient 3x3", lambda: rc.wgrad_nhwc(x, g, 3, stride=st))
             run(name + " weight gradient 1x1", lambda: rc.wgrad_nhwc(x, g, 1, stride=st))
     else:
