@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdelora_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class DeloraHipError(RuntimeError):
@@ -57,7 +57,7 @@ SIGNATURES = {
     "dl_ring_act_pool_pad_bwd_t": (_i32, [_vp, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     "dl_conv2d_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _u32, _vp]),
     "dl_conv2d_dgrad_strided_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
-                                                _u32, _vp]),
+                                                _u32, _vp, _vp]),
     "dl_conv2d_wgrad_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "dl_conv2d_wgrad_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dl_wino_weights_floats": (_sz, [_i32, _i32]),
@@ -77,7 +77,7 @@ SIGNATURES = {
     "dl_conv_weights_batch_h": (_i32, [_vp, _i32, _i32, _vp]),
     "dl_conv2d_nhwc_h": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _u32, _vp]),
     "dl_conv2d_dgrad_strided_nhwc_h": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
-                                              _u32, _vp]),
+                                              _u32, _vp, _vp]),
     "dl_cast_f32_to_h": (_i32, [_vp, _vp, _i64, _i32, _vp]),
     "dl_mean_hw_nhwc_h": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "dl_mean_hw_bwd_act_h": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),

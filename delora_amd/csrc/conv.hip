@@ -53,6 +53,7 @@ struct ConvArgs {
   unsigned epi;
   int Hout, Wout;      // dimensions of the tensor y is written into: Ho x Wo, or the full-resolution image a stride phase scatters into
   int wrap;            // 1: columns outside [0, W) wrap around (the ring); 0: they read zeros (stride phases of an odd-width image)
+  const float* seam;   // [N][Hout][2][K] or null: added to the pixels of column 0 / Wout-1 (the seam terms of an odd-width image)
 };
 
 __device__ __forceinline__ float cv_act(float v, int act) {
@@ -309,6 +310,10 @@ __global__ __launch_bounds__(CV_THREADS, CV_MINWAVES) void k_conv_f32(ConvArgs a
       if (ho0 + th >= a.Ho || wo0 + tw >= a.Wo || oh >= a.Hout || ow >= a.Wout) continue;      // surplus pixel of an overhanging tile
       const size_t o = (out_n + (size_t)oh * a.Wout + ow) * a.K + k0 + wn * EPW + c4 * 4;
       float4 v = *reinterpret_cast<const float4*>(ep + row * ES + c4 * 4);
+      if (a.seam && (ow == 0 || ow == a.Wout - 1)) {      // odd image width: the two terms that cross the seam (k_dgrad_oddw_seam)
+        const float4 t = *reinterpret_cast<const float4*>(a.seam + (((size_t)n * a.Hout + oh) * 2 + (ow != 0)) * a.K + k0 + wn * EPW + c4 * 4);
+        v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+      }
       if (f_addg) {        // an addend that lives on the dense (sub-sampled) grid: the down-sampling branch's gradient
         const float4 t = *reinterpret_cast<const float4*>(a.add + (grid_n + (size_t)(ho0 + th) * a.Wo + (wo0 + tw)) * a.K + k0 + wn * EPW + c4 * 4);
         v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
@@ -609,22 +614,22 @@ static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
 // Wrap-around terms of a stride-2-in-width layer's input gradient when the image width W is ODD (the reference's 64x720 image:
 // layer4's input is 45 pixels wide).  Column 2 wo + s - 1 of the circularly padded image is column (2 wo + s - 1) mod W; for even W
 // the wrap maps stride phases onto themselves (the phase kernels wrap the gradient grid), for odd W it does not: the phases then read
-// zeros outside the grid, and the two terms that cross the seam are added here,
+// zeros outside the grid, and the two terms that cross the seam,
 //     dx[h][0]     += sum_r sum_k g[ho][Wo-1][k] w[k][r][2][c]        (tap s = 2 of the last output column reads column W = 0)
 //     dx[h][W - 1] += sum_r sum_k g[ho][0][k]    w[k][r][0][c]        (tap s = 0 of the first output column reads column -1 = W-1)
-// with h = SH ho + r - 1, times act'(dsrc) when the phases applied it (the epilogue is linear in the convolution term).
+// with h = SH ho + r - 1, are computed here into seam[n][h][side][c] (fp32) BEFORE the phase kernels run; the phase that owns
+// columns 0 and W-1 adds them on its accumulators in front of its epilogue (one rounding, no read-modify-write of dx).
 // One workgroup = FX_ROWS consecutive rows h of one image and one of the two columns; thread = channel c.  ~0.2 GFLOP per launch.
 #define FX_ROWS 16
 #define FX_KC 64
-__global__ __launch_bounds__(CV_THREADS) void k_dgrad_oddw_fix(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ dx,
-                                                               const float* __restrict__ dsrc, int N, int Ho, int Wo, int K, int C, int H,
-                                                               int W, int SH, int act, int f_dact) {
+__global__ __launch_bounds__(CV_THREADS) void k_dgrad_oddw_seam(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ seam,
+                                                                int N, int Ho, int Wo, int K, int C, int H, int SH) {
   constexpr int GROWS = FX_ROWS + 2;                   // grid rows a tile of FX_ROWS image rows can reach (SH = 1), + one row of zeros
   __shared__ float gs[(GROWS + 1) * FX_KC];            // g[ho_lo + i][the column][k chunk]; row GROWS = zeros
   const int side = blockIdx.y;                         // 0: image column 0 (tap s = 2, grid column Wo-1); 1: column W-1 (s = 0, grid column 0)
   const int row_tiles = (H + FX_ROWS - 1) / FX_ROWS;
   const int n = blockIdx.x / row_tiles, h0 = (blockIdx.x % row_tiles) * FX_ROWS;
-  const int s = side ? 0 : 2, wo = side ? 0 : Wo - 1, col = side ? W - 1 : 0;
+  const int s = side ? 0 : 2, wo = side ? 0 : Wo - 1;
   const int ho_lo = h0 > 0 ? (h0 - 1) / SH : 0;        // first grid row that reaches row h0 (h = SH ho + r - 1 with r <= 2)
   // LDS row of the grid row that tap r contributes to image row h0 + i from (GROWS: none)
   int src[FX_ROWS][3];
@@ -664,15 +669,8 @@ __global__ __launch_bounds__(CV_THREADS) void k_dgrad_oddw_fix(const float* __re
     }
     if (c < C) {
 #pragma unroll
-      for (int i = 0; i < FX_ROWS; ++i) {
-        const int h = h0 + i;
-        if (h < H) {
-          const size_t o = (((size_t)n * H + h) * W + col) * C + c;
-          float v = acc[i];
-          if (f_dact) v *= cv_dact(dsrc[o], act);
-          dx[o] += v;
-        }
-      }
+      for (int i = 0; i < FX_ROWS; ++i)
+        if (h0 + i < H) seam[(((size_t)n * H + h0 + i) * 2 + side) * C + c] = acc[i];
     }
   }
 }
@@ -692,7 +690,7 @@ extern "C" int dl_conv2d_nhwc_f32(const float* x, const float* w, float* y, cons
   // output size of the reference's padded convolution (circular pad 1 on W, zero pad 1 on H, kernel 3; or kernel 1 unpadded):
   // floor((X - 1) / stride) + 1 = ceil(X / stride)
   const int Ho = (H + stride_h - 1) / stride_h, Wo = (W + stride_w - 1) / stride_w;
-  ConvArgs a{x, w, y, add, dsrc, N, H, W, C, K, Ho, Wo, act, epilogue, Ho, Wo, 1};
+  ConvArgs a{x, w, y, add, dsrc, N, H, W, C, K, Ho, Wo, act, epilogue, Ho, Wo, 1, nullptr};
   hipStream_t st = (hipStream_t)stream;
   int rc = 1;
   if (ksize == 3 && stride_h == 1 && stride_w == 1)
@@ -722,7 +720,7 @@ static int dgrad_phase(ConvArgs a, bool first_phase, hipStream_t st) {
 extern "C" int dl_conv2d_dgrad_strided_nhwc_f32(const float* g, const float* w, float* dx, const float* add_grid, const float* dsrc,
                                                 int32_t N, int32_t H, int32_t W, int32_t K, int32_t C, int32_t ksize,
                                                 int32_t stride_h, int32_t stride_w, int32_t dense, int32_t act,
-                                                uint32_t epilogue, dl_stream stream) {
+                                                uint32_t epilogue, float* seam_ws, dl_stream stream) {
   if (!g || !w || !dx || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_dgrad_strided_nhwc_f32: bad argument");
   if (((epilogue & CV_EPI_ADD_GRID) && !add_grid) || ((epilogue & CV_EPI_DACT) && !dsrc) || act < 0 || act > 2 ||
@@ -735,9 +733,16 @@ extern "C" int dl_conv2d_dgrad_strided_nhwc_f32(const float* g, const float* w, 
     return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_dgrad_strided_nhwc_f32: tensors beyond 2^31 elements are not supported");
   // in the kernel's terms: input = g (K channels, the reduction), output channels = C.  The stride phases of an image whose width is
   // odd do not close under the wrap-around: they read zeros beside the grid and k_dgrad_oddw_fix adds the two seam terms.
-  const bool odd_w = stride_w == 2 && (W & 1) && ksize == 3;
-  ConvArgs a{g, w, dx, add_grid, dsrc, N, Ho, Wo, K, C, Ho, Wo, act, epilogue, dense ? Ho : H, dense ? Wo : W, odd_w ? 0 : 1};
+  const bool odd_w = stride_w == 2 && (W & 1) && ksize == 3 && !dense && W >= 3;
+  if (odd_w && !seam_ws)
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_dgrad_strided_nhwc_f32: an odd image width (%d) needs seam_ws (N*H*2*C floats)", W);
+  ConvArgs a{g, w, dx, add_grid, dsrc, N, Ho, Wo, K, C, Ho, Wo, act, epilogue, dense ? Ho : H, dense ? Wo : W, odd_w ? 0 : 1,
+             odd_w ? seam_ws : nullptr};
   hipStream_t st = (hipStream_t)stream;
+  if (odd_w) {
+    const int row_tiles = (H + FX_ROWS - 1) / FX_ROWS;
+    hipLaunchKernelGGL(k_dgrad_oddw_seam, dim3(N * row_tiles, 2), dim3(CV_THREADS), 0, st, g, w, seam_ws, N, Ho, Wo, K, C, H, stride_h);
+  }
   int rc = 1;
   if (dense) {                                        // 1x1 layer: only phase (0,0) is non-zero; result kept on the grid
     if (ksize == 1 && stride_h == 1 && stride_w == 2) rc = dispatch_conv<GeomDgrad<1, 1, 2, 0, 0, false>, true, false>(a, st);
@@ -752,11 +757,6 @@ extern "C" int dl_conv2d_dgrad_strided_nhwc_f32(const float* g, const float* w, 
     return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_dgrad_strided_nhwc_f32: kernel %d stride (%d,%d) is not built", ksize, stride_h, stride_w);
   }
   if (rc) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_dgrad_strided_nhwc_f32: shape N=%d H=%d W=%d K=%d C=%d does not tile (K, C %% 64)", N, H, W, K, C);
-  if (odd_w && !dense) {
-    const int row_tiles = (H + FX_ROWS - 1) / FX_ROWS;
-    hipLaunchKernelGGL(k_dgrad_oddw_fix, dim3(N * row_tiles, 2), dim3(CV_THREADS), 0, st, g, w, dx, dsrc, N, Ho, Wo, K, C, H, W, stride_h, act,
-                       (int)((epilogue & CV_EPI_DACT) != 0));
-  }
   return dl_check_launch("dl_conv2d_dgrad_strided_nhwc_f32");
 }
 

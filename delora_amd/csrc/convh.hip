@@ -39,6 +39,9 @@ struct ConvHArgs {
   int N, H, W, C, K, Ho, Wo;
   int act;
   unsigned epi;
+  int Hout, Wout;    // dimensions of the tensor y is written into: Ho x Wo, or the full-resolution image a stride phase scatters into
+  int wrap;          // 1: columns outside [0, W) wrap around; 0: they read zeros (stride phases of an odd-width image)
+  const float* seam; // fp32 [N][Hout][2][K] or null: added to the pixels of column 0 / Wout-1 (the seam terms of an odd-width image)
 };
 
 // BM = TH x TW output pixels, BN output channels, WGM x WGN waves (each (BM/WGM) x (BN/WGN)), G the geometry policy,
@@ -72,7 +75,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
   const int li = lane & 31, half = lane >> 5;
   const int wm = wave / WGN, wn = wave % WGN;
   const int KT = a.K / BN;
-  const int tiles_w = a.Wo / TW, tiles_h = a.Ho / TH;
+  // images that do not divide into tiles: the last tile of a row / column hangs over the edge -- its surplus pixels compute on wrapped
+  // (valid) addresses and are not stored
+  const int tiles_w = (a.Wo + TW - 1) / TW, tiles_h = (a.Ho + TH - 1) / TH;
   const int ntiles = a.N * tiles_h * tiles_w * KT;
   const int t = ch_xcd_swizzle(blockIdx.x, ntiles);
   const int kt = t % KT;
@@ -98,8 +103,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
     const int col = colp * SW + phase;
     const int h = h_base + row;
     int w = w_base + col;
-    w = w < 0 ? w + a.W : (w >= a.W ? w - a.W : w);
-    const bool ok = j < NII && rp < NPL && col < RW && h >= 0 && h < a.H;
+    const bool col_in = w >= 0 && w < a.W;
+    w %= a.W;                                        // (a full modulo: the surplus columns of an overhanging tile lie beyond 2W)
+    w = w < 0 ? w + a.W : w;
+    const bool ok = j < NII && rp < NPL && col < RW && h >= 0 && h < a.H && (a.wrap || col_in);
     in_off[it] = ok ? ((h * a.W + w) * a.C + ((sslot ^ ((colp >> 2) & 3)) * 8)) * 2 : -1;
     in_l[it] = j * 1024;
   }
@@ -144,7 +151,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   // rows outside the image are never written by the DMA: zero both input buffers once if this tile touches the border
-  if (h_base < 0 || h_base + RH > a.H) {
+  if (h_base < 0 || h_base + RH > a.H || !a.wrap) {
     for (int i = tid * 16; i < 2 * IN_BYTES; i += 64 * NWV * 16) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
     __syncthreads();
   }
@@ -205,7 +212,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
   // transposes its 32-pixel slabs through its own LDS region (fp32) so that a lane owns EIGHT consecutive channels of one
   // pixel: fp32 tail arithmetic, 16-byte loads of the half-precision shortcut / saved activation, 16-byte stores.
   float* ep = reinterpret_cast<float*>(lds) + wave * (32 * ES);
-  const size_t out_n = (size_t)n * (a.Ho * G::OSH) * (a.Wo * G::OSW), grid_n = (size_t)n * a.Ho * a.Wo;
+  const size_t out_n = (size_t)n * a.Hout * a.Wout, grid_n = (size_t)n * a.Ho * a.Wo;
   const bool f_add = a.epi & CH_EPI_ADD, f_act = a.epi & CH_EPI_ACT, f_dact = a.epi & CH_EPI_DACT, f_addg = a.epi & CH_EPI_ADD_GRID;
   constexpr int C8 = WN * 4;                              // 8-channel groups per pixel row of the wave's slab
 #pragma unroll
@@ -220,12 +227,20 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
       const int p = (wm * WM + mi) * 32 + row;
       const int th = p / TW, tw = p % TW;
       const size_t ch_o = (size_t)k0 + wn * (WN * 32) + c8 * 8;
-      const size_t o = (out_n + (size_t)((ho0 + th) * G::OSH + G::OPH) * (a.Wo * G::OSW) + ((wo0 + tw) * G::OSW + G::OPW)) * a.K + ch_o;
+      const int oh = (ho0 + th) * G::OSH + G::OPH, ow = (wo0 + tw) * G::OSW + G::OPW;
+      if (ho0 + th >= a.Ho || wo0 + tw >= a.Wo || oh >= a.Hout || ow >= a.Wout) continue;      // surplus pixel of an overhanging tile
+      const size_t o = (out_n + (size_t)oh * a.Wout + ow) * a.K + ch_o;
       float v[8];
       {
         const f32x4 lo = *reinterpret_cast<const f32x4*>(ep + row * ES + c8 * 8), hi = *reinterpret_cast<const f32x4*>(ep + row * ES + c8 * 8 + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) { v[e] = lo[e]; v[4 + e] = hi[e]; }
+      }
+      if (a.seam && (ow == 0 || ow == a.Wout - 1)) {      // odd image width: the two terms that cross the seam (k_dgrad_oddw_seam_h)
+        const float* sp = a.seam + (((size_t)n * a.Hout + oh) * 2 + (ow != 0)) * a.K + ch_o;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(sp), hi = *reinterpret_cast<const f32x4*>(sp + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[e] += lo[e]; v[4 + e] += hi[e]; }
       }
       if (f_addg) {
         const u16x8 tv = *reinterpret_cast<const u16x8*>(a.add + (grid_n + (size_t)(ho0 + th) * a.Wo + (wo0 + tw)) * a.K + ch_o);
@@ -416,11 +431,17 @@ __global__ __launch_bounds__(256) void k_mean_bwd_act_h(const float* __restrict_
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
 
+// share of an Ho x Wo image in the pixels its TH x TW tiles cover (tiles hang over the right / lower edge)
+static double ch_eff(int Ho, int Wo, int TH, int TW) {
+  return ((double)Ho * Wo) / ((double)((Ho + TH - 1) / TH) * TH * (double)((Wo + TW - 1) / TW) * TW);
+}
+
+// launches unless the channels do not tile or the tile shape wastes more than 10 % more of the image than the best shape does
 template <bool F16, int BM, int BN, int WGM, int WGN, int TW, class G, int NG>
-static int launch_convh(const ConvHArgs& a, hipStream_t st) {
+static int launch_convh(const ConvHArgs& a, hipStream_t st, double best_eff = 0.0) {
   constexpr int TH = BM / TW;
-  if (a.Wo % TW || a.Ho % TH || a.K % BN || a.C % 32) return 1;
-  const int ntiles = a.N * (a.Ho / TH) * (a.Wo / TW) * (a.K / BN);
+  if (a.K % BN || a.C % 32 || ch_eff(a.Ho, a.Wo, TH, TW) < 0.9 * best_eff) return 1;
+  const int ntiles = a.N * ((a.Ho + TH - 1) / TH) * ((a.Wo + TW - 1) / TW) * (a.K / BN);
   const double px_ = (double)a.N * a.Ho * a.Wo;
   const DlProfTag tag{"k_convh", std::is_same<G, GeomConv<3, 1, 1>>::value ? "fwd" : (G::ISH * G::ISW > 1 || G::WTAPS == 1 ? "fwd-strided" : "dgrad"),
                       a.N, a.H, a.W, a.C, a.K, G::WTAPS == 9 ? 3 : 1, G::ISH * G::OSH, G::ISW * G::OSW, 2.0 * px_ * a.K * a.C * G::NT, 2.0 * ((double)a.N * a.H * a.W * a.C + px_ * a.K + (double)G::NT * a.K * a.C)};
@@ -455,18 +476,24 @@ static int dispatch_convh(const ConvHArgs& a, hipStream_t st) {
 #endif
     // Tile choice (tools/convh_harness tune, batch 8): up to 128 reduction channels the layer is as much an HBM stream as a GEMM
     // -- 256 pixels x 64 channels, 8 waves, two workgroups per CU (layer1 31 us against 40 with 512 x 64, layer2 46 / 48); from
-    // 256 channels on 512 x 128 while that still gives every CU a workgroup (layer3), else 256 x 128 (layer4).
-    if (a.C <= 128 && !launch_convh<F16, 256, 64, 4, 2, 64, G, NG>(a, st)) return 0;
-    if (a.K % 128 == 0 && pixels / 512 * (a.K / 128) >= 256 && !launch_convh<F16, 512, 128, 4, 2, 64, G, NG>(a, st)) return 0;
-    if (a.K % 128 == 0 && !launch_convh<F16, 256, 128, 4, 2, 64, G, NG>(a, st)) return 0;
-    if (pixels / 512 >= 256 && !launch_convh<F16, 512, 64, 8, 1, 64, G, NG>(a, st)) return 0;
-    if (!launch_convh<F16, 256, 64, 4, 2, 64, G, NG>(a, st)) return 0;
+    // 256 channels on 512 x 128 while that still gives every CU a workgroup (layer3), else 256 x 128 (layer4).  Images that do not
+    // divide (64x720: feature maps 180 / 90 / 45 / 23 wide) skip the shapes that would waste much more of the image than the best one.
+    const double e1 = ch_eff(a.Ho, a.Wo, 8, 64), e2 = ch_eff(a.Ho, a.Wo, 4, 64), e3 = ch_eff(a.Ho, a.Wo, 4, 32);
+    const double best = e1 > e2 ? (e1 > e3 ? e1 : e3) : (e2 > e3 ? e2 : e3);
+    if (a.C <= 128 && !launch_convh<F16, 256, 64, 4, 2, 64, G, NG>(a, st, best)) return 0;
+    if (a.K % 128 == 0 && pixels / 512 * (a.K / 128) >= 256 && !launch_convh<F16, 512, 128, 4, 2, 64, G, NG>(a, st, best)) return 0;
+    if (a.K % 128 == 0 && !launch_convh<F16, 256, 128, 4, 2, 64, G, NG>(a, st, best)) return 0;
+    if (pixels / 512 >= 256 && !launch_convh<F16, 512, 64, 8, 1, 64, G, NG>(a, st, best)) return 0;
+    if (!launch_convh<F16, 256, 64, 4, 2, 64, G, NG>(a, st, best)) return 0;
+    if (a.K % 128 == 0 && !launch_convh<F16, 128, 128, 2, 2, 32, G, NG>(a, st, best)) return 0;
     if (!launch_convh<F16, 128, 64, 2, 2, 32, G, NG>(a, st)) return 0;
     return 1;
   } else {
     // strided layers, their input-gradient phases, 1x1 layers: 128-pixel tiles (the strided input tile is 2-4x the output tile)
-    if (a.K % 128 == 0 && !launch_convh<F16, 128, 128, 2, 2, 64, G, NG>(a, st)) return 0;
-    if (!launch_convh<F16, 128, 64, 2, 2, 64, G, NG>(a, st)) return 0;
+    const double e1 = ch_eff(a.Ho, a.Wo, 2, 64), e2 = ch_eff(a.Ho, a.Wo, 4, 32);
+    const double best = e1 > e2 ? e1 : e2;
+    if (a.K % 128 == 0 && !launch_convh<F16, 128, 128, 2, 2, 64, G, NG>(a, st, best)) return 0;
+    if (!launch_convh<F16, 128, 64, 2, 2, 64, G, NG>(a, st, best)) return 0;
     if (a.K % 128 == 0 && !launch_convh<F16, 128, 128, 2, 2, 32, G, NG>(a, st)) return 0;
     if (!launch_convh<F16, 128, 64, 2, 2, 32, G, NG>(a, st)) return 0;
     return 1;
@@ -503,15 +530,15 @@ extern "C" int dl_conv2d_nhwc_h(const void* x, const void* w, void* y, const voi
   const int rc0 = convh_check(x, w, y, add, dsrc, N, H, W, C, K, ksize, stride_h, stride_w, dtype, act, epilogue,
                               CH_EPI_ADD | CH_EPI_ACT | CH_EPI_DACT, "dl_conv2d_nhwc_h");
   if (rc0) return rc0;
-  if (H % stride_h || W % stride_w) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_h: image size must be a multiple of the stride");
   if ((size_t)N * H * W * C >= ((size_t)1 << 30) || (size_t)N * H * W * K >= ((size_t)1 << 30))
     return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_h: tensors beyond 2^30 elements are not supported (split the batch)");
-  ConvHArgs a{(const u16*)x, (const u16*)w, (u16*)y, (const u16*)add, (const u16*)dsrc, N, H, W, C, K, H / stride_h, W / stride_w, act, epilogue};
+  const int Ho = (H + stride_h - 1) / stride_h, Wo = (W + stride_w - 1) / stride_w;        // ceil: the reference's padded convolution
+  ConvHArgs a{(const u16*)x, (const u16*)w, (u16*)y, (const u16*)add, (const u16*)dsrc, N, H, W, C, K, Ho, Wo, act, epilogue, Ho, Wo, 1, nullptr};
   hipStream_t st = (hipStream_t)stream;
   const int rc = dtype == DL_DTYPE_F16 ? conv2d_h<true>(a, ksize, stride_h, stride_w, transposed, st)
                                        : conv2d_h<false>(a, ksize, stride_h, stride_w, transposed, st);
   if (rc == 2) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_h: kernel %d stride (%d,%d) transposed %d is not built", ksize, stride_h, stride_w, transposed);
-  if (rc) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_h: shape N=%d H=%d W=%d C=%d K=%d does not tile (Wo %% 32, K %% 64, C %% 32)", N, H, W, C, K);
+  if (rc) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_nhwc_h: shape N=%d H=%d W=%d C=%d K=%d does not tile (K %% 64, C %% 32)", N, H, W, C, K);
   return dl_check_launch("dl_conv2d_nhwc_h");
 }
 
@@ -537,23 +564,91 @@ static int dgrad_strided_h(const ConvHArgs& a, int ksize, int sh, int sw, int de
   return 2;
 }
 
+// The two seam terms of a stride-2-in-width layer's input gradient on an ODD image width (see k_dgrad_oddw_seam in conv.hip), from
+// half-precision operands: w = w_bwd [tap][C][K] of the layer; fp32 sums into seam[n][h][side][c], which the phase that owns columns
+// 0 and W-1 adds on its accumulators (so every element of dx is still rounded exactly once).
+#define FXH_ROWS 16
+#define FXH_KC 64
+template <bool F16>
+__global__ __launch_bounds__(256) void k_dgrad_oddw_seam_h(const u16* __restrict__ g, const u16* __restrict__ w, float* __restrict__ seam,
+                                                           int N, int Ho, int Wo, int K, int C, int H, int SH) {
+  constexpr int GROWS = FXH_ROWS + 2;
+  __shared__ float gs[(GROWS + 1) * FXH_KC];
+  const int side = blockIdx.y;
+  const int row_tiles = (H + FXH_ROWS - 1) / FXH_ROWS;
+  const int n = blockIdx.x / row_tiles, h0 = (blockIdx.x % row_tiles) * FXH_ROWS;
+  const int s_tap = side ? 0 : 2, wo = side ? 0 : Wo - 1;
+  const int ho_lo = h0 > 0 ? (h0 - 1) / SH : 0;
+  int src[FXH_ROWS][3];
+#pragma unroll
+  for (int i = 0; i < FXH_ROWS; ++i)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      const int t = h0 + i + 1 - r;
+      const int ho = t / SH;
+      const bool ok = t >= 0 && t % SH == 0 && ho < Ho && ho - ho_lo >= 0 && ho - ho_lo < GROWS;
+      src[i][r] = (ok ? ho - ho_lo : GROWS) * FXH_KC;
+    }
+  for (int q = threadIdx.x; q < FXH_KC; q += 256) gs[GROWS * FXH_KC + q] = 0.f;
+  for (int cb = 0; cb < C; cb += 256) {
+    const int c = cb + threadIdx.x;
+    const int cc = c < C ? c : C - 1;
+    float acc[FXH_ROWS];
+#pragma unroll
+    for (int i = 0; i < FXH_ROWS; ++i) acc[i] = 0.f;
+    for (int k0 = 0; k0 < K; k0 += FXH_KC) {
+      __syncthreads();
+      for (int q = threadIdx.x; q < GROWS * FXH_KC; q += 256) {
+        const int i = q / FXH_KC, kk = q % FXH_KC, ho = ho_lo + i;
+        gs[q] = (ho < Ho && k0 + kk < K) ? ch_h2f<F16>(g[(((size_t)n * Ho + ho) * Wo + wo) * K + k0 + kk]) : 0.f;
+      }
+      __syncthreads();
+      const int kn = K - k0 < FXH_KC ? K - k0 : FXH_KC;
+      for (int kk = 0; kk < kn; ++kk) {
+        float wv[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) wv[r] = ch_h2f<F16>(w[((size_t)(r * 3 + s_tap) * C + cc) * K + k0 + kk]);
+#pragma unroll
+        for (int i = 0; i < FXH_ROWS; ++i)
+#pragma unroll
+          for (int r = 0; r < 3; ++r) acc[i] = fmaf(gs[src[i][r] + kk], wv[r], acc[i]);
+      }
+    }
+    if (c < C) {
+#pragma unroll
+      for (int i = 0; i < FXH_ROWS; ++i)
+        if (h0 + i < H) seam[(((size_t)n * H + h0 + i) * 2 + side) * C + c] = acc[i];
+    }
+  }
+}
+
 /* see include/delora_hip.h */
 extern "C" int dl_conv2d_dgrad_strided_nhwc_h(const void* g, const void* w, void* dx, const void* add_grid, const void* dsrc, int32_t N,
-                                              int32_t Ho, int32_t Wo, int32_t K, int32_t C, int32_t ksize, int32_t stride_h,
+                                              int32_t H, int32_t W, int32_t K, int32_t C, int32_t ksize, int32_t stride_h,
                                               int32_t stride_w, int32_t dense, int32_t dtype, int32_t act, uint32_t epilogue,
-                                              dl_stream stream) {
-  const int rc0 = convh_check(g, w, dx, add_grid, dsrc, N, Ho, Wo, C, K, ksize, stride_h, stride_w, dtype, act, epilogue,
+                                              float* seam_ws, dl_stream stream) {
+  const int rc0 = convh_check(g, w, dx, add_grid, dsrc, N, H, W, C, K, ksize, stride_h, stride_w, dtype, act, epilogue,
                               CH_EPI_ADD_GRID | CH_EPI_DACT, "dl_conv2d_dgrad_strided_nhwc_h");
   if (rc0) return rc0;
-  if ((size_t)N * Ho * stride_h * Wo * stride_w * C >= ((size_t)1 << 30) || (size_t)N * Ho * Wo * K >= ((size_t)1 << 30))
+  const int Ho = (H + stride_h - 1) / stride_h, Wo = (W + stride_w - 1) / stride_w;      // the layer's output grid (= g)
+  if ((size_t)N * H * W * C >= ((size_t)1 << 30) || (size_t)N * Ho * Wo * K >= ((size_t)1 << 30))
     return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_dgrad_strided_nhwc_h: tensors beyond 2^30 elements are not supported");
   // in the kernel's terms: input = g (K channels, the reduction), output channels = C
-  ConvHArgs a{(const u16*)g, (const u16*)w, (u16*)dx, (const u16*)add_grid, (const u16*)dsrc, N, Ho, Wo, K, C, Ho, Wo, act, epilogue};
+  const bool odd_w = stride_w == 2 && (W & 1) && ksize == 3 && !dense && W >= 3;
+  if (odd_w && !seam_ws)
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_dgrad_strided_nhwc_h: an odd image width (%d) needs seam_ws (N*H*2*C floats)", W);
+  ConvHArgs a{(const u16*)g, (const u16*)w, (u16*)dx, (const u16*)add_grid, (const u16*)dsrc, N, Ho, Wo, K, C, Ho, Wo, act, epilogue,
+              dense ? Ho : H, dense ? Wo : W, odd_w ? 0 : 1, odd_w ? seam_ws : nullptr};
   hipStream_t st = (hipStream_t)stream;
+  if (odd_w) {
+    const dim3 grid(N * ((H + FXH_ROWS - 1) / FXH_ROWS), 2);
+    if (dtype == DL_DTYPE_F16) hipLaunchKernelGGL(k_dgrad_oddw_seam_h<true>, grid, dim3(256), 0, st, (const u16*)g, (const u16*)w, seam_ws, N, Ho, Wo, K, C, H, stride_h);
+    else hipLaunchKernelGGL(k_dgrad_oddw_seam_h<false>, grid, dim3(256), 0, st, (const u16*)g, (const u16*)w, seam_ws, N, Ho, Wo, K, C, H, stride_h);
+  }
   const int rc = dtype == DL_DTYPE_F16 ? dgrad_strided_h<true>(a, ksize, stride_h, stride_w, dense, st)
                                        : dgrad_strided_h<false>(a, ksize, stride_h, stride_w, dense, st);
   if (rc == 2) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_dgrad_strided_nhwc_h: kernel %d stride (%d,%d) dense %d is not built", ksize, stride_h, stride_w, dense);
-  if (rc) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_dgrad_strided_nhwc_h: shape N=%d Ho=%d Wo=%d K=%d C=%d does not tile", N, Ho, Wo, K, C);
+  if (rc) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_dgrad_strided_nhwc_h: shape N=%d H=%d W=%d K=%d C=%d does not tile (K, C %% 64)", N, H, W, K, C);
   return dl_check_launch("dl_conv2d_dgrad_strided_nhwc_h");
 }
 

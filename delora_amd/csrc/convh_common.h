@@ -31,9 +31,9 @@ __device__ __forceinline__ u16 ch_f2h(float f) {      // round to nearest even
   if constexpr (F16) return __builtin_bit_cast(u16, (_Float16)f);
   else return __builtin_bit_cast(u16, (__bf16)f);
 }
-// tanh for a result that is rounded to 8 / 11 significant bits: 1 - 2 / (exp(2x) + 1) with the hardware exp2 / rcp
-// (relative error ~1e-6; exp overflow gives 1 - 0, underflow 1 - 2)
-__device__ __forceinline__ float ch_tanh(float x) { return 1.f - 2.f * __builtin_amdgcn_rcpf(__expf(2.f * x) + 1.f); }
+// tanh of the half-precision epilogues: the fp32 kernels' dl_tanh (common.h: <= 2 ulp everywhere; the one-formula form
+// 1 - 2 / (exp(2x) + 1) cancels for small |x| -- an ABSOLUTE error of ~1e-7, i.e. above fp16's 2^-12 relative rounding below |x| ~ 5e-4)
+__device__ __forceinline__ float ch_tanh(float x) { return dl_tanh(x); }
 __device__ __forceinline__ float ch_act(float v, int act) {
   if (act == 1) return ch_tanh(v);
   if (act == 2) return v < 0.f ? 0.f : v;

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64 * (BMK / 32) * 2, 2) void k_wgradh(WgradHArgs a)
   const int kt = t % KT; t /= KT;
   const int slab = t;
   const int k0 = kt * BMK, c0 = ct * BNC;
-  const int cols = a.Wo / PK, rows = a.Ho / PR;
+  const int cols = (a.Wo + PK - 1) / PK, rows = (a.Ho + PR - 1) / PR;       // the last chunk of a row / column may hang over the edge
   const int total_chunks = a.N * rows * cols;
   const int ch_begin = slab * a.chunks_per_slab;
   const int ch_end = min(ch_begin + a.chunks_per_slab, total_chunks);
@@ -121,12 +121,15 @@ __global__ __launch_bounds__(64 * (BMK / 32) * 2, 2) void k_wgradh(WgradHArgs a)
     const int lb_ = (BUFSEL) * BUF;                                                                                   \
     _Pragma("unroll") for (int it = 0; it < NGI_W; ++it) if (g_pix[it] >= 0) {                                        \
       const int pr_ = g_pix[it] / PK, pc_ = g_pix[it] % PK;                                                           \
-      CH_GLDS(gn_ + ((size_t)(ho0_ + pr_) * a.Wo + wo0_ + pc_) * a.K + g_ch[it], lb_ + (wave + it * NWV) * 1024);    \
+      /* output pixels beyond the image contribute nothing: their gradient is read from the page of zeros */           \
+      const char* gsrc_ = (ho0_ + pr_ < a.Ho && wo0_ + pc_ < a.Wo)                                                    \
+          ? reinterpret_cast<const char*>(gn_ + ((size_t)(ho0_ + pr_) * a.Wo + wo0_ + pc_) * a.K + g_ch[it]) : zero;  \
+      CH_GLDS(gsrc_, lb_ + (wave + it * NWV) * 1024);                                                                 \
     }                                                                                                                 \
     _Pragma("unroll") for (int it = 0; it < NXI_W; ++it) if (x_row[it] >= 0) {                                        \
       const int h_ = ho0_ * SH - PAD + x_row[it];                                                                     \
-      int w_ = wo0_ * SW - PAD + x_col[it];                                                                           \
-      w_ = w_ < 0 ? w_ + a.W : (w_ >= a.W ? w_ - a.W : w_);                                                           \
+      int w_ = (wo0_ * SW - PAD + x_col[it]) % a.W;                                                                   \
+      w_ = w_ < 0 ? w_ + a.W : w_;                                                                                    \
       const char* src_ = (h_ >= 0 && h_ < a.H) ? reinterpret_cast<const char*>(xn_ + ((size_t)h_ * a.W + w_) * a.C + x_ch[it]) : zero; \
       CH_GLDS(src_, lb_ + G_BYTES + (wave + it * NWV) * 1024);                                                        \
     }                                                                                                                 \
@@ -230,15 +233,15 @@ struct WgradHPlan {
 // (their input window is twice / four times as large)
 static bool wgradh_plan(int N, int H, int W, int C, int K, int ks, int sh, int sw, WgradHPlan* p) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || (ks != 1 && ks != 3) || (sh != 1 && sh != 2) || (sw != 1 && sw != 2)) return false;
-  if (H % sh || W % sw || C % 64 || K % 64) return false;
-  const int Ho = H / sh, Wo = W / sw;
+  if (C % 64 || K % 64) return false;
+  const int Ho = (H + sh - 1) / sh, Wo = (W + sw - 1) / sw;
   p->pr = 2;
   p->bmk = K % 128 == 0 ? 128 : 64;
-  // 64-channel tiles run 4 waves per workgroup: the short chunk keeps two workgroups resident per CU
-  p->pk = (sh == 1 && sw == 1 && Wo % 64 == 0 && p->bmk == 128) ? 64 : 32;
-  if (Ho % p->pr || Wo % p->pk) return false;
+  // 64-channel tiles run 4 waves per workgroup: the short chunk keeps two workgroups resident per CU.  Rows that do not divide into
+  // chunks end in an overhanging chunk: 64-pixel chunks only where they waste no more of the row than 32-pixel ones
+  p->pk = (sh == 1 && sw == 1 && p->bmk == 128 && (Wo + 63) / 64 * 64 == (Wo + 31) / 32 * 32) ? 64 : 32;
   p->tiles = (K / p->bmk) * (C / 64);
-  p->total_chunks = N * (Ho / p->pr) * (Wo / p->pk);
+  p->total_chunks = N * ((Ho + p->pr - 1) / p->pr) * ((Wo + p->pk - 1) / p->pk);
   int want = (g_wh_want + p->tiles - 1) / p->tiles;
   if (want > p->total_chunks) want = p->total_chunks;
   if (want < 1) want = 1;
@@ -291,12 +294,13 @@ extern "C" int dl_conv2d_wgrad_nhwc_h(const void* x, const void* g, float* dw, v
   if (dtype != DL_DTYPE_F16 && dtype != DL_DTYPE_BF16) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_wgrad_nhwc_h: dtype must be DL_DTYPE_F16 or DL_DTYPE_BF16");
   WgradHPlan p;
   if (!wgradh_plan(N, H, W, C, K, ksize, stride_h, stride_w, &p))
-    return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_wgrad_nhwc_h: N=%d H=%d W=%d C=%d K=%d kernel %d stride (%d,%d) is not supported (C, K %% 64; Ho even; Wo %% 32)",
+    return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_wgrad_nhwc_h: N=%d H=%d W=%d C=%d K=%d kernel %d stride (%d,%d) is not supported (C, K %% 64)",
                    N, H, W, C, K, ksize, stride_h, stride_w);
-  if ((size_t)N * H * W * C >= ((size_t)1 << 30) || (size_t)N * (H / stride_h) * (W / stride_w) * K >= ((size_t)1 << 30))
+  const int Ho = (H + stride_h - 1) / stride_h, Wo = (W + stride_w - 1) / stride_w;
+  if ((size_t)N * H * W * C >= ((size_t)1 << 30) || (size_t)N * Ho * Wo * K >= ((size_t)1 << 30))
     return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_wgrad_nhwc_h: tensors beyond 2^30 elements are not supported");
   hipStream_t st = (hipStream_t)stream;
-  WgradHArgs a{(const u16*)x, (const u16*)g, (float*)workspace, N, H, W, C, K, H / stride_h, W / stride_w, p.chunks_per_slab, p.nslabs};
+  WgradHArgs a{(const u16*)x, (const u16*)g, (float*)workspace, N, H, W, C, K, Ho, Wo, p.chunks_per_slab, p.nslabs};
   const int rc = dtype == DL_DTYPE_F16 ? wgradh_dispatch<true>(a, p, ksize, stride_h, stride_w, st)
                                        : wgradh_dispatch<false>(a, p, ksize, stride_h, stride_w, st);
   if (rc) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_wgrad_nhwc_h: no kernel for this shape");

@@ -189,6 +189,14 @@ def supported(x_shape, blocks):
     return True
 
 
+def _seam_workspace(N, H, W, C, ks, stride, dense, device):
+    """fp32 ``[N,H,2,C]`` scratch for the two seam terms of a stride-2-in-width 3x3 layer on an ODD image width (the stride phases do
+    not close under the wrap-around there; csrc/conv.hip: k_dgrad_oddw_seam), else None."""
+    if ks == 3 and stride[1] == 2 and W % 2 == 1 and W >= 3 and not dense:
+        return torch.empty((N, H, 2, C), dtype=torch.float32, device=device)
+    return None
+
+
 def dgrad_strided(g, w_krsc, stride, in_hw, act=0, epilogue=0, add_grid=None, dsrc=None, dense=False):
     """Input gradient of a strided layer whose INPUT image is ``in_hw`` = (H, W): g ``[N,Ho,Wo,K]`` (Ho = ceil(H / sh), Wo = ceil(W /
     sw)) with the layer's forward weight ``[K,k,k,C]`` -> ``[N,H,W,C]`` (``dense``: the 1x1 layers' gradient kept on the grid
@@ -200,8 +208,9 @@ def dgrad_strided(g, w_krsc, stride, in_hw, act=0, epilogue=0, add_grid=None, ds
     ks, C = w_krsc.shape[1], w_krsc.shape[3]
     shape = (N, Ho, Wo, C) if dense else (N, H, W, C)
     dx = _empty(shape, torch.float32, g.device)
+    seam = _seam_workspace(N, H, W, C, ks, stride, dense, g.device)
     _lib.check(lib.dl_conv2d_dgrad_strided_nhwc_f32(_ptr(g), _ptr(w_krsc), _ptr(dx), _ptr(add_grid), _ptr(dsrc), N, H, W, K, C, ks,
-                                                    stride[0], stride[1], int(dense), int(act), int(epilogue), _stream()),
+                                                    stride[0], stride[1], int(dense), int(act), int(epilogue), _ptr(seam), _stream()),
                "dl_conv2d_dgrad_strided_nhwc_f32")
     return dx
 
@@ -504,21 +513,25 @@ def conv_nhwc_h(x, w_prepared, ks, stride=(1, 1), act=0, epilogue=0, add=None, d
     lib = _lib.load()
     N, H, W, C = x.shape
     K = w_prepared.shape[1]
-    y = torch.empty((N, H // stride[0], W // stride[1], K), dtype=x.dtype, device=x.device)
+    y = torch.empty((N, out_size(H, stride[0]), out_size(W, stride[1]), K), dtype=x.dtype, device=x.device)
     _lib.check(lib.dl_conv2d_nhwc_h(_ptr(x), _ptr(w_prepared), _ptr(y), _ptr(add), _ptr(dsrc), N, H, W, C, K, ks, stride[0], stride[1],
                                     int(transposed), DTYPE_CODE[x.dtype], int(act), int(epilogue), _stream()), "dl_conv2d_nhwc_h")
     return y
 
 
-def dgrad_strided_h(g, w_bwd, ks, stride, act=0, epilogue=0, add_grid=None, dsrc=None, dense=False):
-    """Input gradient of a strided layer from its half-precision output gradient ``[N,Ho,Wo,K]`` and ``w_bwd [k*k,C,K]``."""
+def dgrad_strided_h(g, w_bwd, ks, stride, in_hw, act=0, epilogue=0, add_grid=None, dsrc=None, dense=False):
+    """Input gradient of a strided layer whose INPUT image is ``in_hw`` = (H, W), from its half-precision output gradient
+    ``[N,Ho,Wo,K]`` (Ho = ceil(H / sh), Wo = ceil(W / sw)) and ``w_bwd [k*k,C,K]`` -> ``[N,H,W,C]`` (``dense``: ``[N,Ho,Wo,C]``)."""
     lib = _lib.load()
     N, Ho, Wo, K = g.shape
+    H, W = int(in_hw[0]), int(in_hw[1])
+    assert Ho == out_size(H, stride[0]) and Wo == out_size(W, stride[1]), (g.shape, in_hw, stride)
     C = w_bwd.shape[1]
-    shape = (N, Ho, Wo, C) if dense else (N, Ho * stride[0], Wo * stride[1], C)
+    shape = (N, Ho, Wo, C) if dense else (N, H, W, C)
     dx = torch.empty(shape, dtype=g.dtype, device=g.device)
-    _lib.check(lib.dl_conv2d_dgrad_strided_nhwc_h(_ptr(g), _ptr(w_bwd), _ptr(dx), _ptr(add_grid), _ptr(dsrc), N, Ho, Wo, K, C, ks, stride[0],
-                                                  stride[1], int(dense), DTYPE_CODE[g.dtype], int(act), int(epilogue), _stream()),
+    seam = _seam_workspace(N, H, W, C, ks, stride, dense, g.device)
+    _lib.check(lib.dl_conv2d_dgrad_strided_nhwc_h(_ptr(g), _ptr(w_bwd), _ptr(dx), _ptr(add_grid), _ptr(dsrc), N, H, W, K, C, ks, stride[0],
+                                                  stride[1], int(dense), DTYPE_CODE[g.dtype], int(act), int(epilogue), _ptr(seam), _stream()),
                "dl_conv2d_dgrad_strided_nhwc_h")
     return dx
 
@@ -539,18 +552,9 @@ def wgrad_nhwc_h(x, g, ks, stride=(1, 1)):
 
 
 def supported_h(x_shape, blocks):
-    """Whether the half-precision HIP trunk can run these shapes: channel counts multiples of 64; every feature map 128-pixel
-    tiles (width a multiple of 64 with an even height, or of 32 with a height divisible by 4)."""
-    N, H, W, C = x_shape
-    if C % 64:
-        return False
-    for (cin, cout, stride, _) in blocks:
-        if cin % 64 or cout % 64 or H % stride[0] or W % stride[1]:
-            return False
-        H, W = H // stride[0], W // stride[1]
-        if not ((W % 64 == 0 and H % 2 == 0) or (W % 32 == 0 and H % 4 == 0)):
-            return False
-    return True
+    """Whether the half-precision HIP trunk can run these shapes: as ``supported`` (channel counts multiples of 64, any image size:
+    tiles hang over the edges of feature maps that do not divide)."""
+    return supported(x_shape, blocks)
 
 
 class CastToHalf(torch.autograd.Function):
@@ -624,9 +628,9 @@ class RingSegmentH(torch.autograd.Function):
                 g2 = conv_nhwc_h(g1, w1b, 3, act=act, epilogue=epi, add=g2, dsrc=None if first else x, transposed=True)
             else:
                 grads[wi + 2] = grad_for(wgrad_nhwc_h(x, g2, 1, stride=stride), ctx.w_meta[wi + 2])
-                dxb = dgrad_strided_h(g2, wbs[wi + 2], 1, stride, dense=True)
+                dxb = dgrad_strided_h(g2, wbs[wi + 2], 1, stride, x.shape[1:3], dense=True)
                 epi = EPI_ADD_GRID if first else (EPI_ADD_GRID | EPI_DACT)
-                g2 = dgrad_strided_h(g1, w1b, 3, stride, act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)
+                g2 = dgrad_strided_h(g1, w1b, 3, stride, x.shape[1:3], act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)
         if BACKWARD_TRACE is not None:
             BACKWARD_TRACE.append(("segment", blocks[0][0], blocks[-1][1], nb))
         return (g2, None, None, None, None, *grads)

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 3   /* 3: half-precision convolution family, launch profiler; 2 was never shipped */
+#define DL_ABI_VERSION 4   /* 4: free image sizes in the convolution family (the strided input gradients take the INPUT image size and a seam workspace); 3: half-precision convolutions, launch profiler */
 
 typedef void* dl_stream;
 
@@ -251,8 +251,11 @@ int dl_ring_act_pool_pad_bwd_t(const void* grad_out, const void* y, const int8_t
  *     1 DL_CONV_ADD   v += add[pixel][k]
  *     2 DL_CONV_ACT   v  = act(v)                      act: 0 none, 1 tanh, 2 relu
  *     4 DL_CONV_DACT  v *= act'(dsrc[pixel][k])        dsrc = saved OUTPUT of the activation (tanh' = 1 - y^2)
- *   add, dsrc: [N][Ho][Wo][K] or NULL.  Shapes must tile: Wo % 32 == 0, K % 64 == 0, C % 16 == 0 (DL_ERR_UNSUPPORTED
- *   otherwise; the caller then uses its library convolution).
+ *   add, dsrc: [N][Ho][Wo][K] or NULL.  Ho = ceil(H / stride_h), Wo = ceil(W / stride_w) (the reference's padded convolution:
+ *   floor((X - 1) / stride) + 1).  The IMAGE SIZE IS FREE (ABI 4): tiles hang over the right / lower edge of images that do not
+ *   divide -- the reference's shipped 64x720 image has feature maps 180, 90, 45 and 23 pixels wide (config/config_datasets.yaml:21)
+ *   -- odd sizes included.  Channels must tile: K % 64 == 0, C % 8 == 0 (DL_ERR_UNSUPPORTED otherwise; the caller then uses its
+ *   library convolution).
  */
 #define DL_CONV_ADD  1u
 #define DL_CONV_ACT  2u
@@ -263,22 +266,26 @@ int dl_conv2d_nhwc_f32(const float* x, const float* w, float* y, const float* ad
 
 /* Input gradient of the STRIDED layers (3x3 stride (1,2) / (2,2), 1x1 stride (1,2) / (2,2)), torch autograd of
  * Conv2d(stride) in the reference.  One pass per stride phase over the output-gradient grid, each with exactly the taps
- * whose phase matches (no zero-stuffing): g [N][Ho][Wo][K] (K = the layer's output channels), w = the layer's FORWARD
- * weight [K][ksize][ksize][C], dx [N][Ho*stride_h][Wo*stride_w][C].
+ * whose phase matches (no zero-stuffing).  H, W = the size of the layer's INPUT image (ABI 4; the gradient grid is Ho = ceil(H /
+ * stride_h) x Wo = ceil(W / stride_w)): g [N][Ho][Wo][K] (K = the layer's output channels), w = the layer's FORWARD weight
+ * [K][ksize][ksize][C], dx [N][H][W][C].
  *   dense != 0 (1x1 layers): only phase (0,0) receives gradient; the result is written densely as [N][Ho][Wo][C] and is
  *                            meant to be handed to the 3x3 layer's call as add_grid.
  *   epilogue flags: 8 DL_CONV_ADD_GRID  v += add_grid[n][ho][wo][c] on the phase-(0,0) pixels (the down-sampling
- *                   branch's gradient), 4 DL_CONV_DACT  v *= act'(dsrc[pixel][c]) with dsrc at full resolution. */
+ *                   branch's gradient), 4 DL_CONV_DACT  v *= act'(dsrc[pixel][c]) with dsrc at full resolution.
+ *   seam_ws: fp32 scratch of N*H*2*C floats, REQUIRED when W is odd, stride_w == 2, ksize == 3 and dense == 0 (else may be NULL):
+ *            on an odd width the stride phases do not close under the wrap-around (column 2 wo + s - 1 mod W changes parity at the
+ *            seam); the two terms that cross it are summed into seam_ws first and added by the phase that owns columns 0 and W-1. */
 #define DL_CONV_ADD_GRID 8u
 int dl_conv2d_dgrad_strided_nhwc_f32(const float* g, const float* w, float* dx, const float* add_grid, const float* dsrc,
-                                     int32_t N, int32_t Ho, int32_t Wo, int32_t K, int32_t C, int32_t ksize,
+                                     int32_t N, int32_t H, int32_t W, int32_t K, int32_t C, int32_t ksize,
                                      int32_t stride_h, int32_t stride_w, int32_t dense, int32_t act, uint32_t epilogue,
-                                     dl_stream stream);
+                                     float* seam_ws, dl_stream stream);
 
 /* Weight gradient of the same convolutions: dw[k][tap][c] = sum over output pixels of g[pixel][k] * x[pixel + tap][c]
  * (wrap-around / zero-row addressing as above), slab-wise partial sums added in a fixed order (deterministic).
- *   x [N][H][W][C], g [N][Ho][Wo][K], dw [K][ksize][ksize][C];  workspace: dl_conv2d_wgrad_workspace_bytes(...) bytes.
- *   Shapes must tile: K % 64 == 0, C % 64 == 0, Wo % 32 == 0. */
+ *   x [N][H][W][C], g [N][Ho][Wo][K] (Ho, Wo = ceil), dw [K][ksize][ksize][C];  workspace: dl_conv2d_wgrad_workspace_bytes(...) bytes.
+ *   Any image size; channels must tile: K % 64 == 0, C % 64 == 0. */
 size_t dl_conv2d_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, int32_t ksize,
                                        int32_t stride_h, int32_t stride_w);
 int dl_conv2d_wgrad_nhwc_f32(const float* x, const float* g, float* dw, void* workspace, int32_t N, int32_t H, int32_t W,
@@ -292,7 +299,8 @@ int dl_conv2d_wgrad_nhwc_f32(const float* x, const float* g, float* dw, void* wo
  *                        dl_wino_weights_floats; either may be NULL).  Run once per optimiser step.
  *   dl_wino_conv3x3_nhwc_f32: x [N][H][W][C], u = u_fwd of the layer -> y [N][H][W][K]; for the input gradient pass the
  *                        output gradient as x, u = u_bwd and swap C and K.  epilogue / act / add / dsrc as above.
- *   Shapes: H, W even; C % 8 == 0; K % 64 == 0; W/2 a multiple of 32 with H/2 even, or of 16 with H/2 % 4 == 0.
+ *   Shapes: any image size (a workgroup takes 64 tiles as 2x32, 4x16, 8x8 or 16x4, whichever wastes the fewest; tile groups hang over
+ *   the edges of images that do not divide, odd sizes end in partial tiles); C % 8 == 0; K % 64 == 0.
  */
 size_t dl_wino_weights_floats(int32_t K, int32_t C);
 int dl_wino_weights_f32(const float* w, float* u_fwd, float* u_bwd, int32_t K, int32_t C, dl_stream stream);
@@ -312,7 +320,8 @@ int dl_wino_conv3x3_nhwc_f32(const float* x, const float* u, float* y, const flo
 /*
  * Weight gradient of a stride-1 3x3 layer in the Winograd domain (2.25x fewer multiplications than
  * dl_conv2d_wgrad_nhwc_f32; partial sums in a fixed order): x [N][H][W][C], g [N][H][W][K] -> dw [K][3][3][C].
- * H even, W/2 a multiple of 8, C and K multiples of 64; dl_wino_wgrad_workspace_bytes returns 0 for other shapes.
+ * Any image size (partial 2x2 tiles at odd edges, overhanging chunks of 8 tiles); C and K multiples of 64;
+ * dl_wino_wgrad_workspace_bytes returns 0 for other channel counts.
  */
 size_t dl_wino_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K);
 int dl_wino_wgrad3x3_nhwc_f32(const float* x, const float* g, float* dw, void* workspace, int32_t N, int32_t H, int32_t W,
@@ -327,7 +336,7 @@ int dl_wino_wgrad3x3_nhwc_f32(const float* x, const float* g, float* dw, void* w
  *                         half precision (either may be NULL); once per optimiser step.
  *   dl_conv2d_nhwc_h      as dl_conv2d_nhwc_f32 with x, y, add, dsrc in half precision; w = w_fwd of the layer
  *                         (transposed == 0) or w_bwd of the layer whose input gradient is wanted (transposed == 1, stride 1,
- *                         3x3 only; x is then the output gradient and C / K swap roles).  Wo % 32 == 0, K % 64 == 0, C % 32 == 0.
+ *                         3x3 only; x is then the output gradient and C / K swap roles).  Any image size; K % 64 == 0, C % 32 == 0.
  *   dl_conv2d_dgrad_strided_nhwc_h   as dl_conv2d_dgrad_strided_nhwc_f32; w = w_bwd of the layer.
  *   dl_cast_f32_to_h      n fp32 values -> half precision (n % 8 == 0).
  */
@@ -345,8 +354,8 @@ int dl_conv2d_nhwc_h(const void* x, const void* w, void* y, const void* add, con
                      int32_t C, int32_t K, int32_t ksize, int32_t stride_h, int32_t stride_w, int32_t transposed, int32_t dtype,
                      int32_t act, uint32_t epilogue, dl_stream stream);
 int dl_conv2d_dgrad_strided_nhwc_h(const void* g, const void* w, void* dx, const void* add_grid, const void* dsrc, int32_t N,
-                                   int32_t Ho, int32_t Wo, int32_t K, int32_t C, int32_t ksize, int32_t stride_h, int32_t stride_w,
-                                   int32_t dense, int32_t dtype, int32_t act, uint32_t epilogue, dl_stream stream);
+                                   int32_t H, int32_t W, int32_t K, int32_t C, int32_t ksize, int32_t stride_h, int32_t stride_w,
+                                   int32_t dense, int32_t dtype, int32_t act, uint32_t epilogue, float* seam_ws, dl_stream stream);
 int dl_cast_f32_to_h(const float* src, void* dst, int64_t n, int32_t dtype, dl_stream stream);
 /* Global average pooling of a half-precision channels-last map x [N][P][C] -> y [N][C] fp32 (fixed summation order), and its
  * backward fused with the activation derivative of the layer that produced x:
@@ -356,7 +365,7 @@ int dl_mean_hw_bwd_act_h(const float* grad_y, const void* x, int32_t N, int32_t 
                          void* grad_pre, dl_stream stream);
 /* Weight gradient from half-precision x [N][H][W][C] and g [N][Ho][Wo][K]: dw [K][ksize][ksize][C] in FP32 (the layout and type of
  * the parameter's gradient), fp32 accumulation, slab partials summed in a fixed order.  Fragments are built by the transposing
- * LDS read (ds_read_b64_tr_b16).  C % 64 == 0, K % 64 == 0, Ho even, Wo % 32 == 0; workspace bytes from the first function
+ * LDS read (ds_read_b64_tr_b16).  C % 64 == 0, K % 64 == 0, any image size; workspace bytes from the first function
  * (0 = shape not supported). */
 size_t dl_conv2d_wgrad_h_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, int32_t ksize, int32_t stride_h,
                                          int32_t stride_w);
@@ -381,7 +390,7 @@ int dl_pool3x3s12_nhwc_bwd(const float* g, const float* a, const int8_t* win, in
  * the pooling backward and the activation derivative: g_pooled [N][H][W/4][64] (gradient of the pooled map), a [N][H][W/2][64] and
  * win (forward outputs of conv1 + activation and of dl_pool3x3s12_nhwc_fwd), x8 [N][H][W][8] (the channels-last network input)
  * -> dw [64][8][3][3] (the parameter's default layout).  The 134 MB gradient with respect to conv1's pre-activation is built
- * tile by tile in LDS and never written.  W % 128 == 0; workspace bytes from the first function (0 = not supported). */
+ * tile by tile in LDS and never written.  W % 4 == 0; workspace bytes from the first function (0 = not supported). */
 size_t dl_stem_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t W);
 int dl_stem_wgrad_f32(const float* g_pooled, const float* a, const int8_t* win, const float* x8, int32_t N, int32_t H, int32_t W,
                       int32_t act, void* workspace, float* dw, dl_stream stream);

@@ -178,11 +178,28 @@ def test_hip_trunk_matches_module_path(act, wino, size, monkeypatch):
     util.measured(f"{tagn}: translation hip vs modules (relative)", _rel(out[0][0], out[1][0]), bound=1e-5)       # measured 4-8e-7
     util.measured(f"{tagn}: quaternion hip vs modules (relative)", _rel(out[0][1], out[1][1]), bound=1e-5)
     worst, name = 0.0, ""
+    referee = {}
+    if size == (64, 720):
+        # At this size the LIBRARY's weight gradient of the 8-channel conv1 (module path) deviates from this library's by 4.2e-4
+        # (measured in round 4; every other parameter agrees to 1e-5).  Referee: the same network under torch autograd in float64 on
+        # the CPU -- the HIP stem must agree with it, the module path's deviation is recorded.
+        m_cpu = OdometryModel(dict(util.repo_config(size[0], size[1], device="cpu", activation_fct=act), cnn_impl="modules")).double()
+        m_cpu.load_state_dict({k: v.detach().cpu().double() for k, v in m_hip.state_dict().items()})
+        t, q = m_cpu(x.cpu().double())
+        (t.square().sum() + (q * torch.arange(1, 5, dtype=torch.float64)).sum()).backward()
+        referee = {"resnet.conv1.weight": m_cpu.resnet.conv1.weight.grad.float().to(dev)}
     for (k, p), (_, p2) in zip(m_hip.named_parameters(), m_mod.named_parameters()):
         assert p.grad is not None and p.grad.shape == p.shape, k
+        if k in referee:
+            ref = referee[k]
+            util.measured(f"{tagn}: {k} gradient, HIP stem vs torch-CPU float64 (relative)", float((p.grad - ref).norm() / ref.norm()), bound=5e-5)
+            util.measured(f"{tagn}: {k} gradient, module path (library convolution) vs torch-CPU float64 (relative)", float((p2.grad - ref).norm() / ref.norm()))
+            continue
         e = float((p.grad - p2.grad).norm() / p2.grad.norm().clamp_min(1e-30))
         if e > worst:
             worst, name = e, k
+        if e > 2e-5:
+            print(f"  gradient of {k}: relative difference {e:.3e}")
     util.measured(f"{tagn}: worst relative parameter-gradient difference hip vs modules ({name})", worst, bound=(5e-5 if act == "tanh" else 1e-5))   # measured 4-7e-6 (tanh), 8e-7 (relu: no mask flips on this seeded input; one flipped mask would show as ~1e-4)
     assert m_hip.resnet.layer1[0].conv1.weight.grad.stride() == m_hip.resnet.layer1[0].conv1.weight.stride()
 
@@ -226,7 +243,7 @@ def test_stem_pooling_kernels_against_torch(act):
                   float((gc.permute(0, 3, 1, 2) - pre.grad).abs().max()), bound=2e-6)
 
 
-@pytest.mark.parametrize("act,size", [("tanh", (16, 1024)), ("relu", (16, 1024)), ("tanh", (16, 720)), ("relu", (9, 100))])
+@pytest.mark.parametrize("act,size", [("tanh", (16, 1024)), ("relu", (16, 1024)), ("tanh", (16, 720)), ("relu", (9, 100)), ("tanh", (64, 720))])
 def test_stem_function_against_torch(act, size):
     """RingStem (transposing copy + MFMA conv1 with the activation in the epilogue + pooling; backward: pooling gather +
     weight gradient) against F.pad(circular) + conv2d + act + F.pad(circular) + max_pool2d under torch autograd."""
@@ -241,15 +258,19 @@ def test_stem_function_against_torch(act, size):
     y.backward(gy)
     dw = w1.grad.clone()
     w1.grad = None
-    xr = x.clone().requires_grad_(True)
-    y_ref = _ref_stem(xr, w1, act)
-    y_ref.backward(gy.permute(0, 3, 1, 2))
-    util.measured(f"stem[{act},{size[0]}x{size[1]}]: pooled output vs torch (absolute)", float((y.permute(0, 3, 1, 2) - y_ref.detach()).abs().max()), bound=2e-5)
-    util.measured(f"stem[{act},{size[0]}x{size[1]}]: conv1 weight gradient vs torch autograd (relative)", _rel(dw, w1.grad), bound=TIGHT)     # measured 3-8e-7 (relu: no mask flips on this seeded input)
+    # reference: the same ops under torch autograd in float64 on the CPU (at 64x720, batch 2 the GPU library's own weight gradient of this
+    # 8-channel layer deviates by 4e-4 from this kernel, which agrees with float64 to 4e-7 -- so the library is not the yardstick here)
+    xr = x.detach().cpu().double().requires_grad_(True)
+    w1r = w1.detach().cpu().double().requires_grad_(True)
+    y_ref = _ref_stem(xr, w1r, act)
+    y_ref.backward(gy.permute(0, 3, 1, 2).cpu().double())
+    y_ref, xr_grad, w1r_grad = y_ref.detach().float().to(dev), xr.grad.float().to(dev), w1r.grad.float().to(dev)
+    util.measured(f"stem[{act},{size[0]}x{size[1]}]: pooled output vs torch (absolute)", float((y.permute(0, 3, 1, 2) - y_ref).abs().max()), bound=2e-5)
+    util.measured(f"stem[{act},{size[0]}x{size[1]}]: conv1 weight gradient vs torch autograd (relative)", _rel(dw, w1r_grad), bound=TIGHT)     # measured 3-8e-7 (relu: no mask flips on this seeded input)
     # and the input gradient (not needed by the training step: the image carries none)
     x2 = x.clone().requires_grad_(True)
     rc.RingStem.apply(x2, w1, rc.ACT[act]).backward(gy)
-    util.measured(f"stem[{act},{size[0]}x{size[1]}]: input gradient vs torch autograd (relative)", _rel(x2.grad, xr.grad), bound=TIGHT)     # measured 3-8e-7 (relu: no mask flips on this seeded input)
+    util.measured(f"stem[{act},{size[0]}x{size[1]}]: input gradient vs torch autograd (relative)", _rel(x2.grad, xr_grad), bound=TIGHT)     # measured 3-8e-7 (relu: no mask flips on this seeded input)
 
 
 def test_mean_hw_kernel_against_torch():

@@ -42,6 +42,11 @@ SHAPES = [  # N, H, W, C, K, ks, stride
     (2, 16, 128, 64, 128, 3, (1, 1)), (2, 8, 128, 64, 64, 3, (1, 1)), (1, 4, 64, 128, 128, 3, (1, 1)), (1, 8, 64, 256, 64, 3, (1, 1)),
     (2, 8, 256, 64, 128, 3, (1, 2)), (1, 8, 128, 64, 64, 3, (2, 2)), (2, 16, 128, 128, 256, 3, (2, 2)),
     (2, 8, 128, 64, 128, 1, (1, 2)), (1, 8, 128, 64, 64, 1, (2, 2)),
+    # images that do not divide into tiles (round 4): the feature maps of the reference's 64x720 image (180 / 90 / 45 / 23 wide; a
+    # stride-2 layer on an odd width), 64x512's layer4 (32x16), odd heights
+    (2, 8, 180, 64, 64, 3, (1, 1)), (1, 6, 90, 128, 128, 3, (1, 1)), (2, 5, 45, 64, 128, 3, (1, 1)), (1, 32, 23, 128, 64, 3, (1, 1)),
+    (1, 32, 16, 64, 64, 3, (1, 1)), (2, 8, 180, 64, 128, 3, (1, 2)), (2, 8, 45, 64, 128, 3, (2, 2)), (1, 7, 45, 64, 64, 3, (1, 2)),
+    (2, 8, 45, 64, 128, 1, (2, 2)), (1, 5, 90, 64, 64, 1, (1, 2)),
 ]
 
 
@@ -93,16 +98,16 @@ def test_half_conv_forward_and_both_gradients_against_torch(shape, dtype):
         ref = (dref + extra.float()) * (1 - ysave.float() ** 2)
         util.measured(f"{tag}: fused (dgrad + g) * tanh' (units of one rounding)", _worst(dx2, ref, eps, abs_tol), bound=1.0)
     elif ks == 3:
-        Ho, Wo = H // stride[0], W // stride[1]
+        Ho, Wo = -(-H // stride[0]), -(-W // stride[1])
         addg = torch.randn((N, Ho, Wo, C), generator=g).to(dtype).to(dev)
-        dx = rc.dgrad_strided_h(gy_h, wb, 3, stride, act=rc.ACT["tanh"], epilogue=rc.EPI_ADD_GRID | rc.EPI_DACT, add_grid=addg, dsrc=ysave)
+        dx = rc.dgrad_strided_h(gy_h, wb, 3, stride, (H, W), act=rc.ACT["tanh"], epilogue=rc.EPI_ADD_GRID | rc.EPI_DACT, add_grid=addg, dsrc=ysave)
         ref = dref.clone()
         ref[:, ::stride[0], ::stride[1]] += addg.float()
         ref = ref * (1 - ysave.float() ** 2)
         util.measured(f"{tag}: strided input gradient, all phases + branch gradient + tanh' (units of one rounding)",
                       _worst(dx, ref, eps, abs_tol), bound=1.0)
     else:
-        dx = rc.dgrad_strided_h(gy_h, wb, 1, stride, dense=True)
+        dx = rc.dgrad_strided_h(gy_h, wb, 1, stride, (H, W), dense=True)
         util.measured(f"{tag}: 1x1 input gradient on the grid (units of one rounding)",
                       _worst(dx, dref[:, ::stride[0], ::stride[1]], eps, abs_tol), bound=1.0)
 
@@ -111,14 +116,14 @@ def test_half_conv_rejects_bad_arguments():
     from delora_amd import _lib
     from delora_amd.models import ring_conv as rc
     dev = _dev()
-    x = torch.zeros((1, 4, 24, 64), device=dev, dtype=torch.bfloat16)          # width 24: no 32-pixel tile
-    w = torch.zeros((9, 64, 64), device=dev, dtype=torch.bfloat16)
-    with pytest.raises(_lib.DeloraHipError):
-        rc.conv_nhwc_h(x, w, 3)
+    x = torch.zeros((1, 4, 24, 64), device=dev, dtype=torch.bfloat16)
+    with pytest.raises(_lib.DeloraHipError):                                   # 48 output channels: no 64-channel block
+        rc.conv_nhwc_h(x, torch.zeros((9, 48, 64), device=dev, dtype=torch.bfloat16), 3)
     lib = _lib.load()
-    assert lib.dl_conv2d_wgrad_h_workspace_bytes(1, 4, 24, 64, 64, 3, 1, 1) == 0
+    assert lib.dl_conv2d_wgrad_h_workspace_bytes(1, 4, 24, 48, 64, 3, 1, 1) == 0
+    assert lib.dl_conv2d_wgrad_h_workspace_bytes(1, 4, 24, 64, 64, 3, 1, 1) > 0          # the image size is free since round 4
     assert lib.dl_conv2d_wgrad_h_workspace_bytes(1, 4, 64, 64, 64, 3, 0, 1) == 0          # zero stride: rejected, no division
-    assert not rc.supported_h((1, 4, 24, 64), ((64, 64, (1, 1), False),))
+    assert rc.supported_h((1, 4, 24, 64), ((64, 64, (1, 1), False),)) and not rc.supported_h((1, 4, 24, 32), ((32, 32, (1, 1), False),))
 
 
 def _model_pair(dev, H, W, act="tanh", seed=3):
@@ -134,16 +139,17 @@ def _model_pair(dev, H, W, act="tanh", seed=3):
     return m
 
 
+@pytest.mark.parametrize("size", [(64, 2048), (64, 720)], ids=["64x2048", "64x720"])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
-def test_half_precision_network_against_the_fp32_network_at_full_size(dtype):
+def test_half_precision_network_against_the_fp32_network_at_full_size(dtype, size):
     """64x2048, B=2, the reference's full 11.9 M-parameter network: autocast (HIP half-precision trunk) against fp32 (HIP fp32 trunk)
     on the same weights and input -- translation / quaternion outputs, a loss on them, and every parameter gradient.  The
     deviations are what half-precision storage of 40 activation maps costs; they are recorded, and bounded at a few roundings."""
     dev = _dev()
-    m = _model_pair(dev, 64, 2048)
+    B, (H, W) = 2, size                 # 64x720: the reference's shipped image (feature maps 180 / 90 / 45 / 23 wide: overhanging tiles)
+    m = _model_pair(dev, H, W)
     g = torch.Generator(device="cpu").manual_seed(5)
     # a range-image-like input: xyz + range in metres, smooth along the image, with empty pixels
-    B, H, W = 2, 64, 2048
     az = torch.linspace(-np.pi, np.pi, W).view(1, 1, 1, W)
     el = torch.linspace(-0.4, 0.05, H).view(1, 1, H, 1)
     rng = 8.0 + 6.0 * torch.sin(3 * az + torch.rand((B, 2, 1, 1), generator=g)) + 2.0 * torch.rand((B, 2, H, W), generator=g)
@@ -169,17 +175,17 @@ def test_half_precision_network_against_the_fp32_network_at_full_size(dtype):
     # measured on MI355X: see profiles/r03_parity_measured.json; bounds = a few roundings of the storage type through 17 layers
     rel_pose = {torch.bfloat16: 5e-2, torch.float16: 8e-3}[dtype]
     rel_grad = {torch.bfloat16: 1.5e-1, torch.float16: 3e-2}[dtype]
-    util.measured(f"half network {name} vs fp32 @64x2048: translation (relative to its largest element)",
+    util.measured(f"half network {name} vs fp32 @{H}x{W}: translation (relative to its largest element)",
                   float((th - t32).abs().max() / t32.abs().max()), bound=rel_pose)
-    util.measured(f"half network {name} vs fp32 @64x2048: quaternion (relative to its largest element)",
+    util.measured(f"half network {name} vs fp32 @{H}x{W}: quaternion (relative to its largest element)",
                   float((qh - q32).abs().max() / q32.abs().max()), bound=rel_pose)
-    util.measured(f"half network {name} vs fp32 @64x2048: loss (relative)", abs(lh - l32) / abs(l32), bound=rel_pose)
+    util.measured(f"half network {name} vs fp32 @{H}x{W}: loss (relative)", abs(lh - l32) / abs(l32), bound=rel_pose)
     worst, worst_cos = 0.0, 1.0
     for a, b in zip(gh, g32):
         worst = max(worst, float((a - b).norm() / b.norm().clamp_min(1e-30)))
         worst_cos = min(worst_cos, float(F.cosine_similarity(a.flatten().double(), b.flatten().double(), dim=0)))
-    util.measured(f"half network {name} vs fp32 @64x2048: worst parameter gradient |dg| / |g|", worst, bound=rel_grad)
-    util.measured(f"half network {name} vs fp32 @64x2048: 1 - worst cosine between parameter gradients", 1.0 - worst_cos, bound=rel_grad ** 2)
+    util.measured(f"half network {name} vs fp32 @{H}x{W}: worst parameter gradient |dg| / |g|", worst, bound=rel_grad)
+    util.measured(f"half network {name} vs fp32 @{H}x{W}: 1 - worst cosine between parameter gradients", 1.0 - worst_cos, bound=rel_grad ** 2)
     assert all(torch.isfinite(a).all() for a in gh)
 
 

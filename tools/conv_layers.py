@@ -67,8 +67,8 @@ for name, h, w, c, k, st in layers:
             wdf, wdb = rc.weights_h(wdp, half)
             run(name + " forward 3x3", lambda: rc.conv_nhwc_h(x, wf, 3, stride=st, act=1, epilogue=rc.EPI_ACT))
             run(name + " forward 1x1", lambda: rc.conv_nhwc_h(x, wdf, 1, stride=st))
-            run(name + " input gradient 1x1", lambda: rc.dgrad_strided_h(g, wdb, 1, st, dense=True))
-            run(name + " input gradient 3x3", lambda: rc.dgrad_strided_h(g, wb, 3, st, act=1, epilogue=rc.EPI_DACT, dsrc=gi))
+            run(name + " input gradient 1x1", lambda: rc.dgrad_strided_h(g, wdb, 1, st, (h, w), dense=True))
+            run(name + " input gradient 3x3", lambda: rc.dgrad_strided_h(g, wb, 3, st, (h, w), act=1, epilogue=rc.EPI_DACT, dsrc=gi))
             run(name + " weight gradient 3x3", lambda: rc.wgrad_nhwc_h(x, g, 3, stride=st))
             run(name + " weight gradient 1x1", lambda: rc.wgrad_nhwc_h(x, g, 1, stride=st))
 doc = {"workload": f"one launch per convolution kernel / pass / layer shape of the pose CNN's trunk, batch {B}, 64x2048 input, {mode}", "order": order}
