@@ -57,6 +57,8 @@ def parse(argv=None):
     ap.add_argument("--no-profile", action="store_true", help="no event-carrying launches in the timed steps (no roofline object)")
     ap.add_argument("--conv-table", action="store_true", help="also time every stride-1 layer shape and pass back to back (roofline_cnn)")
     ap.add_argument("--autocast-steps", type=int, default=20, help="timed steps of the extra bf16-autocast leg of the fp32 run (0 = skip); N=1 only")
+    ap.add_argument("--variant-steps", type=int, default=10, help="timed steps of the extra fp32 legs `shipped_image` (64x720, the reference's "
+                    "default KITTI image) and `untrained_network` (randomly initialised heads: whole-image search) (0 = skip); N=1 only")
     ap.add_argument("--amp", default="", help="optional autocast dtype for the CNN (bfloat16/float16); default fp32 = parity mode")
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--cnn", default="", help="CNN implementation override (config key cnn_impl)")
@@ -215,6 +217,41 @@ def autocast_leg(args, device, host_batches, batches, timed_region):
             "hip_graph": out_graph,
             "note": "autocast(bfloat16) around the pose CNN: fp32 stem, layer1-4 on v_mfma_f32_32x32x16_bf16 with bf16 activations, fp32 "
                     "accumulation, fp32 master weights and weight gradients; geometry kernels, loss and Adam unchanged (fp32)"}
+
+
+def variant_leg(args, device, host_batches, batches, timed_region, steps, width=None, pretrained=True):
+    """The fp32 training step on a variant of the workload, a second trainer on the same raw scans: ``width`` = another image width
+    (720: the reference's shipped KITTI image, config/config_datasets.yaml:21 -- feature maps 180 / 90 / 45 / 23 pixels wide, i.e.
+    overhanging tiles and a stride-2 layer on an odd width), ``pretrained`` False = the randomly initialised network of a run from
+    scratch (`unsupervised_at_start: True` without a checkpoint): it predicts a random rotation, so every step's correspondence search
+    is the whole-image walk."""
+    import argparse
+    from delora_amd.deploy.trainer import Trainer
+    from delora_amd.data.dataset import ListDataset
+    a2 = argparse.Namespace(**vars(args))
+    a2.amp = ""
+    if width:
+        a2.width = int(width)
+    cfg = build_config(a2, device)
+    torch.manual_seed(1234)
+    trainer = Trainer(cfg, dataset=ListDataset([d for b in host_batches for d in b]))
+    if pretrained:
+        identity_pretrained_state(trainer.raw_model)
+    counter = {"i": 0}
+
+    def step():
+        batch = batches[counter["i"] % len(batches)]
+        counter["i"] += 1
+        trainer.optimizer.zero_grad(set_to_none=True)
+        ep, _ = trainer.step(preprocessed_dicts=[dict(s) for s in batch], epoch_losses=trainer.new_epoch_losses())
+        return ep
+    for b in batches:                                            # priming: every ragged batch once (allocator), as main() does
+        trainer.optimizer.zero_grad(set_to_none=True)
+        trainer.step(preprocessed_dicts=[dict(s) for s in b], epoch_losses=trainer.new_epoch_losses())
+    el, ep = timed_region(steps, step)
+    return {"steps": steps, "value": round(args.batch * steps / el, 3), "unit": "scan-pairs/s", "ms_per_step": round(1e3 * el / steps, 3),
+            "image": f"{a2.height}x{a2.width}", "final_loss": float(ep["loss_epoch"]), "cnn_impl": cnn_impl_in_use(trainer, a2),
+            "network_state": "identity-pretrained" if pretrained else "random initialisation (no identity pre-training)"}
 
 
 def conv_table(args, device, reps=10):
@@ -843,6 +880,15 @@ def main():
                                           "(async H2D one batch ahead on a side stream)"}
             if not args.amp and args.autocast_steps > 0 and (graphed is None or not graphed.captured):
                 result["autocast"] = autocast_leg(args, device, host_batches, batches, timed_region)
+            if not args.amp and args.variant_steps > 0 and (graphed is None or not graphed.captured):
+                if args.width != 720:
+                    result["shipped_image"] = variant_leg(args, device, host_batches, batches, timed_region, args.variant_steps, width=720)
+                    result["shipped_image"]["note"] = ("the same step on the reference's shipped KITTI image size (config/config_datasets.yaml:21: "
+                                                       "64x720; same raw scans): the HIP stem + trunk with overhanging tiles, not the headline")
+                result["untrained_network"] = variant_leg(args, device, host_batches, batches, timed_region, args.variant_steps, pretrained=False)
+                result["untrained_network"]["note"] = ("the headline workload with the network as torch initialises it (a run from scratch with "
+                                                       "unsupervised_at_start: True): random poses, so the exact search walks the whole image for "
+                                                       "every query; the headline uses the state the reference's identity pre-training leaves")
             if not args.no_cpu_baseline:
                 result["cpu_baseline"], result["cpu_baseline_online_normals"] = cpu_baseline(args, cfg)
         print(json.dumps(result))

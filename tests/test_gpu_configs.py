@@ -290,13 +290,17 @@ def test_bench_final_loss_reproduces():
     mine = float(ep["loss_epoch"])
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "0", "--no-cpu-baseline",
-                        "--kernel-reps", "2", "--feed-steps", "0", "--long-steps", "0", "--no-live-pmc"], capture_output=True, text=True, timeout=900)
+                        "--kernel-reps", "2", "--feed-steps", "0", "--long-steps", "0", "--no-live-pmc", "--variant-steps", "2",
+                        "--autocast-steps", "0"], capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
     j = json.loads(line)
     util.measured("bench.py final_loss vs the same 3 steps in-process (relative)", abs(j["final_loss"] - mine) / abs(mine), bound=REL)
     assert j["n_gpus"] == 1 and j["steps"] == 3 and j["dtype"] == "f32" and j["config"]["global_batch"] == 8
     assert j["roofline"]["bound"] and 0 < j["roofline"]["frac"] < 1.5
+    # the reference's shipped image size runs on the HIP stem + trunk too (overhanging tiles), and a run from scratch has a number
+    assert j["shipped_image"]["image"] == "64x720" and "hip trunk" in j["shipped_image"]["cnn_impl"] and j["shipped_image"]["value"] > 0
+    assert "random" in j["untrained_network"]["network_state"] and j["untrained_network"]["value"] > 0 and np.isfinite(j["untrained_network"]["final_loss"])
 
 
 def test_bench_measures_the_convolution_traffic_itself():
