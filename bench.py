@@ -57,6 +57,8 @@ def parse(argv=None):
     ap.add_argument("--no-profile", action="store_true", help="no event-carrying launches in the timed steps (no roofline object)")
     ap.add_argument("--conv-table", action="store_true", help="also time every stride-1 layer shape and pass back to back (roofline_cnn)")
     ap.add_argument("--autocast-steps", type=int, default=20, help="timed steps of the extra bf16-autocast leg of the fp32 run (0 = skip); N=1 only")
+    ap.add_argument("--disk-pairs", type=int, default=32, help="scan pairs of the synthetic on-disk sequence of the `feed_disk` leg (0 = skip); N=1 only")
+    ap.add_argument("--disk-workers", type=int, default=6, help="DataLoader worker processes of the `feed_disk` leg")
     ap.add_argument("--variant-steps", type=int, default=10, help="timed steps of the extra fp32 legs `shipped_image` (64x720, the reference's "
                     "default KITTI image) and `untrained_network` (randomly initialised heads: whole-image search) (0 = skip); N=1 only")
     ap.add_argument("--amp", default="", help="optional autocast dtype for the CNN (bfloat16/float16); default fp32 = parity mode")
@@ -167,7 +169,7 @@ def cnn_impl_in_use(trainer, args):
     return "modules: library convolutions + fused ring ops"
 
 
-def autocast_leg(args, device, host_batches, batches, timed_region):
+def autocast_leg(args, device, host_batches, batches, timed_region, tree=None):
     """The same training step with the CNN in half precision (config key amp_dtype = torch.autocast around the model call: the
     mixed-precision mode BASELINE.json configs[4] names; the reference itself trains in fp32 only): a second trainer on the same batches, the trunk on
     the bf16 MFMA kernels (csrc/convh.hip, wgradh.hip).  Reported next to the fp32 headline, never as it."""
@@ -194,6 +196,15 @@ def autocast_leg(args, device, host_batches, batches, timed_region):
     gc.collect()
     gc.freeze()                                                  # as Trainer.train does after its set-up (see main)
     el, ep = timed_region(args.autocast_steps, step)
+    out_disk = None
+    if tree is not None:                                         # the 5 ms step fed from the on-disk sequence (see disk_feed_leg)
+        def step_on(batch):
+            trainer.optimizer.zero_grad(set_to_none=True)
+            return trainer.step(preprocessed_dicts=[dict(s) for s in batch], epoch_losses=trainer.new_epoch_losses())[0]
+        try:
+            out_disk = disk_feed_leg(a2, cfg, device, tree, step_on, timed_region, args.batch * args.autocast_steps / el, max(args.autocast_steps, 40))
+        except Exception as e:                                   # noqa: BLE001 -- the leg is informative
+            out_disk = {"error": f"{type(e).__name__}: {e}"}
     out_graph = None
     try:
         from delora_amd.deploy.graph_step import GraphedStep
@@ -214,7 +225,7 @@ def autocast_leg(args, device, host_batches, batches, timed_region):
         out_graph = {"error": f"{type(e).__name__}: {e}"}
     return {"dtype": "bfloat16", "steps": args.autocast_steps, "value": round(args.batch * args.autocast_steps / el, 3), "unit": "scan-pairs/s",
             "ms_per_step": round(1e3 * el / args.autocast_steps, 3), "final_loss": float(ep["loss_epoch"]), "cnn_impl": cnn_impl_in_use(trainer, a2),
-            "hip_graph": out_graph,
+            "hip_graph": out_graph, "feed_disk": out_disk,
             "note": "autocast(bfloat16) around the pose CNN: fp32 stem, layer1-4 on v_mfma_f32_32x32x16_bf16 with bf16 activations, fp32 "
                     "accumulation, fp32 master weights and weight gradients; geometry kernels, loss and Adam unchanged (fp32)"}
 
@@ -252,6 +263,61 @@ def variant_leg(args, device, host_batches, batches, timed_region, steps, width=
     return {"steps": steps, "value": round(args.batch * steps / el, 3), "unit": "scan-pairs/s", "ms_per_step": round(1e3 * el / steps, 3),
             "image": f"{a2.height}x{a2.width}", "final_loss": float(ep["loss_epoch"]), "cnn_impl": cnn_impl_in_use(trainer, a2),
             "network_state": "identity-pretrained" if pretrained else "random initialisation (no identity pre-training)"}
+
+
+def make_disk_tree(args):
+    """A synthetic SEQUENCE written in the reference's on-disk training format (<path>/<seq>/scans/<idx>.npy,
+    src/preprocessing/preprocesser.py:64-68; xyz only -- the normals of this workload are computed online)."""
+    import tempfile
+    from delora_amd.data import synthetic
+    tmp = tempfile.mkdtemp(prefix="delora_feed_")
+    t0 = time.perf_counter()
+    scans, _ = synthetic.make_sequence(4000, args.disk_pairs + 1, rings=args.height, azimuth_steps=2250)
+    synthetic.write_tree(tmp, scans, sequence=0)
+    nbytes = sum(os.path.getsize(os.path.join(tmp, "00", "scans", f)) for f in os.listdir(os.path.join(tmp, "00", "scans")))
+    return {"path": tmp, "bytes": nbytes, "generation_s": round(time.perf_counter() - t0, 1)}
+
+
+def disk_feed_leg(args, cfg, device, tree, run_step, timed_region, resident_pairs_s, steps):
+    """SURVEY.md 8f-1, for real: the tree of `make_disk_tree` is read back by `PreprocessedPointCloudDataset` (src/data/dataset.py:82-154:
+    not kept in RAM) through a DataLoader with worker processes (decode + the [M,3] -> [1,3,M] transposition in the workers, consecutive
+    pairs share their scan, page-locked batches) and the DevicePrefetcher (H2D one batch ahead on a side stream), and the timed steps
+    train on it -- shuffled, as Trainer.train reads a training set.  Reported against the resident rate of the same step."""
+    from delora_amd.data.dataset import PreprocessedPointCloudDataset
+    from delora_amd.data.feed import DevicePrefetcher
+    from delora_amd.deploy.trainer import Trainer
+    dcfg = dict(cfg)
+    dcfg["kitti"] = dict(cfg["kitti"], preprocessed_path=tree["path"], data_identifiers=[0])
+    dcfg.update(store_dataset_in_RAM=False, num_dataloader_workers=args.disk_workers, load_normal_lists=False)
+    ds = PreprocessedPointCloudDataset(dcfg)
+    loader = torch.utils.data.DataLoader(dataset=ds, batch_size=args.batch, shuffle=True, collate_fn=Trainer.list_collate, drop_last=True,
+                                         num_workers=args.disk_workers, pin_memory=True,
+                                         **({"prefetch_factor": 4, "persistent_workers": True} if args.disk_workers > 0 else {}))
+    moved = {"bytes": 0}
+
+    def epochs():
+        while True:
+            for b in DevicePrefetcher(loader, device):
+                yield b
+    it = epochs()
+
+    def fed_step():
+        b = next(it)
+        moved["bytes"] += sum(v.numel() * v.element_size() for d in b for v in d.values() if torch.is_tensor(v))
+        return run_step(b)
+    for _ in range(max(3, 2 * len(loader))):                     # workers up, page cache and allocator primed with this data's sizes
+        fed_step()
+    moved["bytes"] = 0
+    el, _ = timed_region(steps, fed_step)
+    rate = args.batch * steps / el
+    del it, loader
+    return {"steps": steps, "value": round(rate, 3), "unit": "scan-pairs/s", "ms_per_step": round(1e3 * el / steps, 3),
+            "vs_resident": round(rate / resident_pairs_s, 4), "feed_GB_s": round(moved["bytes"] / el / 1e9, 3),
+            "dataset": f"{args.disk_pairs} consecutive pairs of one synthetic sequence, {tree['bytes'] / 1e6:.0f} MB on disk, xyz only, the "
+                       f"reference's layout, store_dataset_in_RAM False", "workers": args.disk_workers, "shuffle": True,
+            "generation_s": tree["generation_s"],
+            "note": "PreprocessedPointCloudDataset -> DataLoader(worker processes, pinned batches) -> DevicePrefetcher -> the same training "
+                    "step; the files sit in the page cache after the first epoch, as a training set that fits in RAM does"}
 
 
 def conv_table(args, device, reps=10):
@@ -878,8 +944,15 @@ def main():
                                   "MB_per_pair": round(moved["bytes"] / (args.batch * args.feed_steps) / 1e6, 3),
                                   "note": "same steps with every batch read from pinned host memory through DataLoader + DevicePrefetcher "
                                           "(async H2D one batch ahead on a side stream)"}
+            tree = None
+            if args.feed_steps > 0 and args.disk_pairs >= args.batch and (graphed is None or not graphed.captured):
+                tree = make_disk_tree(args)
+                result["feed_disk"] = disk_feed_leg(args, cfg, device, tree, run_step, timed_region, result["value"], args.feed_steps)
             if not args.amp and args.autocast_steps > 0 and (graphed is None or not graphed.captured):
-                result["autocast"] = autocast_leg(args, device, host_batches, batches, timed_region)
+                result["autocast"] = autocast_leg(args, device, host_batches, batches, timed_region, tree)
+            if tree is not None:
+                import shutil
+                shutil.rmtree(tree["path"], ignore_errors=True)
             if not args.amp and args.variant_steps > 0 and (graphed is None or not graphed.captured):
                 if args.width != 720:
                     result["shipped_image"] = variant_leg(args, device, host_batches, batches, timed_region, args.variant_steps, width=720)

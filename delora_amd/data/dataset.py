@@ -22,11 +22,19 @@ def _as_list_tensor(array):
 
 
 class PreprocessedPointCloudDataset(torch.utils.data.Dataset):
+    """The reference's dataset of consecutive scan pairs over its on-disk format (src/data/dataset.py:19-157).  Additions for feeding a
+    GPU at rate: a sequence directory WITHOUT ``normals/`` (or config ``load_normal_lists: false``) is an xyz-only tree -- the samples
+    carry ``normal_list_* = None`` and the step estimates the normals online (half the bytes per pair); the scan shared by two
+    consecutive samples (k+1 of one pair = k of the next) is decoded once when samples are visited in order (a two-entry cache per
+    worker process)."""
+
     def __init__(self, config):
         super().__init__()
         self.config = config
         self.store_dataset_in_RAM = config["store_dataset_in_RAM"]
+        self.load_normals = bool(config.get("load_normal_lists", True))
         self.scans_files_in_datasets, self.normals_files_in_datasets = [], []
+        self._recent = {}                            # (dataset, sequence, scan) -> (normals, scan): the last two decoded scans
         table = []                                   # rows: (dataset index, sequence index, scan index)
         for i_ds, name in enumerate(config["datasets"]):
             scans_seq, normals_seq = [], []
@@ -35,11 +43,15 @@ class PreprocessedPointCloudDataset(torch.utils.data.Dataset):
                 if not os.path.exists(root):
                     raise Exception("The specified path and dataset " + root + "does not exist.")
                 scans = sorted(glob.glob(os.path.join(root, "scans/", "*.npy")))
-                normals = sorted(glob.glob(os.path.join(root, "normals/", "*.npy")))
+                normals = sorted(glob.glob(os.path.join(root, "normals/", "*.npy"))) if self.load_normals else []
+                if self.load_normals and not normals and not os.path.isdir(os.path.join(root, "normals")):
+                    self.load_normals = False                                   # an xyz-only tree
+                if self.load_normals and len(normals) != len(scans):
+                    raise Exception("The sequence " + root + " holds " + str(len(scans)) + " scans but " + str(len(normals)) + " normal lists.")
                 scans_seq.append(scans)
                 normals_seq.append(normals)
                 # a sample is the pair (t, t+1): the last scan of a sequence only ever appears as "t+1"
-                table += [(i_ds, i_seq, k) for k in range(len(normals) - 1)]
+                table += [(i_ds, i_seq, k) for k in range(len(scans) - 1)]
             self.scans_files_in_datasets.append(scans_seq)
             self.normals_files_in_datasets.append(normals_seq)
         table = np.asarray(table, dtype=int).reshape(-1, 3)
@@ -57,14 +69,23 @@ class PreprocessedPointCloudDataset(torch.utils.data.Dataset):
             print("Dataset will be kept on disk. For higher performance enable RAM loading.")
 
     def load_files_from_disk(self, index_dataset, index_sequence, index_scan):
-        normals = _as_list_tensor(np.load(self.normals_files_in_datasets[index_dataset][index_sequence][index_scan]))
+        normals = None
+        if self.load_normals:
+            normals = _as_list_tensor(np.load(self.normals_files_in_datasets[index_dataset][index_sequence][index_scan]))
         scan = _as_list_tensor(np.load(self.scans_files_in_datasets[index_dataset][index_sequence][index_scan]))
         return normals, scan
 
     def _get(self, i_ds, i_seq, k):
         if self.store_dataset_in_RAM:
             return self._ram[(i_ds, i_seq, k)]
-        return self.load_files_from_disk(i_ds, i_seq, k)
+        key = (i_ds, i_seq, k)
+        hit = self._recent.get(key)
+        if hit is None:
+            hit = self.load_files_from_disk(i_ds, i_seq, k)
+            if len(self._recent) >= 2:
+                self._recent.pop(next(iter(self._recent)))
+            self._recent[key] = hit
+        return hit
 
     def __getitem__(self, index):
         i_ds, i_seq, k = int(self.indices_dataset[index]), int(self.indices_sequence[index]), int(self.indices_scan[index])

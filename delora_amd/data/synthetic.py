@@ -201,3 +201,37 @@ def digest(arrays):
     for a in arrays:
         h.update(np.ascontiguousarray(a).tobytes())
     return h.hexdigest()
+
+
+def make_sequence(seed, n_scans, rings=64, azimuth_steps=2250, vfov_deg=(-24.5, 2.0), step=(0.45, 0.02, 0.005), max_yaw_deg=1.5, **kw):
+    """``n_scans`` consecutive scans of ONE scene along a smooth trajectory (sensor poses R_k, t_k in the scene frame; every step
+    moves ~``step`` metres and turns by up to ``max_yaw_deg``): a synthetic sequence in the sense of the reference's dataset
+    (src/data/dataset.py:124-154: sample k = the pair (scan k, scan k+1)).  Returns (list of ``[3,N_k]`` fp32 scans, list of 4x4 poses)."""
+    rng = np.random.default_rng(seed)
+    scene = Scene(rng, half_x=40.0)
+    R, t = np.eye(3), np.array([-0.5 * step[0] * n_scans, 0.0, 0.0])
+    scans, poses = [], []
+    for _ in range(n_scans):
+        scans.append(scan_scene(scene, rng, rings, azimuth_steps, vfov_deg, (R, t), **kw))
+        T = np.eye(4)
+        T[:3, :3], T[:3, 3] = R, t
+        poses.append(T)
+        R = R @ _rot_zyx(np.deg2rad(rng.uniform(-max_yaw_deg, max_yaw_deg)), np.deg2rad(rng.uniform(-0.2, 0.2)), np.deg2rad(rng.uniform(-0.2, 0.2)))
+        t = t + R @ (np.asarray(step) * rng.uniform(0.6, 1.4))
+    return scans, poses
+
+
+def write_tree(path, scans, sequence=0, normals=None):
+    """Write one sequence in the reference's on-disk training format (src/preprocessing/preprocesser.py:64-68):
+    ``<path>/<sequence:02d>/scans/<idx:06d>.npy`` = ``[M,3]`` fp32 and, when ``normals`` is given, ``.../normals/<idx:06d>.npy``.
+    Without the ``normals`` directory the tree is an xyz-only one: the step then estimates the normals online."""
+    import os
+    root = os.path.join(path, format(int(sequence), "02d"))
+    os.makedirs(os.path.join(root, "scans"), exist_ok=True)
+    if normals is not None:
+        os.makedirs(os.path.join(root, "normals"), exist_ok=True)
+    for i, s in enumerate(scans):
+        np.save(os.path.join(root, "scans", format(i, "06d") + ".npy"), np.ascontiguousarray(np.asarray(s, dtype=np.float32).T))
+        if normals is not None:
+            np.save(os.path.join(root, "normals", format(i, "06d") + ".npy"), np.ascontiguousarray(np.asarray(normals[i], dtype=np.float32).T))
+    return root

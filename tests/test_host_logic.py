@@ -189,6 +189,54 @@ def test_preprocessed_dataset_reads_reference_layout(tmp_path):
                       "normal_list_1", "normal_list_2"}
 
 
+def test_xyz_only_tree_and_consecutive_pair_reuse(tmp_path, monkeypatch):
+    """a sequence tree without normals/ is an xyz-only dataset (normals are then estimated online: half the bytes per
+    pair), and the scan shared by two consecutive samples is decoded ONCE when the samples are visited in order -- also through a
+    DataLoader with worker processes (each worker decodes whole batches)."""
+    from delora_amd.data import dataset as dsmod, synthetic
+    scans = [np.random.default_rng(i).normal(size=(3, 40 + i)).astype(np.float32) for i in range(9)]
+    synthetic.write_tree(str(tmp_path), scans, sequence=0)
+    cfg = util.repo_config(16, 128)
+    cfg["kitti"]["preprocessed_path"] = str(tmp_path)
+    cfg["kitti"]["data_identifiers"] = [0]
+    ds = dsmod.PreprocessedPointCloudDataset(cfg)
+    assert len(ds) == 8 and not ds.load_normals
+    loads = []
+    real = np.load
+    monkeypatch.setattr(dsmod.np, "load", lambda path, *a, **k: (loads.append(os.path.basename(str(path))), real(path, *a, **k))[1])
+    got = [ds[i] for i in range(8)]
+    assert len(loads) == 9, loads                                # 9 scans for 8 consecutive pairs, not 16
+    for i, s in enumerate(got):
+        assert s["normal_list_1"] is None and s["normal_list_2"] is None
+        assert torch.equal(s["scan_1"][0], torch.from_numpy(scans[i])) and torch.equal(s["scan_2"][0], torch.from_numpy(scans[i + 1]))
+    monkeypatch.undo()
+    loader = torch.utils.data.DataLoader(ds, batch_size=4, shuffle=False, collate_fn=list, drop_last=True, num_workers=2,
+                                         prefetch_factor=2, persistent_workers=True)
+    for epoch in range(2):
+        seen = [int(s["index"]) for batch in loader for s in batch]
+        assert seen == list(range(8))
+    batch = next(iter(loader))
+    assert torch.equal(batch[3]["scan_2"][0], torch.from_numpy(scans[4]))
+    # a tree WITH normals keeps the reference's behaviour, and a mismatch between the two directories is an error
+    synthetic.write_tree(str(tmp_path / "n"), scans[:3], sequence=0, normals=[-s for s in scans[:3]])
+    cfg["kitti"]["preprocessed_path"] = str(tmp_path / "n")
+    ds2 = dsmod.PreprocessedPointCloudDataset(cfg)
+    assert len(ds2) == 2 and torch.equal(ds2[1]["normal_list_2"][0], torch.from_numpy(-scans[2]))
+    os.remove(tmp_path / "n" / "00" / "normals" / "000002.npy")
+    with pytest.raises(Exception):
+        dsmod.PreprocessedPointCloudDataset(cfg)
+    assert not dsmod.PreprocessedPointCloudDataset(dict(cfg, load_normal_lists=False)).load_normals
+
+
+def test_synthetic_sequence_is_a_chain_of_small_motions():
+    from delora_amd.data import synthetic
+    scans, poses = synthetic.make_sequence(5, 4, rings=8, azimuth_steps=90)
+    assert len(scans) == 4 and all(s.shape[0] == 3 and s.dtype == np.float32 and s.shape[1] > 300 for s in scans)
+    for a, b in zip(poses[:-1], poses[1:]):
+        rel = np.linalg.inv(a) @ b
+        assert 0.1 < np.linalg.norm(rel[:3, 3]) < 1.0 and np.degrees(np.arccos(np.clip((np.trace(rel[:3, :3]) - 1) / 2, -1, 1))) < 3.0
+
+
 @pytest.mark.parametrize("name", ["tower_relu", "single_mlp"])
 def test_model_architecture_switches_match_reference(name):
     """pre_feature_extraction / use_single_mlp_at_output / relu: same parameter names, same outputs as the reference."""

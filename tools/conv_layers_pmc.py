@@ -7,7 +7,7 @@ gfx950: read bytes = FETCH_SIZE [KB] x 1024 x 2 (64 B counted per 128-B request 
 WRITE_SIZE [KB] x 1024 uncorrected."""
 import csv, json, sys
 
-FAMILIES = ("k_wino_conv", "k_wino_wgrad(", "k_wgrad_f32", "k_conv_f32", "k_convh", "k_wgradh<", "k_stem_wgrad(")
+FAMILIES = ("k_wino_conv", "k_wino_wgrad<", "k_wino_wgrad(", "k_wgrad_f32", "k_conv_f32", "k_convh", "k_wgradh<", "k_stem_wgrad(")
 
 
 def family_of(row):
