@@ -198,9 +198,9 @@ def autocast_leg(args, device, host_batches, batches, timed_region, tree=None):
     el, ep = timed_region(args.autocast_steps, step)
     out_disk = None
     if tree is not None:                                         # the 5 ms step fed from the on-disk sequence (see disk_feed_leg)
-        def step_on(batch):
+        def step_on(batch):                                       # (a PackedBatch of the feed)
             trainer.optimizer.zero_grad(set_to_none=True)
-            return trainer.step(preprocessed_dicts=[dict(s) for s in batch], epoch_losses=trainer.new_epoch_losses())[0]
+            return trainer.step(preprocessed_dicts=batch, epoch_losses=trainer.new_epoch_losses())[0]
         try:
             out_disk = disk_feed_leg(a2, cfg, device, tree, step_on, timed_region, args.batch * args.autocast_steps / el, max(args.autocast_steps, 40))
         except Exception as e:                                   # noqa: BLE001 -- the leg is informative
@@ -280,44 +280,42 @@ def make_disk_tree(args):
 
 def disk_feed_leg(args, cfg, device, tree, run_step, timed_region, resident_pairs_s, steps):
     """SURVEY.md 8f-1, for real: the tree of `make_disk_tree` is read back by `PreprocessedPointCloudDataset` (src/data/dataset.py:82-154:
-    not kept in RAM) through a DataLoader with worker processes (decode + the [M,3] -> [1,3,M] transposition in the workers, consecutive
-    pairs share their scan, page-locked batches) and the DevicePrefetcher (H2D one batch ahead on a side stream), and the timed steps
-    train on it -- shuffled, as Trainer.train reads a training set.  Reported against the resident rate of the same step."""
+    not kept in RAM) and fed the way `Trainer.train` feeds it when `num_dataloader_workers` > 0 (data/feed.py: PackedFeed -- worker
+    processes decode the files straight into page-locked shared batch slots in the layout of the step's first kernel, consecutive pairs
+    share their scan, ONE host-to-device copy per batch on a side stream, one batch ahead) -- shuffled, as a training set is read.
+    The timed steps train on it; reported against the resident rate of the same step."""
+    from delora_amd.data import feed as feedmod
     from delora_amd.data.dataset import PreprocessedPointCloudDataset
-    from delora_amd.data.feed import DevicePrefetcher
-    from delora_amd.deploy.trainer import Trainer
     dcfg = dict(cfg)
     dcfg["kitti"] = dict(cfg["kitti"], preprocessed_path=tree["path"], data_identifiers=[0])
     dcfg.update(store_dataset_in_RAM=False, num_dataloader_workers=args.disk_workers, load_normal_lists=False)
     ds = PreprocessedPointCloudDataset(dcfg)
-    loader = torch.utils.data.DataLoader(dataset=ds, batch_size=args.batch, shuffle=True, collate_fn=Trainer.list_collate, drop_last=True,
-                                         num_workers=args.disk_workers, pin_memory=True,
-                                         **({"prefetch_factor": 4, "persistent_workers": True} if args.disk_workers > 0 else {}))
-    moved = {"bytes": 0}
+    assert feedmod.packed_feed_applicable(ds, dcfg, device), "the bench's on-disk leg must take the product's packed feed"
+    pf = feedmod.make_packed_feed(ds, dcfg, device, args.batch, shuffle=True)
+    try:
+        def epochs():
+            while True:
+                for b in pf:
+                    yield b
+        it = epochs()
 
-    def epochs():
-        while True:
-            for b in DevicePrefetcher(loader, device):
-                yield b
-    it = epochs()
-
-    def fed_step():
-        b = next(it)
-        moved["bytes"] += sum(v.numel() * v.element_size() for d in b for v in d.values() if torch.is_tensor(v))
-        return run_step(b)
-    for _ in range(max(3, 2 * len(loader))):                     # workers up, page cache and allocator primed with this data's sizes
-        fed_step()
-    moved["bytes"] = 0
-    el, _ = timed_region(steps, fed_step)
-    rate = args.batch * steps / el
-    del it, loader
-    return {"steps": steps, "value": round(rate, 3), "unit": "scan-pairs/s", "ms_per_step": round(1e3 * el / steps, 3),
-            "vs_resident": round(rate / resident_pairs_s, 4), "feed_GB_s": round(moved["bytes"] / el / 1e9, 3),
-            "dataset": f"{args.disk_pairs} consecutive pairs of one synthetic sequence, {tree['bytes'] / 1e6:.0f} MB on disk, xyz only, the "
-                       f"reference's layout, store_dataset_in_RAM False", "workers": args.disk_workers, "shuffle": True,
-            "generation_s": tree["generation_s"],
-            "note": "PreprocessedPointCloudDataset -> DataLoader(worker processes, pinned batches) -> DevicePrefetcher -> the same training "
-                    "step; the files sit in the page cache after the first epoch, as a training set that fits in RAM does"}
+        def fed_step():
+            return run_step(next(it))
+        for _ in range(max(3, 2 * len(pf))):                     # workers up, page cache and allocator primed with this data's sizes
+            fed_step()
+        pf.bytes_moved = 0
+        el, _ = timed_region(steps, fed_step)
+        rate = args.batch * steps / el
+        return {"steps": steps, "value": round(rate, 3), "unit": "scan-pairs/s", "ms_per_step": round(1e3 * el / steps, 3),
+                "vs_resident": round(rate / resident_pairs_s, 4), "feed_GB_s": round(pf.bytes_moved / el / 1e9, 3),
+                "dataset": f"{args.disk_pairs} consecutive pairs of one synthetic sequence, {tree['bytes'] / 1e6:.0f} MB on disk, xyz only, the "
+                           f"reference's layout, store_dataset_in_RAM False", "workers": args.disk_workers, "shuffle": True,
+                "slots_page_locked": bool(pf.pinned), "generation_s": tree["generation_s"],
+                "note": "PreprocessedPointCloudDataset -> PackedFeed (worker processes decode into page-locked shared batch slots; one "
+                        "H2D copy per batch, one batch ahead) -> the same training step; the files sit in the page cache after the first "
+                        "epoch, as a training set that fits in RAM does"}
+    finally:
+        pf.close()
 
 
 def conv_table(args, device, reps=10):
@@ -738,7 +736,8 @@ def main():
             counter["i"] += 1
         trainer.optimizer.zero_grad(set_to_none=True)
         ep = trainer.new_epoch_losses()
-        ep, T = trainer.step(preprocessed_dicts=[dict(s) for s in batch], epoch_losses=ep)
+        from delora_amd.deploy.step_geometry import PackedBatch
+        ep, T = trainer.step(preprocessed_dicts=batch if isinstance(batch, PackedBatch) else [dict(s) for s in batch], epoch_losses=ep)
         return ep
 
     # Priming (set-up, not warm-up): one step on each of the distinct ragged batches, so that torch's caching allocator has seen every

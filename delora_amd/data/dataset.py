@@ -87,6 +87,35 @@ class PreprocessedPointCloudDataset(torch.utils.data.Dataset):
             self._recent[key] = hit
         return hit
 
+    # -- raw access for data.feed.PackedFeed (worker processes write the files straight into the step's planar batch buffer)
+    def _arrays(self, i_ds, i_seq, k):
+        key = ("raw", i_ds, i_seq, k)
+        hit = self._recent.get(key)
+        if hit is None:
+            xyz = np.load(self.scans_files_in_datasets[i_ds][i_seq][k])
+            nrm = np.load(self.normals_files_in_datasets[i_ds][i_seq][k]) if self.load_normals else None
+            hit = (np.asarray(xyz, dtype=np.float32), None if nrm is None else np.asarray(nrm, dtype=np.float32))
+            if len(self._recent) >= 2:
+                self._recent.pop(next(iter(self._recent)))
+            self._recent[key] = hit
+        return hit
+
+    def load_pair_arrays(self, index):
+        """[(xyz [M,3], normals [M,3] | None) of scan k, the same of scan k+1] as stored on disk (no transposition, no tensors)."""
+        i_ds, i_seq, k = int(self.indices_dataset[index]), int(self.indices_sequence[index]), int(self.indices_scan[index])
+        return [self._arrays(i_ds, i_seq, k), self._arrays(i_ds, i_seq, k + 1)]
+
+    def max_points_per_scan(self):
+        """Upper bound of a stored list's length: the preprocessing image of its dataset block (vertical_cells x
+        horizontal_cells_preprocessing, src/preprocessing/preprocesser.py:50-61), or config ``feed_points_per_scan``."""
+        if self.config.get("feed_points_per_scan"):
+            return int(self.config["feed_points_per_scan"])
+        best = 0
+        for name in self.config["datasets"]:
+            block = self.config[name]
+            best = max(best, int(block["vertical_cells"]) * int(block.get("horizontal_cells_preprocessing", block["horizontal_cells"])))
+        return best
+
     def __getitem__(self, index):
         i_ds, i_seq, k = int(self.indices_dataset[index]), int(self.indices_sequence[index]), int(self.indices_scan[index])
         normal_list_1, scan_1 = self._get(i_ds, i_seq, k)

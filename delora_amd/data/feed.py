@@ -52,3 +52,212 @@ class DevicePrefetcher:
             except StopIteration:
                 nxt = None
             yield cur
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# PackedFeed: worker processes decode whole batches straight into page-locked shared memory, in the layout the step's first kernel
+# reads.
+#
+# What a step consumes is ONE planar point buffer ``pts [C, sumN]`` (the 2B scans of the batch back to back, C = 3, or 6 with the
+# stored normal lists as extra rows) plus CSR offsets (deploy/step_geometry.PackedBatch).  torch's DataLoader hands a batch over as
+# 16-32 separate tensors through per-tensor shared-memory files and re-pins every one of them (hipHostMalloc per tensor and batch:
+# measured 23 ms per batch of 8 pairs, 0.63x of the resident rate at fp32 and 0.32x at bf16).  Here:
+#   * a ring of batch SLOTS is allocated once in shared memory and page-locked once (hipHostRegister) -- no allocation, no pinning
+#     and no pickling of tensor data afterwards;
+#   * worker processes (forked after the slots exist) np.load the ``[M,3]`` files of a batch and write them TRANSPOSED straight into
+#     their slot (one pass: decode -> planar slot), a scan shared by consecutive pairs once;
+#   * the consumer starts ONE host-to-device copy per batch on a side stream, one batch ahead of the step, and recycles the slot when
+#     the copy has finished.
+# The order of the samples is torch's own (RandomSampler / DistributedSampler(drop_last) + BatchSampler), so an epoch visits what
+# Trainer.make_dataloader's DataLoader would visit.  Reference: src/data/dataset.py:82-154, src/deploy/trainer.py:95-101.
+import multiprocessing as _mp
+import queue as _queue
+
+import numpy as _np
+
+
+def _feed_worker(dataset, slots, tasks, done, rows):
+    """Worker loop: (batch id, sample indices, slot) -> the slot filled as ``[rows, total]`` planar fp32 + the scan lengths."""
+    torch.set_num_threads(1)
+    while True:
+        task = tasks.get()
+        if task is None:
+            return
+        bid, indices, slot = task
+        try:
+            arrays = []
+            for i in indices:
+                arrays += dataset.load_pair_arrays(int(i))          # [(xyz [M,3], normals [M,3] | None)] x 2, scan reuse inside
+            lengths = [a[0].shape[0] for a in arrays]
+            total = int(sum(lengths))
+            buf = slots[slot].numpy()
+            if rows * total > buf.size:
+                done.put((bid, slot, None, f"batch of {total} points exceeds the slot capacity {buf.size // rows}"))
+                continue
+            out = buf[:rows * total].reshape(rows, total)
+            o = 0
+            for (xyz, nrm), n in zip(arrays, lengths):
+                out[:3, o:o + n] = xyz[:, :3].T                       # decode -> planar slot in one pass
+                if rows == 6:
+                    out[3:6, o:o + n] = nrm.T
+                o += n
+            done.put((bid, slot, lengths, None))
+        except Exception as e:                                       # noqa: BLE001 -- reported to the consumer, which raises
+            done.put((bid, slot, None, f"{type(e).__name__}: {e}"))
+
+
+class PackedFeed:
+    """Iterable over the batches of one epoch as ``PackedBatch`` objects on ``device`` (see the block comment above).
+
+    ``dataset``: a ``PreprocessedPointCloudDataset`` over ONE dataset block (one sensor); ``batch_sampler``: an iterable of index
+    lists per epoch (torch's BatchSampler); ``workers`` >= 1 processes; ``points_per_scan``: upper bound of a stored list's length
+    (the slot capacity is 2 * batch_size * that many points)."""
+
+    def __init__(self, dataset, batch_sampler, batch_size, device, workers=4, points_per_scan=None, slots=None, ahead=None):
+        from ..deploy.step_geometry import PackedBatch
+        self._PackedBatch = PackedBatch
+        self.dataset, self.batch_sampler, self.B, self.device = dataset, batch_sampler, int(batch_size), device
+        self.cuda = getattr(device, "type", str(device)) == "cuda"
+        self.rows = 6 if dataset.load_normals else 3
+        self.dataset_name = dataset.config["datasets"][0]
+        self.workers = max(1, int(workers))
+        self.ahead = int(ahead) if ahead else 2 * self.workers            # batches in flight
+        n_slots = int(slots) if slots else self.ahead + 2
+        cap = int(points_per_scan or dataset.max_points_per_scan())
+        self.capacity = 2 * self.B * cap
+        # the ring of slots: shared between the processes (allocated before the fork), page-locked for asynchronous copies
+        self.slots = [torch.empty((self.rows * self.capacity,), dtype=torch.float32).share_memory_() for _ in range(n_slots)]
+        self.pinned = False
+        if self.cuda:
+            rt = torch.cuda.cudart()
+            self.pinned = all(int(rt.cudaHostRegister(s.data_ptr(), s.numel() * 4, 0)) == 0 for s in self.slots)
+        self.stream = torch.cuda.Stream(device=device) if self.cuda else None
+        ctx = _mp.get_context("fork")
+        self.tasks, self.done = ctx.Queue(), ctx.Queue()
+        self.procs = [ctx.Process(target=_feed_worker, args=(dataset, self.slots, self.tasks, self.done, self.rows), daemon=True)
+                      for _ in range(self.workers)]
+        for p in self.procs:
+            p.start()
+        self.bytes_moved = 0
+
+    def __len__(self):
+        return len(self.batch_sampler)
+
+    def close(self):
+        for _ in self.procs:
+            self.tasks.put(None)
+        for p in self.procs:
+            p.join(timeout=2)
+            if p.is_alive():
+                p.terminate()
+        if self.cuda and self.pinned:
+            rt = torch.cuda.cudart()
+            for s in self.slots:
+                rt.cudaHostUnregister(s.data_ptr())
+        self.procs, self.slots = [], []
+
+    def __del__(self):
+        try:
+            if self.procs:
+                self.close()
+        except Exception:                                            # noqa: BLE001 -- interpreter shutdown
+            pass
+
+    def _upload(self, slot, lengths):
+        """Slot -> device (side stream); returns (PackedBatch, event after which the slot may be refilled)."""
+        total = int(sum(lengths))
+        host = self.slots[slot][:self.rows * total].view(self.rows, total)
+        offs = [0]
+        for n in lengths:
+            offs.append(offs[-1] + n)
+        if not self.cuda:
+            return self._PackedBatch(host.clone(), torch.tensor(offs, dtype=torch.int32), max(lengths), self.B, self.dataset_name,
+                                     self.rows == 6), None
+        with torch.cuda.stream(self.stream):
+            pts = torch.empty((self.rows, total), dtype=torch.float32, device=self.device)
+            pts.copy_(host, non_blocking=True)
+            offs_t = torch.tensor(offs, dtype=torch.int32).pin_memory().to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        self.bytes_moved += pts.numel() * 4
+        return self._PackedBatch(pts, offs_t, max(lengths), self.B, self.dataset_name, self.rows == 6), ev
+
+    def __iter__(self):
+        batches = iter(self.batch_sampler)
+        free = list(range(len(self.slots)))
+        busy = []                                   # (event, slot): uploads in flight
+        arrived = {}                                # batch id -> (slot, lengths)
+        issued = consumed = 0
+        exhausted = False
+        staged = None                               # the uploaded batch waiting to be handed out (one ahead of the step)
+
+        def reclaim(block):
+            while busy and (block or busy[0][0] is None or busy[0][0].query()):
+                ev, slot = busy.pop(0)
+                if ev is not None:
+                    ev.synchronize()
+                free.append(slot)
+                block = False
+
+        def issue():
+            nonlocal issued, exhausted
+            while not exhausted and free and issued - consumed < self.ahead:
+                try:
+                    idx = next(batches)
+                except StopIteration:
+                    exhausted = True
+                    return
+                self.tasks.put((issued, [int(i) for i in idx], free.pop(0)))
+                issued += 1
+
+        def next_uploaded():
+            nonlocal consumed
+            if consumed >= issued:
+                return None
+            while consumed not in arrived:
+                try:
+                    bid, slot, lengths, err = self.done.get(timeout=120)
+                except _queue.Empty:
+                    raise RuntimeError("PackedFeed: no batch from the worker processes for 120 s")
+                if err is not None:
+                    raise RuntimeError("PackedFeed worker: " + err)
+                arrived[bid] = (slot, lengths)
+            slot, lengths = arrived.pop(consumed)
+            consumed += 1
+            packed, ev = self._upload(slot, lengths)
+            busy.append((ev, slot))
+            return packed
+
+        issue()
+        staged = next_uploaded()
+        while staged is not None:
+            reclaim(block=not free and not exhausted)
+            issue()
+            cur = staged
+            if self.cuda:
+                torch.cuda.current_stream(self.device).wait_stream(self.stream)
+                cur.pts.record_stream(torch.cuda.current_stream(self.device))
+                cur.offs.record_stream(torch.cuda.current_stream(self.device))
+            staged = next_uploaded()                # the next batch's copy runs while the caller's step is enqueued
+            yield cur
+        reclaim(block=True)
+
+
+def packed_feed_applicable(dataset, config, device):
+    """Whether the training set can go through ``PackedFeed``: worker processes requested, a CUDA device, the reference's on-disk
+    dataset over ONE dataset block (one sensor per batch), no per-sample host preprocessing (augmentation / range normalisation work
+    on the sample dicts)."""
+    from .dataset import PreprocessedPointCloudDataset
+    return (isinstance(dataset, PreprocessedPointCloudDataset) and not dataset.store_dataset_in_RAM and len(config["datasets"]) == 1
+            and int(config.get("num_dataloader_workers", 0)) > 0 and bool(config.get("packed_feed", True))
+            and not config.get("normalization_scaling") and not config.get("random_point_cloud_rotations")
+            and getattr(device, "type", str(device)) == "cuda")
+
+
+def make_packed_feed(dataset, config, device, batch_size, sampler=None, shuffle=True):
+    """``PackedFeed`` over torch's own samplers: RandomSampler (or the given DistributedSampler) + BatchSampler(drop_last)."""
+    if sampler is None:
+        sampler = torch.utils.data.RandomSampler(dataset) if shuffle else torch.utils.data.SequentialSampler(dataset)
+    batches = torch.utils.data.BatchSampler(sampler, batch_size=batch_size, drop_last=True)
+    return PackedFeed(dataset, batches, batch_size, device, workers=int(config["num_dataloader_workers"]),
+                      points_per_scan=config.get("feed_points_per_scan"))

@@ -79,7 +79,8 @@ class Trainer(deployer.Deployer):
 
     def train_epoch(self, epoch, dataloader):
         epoch_losses = self.new_epoch_losses()
-        iterator = feed.DevicePrefetcher(dataloader, self.device)       # next batch is copied while this step runs
+        # next batch is copied while this step runs (a PackedFeed does that itself and yields device-resident PackedBatch objects)
+        iterator = dataloader if isinstance(dataloader, feed.PackedFeed) else feed.DevicePrefetcher(dataloader, self.device)
         show = self.rank == 0 and qqdm is not None
         if show:
             iterator = qqdm.qqdm(iterator, desc=qqdm.format_str("blue", "Epoch " + str(epoch)))
@@ -138,6 +139,10 @@ class Trainer(deployer.Deployer):
         if self.world_size > 1:
             sampler = torch.utils.data.distributed.DistributedSampler(self.dataset, num_replicas=self.world_size,
                                                                       rank=self.rank, shuffle=True, drop_last=True)
+        if feed.packed_feed_applicable(self.dataset, self.config, self.device) and not self.config.get("hip_graph", False):
+            # the reference's on-disk training set with worker processes: batches are decoded straight into page-locked shared memory
+            # in the layout of the step's first kernel and reach the GPU as ONE copy per batch (data/feed.py: PackedFeed)
+            return feed.make_packed_feed(self.dataset, self.config, self.device, self.batch_size, sampler=sampler), sampler
         workers = int(self.config["num_dataloader_workers"])
         # worker processes decode whole batches ahead of the step (np.load + the [M,3] -> [1,3,M] transposition: ~3 ms per pair) and
         # stay alive between epochs; the loader's pinning thread copies each batch into page-locked memory, from where the

@@ -285,6 +285,52 @@ def test_train_loop_with_prefetcher_and_checkpoints(tmp_path):
     assert np.isfinite(ck["loss"])
 
 
+@pytest.mark.parametrize("with_normals", [False, True])
+def test_training_from_the_on_disk_format_through_the_packed_feed(tmp_path, with_normals):
+    """`Trainer.train` on a tree in the reference's on-disk format (src/preprocessing/preprocesser.py:64-68) with worker
+    processes: the batches come through data/feed.py: PackedFeed (page-locked shared slots, one H2D copy per batch) as PackedBatch
+    objects, and the epoch's metrics equal those of the same run fed by the plain DataLoader (same sampler seed, same samples, same
+    kernels -- the packed buffer is just the concatenation `HipStepGeometry.prepare` would build on the device)."""
+    from delora_amd.data import feed, synthetic
+    from delora_amd.data.dataset import PreprocessedPointCloudDataset
+    from delora_amd.deploy.trainer import Trainer
+    dev = _dev()
+    scans, _ = synthetic.make_sequence(11, 7, rings=16, azimuth_steps=160)
+    normals = None
+    if with_normals:
+        g = np.random.default_rng(2)
+        normals = []
+        for sc in scans:
+            n = g.normal(size=sc.shape).astype(np.float32)
+            normals.append(n / np.linalg.norm(n, axis=0, keepdims=True))
+    synthetic.write_tree(str(tmp_path / "data"), scans, sequence=0, normals=normals)
+    results = []
+    for workers in (0, 2):
+        cfg = util.repo_config(16, 128, device="cuda:0", factor_fewer_resnet_channels=8, resnet_outputs=64, batch_size=2,
+                               unsupervised_at_start=True, inference_only=False, checkpoint_dir=str(tmp_path), learning_rate=1e-4,
+                               num_dataloader_workers=workers, store_dataset_in_RAM=False)
+        cfg["kitti"]["preprocessed_path"] = str(tmp_path / "data")
+        cfg["kitti"]["data_identifiers"] = cfg["kitti"]["training_identifiers"] = [0]
+        torch.manual_seed(7)
+        tr = Trainer(cfg, dataset=PreprocessedPointCloudDataset(cfg))
+        loader, sampler = tr.make_dataloader()
+        assert isinstance(loader, feed.PackedFeed) == (workers > 0)
+        if workers:
+            assert loader.pinned, "the slots of the feed must be page-locked (hipHostRegister) on a GPU box"
+        tr.steps_per_epoch_effective = len(loader)
+        torch.manual_seed(99)                                     # the sampler draws its permutation from the global generator
+        metrics = tr._reduce_metrics(tr.train_epoch(epoch=0, dataloader=loader))
+        results.append((metrics, [p.detach().clone() for p in tr.raw_model.parameters()]))
+        if workers:
+            loader.close()
+    (m0, p0), (m1, p1) = results
+    assert len(tr.dataset) == 6 and np.isfinite(m0["loss_epoch"]) and m0["loss_epoch"] > 0
+    for k in m0:
+        assert np.isclose(m0[k], m1[k], rtol=1e-6, atol=1e-9), (k, m0[k], m1[k])
+    util.measured(f"packed feed vs DataLoader ({'stored normals' if with_normals else 'xyz only'}): largest parameter difference after one epoch",
+                  max(float((a - b).abs().max()) for a, b in zip(p0, p1)), bound=1e-7)
+
+
 def test_device_prefetcher_on_gpu():
     from delora_amd.data.feed import DevicePrefetcher
     dev = _dev()

@@ -228,6 +228,45 @@ def test_xyz_only_tree_and_consecutive_pair_reuse(tmp_path, monkeypatch):
     assert not dsmod.PreprocessedPointCloudDataset(dict(cfg, load_normal_lists=False)).load_normals
 
 
+@pytest.mark.parametrize("with_normals", [False, True])
+def test_packed_feed_delivers_the_batches_of_the_sampler_in_the_steps_layout(tmp_path, with_normals):
+    """data/feed.py: PackedFeed -- worker processes decode the reference's on-disk files straight into shared batch slots, planar
+    [C, sumN] + CSR offsets in the order b0.scan_1, b0.scan_2, b1.scan_1 ... (what dl_project reads): every batch of the sampler, in
+    order, with exactly the bytes of the files, over two epochs, with fewer slots than batches (slots are recycled)."""
+    from delora_amd.data import dataset as dsmod, feed, synthetic
+    rng = np.random.default_rng(3)
+    scans = [rng.normal(size=(3, 30 + 7 * i)).astype(np.float32) for i in range(11)]
+    normals = [rng.normal(size=s.shape).astype(np.float32) for s in scans] if with_normals else None
+    synthetic.write_tree(str(tmp_path), scans, sequence=0, normals=normals)
+    cfg = util.repo_config(16, 128)
+    cfg["kitti"]["preprocessed_path"] = str(tmp_path)
+    cfg["kitti"]["data_identifiers"] = [0]
+    cfg["num_dataloader_workers"] = 2
+    ds = dsmod.PreprocessedPointCloudDataset(cfg)
+    assert not feed.packed_feed_applicable(ds, cfg, torch.device("cpu"))          # a CUDA feed: the CPU keeps the DataLoader
+    order = [[3, 0], [9, 4], [1, 2], [7, 8], [5, 6]]
+    pf = feed.PackedFeed(ds, order, 2, torch.device("cpu"), workers=2, points_per_scan=200, slots=3, ahead=2)
+    try:
+        for epoch in range(2):
+            got = list(pf)
+            assert len(got) == len(order)
+            for batch, idx in zip(got, order):
+                assert len(batch) == 2 and batch.with_lists == with_normals and batch.dataset == "kitti"
+                want = [scans[i + d] for i in idx for d in (0, 1)]
+                offs = batch.offs.tolist()
+                assert offs == list(np.cumsum([0] + [w.shape[1] for w in want])) and batch.max_points == max(w.shape[1] for w in want)
+                assert torch.equal(batch.pts[:3], torch.from_numpy(np.concatenate(want, axis=1)))
+                if with_normals:
+                    assert torch.equal(batch.pts[3:], torch.from_numpy(np.concatenate([normals[i + d] for i in idx for d in (0, 1)], axis=1)))
+        # a batch beyond the slot capacity is an error of the feed, not a silent truncation
+        small = feed.PackedFeed(ds, [[0, 1]], 2, torch.device("cpu"), workers=1, points_per_scan=20)
+        with pytest.raises(RuntimeError):
+            list(small)
+        small.close()
+    finally:
+        pf.close()
+
+
 def test_synthetic_sequence_is_a_chain_of_small_motions():
     from delora_amd.data import synthetic
     scans, poses = synthetic.make_sequence(5, 4, rings=8, azimuth_steps=90)
