@@ -139,16 +139,17 @@ class Trainer(deployer.Deployer):
         if self.world_size > 1:
             sampler = torch.utils.data.distributed.DistributedSampler(self.dataset, num_replicas=self.world_size,
                                                                       rank=self.rank, shuffle=True, drop_last=True)
+        shuffle = bool(self.config.get("shuffle_training_data", True))          # the reference always shuffles (trainer.py:95-101)
         if feed.packed_feed_applicable(self.dataset, self.config, self.device) and not self.config.get("hip_graph", False):
             # the reference's on-disk training set with worker processes: batches are decoded straight into page-locked shared memory
             # in the layout of the step's first kernel and reach the GPU as ONE copy per batch (data/feed.py: PackedFeed)
-            return feed.make_packed_feed(self.dataset, self.config, self.device, self.batch_size, sampler=sampler), sampler
+            return feed.make_packed_feed(self.dataset, self.config, self.device, self.batch_size, sampler=sampler, shuffle=shuffle), sampler
         workers = int(self.config["num_dataloader_workers"])
         # worker processes decode whole batches ahead of the step (np.load + the [M,3] -> [1,3,M] transposition: ~3 ms per pair) and
         # stay alive between epochs; the loader's pinning thread copies each batch into page-locked memory, from where the
         # DevicePrefetcher's side stream takes it to the GPU while the previous step runs
         extra = {"prefetch_factor": int(self.config.get("dataloader_prefetch_factor", 4)), "persistent_workers": True} if workers > 0 else {}
-        loader = torch.utils.data.DataLoader(dataset=self.dataset, batch_size=self.batch_size, shuffle=sampler is None,
+        loader = torch.utils.data.DataLoader(dataset=self.dataset, batch_size=self.batch_size, shuffle=sampler is None and shuffle,
                                              sampler=sampler, collate_fn=Trainer.list_collate, drop_last=True,
                                              num_workers=workers, pin_memory=getattr(self.device, "type", "cpu") == "cuda", **extra)
         return loader, sampler

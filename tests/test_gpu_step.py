@@ -289,7 +289,7 @@ def test_train_loop_with_prefetcher_and_checkpoints(tmp_path):
 def test_training_from_the_on_disk_format_through_the_packed_feed(tmp_path, with_normals):
     """`Trainer.train` on a tree in the reference's on-disk format (src/preprocessing/preprocesser.py:64-68) with worker
     processes: the batches come through data/feed.py: PackedFeed (page-locked shared slots, one H2D copy per batch) as PackedBatch
-    objects, and the epoch's metrics equal those of the same run fed by the plain DataLoader (same sampler seed, same samples, same
+    objects, and the epoch's metrics equal those of the same run fed by the plain DataLoader (same sample order, same
     kernels -- the packed buffer is just the concatenation `HipStepGeometry.prepare` would build on the device)."""
     from delora_amd.data import feed, synthetic
     from delora_amd.data.dataset import PreprocessedPointCloudDataset
@@ -308,7 +308,7 @@ def test_training_from_the_on_disk_format_through_the_packed_feed(tmp_path, with
     for workers in (0, 2):
         cfg = util.repo_config(16, 128, device="cuda:0", factor_fewer_resnet_channels=8, resnet_outputs=64, batch_size=2,
                                unsupervised_at_start=True, inference_only=False, checkpoint_dir=str(tmp_path), learning_rate=1e-4,
-                               num_dataloader_workers=workers, store_dataset_in_RAM=False)
+                               num_dataloader_workers=workers, store_dataset_in_RAM=False, shuffle_training_data=False)
         cfg["kitti"]["preprocessed_path"] = str(tmp_path / "data")
         cfg["kitti"]["data_identifiers"] = cfg["kitti"]["training_identifiers"] = [0]
         torch.manual_seed(7)
@@ -318,7 +318,6 @@ def test_training_from_the_on_disk_format_through_the_packed_feed(tmp_path, with
         if workers:
             assert loader.pinned, "the slots of the feed must be page-locked (hipHostRegister) on a GPU box"
         tr.steps_per_epoch_effective = len(loader)
-        torch.manual_seed(99)                                     # the sampler draws its permutation from the global generator
         metrics = tr._reduce_metrics(tr.train_epoch(epoch=0, dataloader=loader))
         results.append((metrics, [p.detach().clone() for p in tr.raw_model.parameters()]))
         if workers:
