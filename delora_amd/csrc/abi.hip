@@ -86,9 +86,13 @@ void dl_prof_events(const DlProfTag& tag, hipEvent_t* e0, hipEvent_t* e1) {
 extern "C" int dl_profile_begin(int32_t max_launches, const char* only_kernel) {
   std::lock_guard<std::mutex> lock(g_prof.mu);
   if (g_prof.open.load() || max_launches <= 0) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_profile_begin: a profile is already open / bad size");
-  g_prof.ev.resize((size_t)2 * max_launches);
-  for (auto& e : g_prof.ev)
-    if (hipEventCreate(&e) != hipSuccess) return dl_fail(DL_ERR_LAUNCH, "dl_profile_begin: hipEventCreate failed");
+  g_prof.ev.assign((size_t)2 * max_launches, nullptr);
+  for (size_t i = 0; i < g_prof.ev.size(); ++i)
+    if (hipEventCreate(&g_prof.ev[i]) != hipSuccess) {
+      for (size_t j = 0; j < i; ++j) (void)hipEventDestroy(g_prof.ev[j]);      // nothing half-created survives a failed begin
+      g_prof.ev.clear();
+      return dl_fail(DL_ERR_LAUNCH, "dl_profile_begin: hipEventCreate failed");
+    }
   g_prof.used = g_prof.skipped = 0;
   g_prof.rows.clear();
   g_prof.only = only_kernel ? only_kernel : "";

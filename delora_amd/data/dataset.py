@@ -92,9 +92,12 @@ class PreprocessedPointCloudDataset(torch.utils.data.Dataset):
         key = ("raw", i_ds, i_seq, k)
         hit = self._recent.get(key)
         if hit is None:
-            xyz = np.load(self.scans_files_in_datasets[i_ds][i_seq][k])
-            nrm = np.load(self.normals_files_in_datasets[i_ds][i_seq][k]) if self.load_normals else None
-            hit = (np.asarray(xyz, dtype=np.float32), None if nrm is None else np.asarray(nrm, dtype=np.float32))
+            # memory-mapped: the one pass that transposes the file into the batch slot reads it straight from the page cache
+            xyz = np.load(self.scans_files_in_datasets[i_ds][i_seq][k], mmap_mode="r")
+            nrm = np.load(self.normals_files_in_datasets[i_ds][i_seq][k], mmap_mode="r") if self.load_normals else None
+            if xyz.dtype != np.float32 or (nrm is not None and nrm.dtype != np.float32):
+                xyz, nrm = np.asarray(xyz, dtype=np.float32), (None if nrm is None else np.asarray(nrm, dtype=np.float32))
+            hit = (xyz, nrm)
             if len(self._recent) >= 2:
                 self._recent.pop(next(iter(self._recent)))
             self._recent[key] = hit
