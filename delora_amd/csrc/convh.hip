@@ -471,6 +471,9 @@ static int dispatch_convh(const ConvHArgs& a, hipStream_t st) {
       case 8: return launch_convh<F16, 256, 64, 2, 2, 64, G, NG>(a, st);
       case 9: return launch_convh<F16, 128, 64, 2, 2, 64, G, NG>(a, st);
       case 10: return launch_convh<F16, 128, 128, 2, 2, 64, G, NG>(a, st);
+      case 11: return launch_convh<F16, 256, 256, 2, 2, 64, G, NG>(a, st);       // 128 x 128 per wave: half the LDS reads per MFMA
+      case 12: return launch_convh<F16, 512, 128, 4, 1, 64, G, NG>(a, st);
+      case 13: return launch_convh<F16, 256, 128, 2, 1, 64, G, NG>(a, st);
       default: break;
     }
 #endif

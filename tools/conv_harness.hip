@@ -233,8 +233,8 @@ static int check_shape(const Shape& s, std::mt19937& gen) {
     const size_t ngrid = (size_t)s.N * Ho * Wo * s.C;
     auto addg = rnd(ngrid, gen, 1.f);
     float* daddg = dev(addg);
-    if (s.ks == 3) rc = dl_conv2d_dgrad_strided_nhwc_f32(dg, dw, dgi, daddg, dsrc, s.N, Ho, Wo, s.K, s.C, 3, s.sh, s.sw, 0, 1, DL_CONV_ADD_GRID | DL_CONV_DACT, nullptr);
-    else rc = dl_conv2d_dgrad_strided_nhwc_f32(dg, dw, dgi, nullptr, nullptr, s.N, Ho, Wo, s.K, s.C, 1, s.sh, s.sw, 1, 0, 0, nullptr);
+    if (s.ks == 3) rc = dl_conv2d_dgrad_strided_nhwc_f32(dg, dw, dgi, daddg, dsrc, s.N, s.H, s.W, s.K, s.C, 3, s.sh, s.sw, 0, 1, DL_CONV_ADD_GRID | DL_CONV_DACT, nullptr, nullptr);
+    else rc = dl_conv2d_dgrad_strided_nhwc_f32(dg, dw, dgi, nullptr, nullptr, s.N, s.H, s.W, s.K, s.C, 1, s.sh, s.sw, 1, 0, 0, nullptr, nullptr);
     if (rc) { printf("  %s dgrad-strided: rc %d %s\n", s.name, rc, dl_last_error()); bad++; }
     else {
       CK(hipDeviceSynchronize());
@@ -372,8 +372,8 @@ static void time_shape(const Shape& s, int reps, std::mt19937& gen, double* tota
   if (s.ks == 3 && s.sh == 1 && s.sw == 1)
     run("dgrad", [&] { return dl_conv2d_nhwc_f32(dg, dw, dgi, nullptr, dx, s.N, s.H, s.W, s.K, s.C, 3, 1, 1, 1, 1, DL_CONV_DACT, nullptr); });
   if (s.sh > 1 || s.sw > 1)
-    run("dgrad", [&] { return dl_conv2d_dgrad_strided_nhwc_f32(dg, dw, dgi, nullptr, s.ks == 3 ? dx : nullptr, s.N, Ho, Wo, s.K, s.C, s.ks, s.sh, s.sw,
-                                                               s.ks == 1, 1, s.ks == 3 ? DL_CONV_DACT : 0, nullptr); });
+    run("dgrad", [&] { return dl_conv2d_dgrad_strided_nhwc_f32(dg, dw, dgi, nullptr, s.ks == 3 ? dx : nullptr, s.N, s.H, s.W, s.K, s.C, s.ks, s.sh, s.sw,
+                                                               s.ks == 1, 1, s.ks == 3 ? DL_CONV_DACT : 0, nullptr, nullptr); });
   if (with_wgrad) run("wgrad", [&] { return dl_conv2d_wgrad_nhwc_f32(dx, dg, ddw, ws, s.N, s.H, s.W, s.C, s.K, s.ks, s.sh, s.sw, nullptr); });
   CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dg)); CK(hipFree(dy)); CK(hipFree(dgi)); CK(hipFree(ddw)); CK(hipFree(ws));
 }

@@ -220,8 +220,8 @@ static int check_shape(const Shape& s, std::mt19937& gen, int variant) {
     g_ch_variant = 0;
     const size_t ngrid = (size_t)s.N * Ho * Wo * s.C;
     HalfTensor addg = rnd_half(ngrid, gen, 1.f);
-    if (s.ks == 3) rc = dl_conv2d_dgrad_strided_nhwc_h(g.d, wbk, dgi, addg.d, dsx.d, s.N, Ho, Wo, s.K, s.C, 3, s.sh, s.sw, 0, g_dtype, 1, CH_EPI_ADD_GRID | CH_EPI_DACT, nullptr);
-    else rc = dl_conv2d_dgrad_strided_nhwc_h(g.d, wbk, dgi, nullptr, nullptr, s.N, Ho, Wo, s.K, s.C, 1, s.sh, s.sw, 1, g_dtype, 0, 0, nullptr);
+    if (s.ks == 3) rc = dl_conv2d_dgrad_strided_nhwc_h(g.d, wbk, dgi, addg.d, dsx.d, s.N, s.H, s.W, s.K, s.C, 3, s.sh, s.sw, 0, g_dtype, 1, CH_EPI_ADD_GRID | CH_EPI_DACT, nullptr, nullptr);
+    else rc = dl_conv2d_dgrad_strided_nhwc_h(g.d, wbk, dgi, nullptr, nullptr, s.N, s.H, s.W, s.K, s.C, 1, s.sh, s.sw, 1, g_dtype, 0, 0, nullptr, nullptr);
     if (rc) { printf("  %-30s dgrad-strided: rc %d %s\n", s.name, rc, dl_last_error()); bad++; }
     else {
       CK(hipDeviceSynchronize());
@@ -315,8 +315,8 @@ static void time_shape(const Shape& s, int reps, std::mt19937& gen, double* tota
   if (s.ks == 3 && s.sh == 1 && s.sw == 1)
     run("dgrad", (2 * nx + ny + nw) * 2.0, [&] { return dl_conv2d_nhwc_h(g.d, wbk, dgi, nullptr, x.d, s.N, s.H, s.W, s.K, s.C, 3, 1, 1, 1, g_dtype, 1, CH_EPI_DACT, nullptr); });
   else
-    run("dgrad", (2 * nx + ny + nw) * 2.0, [&] { return dl_conv2d_dgrad_strided_nhwc_h(g.d, wbk, dgi, nullptr, s.ks == 3 ? x.d : nullptr, s.N, Ho, Wo, s.K, s.C, s.ks, s.sh, s.sw,
-                                                                                         s.ks == 1, g_dtype, 1, s.ks == 3 ? CH_EPI_DACT : 0, nullptr); });
+    run("dgrad", (2 * nx + ny + nw) * 2.0, [&] { return dl_conv2d_dgrad_strided_nhwc_h(g.d, wbk, dgi, nullptr, s.ks == 3 ? x.d : nullptr, s.N, s.H, s.W, s.K, s.C, s.ks, s.sh, s.sw,
+                                                                                         s.ks == 1, g_dtype, 1, s.ks == 3 ? CH_EPI_DACT : 0, nullptr, nullptr); });
   {
     const size_t wsb = dl_conv2d_wgrad_h_workspace_bytes(s.N, s.H, s.W, s.C, s.K, s.ks, s.sh, s.sw);
     void* ws; float* ddw;
@@ -343,7 +343,7 @@ int main(int argc, char** argv) {
     printf("storage type: %s\n", g_dtype == DL_DTYPE_BF16 ? "bf16" : "f16");
     // every tile variant of the stride-1 kernel on a shape it tiles (variant 0 = the product's own choice)
     const Shape base = {"3x3 s1 2x16x128 64->128", 2, 16, 128, 64, 128, 3, 1, 1};
-    for (int v = 0; v <= 10; ++v) bad += check_shape(base, gen, v);
+    for (int v = 0; v <= 13; ++v) bad += check_shape(base, gen, v);
     const Shape small[] = {
         {"3x3 s1 2x8x128 64->64", 2, 8, 128, 64, 64, 3, 1, 1},     {"3x3 s1 1x4x64 128->128", 1, 4, 64, 128, 128, 3, 1, 1},
         {"3x3 s1 2x8x32 32->128", 2, 8, 32, 32, 128, 3, 1, 1},     {"3x3 s1 1x64x64 96->64", 1, 64, 64, 96, 64, 3, 1, 1},
@@ -370,7 +370,7 @@ int main(int argc, char** argv) {
   }
   if (!strcmp(mode, "tune")) {
     const int reps = argc >= 3 && atoi(argv[2]) > 0 ? atoi(argv[2]) : 10;
-    for (int v = 0; v <= 10; ++v) {
+    for (int v = 0; v <= 13; ++v) {
       g_ch_variant = v;
       printf("---- variant %d\n", v);
       for (const auto& s : s1) time_shape(s, reps, gen, nullptr);
