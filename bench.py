@@ -316,14 +316,17 @@ def disk_feed_leg(args, cfg, device, tree, run_step, timed_region, resident_pair
         resident_same = args.batch * steps / el_r
         del kept
         pf.bytes_moved = 0
+        for k_ in pf.host_seconds:
+            pf.host_seconds[k_] = 0.0
         el, _ = timed_region(steps, fed_step)
         rate = args.batch * steps / el
+        host_ms = {k_: round(1e3 * v_ / steps, 3) for k_, v_ in pf.host_seconds.items()}
         return {"steps": steps, "value": round(rate, 3), "unit": "scan-pairs/s", "ms_per_step": round(1e3 * el / steps, 3),
                 "resident_same_data": round(resident_same, 3), "vs_resident": round(rate / resident_same, 4),
                 "vs_headline_workload": round(rate / resident_pairs_s, 4), "feed_GB_s": round(pf.bytes_moved / el / 1e9, 3),
                 "dataset": f"{args.disk_pairs} consecutive pairs of one synthetic sequence, {tree['bytes'] / 1e6:.0f} MB on disk, xyz only, the "
                            f"reference's layout, store_dataset_in_RAM False", "workers": args.disk_workers, "shuffle": True,
-                "slots_page_locked": bool(pf.pinned), "generation_s": tree["generation_s"],
+                "slots_page_locked": bool(pf.pinned), "consumer_host_ms_per_step": host_ms, "generation_s": tree["generation_s"],
                 "note": "PreprocessedPointCloudDataset -> PackedFeed (worker processes decode into page-locked shared batch slots; one "
                         "H2D copy per batch, one batch ahead) -> the same training step; the files sit in the page cache after the first "
                         "epoch, as a training set that fits in RAM does"}

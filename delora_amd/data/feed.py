@@ -139,6 +139,7 @@ class PackedFeed:
         for p in self.procs:
             p.start()
         self.bytes_moved = 0
+        self.host_seconds = {"wait_for_workers": 0.0, "upload_enqueue": 0.0, "reclaim": 0.0}      # where the consumer's time goes
 
     def __len__(self):
         return len(self.batch_sampler)
@@ -191,7 +192,14 @@ class PackedFeed:
         exhausted = False
         staged = None                               # the uploaded batch waiting to be handed out (one ahead of the step)
 
+        import time as _time
+
         def reclaim(block):
+            t0 = _time.perf_counter()
+            _reclaim(block)
+            self.host_seconds["reclaim"] += _time.perf_counter() - t0
+
+        def _reclaim(block):
             while busy and (block or busy[0][0] is None or busy[0][0].query()):
                 ev, slot = busy.pop(0)
                 if ev is not None:
@@ -214,6 +222,7 @@ class PackedFeed:
             nonlocal consumed
             if consumed >= issued:
                 return None
+            t0 = _time.perf_counter()
             while consumed not in arrived:
                 try:
                     bid, slot, lengths, err = self.done.get(timeout=120)
@@ -224,8 +233,11 @@ class PackedFeed:
                 arrived[bid] = (slot, lengths)
             slot, lengths = arrived.pop(consumed)
             consumed += 1
+            t1 = _time.perf_counter()
             packed, ev = self._upload(slot, lengths)
             busy.append((ev, slot))
+            self.host_seconds["wait_for_workers"] += t1 - t0
+            self.host_seconds["upload_enqueue"] += _time.perf_counter() - t1
             return packed
 
         issue()
