@@ -88,15 +88,35 @@ class PreprocessedPointCloudDataset(torch.utils.data.Dataset):
         return hit
 
     # -- raw access for data.feed.PackedFeed (worker processes write the files straight into the step's planar batch buffer)
+    def _read_npy_into(self, path, pool):
+        """The ``[M,3]`` fp32 array of an .npy file, read with ``readinto`` into one of this process's persistent scratch buffers: no
+        allocation per file.  (np.load allocates -- and the kernel zero-fills and later unmaps -- 1.7 MB per scan: at 3000 scans/s the
+        page faults of six worker processes slowed every process of the container down, the training thread included.)"""
+        import numpy.lib.format as fmt
+        with open(path, "rb") as f:
+            major, _ = fmt.read_magic(f)
+            shape, fortran, dtype = fmt.read_array_header_1_0(f) if major == 1 else fmt.read_array_header_2_0(f)
+            if fortran or dtype != np.float32 or len(shape) != 2:
+                f.seek(0)
+                return np.ascontiguousarray(np.load(f), dtype=np.float32)
+            count = int(shape[0]) * int(shape[1])
+            slot = pool["next"] = (pool.get("next", -1) + 1) % 4            # four buffers: two cached scans + the two being read
+            buf = pool.get(slot)
+            if buf is None or buf.size < count:
+                buf = pool[slot] = np.empty((max(count, 3 * self.max_points_per_scan()),), dtype=np.float32)
+            view = buf[:count]
+            got = f.readinto(memoryview(view).cast("B"))
+            if got != count * 4:
+                raise IOError(f"{path}: short read ({got} of {count * 4} bytes)")
+            return view.reshape(shape)
+
     def _arrays(self, i_ds, i_seq, k):
         key = ("raw", i_ds, i_seq, k)
         hit = self._recent.get(key)
         if hit is None:
-            # memory-mapped: the one pass that transposes the file into the batch slot reads it straight from the page cache
-            xyz = np.load(self.scans_files_in_datasets[i_ds][i_seq][k], mmap_mode="r")
-            nrm = np.load(self.normals_files_in_datasets[i_ds][i_seq][k], mmap_mode="r") if self.load_normals else None
-            if xyz.dtype != np.float32 or (nrm is not None and nrm.dtype != np.float32):
-                xyz, nrm = np.asarray(xyz, dtype=np.float32), (None if nrm is None else np.asarray(nrm, dtype=np.float32))
+            pools = self.__dict__.setdefault("_scratch", ({}, {}))
+            xyz = self._read_npy_into(self.scans_files_in_datasets[i_ds][i_seq][k], pools[0])
+            nrm = self._read_npy_into(self.normals_files_in_datasets[i_ds][i_seq][k], pools[1]) if self.load_normals else None
             hit = (xyz, nrm)
             if len(self._recent) >= 2:
                 self._recent.pop(next(iter(self._recent)))

@@ -76,34 +76,37 @@ import queue as _queue
 import numpy as _np
 
 
-def _feed_worker(dataset, slots, tasks, done, rows):
-    """Worker loop: (batch id, sample indices, slot) -> the slot filled as ``[rows, total]`` planar fp32 + the scan lengths."""
+def _feed_worker(dataset, slots, tasks, done, rows, capacity):
+    """Worker loop: (batch id, sample indices, slot) -> the slot filled as ``[rows][capacity]`` planar fp32 (row c holds coordinate c of
+    the batch's scans back to back) + the scan lengths."""
     torch.set_num_threads(1)
+    import time as _t
     while True:
         task = tasks.get()
         if task is None:
             return
         bid, indices, slot = task
         try:
-            arrays = []
+            out = slots[slot].numpy().reshape(rows, capacity)
+            lengths, o, t_read, t_copy = [], 0, 0.0, 0.0
             for i in indices:
-                arrays += dataset.load_pair_arrays(int(i))          # [(xyz [M,3], normals [M,3] | None)] x 2, scan reuse inside
-            lengths = [a[0].shape[0] for a in arrays]
-            total = int(sum(lengths))
-            buf = slots[slot].numpy()
-            if rows * total > buf.size:
-                done.put((bid, slot, None, f"batch of {total} points exceeds the slot capacity {buf.size // rows}"))
-                continue
-            out = buf[:rows * total].reshape(rows, total)
-            o = 0
-            for (xyz, nrm), n in zip(arrays, lengths):
-                out[:3, o:o + n] = xyz[:, :3].T                       # decode -> planar slot in one pass
-                if rows == 6:
-                    out[3:6, o:o + n] = nrm.T
-                o += n
-            done.put((bid, slot, lengths, None))
+                t0 = _t.perf_counter()
+                pair = dataset.load_pair_arrays(int(i))                  # [(xyz [M,3], normals [M,3] | None)] x 2, scan reuse inside
+                t1 = _t.perf_counter()
+                for xyz, nrm in pair:
+                    n = xyz.shape[0]
+                    if o + n > capacity:
+                        raise ValueError(f"batch exceeds the slot capacity of {capacity} points (config feed_points_per_scan)")
+                    out[:3, o:o + n] = xyz[:, :3].T                       # decode -> planar slot in one pass
+                    if rows == 6:
+                        out[3:6, o:o + n] = nrm.T
+                    lengths.append(n)
+                    o += n
+                t_read += t1 - t0
+                t_copy += _t.perf_counter() - t1
+            done.put((bid, slot, lengths, (t_read, t_copy), None))
         except Exception as e:                                       # noqa: BLE001 -- reported to the consumer, which raises
-            done.put((bid, slot, None, f"{type(e).__name__}: {e}"))
+            done.put((bid, slot, None, None, f"{type(e).__name__}: {e}"))
 
 
 class PackedFeed:
@@ -121,7 +124,7 @@ class PackedFeed:
         self.rows = 6 if dataset.load_normals else 3
         self.dataset_name = dataset.config["datasets"][0]
         self.workers = max(1, int(workers))
-        self.ahead = int(ahead) if ahead else 2 * self.workers            # batches in flight
+        self.ahead = int(ahead) if ahead else self.workers + 2            # batches in flight
         n_slots = int(slots) if slots else self.ahead + 2
         cap = int(points_per_scan or dataset.max_points_per_scan())
         self.capacity = 2 * self.B * cap
@@ -134,7 +137,7 @@ class PackedFeed:
         self.stream = torch.cuda.Stream(device=device) if self.cuda else None
         ctx = _mp.get_context("fork")
         self.tasks, self.done = ctx.Queue(), ctx.Queue()
-        self.procs = [ctx.Process(target=_feed_worker, args=(dataset, self.slots, self.tasks, self.done, self.rows), daemon=True)
+        self.procs = [ctx.Process(target=_feed_worker, args=(dataset, self.slots, self.tasks, self.done, self.rows, self.capacity), daemon=True)
                       for _ in range(self.workers)]
         for p in self.procs:
             p.start()
@@ -167,7 +170,7 @@ class PackedFeed:
     def _upload(self, slot, lengths):
         """Slot -> device (side stream); returns (PackedBatch, event after which the slot may be refilled)."""
         total = int(sum(lengths))
-        host = self.slots[slot][:self.rows * total].view(self.rows, total)
+        host = self.slots[slot].view(self.rows, self.capacity)[:, :total]          # row stride = the slot capacity
         offs = [0]
         for n in lengths:
             offs.append(offs[-1] + n)
@@ -176,7 +179,8 @@ class PackedFeed:
                                      self.rows == 6), None
         with torch.cuda.stream(self.stream):
             pts = torch.empty((self.rows, total), dtype=torch.float32, device=self.device)
-            pts.copy_(host, non_blocking=True)
+            for c in range(self.rows):                                   # one contiguous DMA per coordinate row
+                pts[c].copy_(host[c], non_blocking=True)
             offs_t = torch.tensor(offs, dtype=torch.int32).pin_memory().to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
@@ -225,11 +229,13 @@ class PackedFeed:
             t0 = _time.perf_counter()
             while consumed not in arrived:
                 try:
-                    bid, slot, lengths, err = self.done.get(timeout=120)
+                    bid, slot, lengths, spent, err = self.done.get(timeout=120)
                 except _queue.Empty:
                     raise RuntimeError("PackedFeed: no batch from the worker processes for 120 s")
                 if err is not None:
                     raise RuntimeError("PackedFeed worker: " + err)
+                self.host_seconds["worker_read_files"] = self.host_seconds.get("worker_read_files", 0.0) + spent[0]
+                self.host_seconds["worker_transpose_into_slot"] = self.host_seconds.get("worker_transpose_into_slot", 0.0) + spent[1]
                 arrived[bid] = (slot, lengths)
             slot, lengths = arrived.pop(consumed)
             consumed += 1
