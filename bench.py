@@ -312,15 +312,18 @@ def disk_feed_leg(args, cfg, device, tree, run_step, timed_region, resident_pair
             return run_step(kept[k["i"] % len(kept)])
         for _ in range(3):
             resident_step()
-        el_r, _ = timed_region(steps, resident_step)
-        resident_same = args.batch * steps / el_r
-        del kept
+        el_r, _ = timed_region(steps, resident_step)              # A - B - A: resident, fed, resident (clock and thermal drift cancel)
         pf.bytes_moved = 0
         for k_ in pf.host_seconds:
             pf.host_seconds[k_] = 0.0
         el, _ = timed_region(steps, fed_step)
         rate = args.batch * steps / el
         host_ms = {k_: round(1e3 * v_ / steps, 3) for k_, v_ in pf.host_seconds.items()}
+        for _ in range(3):
+            resident_step()
+        el_r2, _ = timed_region(steps, resident_step)
+        resident_same = args.batch * steps / (0.5 * (el_r + el_r2))
+        del kept
         return {"steps": steps, "value": round(rate, 3), "unit": "scan-pairs/s", "ms_per_step": round(1e3 * el / steps, 3),
                 "resident_same_data": round(resident_same, 3), "vs_resident": round(rate / resident_same, 4),
                 "vs_headline_workload": round(rate / resident_pairs_s, 4), "feed_GB_s": round(pf.bytes_moved / el / 1e9, 3),
