@@ -79,6 +79,9 @@ SIGNATURES = {
     "dl_conv2d_dgrad_strided_nhwc_h": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                               _u32, _vp, _vp]),
     "dl_cast_f32_to_h": (_i32, [_vp, _vp, _i64, _i32, _vp]),
+    "dl_heads_fwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dl_heads_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "dl_heads_bwd": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dl_mean_hw_nhwc_h": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "dl_mean_hw_bwd_act_h": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "dl_conv2d_wgrad_h_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
@@ -95,6 +98,11 @@ class WinoLayer(ctypes.Structure):
 
 
 WINO_BATCH = 16
+
+
+class HeadsParams(ctypes.Structure):
+    """``dl_heads_params`` of include/delora_hip.h (ten pointers: parameters, or buffers for their gradients)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("fc_w", "fc_b", "r1_w", "r1_b", "r3_w", "r3_b", "t1_w", "t1_b", "t3_w", "t3_b")]
 
 
 class ConvHLayer(ctypes.Structure):

@@ -55,9 +55,25 @@ class OdometryModel(torch.nn.Module):
         return self.resnet(x)
 
     def forward_stacked(self, stacked):
-        """Same as forward() for an already channel-stacked ``[B,8,H,W]`` pair (no concatenation copy)."""
+        """Same as forward() for an already channel-stacked ``[B,8,H,W]`` pair (no concatenation copy).  When the CNN runs on the HIP
+        stem + trunk, fc and the two heads run as ``model_parts.FusedHeads`` (csrc/heads.hip: 3 + 4 launches instead of ~45)."""
+        if self._fused_heads_ok(stacked):
+            pooled, _ = self.resnet.pooled_features(stacked)
+            if pooled is not None:
+                act = 2 if self.config["activation_fct"] == "relu" else 1
+                fr, ft = self.fully_connected_rotation, self.fully_connected_translation
+                with torch.autocast("cuda", enabled=False):
+                    translation, rotation = model_parts.FusedHeads.apply(
+                        pooled.float(), act, self.resnet.fc.weight, self.resnet.fc.bias, fr[1].weight, fr[1].bias, fr[3].weight, fr[3].bias,
+                        ft[1].weight, ft[1].bias, ft[3].weight, ft[3].bias)
+                return translation, rotation
         feat = self.resnet(stacked)[-1]
         return self._heads(feat)
+
+    def _fused_heads_ok(self, x):
+        """fc + heads as one fused Function: CUDA input, the default two-head architecture, no active dropout, a batch of at most 16."""
+        return (x.is_cuda and not self.config["use_single_mlp_at_output"] and x.shape[0] <= 16 and self.config.get("fused_heads", True)
+                and not (self.resnet.use_dropout and self.training) and self.config.get("cnn_impl", "auto") != "modules")
 
     def _heads(self, feat):
         if self.config["use_single_mlp_at_output"]:

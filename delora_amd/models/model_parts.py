@@ -86,3 +86,65 @@ class GeometryHandler:
         top = torch.cat((R, translation.reshape(B, 3, 1).to(R.dtype)), dim=2)
         bottom = torch.cat((R.new_zeros((B, 1, 3)), R.new_ones((B, 1, 1))), dim=2)   # device-side fills: graph-capturable
         return torch.cat((top, bottom), dim=1)
+
+
+class FusedHeads(torch.autograd.Function):
+    """fc -> the two two-layer heads -> whole-batch quaternion norm as ``dl_heads_fwd`` / ``dl_heads_bwd`` (csrc/heads.hip): three launches
+    forward and four backward instead of ~45 small library launches (reference: src/models/resnet_modified.py:118-120 ``fc``,
+    src/models/model.py:74-83 the heads, :114 the norm).  ``forward(x [B,F], act, fc.w, fc.b, rot.1.w, rot.1.b, rot.3.w, rot.3.b,
+    tr.1.w, tr.1.b, tr.3.w, tr.3.b) -> (translation [B,3], rotation [B,4])``; fp32 CUDA tensors, B <= 16."""
+
+    ORDER = ("fc_w", "fc_b", "r1_w", "r1_b", "r3_w", "r3_b", "t1_w", "t1_b", "t3_w", "t3_b")
+
+    @staticmethod
+    def _struct(tensors):
+        from .. import _lib
+        st = _lib.HeadsParams()
+        for name, t in zip(FusedHeads.ORDER, tensors):
+            setattr(st, name, t.data_ptr())
+        return st
+
+    @staticmethod
+    def forward(ctx, x, act, *params):
+        import ctypes
+        from .. import _lib
+        lib = _lib.load()
+        x = x.contiguous()
+        params = tuple(p.contiguous() for p in params)
+        B, F = x.shape
+        R, Hd = params[0].shape[0], params[2].shape[0]
+        dev = x.device
+        a1 = torch.empty((B, R), dtype=torch.float32, device=dev)
+        a2 = torch.empty((B, 2, Hd), dtype=torch.float32, device=dev)
+        small = torch.empty((B * 11 + 1,), dtype=torch.float32, device=dev)         # rot_raw [B,4] | translation [B,3] | rotation [B,4] | norm
+        rot_raw, translation, rotation, norm = small[:4 * B].view(B, 4), small[4 * B:7 * B].view(B, 3), small[7 * B:11 * B].view(B, 4), small[11 * B:]
+        st = FusedHeads._struct(params)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())                                  # noqa: E731
+        _lib.check(lib.dl_heads_fwd(vp(x), ctypes.byref(st), B, F, R, Hd, int(act), vp(a1), vp(a2), vp(rot_raw), vp(translation), vp(rotation),
+                                    vp(norm), stream), "dl_heads_fwd")
+        ctx.act = int(act)
+        ctx.save_for_backward(x, a1, a2, small, *params)
+        return translation, rotation
+
+    @staticmethod
+    def backward(ctx, g_translation, g_rotation):
+        import ctypes
+        from .. import _lib
+        lib = _lib.load()
+        x, a1, a2, small, *params = ctx.saved_tensors
+        B, F = x.shape
+        R, Hd = params[0].shape[0], params[2].shape[0]
+        rot_raw, norm = small[:4 * B], small[11 * B:]
+        dev = x.device
+        gt = (g_translation if g_translation is not None else torch.zeros((B, 3), device=dev)).contiguous().float()
+        gr = (g_rotation if g_rotation is not None else torch.zeros((B, 4), device=dev)).contiguous().float()
+        grads = [torch.empty_like(p) for p in params]
+        gx = torch.empty_like(x)
+        ws = torch.empty((lib.dl_heads_bwd_workspace_bytes(B, F, R, Hd) // 4,), dtype=torch.float32, device=dev)
+        st, gs = FusedHeads._struct(params), FusedHeads._struct(grads)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        vp = lambda t: ctypes.c_void_p(t.data_ptr())                                  # noqa: E731
+        _lib.check(lib.dl_heads_bwd(vp(x), ctypes.byref(st), B, F, R, Hd, ctx.act, vp(a1), vp(a2), vp(rot_raw), vp(norm), vp(gt), vp(gr),
+                                    ctypes.byref(gs), vp(gx), vp(ws), stream), "dl_heads_bwd")
+        return (gx, None, *grads)

@@ -163,9 +163,10 @@ class ResNetModified(torch.nn.Module):
             return None
         return dtype if ring_conv.supported_h((N, Hin, Win // 4, C0), self._trunk_blocks()[0]) else None
 
-    def forward(self, x):
+    def pooled_features(self, x):
+        """The globally pooled feature ``[N,C']`` (fp32; the input of ``fc``) when the whole CNN runs on the HIP stem + trunk -- fp32, or
+        half precision inside autocast -- else None.  Returns (feat, last feature map as NCHW view or None)."""
         act = "relu" if self.activation_fct == "relu" else "tanh"
-        x = self.dropout_values(x)
         N, Cin, Hin, Win = x.shape
         C0 = self.conv1.out_channels
         half = self.hip_half_applicable(x)
@@ -175,16 +176,26 @@ class ResNetModified(torch.nn.Module):
             with torch.autocast("cuda", enabled=False):
                 x0 = ring_conv.RingStem.apply(x.float(), self.conv1.weight, ring_conv.ACT[act])          # [N,H,W/4,C0] fp32
                 feat = ring_conv.RingTrunkH.apply(x0, ring_conv.ACT[act], blocks, half, *weights)     # [N,C'] fp32
-            out = self.dropout_values(self.fc(feat))
-            return [None, None, None, None, out]
+            return feat, None
         if (self.hip_trunk_applicable((N, Hin, Win // 4, C0), x) and Win % 4 == 0
                 and ring_conv.stem_supported(tuple(x.shape), C0)):
             # channels-last from the first layer on: stem (conv1 + act + pool) and layer1..layer4 on the HIP kernels
             blocks, weights = self._trunk_blocks()
             x0 = ring_conv.RingStem.apply(x, self.conv1.weight, ring_conv.ACT[act])              # [N,H,W/4,C0]
             x4 = ring_conv.RingTrunk.apply(x0, ring_conv.ACT[act], blocks, *weights)          # [N,H',W',C']
-            out = self.dropout_values(self.fc(ring_conv.MeanHW.apply(x4)))
-            return [None, None, None, x4.permute(0, 3, 1, 2), out]
+            return ring_conv.MeanHW.apply(x4), x4.permute(0, 3, 1, 2)
+        return None, None
+
+    def forward(self, x):
+        act = "relu" if self.activation_fct == "relu" else "tanh"
+        x = self.dropout_values(x)
+        N, Cin, Hin, Win = x.shape
+        C0 = self.conv1.out_channels
+        feat, x4 = self.pooled_features(x)
+        if feat is not None:
+            with torch.autocast("cuda", enabled=False):
+                out = self.dropout_values(self.fc(feat))
+            return [None, None, None, x4, out]
         p = ring_act_pad(x, "none", pad=True)
         p = ring_act_pool_pad(self.conv1(p), act)                    # act + wrap + self.maxpool + wrap, fused
         N, C0, H0, Wp = p.shape

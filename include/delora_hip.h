@@ -395,6 +395,30 @@ size_t dl_stem_wgrad_workspace_bytes(int32_t N, int32_t H, int32_t W);
 int dl_stem_wgrad_f32(const float* g_pooled, const float* a, const int8_t* win, const float* x8, int32_t N, int32_t H, int32_t W,
                       int32_t act, void* workspace, float* dw, dl_stream stream);
 
+/*
+ * The pose heads in seven launches (csrc/heads.hip): fc -> the two two-layer MLPs -> whole-batch quaternion norm, forward and backward
+ * (reference src/models/resnet_modified.py:118-120, src/models/model.py:74-83, :114; torch autograd through them).  fp32.
+ *   x [B][F] pooled feature; fc [R][F]; first layers [Hd][R]; last layers [4][Hd] (rotation), [3][Hd] (translation); 1 <= B <= 16;
+ *   act: 0 none, 1 tanh, 2 relu (applied to the fc output and to the hidden layers, as the reference's `[act, Linear, act, Linear]`).
+ *   dl_heads_fwd  -> a1 [B][R] = act(fc(x)), a2 [B][2][Hd] = act(hidden), rot_raw [B][4], translation [B][3],
+ *                    rotation [B][4] = rot_raw / ||rot_raw||_F (ONE norm over the whole batch), norm [1]   (a1, a2, rot_raw, norm: saved)
+ *   dl_heads_bwd  -> the ten parameter gradients (`grads`: same struct, pointers to writable buffers of the parameters' shapes) and
+ *                    grad_x [B][F]; workspace: dl_heads_bwd_workspace_bytes.  Deterministic (fixed summation orders).
+ */
+typedef struct {
+  const float *fc_w, *fc_b;   /* [R][F], [R] */
+  const float *r1_w, *r1_b;   /* rotation head, first layer [Hd][R], [Hd] */
+  const float *r3_w, *r3_b;   /* rotation head, last layer [4][Hd], [4] */
+  const float *t1_w, *t1_b;   /* translation head, first layer [Hd][R], [Hd] */
+  const float *t3_w, *t3_b;   /* translation head, last layer [3][Hd], [3] */
+} dl_heads_params;
+int dl_heads_fwd(const float* x, const dl_heads_params* params, int32_t B, int32_t F, int32_t R, int32_t Hd, int32_t act, float* a1,
+                 float* a2, float* rot_raw, float* translation, float* rotation, float* norm, dl_stream stream);
+size_t dl_heads_bwd_workspace_bytes(int32_t B, int32_t F, int32_t R, int32_t Hd);
+int dl_heads_bwd(const float* x, const dl_heads_params* params, int32_t B, int32_t F, int32_t R, int32_t Hd, int32_t act, const float* a1,
+                 const float* a2, const float* rot_raw, const float* norm, const float* grad_translation, const float* grad_rotation,
+                 const dl_heads_params* grads, float* grad_x, void* workspace, dl_stream stream);
+
 /* Quaternion (x,y,z,w) + translation -> T [B][4][4] = [[R, t], [0, 1]] and its backward (reference src/models/model_parts.py:
  * 24-44; R = kornia 0.3.0 quaternion_to_rotation_matrix: normalise with eps, then the element-wise formula):
  *   dl_quat_to_T_fwd: translation [B][3], quaternion [B][4] -> T

@@ -340,3 +340,40 @@ def test_epilogue_tanh_is_within_two_ulp_of_float64():
     err = np.abs(got[~nan] - ref[~nan]) / ulp
     util.measured("epilogue tanh vs float64 (ulp of the float32 result)", float(err.max()), bound=2.5)
     assert got[0, 2, 0, 0] == 0.0 and got[0, 2, 0, 1] == 0.0
+
+
+@pytest.mark.parametrize("act,B", [("tanh", 8), ("relu", 3), ("tanh", 1), ("tanh", 16)])
+def test_fused_heads_against_the_torch_modules(act, B):
+    """csrc/heads.hip (fc -> two two-layer heads -> whole-batch quaternion norm; 3 launches forward, 4 backward) against the same
+    layers as torch modules under autograd (reference src/models/model.py:74-83, :114): outputs, the gradient of the pooled feature and
+    of all ten parameters."""
+    from delora_amd.models.model import OdometryModel
+    from delora_amd.models import model_parts
+    dev = _dev()
+    cfg = util.repo_config(64, 2048, device="cuda:0", activation_fct=act)
+    torch.manual_seed(3)
+    m = OdometryModel(cfg).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(B)
+    feat = torch.randn((B, 512), generator=g).to(dev)
+    gt, gr = torch.randn((B, 3), generator=g).to(dev), torch.randn((B, 4), generator=g).to(dev)
+    names = ["resnet.fc.weight", "resnet.fc.bias", "fully_connected_rotation.1.weight", "fully_connected_rotation.1.bias",
+             "fully_connected_rotation.3.weight", "fully_connected_rotation.3.bias", "fully_connected_translation.1.weight",
+             "fully_connected_translation.1.bias", "fully_connected_translation.3.weight", "fully_connected_translation.3.bias"]
+    params = dict(m.named_parameters())
+    # torch modules
+    x1 = feat.clone().requires_grad_(True)
+    t1, r1 = m._heads(m.resnet.fc(x1))
+    ((t1 * gt).sum() + (r1 * gr).sum()).backward()
+    ref = {n: params[n].grad.clone() for n in names}
+    gx_ref = x1.grad.clone()
+    m.zero_grad(set_to_none=True)
+    # fused
+    x2 = feat.clone().requires_grad_(True)
+    t2, r2 = model_parts.FusedHeads.apply(x2, 2 if act == "relu" else 1, *[params[n] for n in names])
+    ((t2 * gt).sum() + (r2 * gr).sum()).backward()
+    tag = f"fused heads[{act},B={B}]"
+    util.measured(f"{tag}: translation vs torch modules (relative)", _rel(t2, t1.detach()), bound=TIGHT)
+    util.measured(f"{tag}: rotation vs torch modules (relative)", _rel(r2, r1.detach()), bound=TIGHT)
+    util.measured(f"{tag}: gradient of the pooled feature (relative)", _rel(x2.grad, gx_ref), bound=TIGHT)
+    worst = max(_rel(params[n].grad, ref[n]) for n in names)
+    util.measured(f"{tag}: worst parameter gradient vs torch autograd (relative)", worst, bound=TIGHT)
