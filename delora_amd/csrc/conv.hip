@@ -621,14 +621,20 @@ static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
 // columns 0 and W-1 adds them on its accumulators in front of its epilogue (one rounding, no read-modify-write of dx).
 // One workgroup = FX_ROWS consecutive rows h of one image and one of the two columns; thread = channel c.  ~0.2 GFLOP per launch.
 #define FX_ROWS 16
-#define FX_KC 64
+#define FX_KMAX 512                       // reduction channels staged per pass
+// One workgroup (4 waves) = FX_ROWS consecutive rows h of one image, one of the two columns and 64 channels c (lane = channel); the four
+// waves split the reduction over k into quarters and their partial sums are added in wave order through LDS (deterministic).
+// ~0.2 GFLOP per launch; 256 workgroups at the 64x720 shape (the first version -- 64 workgroups, a serial k loop with three dependent
+// L2 loads per step -- took 295 us, more than the stride phases themselves).
 __global__ __launch_bounds__(CV_THREADS) void k_dgrad_oddw_seam(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ seam,
                                                                 int N, int Ho, int Wo, int K, int C, int H, int SH) {
   constexpr int GROWS = FX_ROWS + 2;                   // grid rows a tile of FX_ROWS image rows can reach (SH = 1), + one row of zeros
-  __shared__ float gs[(GROWS + 1) * FX_KC];            // g[ho_lo + i][the column][k chunk]; row GROWS = zeros
+  __shared__ float gs[(GROWS + 1) * FX_KMAX];          // g[ho_lo + i][the column][k]; row GROWS = zeros; reused for the final reduction
   const int side = blockIdx.y;                         // 0: image column 0 (tap s = 2, grid column Wo-1); 1: column W-1 (s = 0, grid column 0)
   const int row_tiles = (H + FX_ROWS - 1) / FX_ROWS;
   const int n = blockIdx.x / row_tiles, h0 = (blockIdx.x % row_tiles) * FX_ROWS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.z * 64 + lane, cc = c < C ? c : C - 1;
   const int s = side ? 0 : 2, wo = side ? 0 : Wo - 1;
   const int ho_lo = h0 > 0 ? (h0 - 1) / SH : 0;        // first grid row that reaches row h0 (h = SH ho + r - 1 with r <= 2)
   // LDS row of the grid row that tap r contributes to image row h0 + i from (GROWS: none)
@@ -640,38 +646,42 @@ __global__ __launch_bounds__(CV_THREADS) void k_dgrad_oddw_seam(const float* __r
       const int t = h0 + i + 1 - r;                    // = SH * ho
       const int ho = t / SH;
       const bool ok = t >= 0 && t % SH == 0 && ho < Ho && ho - ho_lo >= 0 && ho - ho_lo < GROWS;
-      src[i][r] = (ok ? ho - ho_lo : GROWS) * FX_KC;
+      src[i][r] = (ok ? ho - ho_lo : GROWS) * FX_KMAX;
     }
-  for (int q = threadIdx.x; q < FX_KC; q += CV_THREADS) gs[GROWS * FX_KC + q] = 0.f;
-  for (int cb = 0; cb < C; cb += CV_THREADS) {
-    const int c = cb + threadIdx.x;
-    const int cc = c < C ? c : C - 1;
-    float acc[FX_ROWS];
+  float acc[FX_ROWS];
 #pragma unroll
-    for (int i = 0; i < FX_ROWS; ++i) acc[i] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += FX_KC) {
-      __syncthreads();
-      for (int q = threadIdx.x; q < GROWS * FX_KC; q += CV_THREADS) {
-        const int i = q / FX_KC, kk = q % FX_KC, ho = ho_lo + i;
-        gs[q] = (ho < Ho && k0 + kk < K) ? g[(((size_t)n * Ho + ho) * Wo + wo) * K + k0 + kk] : 0.f;
-      }
-      __syncthreads();
-      const int kn = K - k0 < FX_KC ? K - k0 : FX_KC;
-      for (int kk = 0; kk < kn; ++kk) {
-        float wv[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) wv[r] = w[(((size_t)(k0 + kk) * 3 + r) * 3 + s) * C + cc];
-#pragma unroll
-        for (int i = 0; i < FX_ROWS; ++i)
-#pragma unroll
-          for (int r = 0; r < 3; ++r) acc[i] = fmaf(gs[src[i][r] + kk], wv[r], acc[i]);
-      }
+  for (int i = 0; i < FX_ROWS; ++i) acc[i] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += FX_KMAX) {
+    const int kn = K - k0 < FX_KMAX ? K - k0 : FX_KMAX;
+    __syncthreads();
+    for (int q = threadIdx.x; q < (GROWS + 1) * FX_KMAX; q += CV_THREADS) {
+      const int i = q / FX_KMAX, kk = q % FX_KMAX, ho = ho_lo + i;
+      gs[q] = (i < GROWS && ho < Ho && kk < kn) ? g[(((size_t)n * Ho + ho) * Wo + wo) * K + k0 + kk] : 0.f;
     }
-    if (c < C) {
+    __syncthreads();
+    const int per = (kn + 3) / 4, kb = wave * per, ke = kb + per < kn ? kb + per : kn;       // this wave's quarter of the chunk
+#pragma unroll 4
+    for (int kk = kb; kk < ke; ++kk) {
+      float wv[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) wv[r] = w[(((size_t)(k0 + kk) * 3 + r) * 3 + s) * C + cc];
 #pragma unroll
       for (int i = 0; i < FX_ROWS; ++i)
-        if (h0 + i < H) seam[(((size_t)n * H + h0 + i) * 2 + side) * C + c] = acc[i];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) acc[i] = fmaf(gs[src[i][r] + kk], wv[r], acc[i]);
     }
+  }
+  __syncthreads();
+  float* red = gs;                                     // [wave][row][lane]
+#pragma unroll
+  for (int i = 0; i < FX_ROWS; ++i) red[(wave * FX_ROWS + i) * 64 + lane] = acc[i];
+  __syncthreads();
+  if (wave == 0 && c < C) {
+#pragma unroll
+    for (int i = 0; i < FX_ROWS; ++i)
+      if (h0 + i < H)
+        seam[(((size_t)n * H + h0 + i) * 2 + side) * C + c] =
+            ((red[i * 64 + lane] + red[(FX_ROWS + i) * 64 + lane]) + red[(2 * FX_ROWS + i) * 64 + lane]) + red[(3 * FX_ROWS + i) * 64 + lane];
   }
 }
 
@@ -741,7 +751,7 @@ extern "C" int dl_conv2d_dgrad_strided_nhwc_f32(const float* g, const float* w, 
   hipStream_t st = (hipStream_t)stream;
   if (odd_w) {
     const int row_tiles = (H + FX_ROWS - 1) / FX_ROWS;
-    hipLaunchKernelGGL(k_dgrad_oddw_seam, dim3(N * row_tiles, 2), dim3(CV_THREADS), 0, st, g, w, seam_ws, N, Ho, Wo, K, C, H, stride_h);
+    hipLaunchKernelGGL(k_dgrad_oddw_seam, dim3(N * row_tiles, 2, (C + 63) / 64), dim3(CV_THREADS), 0, st, g, w, seam_ws, N, Ho, Wo, K, C, H, stride_h);
   }
   int rc = 1;
   if (dense) {                                        // 1x1 layer: only phase (0,0) is non-zero; result kept on the grid

@@ -571,15 +571,17 @@ static int dgrad_strided_h(const ConvHArgs& a, int ksize, int sh, int sw, int de
 // half-precision operands: w = w_bwd [tap][C][K] of the layer; fp32 sums into seam[n][h][side][c], which the phase that owns columns
 // 0 and W-1 adds on its accumulators (so every element of dx is still rounded exactly once).
 #define FXH_ROWS 16
-#define FXH_KC 64
+#define FXH_KMAX 512
 template <bool F16>
 __global__ __launch_bounds__(256) void k_dgrad_oddw_seam_h(const u16* __restrict__ g, const u16* __restrict__ w, float* __restrict__ seam,
                                                            int N, int Ho, int Wo, int K, int C, int H, int SH) {
   constexpr int GROWS = FXH_ROWS + 2;
-  __shared__ float gs[(GROWS + 1) * FXH_KC];
+  __shared__ float gs[(GROWS + 1) * FXH_KMAX];
   const int side = blockIdx.y;
   const int row_tiles = (H + FXH_ROWS - 1) / FXH_ROWS;
   const int n = blockIdx.x / row_tiles, h0 = (blockIdx.x % row_tiles) * FXH_ROWS;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int c = blockIdx.z * 64 + lane, cc = c < C ? c : C - 1;
   const int s_tap = side ? 0 : 2, wo = side ? 0 : Wo - 1;
   const int ho_lo = h0 > 0 ? (h0 - 1) / SH : 0;
   int src[FXH_ROWS][3];
@@ -590,38 +592,42 @@ __global__ __launch_bounds__(256) void k_dgrad_oddw_seam_h(const u16* __restrict
       const int t = h0 + i + 1 - r;
       const int ho = t / SH;
       const bool ok = t >= 0 && t % SH == 0 && ho < Ho && ho - ho_lo >= 0 && ho - ho_lo < GROWS;
-      src[i][r] = (ok ? ho - ho_lo : GROWS) * FXH_KC;
+      src[i][r] = (ok ? ho - ho_lo : GROWS) * FXH_KMAX;
     }
-  for (int q = threadIdx.x; q < FXH_KC; q += 256) gs[GROWS * FXH_KC + q] = 0.f;
-  for (int cb = 0; cb < C; cb += 256) {
-    const int c = cb + threadIdx.x;
-    const int cc = c < C ? c : C - 1;
-    float acc[FXH_ROWS];
+  float acc[FXH_ROWS];
 #pragma unroll
-    for (int i = 0; i < FXH_ROWS; ++i) acc[i] = 0.f;
-    for (int k0 = 0; k0 < K; k0 += FXH_KC) {
-      __syncthreads();
-      for (int q = threadIdx.x; q < GROWS * FXH_KC; q += 256) {
-        const int i = q / FXH_KC, kk = q % FXH_KC, ho = ho_lo + i;
-        gs[q] = (ho < Ho && k0 + kk < K) ? ch_h2f<F16>(g[(((size_t)n * Ho + ho) * Wo + wo) * K + k0 + kk]) : 0.f;
-      }
-      __syncthreads();
-      const int kn = K - k0 < FXH_KC ? K - k0 : FXH_KC;
-      for (int kk = 0; kk < kn; ++kk) {
-        float wv[3];
-#pragma unroll
-        for (int r = 0; r < 3; ++r) wv[r] = ch_h2f<F16>(w[((size_t)(r * 3 + s_tap) * C + cc) * K + k0 + kk]);
-#pragma unroll
-        for (int i = 0; i < FXH_ROWS; ++i)
-#pragma unroll
-          for (int r = 0; r < 3; ++r) acc[i] = fmaf(gs[src[i][r] + kk], wv[r], acc[i]);
-      }
+  for (int i = 0; i < FXH_ROWS; ++i) acc[i] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += FXH_KMAX) {
+    const int kn = K - k0 < FXH_KMAX ? K - k0 : FXH_KMAX;
+    __syncthreads();
+    for (int q = threadIdx.x; q < (GROWS + 1) * FXH_KMAX; q += 256) {
+      const int i = q / FXH_KMAX, kk = q % FXH_KMAX, ho = ho_lo + i;
+      gs[q] = (i < GROWS && ho < Ho && kk < kn) ? ch_h2f<F16>(g[(((size_t)n * Ho + ho) * Wo + wo) * K + k0 + kk]) : 0.f;
     }
-    if (c < C) {
+    __syncthreads();
+    const int per = (kn + 3) / 4, kb = wave * per, ke = kb + per < kn ? kb + per : kn;
+#pragma unroll 4
+    for (int kk = kb; kk < ke; ++kk) {
+      float wv[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) wv[r] = ch_h2f<F16>(w[((size_t)(r * 3 + s_tap) * C + cc) * K + k0 + kk]);
 #pragma unroll
       for (int i = 0; i < FXH_ROWS; ++i)
-        if (h0 + i < H) seam[(((size_t)n * H + h0 + i) * 2 + side) * C + c] = acc[i];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) acc[i] = fmaf(gs[src[i][r] + kk], wv[r], acc[i]);
     }
+  }
+  __syncthreads();
+  float* red = gs;
+#pragma unroll
+  for (int i = 0; i < FXH_ROWS; ++i) red[(wave * FXH_ROWS + i) * 64 + lane] = acc[i];
+  __syncthreads();
+  if (wave == 0 && c < C) {
+#pragma unroll
+    for (int i = 0; i < FXH_ROWS; ++i)
+      if (h0 + i < H)
+        seam[(((size_t)n * H + h0 + i) * 2 + side) * C + c] =
+            ((red[i * 64 + lane] + red[(FXH_ROWS + i) * 64 + lane]) + red[(2 * FXH_ROWS + i) * 64 + lane]) + red[(3 * FXH_ROWS + i) * 64 + lane];
   }
 }
 
@@ -644,7 +650,7 @@ extern "C" int dl_conv2d_dgrad_strided_nhwc_h(const void* g, const void* w, void
               dense ? Ho : H, dense ? Wo : W, odd_w ? 0 : 1, odd_w ? seam_ws : nullptr};
   hipStream_t st = (hipStream_t)stream;
   if (odd_w) {
-    const dim3 grid(N * ((H + FXH_ROWS - 1) / FXH_ROWS), 2);
+    const dim3 grid(N * ((H + FXH_ROWS - 1) / FXH_ROWS), 2, (C + 63) / 64);
     if (dtype == DL_DTYPE_F16) hipLaunchKernelGGL(k_dgrad_oddw_seam_h<true>, grid, dim3(256), 0, st, (const u16*)g, (const u16*)w, seam_ws, N, Ho, Wo, K, C, H, stride_h);
     else hipLaunchKernelGGL(k_dgrad_oddw_seam_h<false>, grid, dim3(256), 0, st, (const u16*)g, (const u16*)w, seam_ws, N, Ho, Wo, K, C, H, stride_h);
   }

@@ -28,10 +28,14 @@ __device__ __forceinline__ float hd_act(float v, int act) { return act == 1 ? dl
 __device__ __forceinline__ float hd_dact(float a, int act) { return act == 1 ? 1.f - a * a : (act == 2 ? (a > 0.f ? 1.f : 0.f) : 1.f); }
 
 // y[b][row] = act(sum_k x[b][k] * w[row][k] + bias[row]) for the rows of `nmat` matrices that share the input x (fc: one matrix; the
-// two heads' first layers: two).  One wave per output row, lanes along k.
+// two heads' first layers: two).  One wave per output row, lanes along k; x is staged in LDS once per workgroup (the first version
+// re-read it from global memory inside the k loop: 31 us per launch, all of it load latency).
 __global__ __launch_bounds__(256) void k_heads_rows(const float* __restrict__ x, int B, int K, const float* __restrict__ w0, const float* __restrict__ b0,
                                                     const float* __restrict__ w1, const float* __restrict__ b1, int rows, int nmat, int act,
                                                     float* __restrict__ y /* [B][nmat][rows] */) {
+  extern __shared__ float sx[];                             // [B][K]
+  for (int q = threadIdx.x; q < B * K; q += 256) sx[q] = x[q];
+  __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int gr = blockIdx.x * 4 + wave;                     // global row over the nmat matrices
   if (gr >= rows * nmat) return;
@@ -40,11 +44,12 @@ __global__ __launch_bounds__(256) void k_heads_rows(const float* __restrict__ x,
   float acc[HD_MAXB];
 #pragma unroll
   for (int b = 0; b < HD_MAXB; ++b) acc[b] = 0.f;
+#pragma unroll 8
   for (int k = lane; k < K; k += 64) {
     const float wv = wr[k];
 #pragma unroll
     for (int b = 0; b < HD_MAXB; ++b)
-      if (b < B) acc[b] = fmaf(x[(size_t)b * K + k], wv, acc[b]);
+      if (b < B) acc[b] = fmaf(sx[b * K + k], wv, acc[b]);
   }
   const float bias = (m == 0 ? b0 : b1)[r];
 #pragma unroll
@@ -130,44 +135,57 @@ __global__ __launch_bounds__(256) void k_heads_out_bwd(const float* __restrict__
   }
 }
 
-// backward of the heads' first layers: one thread per column j of the [Hd][R] matrices.  d_w1[m][j] = sum_b gh[b][head][m] a1[b][j];
-// gout[b][j] = (sum_{head,m} gh[b][head][m] w1[m][j]) * act'(a1[b][j]);  d_b1[m] = sum_b gh[b][head][m]
-__global__ __launch_bounds__(64) void k_heads_hidden_bwd(const float* __restrict__ a1, const float* __restrict__ gh, HeadsP p, int B, int R, int Hd, int act,
-                                                         float* __restrict__ d_r1w, float* __restrict__ d_r1b, float* __restrict__ d_t1w,
-                                                         float* __restrict__ d_t1b, float* __restrict__ gout) {
-  extern __shared__ float sgh[];             // [B][2][Hd]
+// backward of the heads' first layers: lane = column j of the [Hd][R] matrices, the eight waves of a workgroup split the 2 Hd rows.
+// d_w1[m][j] = sum_b gh[b][head][m] a1[b][j];  gout[b][j] = (sum_{head,m} gh[b][head][m] w1[m][j]) * act'(a1[b][j]) (the waves' partial
+// sums added in wave order through LDS);  d_b1[m] = sum_b gh[b][head][m]
+#define HD_HB_WAVES 8
+__global__ __launch_bounds__(64 * HD_HB_WAVES) void k_heads_hidden_bwd(const float* __restrict__ a1, const float* __restrict__ gh, HeadsP p, int B, int R, int Hd,
+                                                                       int act, float* __restrict__ d_r1w, float* __restrict__ d_r1b,
+                                                                       float* __restrict__ d_t1w, float* __restrict__ d_t1b, float* __restrict__ gout) {
+  extern __shared__ float sgh[];             // [B][2 Hd], then [waves][HD_MAXB][64] for the reduction
+  float* red = sgh + B * 2 * Hd;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int q = threadIdx.x; q < B * 2 * Hd; q += blockDim.x) sgh[q] = gh[q];
   __syncthreads();
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (blockIdx.x == 0)
     for (int q = threadIdx.x; q < 2 * Hd; q += blockDim.x) {
       float s = 0.f;
       for (int b = 0; b < B; ++b) s += sgh[b * 2 * Hd + q];
       if (q < Hd) d_r1b[q] = s; else d_t1b[q - Hd] = s;
     }
-  if (j >= R) return;
+  const int j = blockIdx.x * 64 + lane, jj = j < R ? j : R - 1;
   float av[HD_MAXB], ga[HD_MAXB];
 #pragma unroll
-  for (int b = 0; b < HD_MAXB; ++b) { av[b] = b < B ? a1[(size_t)b * R + j] : 0.f; ga[b] = 0.f; }
-  for (int head = 0; head < 2; ++head) {
-    const float* w1 = head == 0 ? p.r1_w : p.t1_w;
-    float* dw = head == 0 ? d_r1w : d_t1w;
-    for (int m = 0; m < Hd; ++m) {
-      const float wv = w1[(size_t)m * R + j];
-      float s = 0.f;
+  for (int b = 0; b < HD_MAXB; ++b) { av[b] = b < B ? a1[(size_t)b * R + jj] : 0.f; ga[b] = 0.f; }
+  const int per = (2 * Hd + HD_HB_WAVES - 1) / HD_HB_WAVES, r0 = wave * per, r1 = min(r0 + per, 2 * Hd);
+#pragma unroll 5
+  for (int row = r0; row < r1; ++row) {
+    const bool rot = row < Hd;
+    const size_t o = (size_t)(rot ? row : row - Hd) * R + jj;
+    const float wv = (rot ? p.r1_w : p.t1_w)[o];
+    float s = 0.f;
 #pragma unroll
-      for (int b = 0; b < HD_MAXB; ++b)
-        if (b < B) {
-          const float gv = sgh[(b * 2 + head) * Hd + m];
-          ga[b] = fmaf(gv, wv, ga[b]);
-          s = fmaf(gv, av[b], s);
-        }
-      dw[(size_t)m * R + j] = s;
-    }
+    for (int b = 0; b < HD_MAXB; ++b)
+      if (b < B) {
+        const float gv = sgh[b * 2 * Hd + row];
+        ga[b] = fmaf(gv, wv, ga[b]);
+        s = fmaf(gv, av[b], s);
+      }
+    if (j < R) (rot ? d_r1w : d_t1w)[o] = s;
   }
 #pragma unroll
-  for (int b = 0; b < HD_MAXB; ++b)
-    if (b < B) gout[(size_t)b * R + j] = ga[b] * hd_dact(av[b], act);
+  for (int b = 0; b < HD_MAXB; ++b) red[(wave * HD_MAXB + b) * 64 + lane] = ga[b];
+  __syncthreads();
+  if (wave == 0 && j < R) {
+#pragma unroll
+    for (int b = 0; b < HD_MAXB; ++b)
+      if (b < B) {
+        float s = 0.f;
+#pragma unroll
+        for (int wv_ = 0; wv_ < HD_HB_WAVES; ++wv_) s += red[(wv_ * HD_MAXB + b) * 64 + lane];
+        gout[(size_t)b * R + j] = s * hd_dact(av[b], act);
+      }
+  }
 }
 
 // backward of fc: thread = column c of the [R][F] matrix, workgroup = (column tile, chunk of HD_JC rows).  d_fcw[j][c] = sum_b gout[b][j]
@@ -232,8 +250,9 @@ extern "C" int dl_heads_fwd(const float* x, const dl_heads_params* params, int32
   if (!a2 || !rot_raw || !translation || !rotation || !norm) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_heads_fwd: null output");
   const HeadsP p = heads_params(params);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_heads_rows, dim3((R + 3) / 4), dim3(256), 0, st, x, B, F, p.fc_w, p.fc_b, (const float*)nullptr, (const float*)nullptr, R, 1, act, a1);
-  hipLaunchKernelGGL(k_heads_rows, dim3((2 * Hd + 3) / 4), dim3(256), 0, st, (const float*)a1, B, R, p.r1_w, p.r1_b, p.t1_w, p.t1_b, Hd, 2, act, a2);
+  if ((size_t)B * (F > R ? F : R) * sizeof(float) > 60000) return dl_fail(DL_ERR_UNSUPPORTED, "dl_heads_fwd: layer too wide for the LDS copy of its input");
+  hipLaunchKernelGGL(k_heads_rows, dim3((R + 3) / 4), dim3(256), (size_t)B * F * sizeof(float), st, x, B, F, p.fc_w, p.fc_b, (const float*)nullptr, (const float*)nullptr, R, 1, act, a1);
+  hipLaunchKernelGGL(k_heads_rows, dim3((2 * Hd + 3) / 4), dim3(256), (size_t)B * R * sizeof(float), st, (const float*)a1, B, R, p.r1_w, p.r1_b, p.t1_w, p.t1_b, Hd, 2, act, a2);
   hipLaunchKernelGGL(k_heads_out, dim3(1), dim3(256), 0, st, (const float*)a2, p, B, Hd, rot_raw, translation, rotation, norm);
   return dl_check_launch("dl_heads_fwd");
 }
@@ -253,7 +272,7 @@ extern "C" int dl_heads_bwd(const float* x, const dl_heads_params* params, int32
   if (int rc = heads_check("dl_heads_bwd (grads)", x, a1, grads, B, F, R, Hd, act)) return rc;
   if (!a2 || !rot_raw || !norm || !grad_translation || !grad_rotation || !grad_x || !workspace)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_heads_bwd: null pointer argument");
-  if ((size_t)B * 2 * Hd * sizeof(float) > 60000) return dl_fail(DL_ERR_UNSUPPORTED, "dl_heads_bwd: hidden layer too wide for the LDS copy");
+  if (((size_t)B * 2 * Hd + HD_HB_WAVES * HD_MAXB * 64) * sizeof(float) > 60000) return dl_fail(DL_ERR_UNSUPPORTED, "dl_heads_bwd: hidden layer too wide for the LDS copy");
   const HeadsP p = heads_params(params);
   float* gh = (float*)workspace;
   float* gout = gh + (size_t)B * 2 * Hd;
@@ -262,7 +281,8 @@ extern "C" int dl_heads_bwd(const float* x, const dl_heads_params* params, int32
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_heads_out_bwd, dim3(1), dim3(256), 0, st, a2, p, B, Hd, act, rot_raw, norm, grad_translation, grad_rotation,
                      (float*)grads->r3_w, (float*)grads->r3_b, (float*)grads->t3_w, (float*)grads->t3_b, gh);
-  hipLaunchKernelGGL(k_heads_hidden_bwd, dim3((R + 63) / 64), dim3(64), (size_t)B * 2 * Hd * sizeof(float), st, a1, (const float*)gh, p, B, R, Hd, act,
+  hipLaunchKernelGGL(k_heads_hidden_bwd, dim3((R + 63) / 64), dim3(64 * HD_HB_WAVES), ((size_t)B * 2 * Hd + HD_HB_WAVES * HD_MAXB * 64) * sizeof(float), st, a1,
+                     (const float*)gh, p, B, R, Hd, act,
                      (float*)grads->r1_w, (float*)grads->r1_b, (float*)grads->t1_w, (float*)grads->t1_b, gout);
   hipLaunchKernelGGL(k_heads_fc_bwd, dim3((F + 255) / 256, chunks), dim3(256), 0, st, x, (const float*)gout, p.fc_w, B, F, R, (float*)grads->fc_w,
                      (float*)grads->fc_b, part);
