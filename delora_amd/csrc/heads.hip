@@ -32,25 +32,29 @@ __device__ __forceinline__ float hd_dact(float a, int act) { return act == 1 ? 1
 // re-read it from global memory inside the k loop: 31 us per launch, all of it load latency).
 __global__ __launch_bounds__(256) void k_heads_rows(const float* __restrict__ x, int B, int K, const float* __restrict__ w0, const float* __restrict__ b0,
                                                     const float* __restrict__ w1, const float* __restrict__ b1, int rows, int nmat, int act,
-                                                    float* __restrict__ y /* [B][nmat][rows] */) {
-  extern __shared__ float sx[];                             // [B][K]
-  for (int q = threadIdx.x; q < B * K; q += 256) sx[q] = x[q];
-  __syncthreads();
+                                                    int KC, float* __restrict__ y /* [B][nmat][rows] */) {
+  extern __shared__ float sx[];                             // [B][KC]: a chunk of KC reduction elements of every sample
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int gr = blockIdx.x * 4 + wave;                     // global row over the nmat matrices
-  if (gr >= rows * nmat) return;
+  const int gr = min(blockIdx.x * 4 + wave, rows * nmat - 1);                     // global row over the nmat matrices (surplus waves repeat the last)
   const int m = gr / rows, r = gr % rows;
   const float* wr = (m == 0 ? w0 : w1) + (size_t)r * K;
   float acc[HD_MAXB];
 #pragma unroll
   for (int b = 0; b < HD_MAXB; ++b) acc[b] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    const int kn = min(KC, K - k0);
+    __syncthreads();
+    for (int q = threadIdx.x; q < B * kn; q += 256) sx[(q / kn) * KC + q % kn] = x[(size_t)(q / kn) * K + k0 + q % kn];
+    __syncthreads();
 #pragma unroll 8
-  for (int k = lane; k < K; k += 64) {
-    const float wv = wr[k];
+    for (int k = lane; k < kn; k += 64) {
+      const float wv = wr[k0 + k];
 #pragma unroll
-    for (int b = 0; b < HD_MAXB; ++b)
-      if (b < B) acc[b] = fmaf(sx[b * K + k], wv, acc[b]);
+      for (int b = 0; b < HD_MAXB; ++b)
+        if (b < B) acc[b] = fmaf(sx[b * KC + k], wv, acc[b]);
+    }
   }
+  if (blockIdx.x * 4 + wave >= rows * nmat) return;
   const float bias = (m == 0 ? b0 : b1)[r];
 #pragma unroll
   for (int b = 0; b < HD_MAXB; ++b) {
@@ -239,6 +243,10 @@ static int heads_check(const char* who, const void* a, const void* b, const dl_h
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "%s: bad size (1 <= B <= %d) or activation", who, HD_MAXB);
   return DL_OK;
 }
+static int heads_kc(int B, int K) {
+  int kc = (48 * 1024 / 4 / B) & ~63;
+  return kc >= K ? K : kc;
+}
 static HeadsP heads_params(const dl_heads_params* p) {
   return HeadsP{p->fc_w, p->fc_b, p->r1_w, p->r1_b, p->r3_w, p->r3_b, p->t1_w, p->t1_b, p->t3_w, p->t3_b};
 }
@@ -250,9 +258,10 @@ extern "C" int dl_heads_fwd(const float* x, const dl_heads_params* params, int32
   if (!a2 || !rot_raw || !translation || !rotation || !norm) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_heads_fwd: null output");
   const HeadsP p = heads_params(params);
   hipStream_t st = (hipStream_t)stream;
-  if ((size_t)B * (F > R ? F : R) * sizeof(float) > 60000) return dl_fail(DL_ERR_UNSUPPORTED, "dl_heads_fwd: layer too wide for the LDS copy of its input");
-  hipLaunchKernelGGL(k_heads_rows, dim3((R + 3) / 4), dim3(256), (size_t)B * F * sizeof(float), st, x, B, F, p.fc_w, p.fc_b, (const float*)nullptr, (const float*)nullptr, R, 1, act, a1);
-  hipLaunchKernelGGL(k_heads_rows, dim3((2 * Hd + 3) / 4), dim3(256), (size_t)B * R * sizeof(float), st, (const float*)a1, B, R, p.r1_w, p.r1_b, p.t1_w, p.t1_b, Hd, 2, act, a2);
+  // the layer input is staged in LDS in chunks of KC reduction elements per sample (at most 48 KB)
+  const int kc_f = heads_kc(B, F), kc_r = heads_kc(B, R);
+  hipLaunchKernelGGL(k_heads_rows, dim3((R + 3) / 4), dim3(256), (size_t)B * kc_f * sizeof(float), st, x, B, F, p.fc_w, p.fc_b, (const float*)nullptr, (const float*)nullptr, R, 1, act, kc_f, a1);
+  hipLaunchKernelGGL(k_heads_rows, dim3((2 * Hd + 3) / 4), dim3(256), (size_t)B * kc_r * sizeof(float), st, (const float*)a1, B, R, p.r1_w, p.r1_b, p.t1_w, p.t1_b, Hd, 2, act, kc_r, a2);
   hipLaunchKernelGGL(k_heads_out, dim3(1), dim3(256), 0, st, (const float*)a2, p, B, Hd, rot_raw, translation, rotation, norm);
   return dl_check_launch("dl_heads_fwd");
 }
