@@ -4,7 +4,7 @@
 # launch table + FETCH_SIZE / WRITE_SIZE per layer (tools/conv_layers.py), matrix-core counters of the Winograd and the
 # half-precision kernels.  Counters are collected in their own runs, with --kernel-trace only.
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 out=gpurun_out/profiles_$R; rm -rf $out; mkdir -p $out
 T=/tmp/prof_$R; rm -rf $T; mkdir -p $T
 python bench.py > $out/bench.json 2> $out/bench.err; tail -1 $out/bench.json | cut -c1-300
