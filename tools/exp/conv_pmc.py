@@ -6,7 +6,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 KERNEL = sys.argv[2] if len(sys.argv) > 2 else "k_wino_conv"
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
-    if KERNEL + ("<" if KERNEL == "k_wino_conv" else "(") in r["Kernel_Name"] and int(r["Grid_Size"]) > 100000:
+    if (KERNEL + "<" in r["Kernel_Name"] or KERNEL + "(" in r["Kernel_Name"]) and int(r["Grid_Size"]) > 100000:
         agg[(r["Kernel_Name"][:28], r["Grid_Size"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for (k, grid), v in agg.items():
     m = {c: sum(x) / len(x) for c, x in v.items()}
