@@ -143,6 +143,8 @@ class PackedFeed:
             p.start()
         self.bytes_moved = 0
         self.host_seconds = {"wait_for_workers": 0.0, "upload_enqueue": 0.0, "reclaim": 0.0}      # where the consumer's time goes
+        self._outstanding = 0                       # tasks handed to the workers whose result has not been received yet
+        self._uploads = []                          # (event, slot): copies of an abandoned epoch still in flight
 
     def __len__(self):
         return len(self.batch_sampler)
@@ -187,10 +189,25 @@ class PackedFeed:
         self.bytes_moved += pts.numel() * 4
         return self._PackedBatch(pts, offs_t, max(lengths), self.B, self.dataset_name, self.rows == 6), ev
 
+    def _drain(self):
+        """An epoch that was abandoned half-way (an exception in the training loop, a `break`) leaves tasks with the workers and copies
+        in flight: collect them, so that the next epoch starts with every slot free and an empty result queue."""
+        while self._outstanding > 0:
+            try:
+                self.done.get(timeout=120)
+            except _queue.Empty:
+                raise RuntimeError("PackedFeed: the worker processes do not answer")
+            self._outstanding -= 1
+        for ev, _ in self._uploads:
+            if ev is not None:
+                ev.synchronize()
+        self._uploads = []
+
     def __iter__(self):
+        self._drain()
         batches = iter(self.batch_sampler)
         free = list(range(len(self.slots)))
-        busy = []                                   # (event, slot): uploads in flight
+        busy = self._uploads                        # (event, slot): uploads in flight
         arrived = {}                                # batch id -> (slot, lengths)
         issued = consumed = 0
         exhausted = False
@@ -220,6 +237,7 @@ class PackedFeed:
                     exhausted = True
                     return
                 self.tasks.put((issued, [int(i) for i in idx], free.pop(0)))
+                self._outstanding += 1
                 issued += 1
 
         def next_uploaded():
@@ -232,6 +250,7 @@ class PackedFeed:
                     bid, slot, lengths, spent, err = self.done.get(timeout=120)
                 except _queue.Empty:
                     raise RuntimeError("PackedFeed: no batch from the worker processes for 120 s")
+                self._outstanding -= 1
                 if err is not None:
                     raise RuntimeError("PackedFeed worker: " + err)
                 self.host_seconds["worker_read_files"] = self.host_seconds.get("worker_read_files", 0.0) + spent[0]
