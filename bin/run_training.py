@@ -40,4 +40,5 @@ if __name__ == "__main__":
         torch.distributed.init_process_group(backend="nccl")
     cfg = config(standalone_mode=False)
     trainer = deploy.trainer.Trainer(config=cfg)
-    trainer.train()
+    # the reference trains until it is interrupted (src/deploy/trainer.py:93-186: 10000 epochs); DELORA_MAX_EPOCHS bounds a run (tests, CI)
+    trainer.train(max_epochs=int(os.environ.get("DELORA_MAX_EPOCHS", "10000")))
