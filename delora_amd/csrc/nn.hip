@@ -58,6 +58,8 @@ struct NNWorkspace {
   NNHard* mid;                 // [B*HW]: tile-walk queries with one 16-lane group each (counter[2])
   float4* tiles;               // [B][ceil(H/4)][ceil(W/16)] bounding sphere (cx,cy,cz,radius) of every target tile; radius < 0: empty
   float4* super;               // [B][ceil(ntr/4)][ceil(ntc/8)] bounding sphere of every 4 x 8 block of tiles (16 x 128 pixels)
+  float4* tbox;                // [B][tiles][2] tight axis-aligned bounding box (lo, hi) of every target tile's points; empty: lo > hi
+  float4* sbox;                // [B][supers][2] the same for every super tile (the union of its children's boxes)
 };
 
 #define NN_SR 4                 // super tile: 4 x 8 tiles = 32 child spheres (half a wave)
@@ -81,11 +83,13 @@ static inline NNWorkspace carve_nn(void* ws, int B, int H, int W) {
   w.mid = w.hard + (size_t)B * H * W;
   w.tiles = (float4*)((char*)w.mid + (size_t)B * H * W * sizeof(NNHard));
   w.super = w.tiles + (size_t)B * nn_tiles(H, W);
+  w.tbox = w.super + (size_t)B * nn_supers(H, W);
+  w.sbox = w.tbox + 2 * (size_t)B * nn_tiles(H, W);
   return w;
 }
 
 extern "C" size_t dl_nn_workspace_bytes(int32_t B, int32_t H, int32_t W) {
-  return nn_header_bytes(B) + 2 * (size_t)B * H * W * sizeof(NNHard) + (size_t)B * (nn_tiles(H, W) + nn_supers(H, W)) * sizeof(float4);
+  return nn_header_bytes(B) + 2 * (size_t)B * H * W * sizeof(NNHard) + 3 * (size_t)B * (nn_tiles(H, W) + nn_supers(H, W)) * sizeof(float4);
 }
 
 // Angular description of a query in fp32.  The image is only a spatial index here: these values pick WHICH pixels
@@ -330,7 +334,7 @@ __device__ __forceinline__ float wave_min_sf(float v) {       // signed values (
 // rounded up).  A second level of the image-as-index: a tile whose sphere is farther from q than the best distance
 // cannot hold the neighbour, which turns the large windows of pass B from pixel scans into tile tests.
 __global__ __launch_bounds__(DL_BLOCK) void k_nn_tiles(const float4* __restrict__ tgt, int64_t tgt_ss4, int H, int W,
-                                                       int nb, float4* __restrict__ tiles) {
+                                                       int nb, float4* __restrict__ tiles, float4* __restrict__ tbox) {
   const int lane = threadIdx.x & (DL_WAVE - 1);
   const int ntr = (H + NN_TR - 1) / NN_TR, ntc = (W + NN_TC - 1) / NN_TC;
   const int t = (blockIdx.x * DL_BLOCK + threadIdx.x) / DL_WAVE;
@@ -352,7 +356,27 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_tiles(const float4* __restrict_
     const float r2 = wave_max_f(occ ? fmaf(dz, dz, fmaf(dy, dy, dx * dx)) : 0.f);
     out = make_float4(cx, cy, cz, sqrtf(r2) * (1.0f + 2e-6f) + 1e-7f);
   }
-  if (lane == 0) tiles[t] = out;
+  if (lane == 0) {
+    tiles[t] = out;
+    tbox[2 * (size_t)t] = make_float4(xmin, ymin, zmin, 0.f);          // (an empty tile: lo = 3e38 > hi = -3e38)
+    tbox[2 * (size_t)t + 1] = make_float4(xmax, ymax, zmax, 0.f);
+  }
+}
+
+// Bounds of the distance from q to the points inside a TIGHT axis-aligned bounding box (every face touches a point), both
+// rigorous: lower = distance to the box; upper = MINMAXDIST of the R-tree literature (Roussopoulos et al.): some point lies on the
+// nearer face of every axis, at most as far as that face's farthest corner -- the minimum over the three axes.  fp32 with explicit
+// round-down / round-up factors (the decisive distances are fp64, these only decide WHICH tiles are read).
+__device__ __forceinline__ void box_bounds(const float4 lo, const float4 hi, float qx, float qy, float qz, float& lower, float& upper) {
+  const float ex = fmaxf(fmaxf(lo.x - qx, qx - hi.x), 0.f), ey = fmaxf(fmaxf(lo.y - qy, qy - hi.y), 0.f), ez = fmaxf(fmaxf(lo.z - qz, qz - hi.z), 0.f);
+  const float dl = sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex)));
+  lower = dl * (1.0f - 8e-6f) - 1e-6f;
+  // per axis: nearer face coordinate (n) and farther coordinate (f)
+  const float nx = fminf(fabsf(qx - lo.x), fabsf(qx - hi.x)), fx = fmaxf(fabsf(qx - lo.x), fabsf(qx - hi.x));
+  const float ny = fminf(fabsf(qy - lo.y), fabsf(qy - hi.y)), fy = fmaxf(fabsf(qy - lo.y), fabsf(qy - hi.y));
+  const float nz = fminf(fabsf(qz - lo.z), fabsf(qz - hi.z)), fz = fmaxf(fabsf(qz - lo.z), fabsf(qz - hi.z));
+  const float mx = fmaf(fz, fz, fmaf(fy, fy, nx * nx)), my = fmaf(fz, fz, fmaf(ny, ny, fx * fx)), mz = fmaf(nz, nz, fmaf(fy, fy, fx * fx));
+  upper = sqrtf(fminf(mx, fminf(my, mz))) * (1.0f + 8e-6f) + 1e-6f;      // (sums of squares: no cancellation)
 }
 
 // Final, exact stage of pass B for one query (wave-uniform arguments): the bound window is walked tile by tile; 64
@@ -438,7 +462,8 @@ __device__ __forceinline__ void scan_tiles(const Window& w, const float4* __rest
 
 // Second level of the pyramid: one wave per super tile (4 x 8 tiles, lanes 0..31 = children): a sphere that encloses the
 // children's spheres (centre = middle of the box around them, radius = largest |c_child - centre| + r_child, rounded up).
-__global__ __launch_bounds__(DL_BLOCK) void k_nn_supers(const float4* __restrict__ tiles, int H, int W, int nb, float4* __restrict__ super) {
+__global__ __launch_bounds__(DL_BLOCK) void k_nn_supers(const float4* __restrict__ tiles, const float4* __restrict__ tbox, int H, int W, int nb,
+                                                        float4* __restrict__ super, float4* __restrict__ sbox) {
   const int lane = threadIdx.x & (DL_WAVE - 1);
   const int ntr = (H + NN_TR - 1) / NN_TR, ntc = (W + NN_TC - 1) / NN_TC;
   const int nsr = (ntr + NN_SR - 1) / NN_SR, nsc = (ntc + NN_SC - 1) / NN_SC;
@@ -461,7 +486,20 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_supers(const float4* __restrict
     const float rr = wave_max_f(occ ? sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx))) * (1.0f + 2e-6f) + c.w : 0.f);
     out = make_float4(cx, cy, cz, rr * (1.0f + 2e-6f) + 1e-7f);
   }
-  if (lane == 0) super[t] = out;
+  // the tight box of the super tile's points = the union of its children's tight boxes
+  float4 clo = make_float4(big, big, big, 0.f), chi = make_float4(-big, -big, -big, 0.f);
+  if (occ) {
+    const size_t ct = (size_t)b * ntr * ntc + tr * ntc + tc;
+    clo = tbox[2 * ct];
+    chi = tbox[2 * ct + 1];
+  }
+  const float bx0 = wave_min_sf(clo.x), by0 = wave_min_sf(clo.y), bz0 = wave_min_sf(clo.z);
+  const float bx1 = wave_max_f(chi.x), by1 = wave_max_f(chi.y), bz1 = wave_max_f(chi.z);
+  if (lane == 0) {
+    super[t] = out;
+    sbox[2 * (size_t)t] = make_float4(bx0, by0, bz0, 0.f);
+    sbox[2 * (size_t)t + 1] = make_float4(bx1, by1, bz1, 0.f);
+  }
 }
 
 // Exact search of the WHOLE image for one query (wave-uniform arguments) through the two-level sphere pyramid, best first.
@@ -473,6 +511,7 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_supers(const float4* __restrict
 // exceeds the cull distance; (3) a visited super tile tests its 32 child spheres (again tightening the cull distance by
 // their upper bounds) and scans the surviving tiles, one pixel per lane, four tiles per round trip.
 __device__ __forceinline__ void pyramid_walk(const float4* __restrict__ super_b, const float4* __restrict__ tiles_b,
+                                             const float4* __restrict__ sbox_b, const float4* __restrict__ tbox_b,
                                              const float4* __restrict__ tp, int H, int W, float qx, float qy, float qz, int lane,
                                              double& best, int& bidx) {
   const int ntr = (H + NN_TR - 1) / NN_TR, ntc = (W + NN_TC - 1) / NN_TC;
@@ -494,6 +533,11 @@ __device__ __forceinline__ void pyramid_walk(const float4* __restrict__ super_b,
         const float dist = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
         lb2[k] = (dist - s4.w) - 4e-6f * (dist + s4.w) - 1e-7f;
         ub = (dist + s4.w) * (1.0f + 4e-6f) + 1e-7f;
+        // the tight box is the better bound for flat point sets (ground, walls): thin slabs inside large spheres
+        float bl, bu;
+        box_bounds(sbox_b[2 * sidx], sbox_b[2 * sidx + 1], qx, qy, qz, bl, bu);
+        lb2[k] = fmaxf(lb2[k], bl);
+        ub = fminf(ub, bu);
       }
     }
     dcur = fminf(dcur, wave_min_f(ub));
@@ -544,6 +588,10 @@ __device__ __forceinline__ void pyramid_walk(const float4* __restrict__ super_b,
         const float dist = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
         lb1 = (dist - s4.w) - 4e-6f * (dist + s4.w) - 1e-7f;
         ub = (dist + s4.w) * (1.0f + 4e-6f) + 1e-7f;
+        float bl, bu;
+        box_bounds(tbox_b[2 * (tr * ntc + tc)], tbox_b[2 * (tr * ntc + tc) + 1], qx, qy, qz, bl, bu);
+        lb1 = fmaxf(lb1, bl);
+        ub = fminf(ub, bu);
         survive = true;
       }
     }
@@ -830,7 +878,8 @@ __device__ __forceinline__ void nn_hard(const int vblock, const int vgrid, const
       // only a far candidate -- for an untrained network's random pose that is EVERY query.  The bound window is useless then:
       // search the whole image through the two-level sphere pyramid, best first (pyramid_walk).  Round 2 walked the window's
       // tiles in raster order after a seed scan around q's pixel: 9.6 ms per batch for random poses.
-      pyramid_walk(ws.super + (size_t)b * nsuper_img, tiles_b, tp, H, W, rec.qx, rec.qy, rec.qz, lane, best, bidx);
+      pyramid_walk(ws.super + (size_t)b * nsuper_img, tiles_b, ws.sbox + 2 * (size_t)b * nsuper_img, ws.tbox + 2 * (size_t)b * ntiles_img, tp, H, W,
+                   rec.qx, rec.qy, rec.qz, lane, best, bidx);
     } else {
       scan_tiles(w, tiles_b, tp, H, W, rec.qx, rec.qy, rec.qz, lane, best, bidx);
     }
@@ -889,12 +938,12 @@ extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const f
   {
     const int waves = (int)(B * nn_tiles(sen.H, sen.W));
     hipLaunchKernelGGL(k_nn_tiles, dim3((waves * DL_WAVE + DL_BLOCK - 1) / DL_BLOCK), dim3(DL_BLOCK), 0, st,
-                       (const float4*)tgt_packed, tgt_ss / 4, sen.H, sen.W, B, ws.tiles);
+                       (const float4*)tgt_packed, tgt_ss / 4, sen.H, sen.W, B, ws.tiles, ws.tbox);
   }
   {
     const int waves = (int)(B * nn_supers(sen.H, sen.W));
-    hipLaunchKernelGGL(k_nn_supers, dim3((waves * DL_WAVE + DL_BLOCK - 1) / DL_BLOCK), dim3(DL_BLOCK), 0, st, (const float4*)ws.tiles, sen.H, sen.W,
-                       B, ws.super);
+    hipLaunchKernelGGL(k_nn_supers, dim3((waves * DL_WAVE + DL_BLOCK - 1) / DL_BLOCK), dim3(DL_BLOCK), 0, st, (const float4*)ws.tiles, (const float4*)ws.tbox, sen.H, sen.W,
+                       B, ws.super, ws.sbox);
   }
   hipLaunchKernelGGL(k_nn_window, dim3((sen.HW + DL_BLOCK - 1) / DL_BLOCK, B), dim3(DL_BLOCK), 0, st,
                      src_image4, src_ss, src_normals, srcn_ss, (const float4*)tgt_packed, tgt_ss / 4,
