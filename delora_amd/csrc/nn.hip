@@ -379,10 +379,15 @@ __device__ __forceinline__ void box_bounds(const float4 lo, const float4 hi, flo
   upper = sqrtf(fminf(mx, fminf(my, mz))) * (1.0f + 8e-6f) + 1e-6f;      // (sums of squares: no cancellation)
 }
 
+__device__ __forceinline__ float box_lower(const float4 lo, const float4 hi, float qx, float qy, float qz) {
+  const float ex = fmaxf(fmaxf(lo.x - qx, qx - hi.x), 0.f), ey = fmaxf(fmaxf(lo.y - qy, qy - hi.y), 0.f), ez = fmaxf(fmaxf(lo.z - qz, qz - hi.z), 0.f);
+  return sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * (1.0f - 8e-6f) - 1e-6f;
+}
+
 // Final, exact stage of pass B for one query (wave-uniform arguments): the bound window is walked tile by tile; 64
 // tiles are tested per trip (one per lane: sphere distance against the best distance so far) and surviving tiles are
 // scanned one pixel per lane; the cull distance is refreshed once per trip.
-__device__ __forceinline__ void scan_tiles(const Window& w, const float4* __restrict__ tiles_b,
+__device__ __forceinline__ void scan_tiles(const Window& w, const float4* __restrict__ tiles_b, const float4* __restrict__ tbox_b,
                                            const float4* __restrict__ tp, int H, int W, float qx, float qy, float qz,
                                            int lane, double& best, int& bidx) {
   const int ntr = (H + NN_TR - 1) / NN_TR, ntc_all = (W + NN_TC - 1) / NN_TC;
@@ -411,7 +416,8 @@ __device__ __forceinline__ void scan_tiles(const Window& w, const float4* __rest
       const float4 s4 = tiles_b[tr * ntc_all + tc];
       const float dx = qx - s4.x, dy = qy - s4.y, dz = qz - s4.z;
       const float dist = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
-      survive = s4.w >= 0.f && (dist - s4.w) <= dcur + 2e-6f * dist;
+      survive = s4.w >= 0.f && (dist - s4.w) <= dcur + 2e-6f * dist &&
+                box_lower(tbox_b[2 * (tr * ntc_all + tc)], tbox_b[2 * (tr * ntc_all + tc) + 1], qx, qy, qz) <= dcur;
     }
     unsigned long long mask = __ballot(survive);
     while (mask) {
@@ -755,6 +761,7 @@ __device__ __forceinline__ void nn_hard16(const int vblock, const int vgrid, con
     const float qx = rec.qx, qy = rec.qy, qz = rec.qz;
     const float4* tp = tgt + (size_t)b * tgt_ss4;
     const float4* tiles_b = ws.tiles + (size_t)b * ntiles_img;
+    const float4* tbox_b = ws.tbox + 2 * (size_t)b * ntiles_img;
     const int r0 = (int)(rec.rows & 0xffffu), r1 = (int)(rec.rows >> 16);
     const int c0 = (int)(rec.cols & 0xffffu), nc = (int)(rec.cols >> 16) + 1;
     const int tr0 = r0 / NN_TR, tr1 = r1 / NN_TR;
@@ -780,7 +787,8 @@ __device__ __forceinline__ void nn_hard16(const int vblock, const int vgrid, con
         const float4 s4 = tiles_b[tr * ntc_all + tc];
         const float dx = qx - s4.x, dy = qy - s4.y, dz = qz - s4.z;
         const float dist = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
-        survive = s4.w >= 0.f && (dist - s4.w) <= dcur + 2e-6f * dist;
+        survive = s4.w >= 0.f && (dist - s4.w) <= dcur + 2e-6f * dist &&
+                  box_lower(tbox_b[2 * (tr * ntc_all + tc)], tbox_b[2 * (tr * ntc_all + tc) + 1], qx, qy, qz) <= dcur;
       }
       // this row's 16 survivor bits
       unsigned gmask = (unsigned)((__ballot(survive) >> rowbase) & 0xffffull);
@@ -881,7 +889,7 @@ __device__ __forceinline__ void nn_hard(const int vblock, const int vgrid, const
       pyramid_walk(ws.super + (size_t)b * nsuper_img, tiles_b, ws.sbox + 2 * (size_t)b * nsuper_img, ws.tbox + 2 * (size_t)b * ntiles_img, tp, H, W,
                    rec.qx, rec.qy, rec.qz, lane, best, bidx);
     } else {
-      scan_tiles(w, tiles_b, tp, H, W, rec.qx, rec.qy, rec.qz, lane, best, bidx);
+      scan_tiles(w, tiles_b, ws.tbox + 2 * (size_t)b * ntiles_img, tp, H, W, rec.qx, rec.qy, rec.qz, lane, best, bidx);
     }
     // the result: lanes 0-2 fetch and store the matched point's coordinates, lanes 3-5 the normal's
     if (lane == 0) nn_pix[rec.slot] = bidx;
