@@ -73,8 +73,6 @@ class DevicePrefetcher:
 import multiprocessing as _mp
 import queue as _queue
 
-import numpy as _np
-
 
 def _feed_worker(dataset, slots, tasks, done, rows, capacity):
     """Worker loop: (batch id, sample indices, slot) -> the slot filled as ``[rows][capacity]`` planar fp32 (row c holds coordinate c of

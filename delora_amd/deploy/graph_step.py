@@ -43,7 +43,8 @@ class GraphedStep:
         # a PackedBatch cannot be augmented or rescaled (Deployer.step rejects it) and one capture serves one sensor and one rank:
         # when a requirement does not hold every call runs the eager step on the caller's own list of dicts
         self.eligible = not (trainer.world_size != 1 or cfg["normalization_scaling"] or cfg["random_point_cloud_rotations"]
-                             or len({d["dataset"] for d in example_batch}) != 1 or self.B != trainer.batch_size)
+                             or len({d["dataset"] for d in example_batch}) != 1 or self.B != trainer.batch_size
+                             or getattr(trainer, "grad_scaler", None) is not None)          # float16 loss scaling: left eager
         if not self.eligible:
             return
         for group in trainer.optimizer.param_groups:
