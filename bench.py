@@ -289,6 +289,8 @@ def disk_feed_leg(args, cfg, device, tree, run_step, timed_region, resident_pair
     dcfg = dict(cfg)
     dcfg["kitti"] = dict(cfg["kitti"], preprocessed_path=tree["path"], data_identifiers=[0])
     dcfg.update(store_dataset_in_RAM=False, num_dataloader_workers=args.disk_workers, load_normal_lists=False)
+    if os.environ.get("DELORA_FEED_AHEAD"):
+        dcfg["feed_batches_ahead"] = int(os.environ["DELORA_FEED_AHEAD"])
     ds = PreprocessedPointCloudDataset(dcfg)
     assert feedmod.packed_feed_applicable(ds, dcfg, device), "the bench's on-disk leg must take the product's packed feed"
     pf = feedmod.make_packed_feed(ds, dcfg, device, args.batch, shuffle=True)

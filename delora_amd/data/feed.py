@@ -295,4 +295,4 @@ def make_packed_feed(dataset, config, device, batch_size, sampler=None, shuffle=
         sampler = torch.utils.data.RandomSampler(dataset) if shuffle else torch.utils.data.SequentialSampler(dataset)
     batches = torch.utils.data.BatchSampler(sampler, batch_size=batch_size, drop_last=True)
     return PackedFeed(dataset, batches, batch_size, device, workers=int(config["num_dataloader_workers"]),
-                      points_per_scan=config.get("feed_points_per_scan"))
+                      points_per_scan=config.get("feed_points_per_scan"), ahead=config.get("feed_batches_ahead"))
