@@ -58,7 +58,7 @@ def parse(argv=None):
     ap.add_argument("--conv-table", action="store_true", help="also time every stride-1 layer shape and pass back to back (roofline_cnn)")
     ap.add_argument("--autocast-steps", type=int, default=20, help="timed steps of the extra bf16-autocast leg of the fp32 run (0 = skip); N=1 only")
     ap.add_argument("--disk-pairs", type=int, default=32, help="scan pairs of the synthetic on-disk sequence of the `feed_disk` leg (0 = skip); N=1 only")
-    ap.add_argument("--disk-workers", type=int, default=3, help="DataLoader worker processes of the `feed_disk` leg")
+    ap.add_argument("--disk-workers", type=int, default=2, help="DataLoader worker processes of the `feed_disk` leg")
     ap.add_argument("--variant-steps", type=int, default=10, help="timed steps of the extra fp32 legs `shipped_image` (64x720, the reference's "
                     "default KITTI image) and `untrained_network` (randomly initialised heads: whole-image search) (0 = skip); N=1 only")
     ap.add_argument("--amp", default="", help="optional autocast dtype for the CNN (bfloat16/float16); default fp32 = parity mode")
