@@ -554,7 +554,7 @@ extern "C" int dl_wino_weights_f32(const float* w, float* u_fwd, float* u_bwd, i
 //   dU[xi][k][c] += Gh[xi][tile][k] * Dh[xi][tile][c]   (16 products per tile and (k,c) pair instead of 36)
 // Workgroup = 512 threads, output block 64 k x 64 c x 16 planes (the accumulator layout of k_wino_conv), reduction index =
 // tiles, 8 consecutive tiles of one tile row per chunk; a workgroup walks a slab of chunks and writes one partial
-// [16][K][C] block; k_wino_wgrad_out adds the slabs in a fixed order (deterministic) and applies G^T . G.
+// [16][K][C] block; k_wino_wgrad_sum adds the slabs in a fixed order (deterministic), k_wino_wgrad_out applies G^T . G.
 // Per chunk every thread produces, for ONE channel and FOUR tiles, one column of B^T d B (from the raw patch that the LDS
 // DMA brought in) and one column of A g A^T (16 scalar loads of g, coalesced over the 64 channels of a wave), written as
 // 16-byte rows [xi][channel][4 tiles]: lane (i, half) reads tiles 4 half .. 4 half+3 of its row, MFMA j reduces over tiles
@@ -806,40 +806,37 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
   }
 }
 
-// dw[k][r][s][c] = (G^T U G)[r][s] with U[xi][k][c] = sum over the slabs of ws[slab][xi][k][c] in slab order (deterministic): the slab sum
-// and the back-transform in one kernel (they were two launches and a round trip of 16 K C floats per layer).  Workgroup = 64 (k, c)
-// pairs (lane) x the four rows of the 4x4 Winograd domain (wave q sums planes 4q .. 4q+3: 256-byte runs per load); the rows are
-// exchanged through LDS and wave q < 3 writes filter row q.
-__global__ __launch_bounds__(256) void k_wino_wgrad_out(const float* __restrict__ ws, int nslabs, int K, int C, float* __restrict__ dw) {
-  __shared__ float ex[4][4][64];
-  const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
-  const size_t i = (size_t)blockIdx.x * 64 + lane;            // (k, c) pair, c fastest
-  const bool live = i < (size_t)K * C;
-  const size_t ii = live ? i : 0;
-  const int k = (int)(ii / C), c = (int)(ii % C);
-  const size_t plane = (size_t)K * C, slab_stride = 16 * plane;
-  float row[4] = {0.f, 0.f, 0.f, 0.f};
-  const float* base = ws + (size_t)(4 * q) * plane + ii;
-#pragma unroll 4
-  for (int sl = 0; sl < nslabs; ++sl) {
-    const float* uu = base + (size_t)sl * slab_stride;
+// U[xi][k][c] = sum over slabs of ws[slab][xi][k][c] in a fixed order (deterministic), four channels per thread
+__global__ __launch_bounds__(256) void k_wino_wgrad_sum(const float* __restrict__ ws, int nslabs, size_t count4, float* __restrict__ u) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count4) return;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int sl = 0; sl < nslabs; ++sl) s += reinterpret_cast<const f32x4*>(ws)[(size_t)sl * count4 + i];
+  reinterpret_cast<f32x4*>(u)[i] = s;
+}
+
+// dw[k][r][s][c] = (G^T U G)[r][s]
+__global__ __launch_bounds__(256) void k_wino_wgrad_out(const float* __restrict__ uu, int K, int C, float* __restrict__ dw) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (size_t)K * C) return;
+  const int k = (int)(i / C), c = (int)(i % C);
+  float u[4][4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) row[j] += uu[(size_t)j * plane];
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) ex[q][j][lane] = row[j];
-  __syncthreads();
-  if (!live || q == 3) return;
-  // G^T = [[1, 1/2, 1/2, 0], [0, 1/2, -1/2, 0], [0, 1/2, 1/2, 1]]: filter row q from the columns of U
-  float p[4];
+  for (int xi = 0; xi < 16; ++xi) u[xi / 4][xi % 4] = uu[((size_t)xi * K + k) * C + c];
+  // G^T = [[1, 1/2, 1/2, 0], [0, 1/2, -1/2, 0], [0, 1/2, 1/2, 1]]
+  float p[3][4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const float u0 = ex[0][j][lane], u1 = ex[1][j][lane], u2 = ex[2][j][lane], u3 = ex[3][j][lane];
-    p[j] = q == 0 ? u0 + 0.5f * (u1 + u2) : (q == 1 ? 0.5f * (u1 - u2) : 0.5f * (u1 + u2) + u3);
+    p[0][j] = u[0][j] + 0.5f * (u[1][j] + u[2][j]);
+    p[1][j] = 0.5f * (u[1][j] - u[2][j]);
+    p[2][j] = 0.5f * (u[1][j] + u[2][j]) + u[3][j];
   }
-  dw[(((size_t)k * 3 + q) * 3 + 0) * C + c] = p[0] + 0.5f * (p[1] + p[2]);
-  dw[(((size_t)k * 3 + q) * 3 + 1) * C + c] = 0.5f * (p[1] - p[2]);
-  dw[(((size_t)k * 3 + q) * 3 + 2) * C + c] = 0.5f * (p[1] + p[2]) + p[3];
+#pragma unroll
+  for (int rr = 0; rr < 3; ++rr) {
+    dw[(((size_t)k * 3 + rr) * 3 + 0) * C + c] = p[rr][0] + 0.5f * (p[rr][1] + p[rr][2]);
+    dw[(((size_t)k * 3 + rr) * 3 + 1) * C + c] = 0.5f * (p[rr][1] - p[rr][2]);
+    dw[(((size_t)k * 3 + rr) * 3 + 2) * C + c] = 0.5f * (p[rr][1] + p[rr][2]) + p[rr][3];
+  }
 }
 
 // CU count of the current device (the persistent grid's size), cached per device id
@@ -893,7 +890,10 @@ extern "C" int dl_wino_wgrad3x3_nhwc_f32(const float* x, const float* g, float* 
                       4.0 * ((double)N * H * W * (C + K) + 9.0 * C * K)};
   if (ww_exact(H, W)) DL_LAUNCH(tag, k_wino_wgrad<false>, dim3(tiles * nslabs), dim3(WW_THREADS), st, a);
   else DL_LAUNCH(tag, k_wino_wgrad<true>, dim3(tiles * nslabs), dim3(WW_THREADS), st, a);
-  hipLaunchKernelGGL(k_wino_wgrad_out, dim3((unsigned)(((size_t)K * C + 63) / 64)), dim3(256), 0, st, (const float*)ws, nslabs, K, C, dw);
+  const size_t count4 = (size_t)16 * K * C / 4;
+  float* usum = ws + (size_t)nslabs * 16 * K * C;
+  hipLaunchKernelGGL(k_wino_wgrad_sum, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nslabs, count4, usum);
+  hipLaunchKernelGGL(k_wino_wgrad_out, dim3((unsigned)(((size_t)K * C + 255) / 256)), dim3(256), 0, st, (const float*)usum, K, C, dw);
   return dl_check_launch("dl_wino_wgrad3x3_nhwc_f32");
 }
 
