@@ -20,7 +20,7 @@ if NEW:
         if os.path.exists(os.path.join(src, a)):
             json.dump(last_json(os.path.join(src, a)), open(os.path.join(dst, f"{R}_{a}"), "w"), indent=1)
     for name in ("bench_kernel_stats_f32.csv", "bench_kernel_stats_bf16.csv", "step_breakdown_f32.txt", "step_breakdown_bf16.txt",
-                 "geometry_kernel_stats.csv", "loss_calibration.txt", "loss_warm.txt", "conv_harness.txt", "convh_harness.txt",
+                 "geometry_kernel_stats.csv", "loss_calibration.txt", "loss_warm.txt", "loss_cold.txt", "conv_harness.txt", "convh_harness.txt",
                  "conv_layers_float32.txt", "conv_layers_bfloat16.txt", "conv_pmc.txt", "convh_pmc.txt", "scatter_probe.txt"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{R}_{name}"))

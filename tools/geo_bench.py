@@ -27,15 +27,25 @@ for _ in range(reps):
     prep = geo.prepare(batch, sensor, (3, 5, 0.5, 10))
     nn, vis, match = G.nn_correspond(img[:, 1], nrm[:, 1], tpk, tnpk, T, sensor)
     terms, counts = G.icp_loss(T, img[:, 1], nrm[:, 1], match, nn, flags)
-# calibration of the loss kernel: its read-only twin (same 13 streams, no arithmetic) and the kernel itself, each with the
-# caches flushed before every launch ("cold": ~1 GB of unrelated traffic) and back to back ("warm")
+# calibration of the loss kernel: its read-only twin (same 13 streams, no arithmetic) and the kernel itself,
+#   cold behind DIRTY foreign lines (1 GB of unrelated read-modify-write just before: the infinity cache is full of dirty lines whose
+#        write-back shares the HBM with the kernel),
+#   back to back ("warm"),
+#   cold behind CLEAN foreign lines (the same, followed by 1 GiB of unrelated reads, which push the dirty lines out)
 flush = torch.empty(128_000_000, device=dev)
+flush2 = torch.zeros(256 * 1024 * 1024, device=dev)
+sink = torch.zeros(1, device=dev)
 for _ in range(reps):
     flush.add_(1.0); G.probe_stream_read(img[:, 1], nrm[:, 1], match, nn)
 for _ in range(reps):
     G.probe_stream_read(img[:, 1], nrm[:, 1], match, nn)
 for _ in range(reps):
     flush.add_(1.0); G.icp_loss(T, img[:, 1], nrm[:, 1], match, nn, flags)
+for _ in range(reps):
+    flush.add_(1.0); sink.add_(flush2.sum()); G.probe_stream_read(img[:, 1], nrm[:, 1], match, nn)
+for _ in range(reps):
+    flush.add_(1.0); sink.add_(flush2.sum()); G.icp_loss(T, img[:, 1], nrm[:, 1], match, nn, flags)
+del flush2
 del flush
 # calibration: plain torch streaming kernels over the same number of bytes as the loss kernel moves (53 MB)
 xa = torch.randn(53_000_000 // 4, device=dev); xb = torch.empty(53_000_000 // 8, device=dev); xc = torch.randn(53_000_000 // 8, device=dev)

@@ -26,6 +26,7 @@ mkdir -p $out/geo_fetch $out/geo_write
 cp $(find $T/geo_fetch -name "*counter_collection.csv" | head -1) $out/geo_fetch/geo_counter_collection.csv
 cp $(find $T/geo_write -name "*counter_collection.csv" | head -1) $out/geo_write/geo_counter_collection.csv
 python tools/loss_warm.py 50 > $out/loss_warm.txt 2>/dev/null
+python tools/exp/loss_cold.py 2>/dev/null | grep '^B=' > $out/loss_cold.txt
 # convolution kernels: stand-alone harnesses (host-checked correctness + per-layer times)
 (tools/bin/conv_harness all 10; tools/bin/conv_harness wino 10; tools/bin/wino_wgrad check; tools/bin/wino_wgrad time 10) > $out/conv_harness.txt 2>&1
 (tools/bin/convh_harness check; tools/bin/convh_harness time 10; tools/bin/convh_harness check f16 | tail -3; tools/bin/hw_probe | tail -3) > $out/convh_harness.txt 2>&1
