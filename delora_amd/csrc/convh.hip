@@ -451,7 +451,25 @@ static int launch_convh(const ConvHArgs& a, hipStream_t st, double best_eff = 0.
 
 #ifdef CH_TUNE
 int g_ch_variant = 0;
+int g_ch_svariant = 0;       // tile variant of the strided / phase / 1x1 passes
 #endif
+
+// LDS bytes of a k_convh instantiation (the kernel's own formulas): tile shapes that do not fit a CU's 160 KB are not instantiated
+template <int BM, int BN, int WGM, int WGN, int TW, class G, int NG>
+constexpr int convh_lds_bytes() {
+  constexpr int TH = BM / TW, SH = G::ISH, SW = G::ISW;
+  constexpr int RH = (TH - 1) * SH + G::EH, RW = (TW - 1) * SW + G::EW;
+  constexpr int RWC = (RW + SW - 1) / SW, RWP = (RWC + 3) & ~3;
+  constexpr int NII = (RH * SW * RWP * 4 + 63) / 64;
+  constexpr int MAIN = 2 * NII * 1024 + 2 * (G::NT / NG) * BN * 64;
+  constexpr int EPI = WGM * WGN * 32 * ((BN / 32 / WGN) * 32 + 4) * 4;
+  return MAIN > EPI ? MAIN : EPI;
+}
+template <bool F16, int BM, int BN, int WGM, int WGN, int TW, class G, int NG>
+static int launch_convh_if_fits(const ConvHArgs& a, hipStream_t st, double best_eff = 0.0) {
+  if constexpr (convh_lds_bytes<BM, BN, WGM, WGN, TW, G, NG>() <= 163840) return launch_convh<F16, BM, BN, WGM, WGN, TW, G, NG>(a, st, best_eff);
+  else return 1;
+}
 
 // Tile choice.  STRIDE1: a stride-1 3x3 pass (layer or input gradient): tall tiles, 3 tap groups.
 template <bool F16, class G, bool STRIDE1>
@@ -492,10 +510,35 @@ static int dispatch_convh(const ConvHArgs& a, hipStream_t st) {
     if (!launch_convh<F16, 128, 64, 2, 2, 32, G, NG>(a, st)) return 0;
     return 1;
   } else {
-    // strided layers, their input-gradient phases, 1x1 layers: 128-pixel tiles (the strided input tile is 2-4x the output tile)
-    const double e1 = ch_eff(a.Ho, a.Wo, 2, 64), e2 = ch_eff(a.Ho, a.Wo, 4, 32);
-    const double best = e1 > e2 ? e1 : e2;
-    if (a.K % 128 == 0 && !launch_convh<F16, 128, 128, 2, 2, 64, G, NG>(a, st, best)) return 0;
+    // strided layers, their input-gradient phases, 1x1 layers (tools/convh_harness tune-s, batch 8; round 4 -- until then every such
+    // pass ran 128 pixels x 128 channels on FOUR waves, one workgroup per CU, matrix pipe 6-21 % busy, waves waiting 40-60 %):
+    //   * 256 pixels (8 rows x 32 columns) x 128 channels on 8 waves where the staged input tile fits the LDS (every pass but the
+    //     forward of a stride-(2,2) 3x3 layer, whose tile is 4x its output) and the image still gives every CU a workgroup
+    //     (layer2.0 forward 66 -> 43 us, layer3.0 forward 86 -> 56, its input gradient 77 -> 56); a 1x1 pass is a memory stream and
+    //     wants two workgroups per CU before the larger tile pays (layer3.0 shortcut 29 -> 23 us);
+    //   * 256 x 64 for 64 output channels (layer2.0 input gradient 62 -> 43 us);
+    //   * else 128 x 128 on EIGHT waves (32 x 64 per wave: more LDS reads per MFMA, but twice the waves to hide the DMA latency:
+    //     layer4.0 forward 70 -> 61 us, its input-gradient phases 93 -> 75).
+    const double e1 = ch_eff(a.Ho, a.Wo, 2, 64), e2 = ch_eff(a.Ho, a.Wo, 4, 32), e3 = ch_eff(a.Ho, a.Wo, 8, 32), e4 = ch_eff(a.Ho, a.Wo, 4, 64);
+    const double e12 = e1 > e2 ? e1 : e2, e34 = e3 > e4 ? e3 : e4;
+    const double best = e12 > e34 ? e12 : e34;
+#ifdef CH_TUNE
+    switch (g_ch_svariant) {
+      case 1: if (!launch_convh_if_fits<F16, 256, 128, 4, 2, 64, G, NG>(a, st)) return 0; break;
+      case 2: if (!launch_convh_if_fits<F16, 128, 128, 4, 2, 64, G, NG>(a, st)) return 0; break;
+      case 3: if (!launch_convh_if_fits<F16, 256, 64, 4, 2, 64, G, NG>(a, st)) return 0; break;
+      case 4: if (!launch_convh_if_fits<F16, 128, 128, 2, 2, 32, G, NG>(a, st)) return 0; break;
+      case 5: if (!launch_convh_if_fits<F16, 128, 128, 2, 2, 64, G, NG>(a, st)) return 0; break;
+      case 6: if (!launch_convh_if_fits<F16, 256, 128, 4, 2, 32, G, NG>(a, st)) return 0; break;
+      default: break;
+    }
+#endif
+    const long wg256 = (pixels + 255) / 256;
+    const long need = G::NT > 1 ? 256 : 512;
+    if (a.K % 128 == 0) {
+      if (wg256 * (a.K / 128) >= need && !launch_convh_if_fits<F16, 256, 128, 4, 2, 32, G, NG>(a, st, best)) return 0;
+      if (!launch_convh_if_fits<F16, 128, 128, 4, 2, 64, G, NG>(a, st, best)) return 0;
+    } else if (wg256 * (a.K / 64) >= need && !launch_convh_if_fits<F16, 256, 64, 4, 2, 64, G, NG>(a, st, best)) return 0;
     if (!launch_convh<F16, 128, 64, 2, 2, 64, G, NG>(a, st, best)) return 0;
     if (a.K % 128 == 0 && !launch_convh<F16, 128, 128, 2, 2, 32, G, NG>(a, st)) return 0;
     if (!launch_convh<F16, 128, 64, 2, 2, 32, G, NG>(a, st)) return 0;

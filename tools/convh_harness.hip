@@ -369,6 +369,19 @@ int main(int argc, char** argv) {
     for (const auto& s : layers) time_shape(s, reps, gen, &total);
     printf("sum of the listed launches: %.1f us\n", total);
   }
+  if (!strcmp(mode, "tune-s")) {
+    // the strided 3x3 / 1x1 layers and their input-gradient phases with every tile variant of the tuning build (0 = the product's choice)
+    const int reps = argc >= 3 && atoi(argv[2]) > 0 ? atoi(argv[2]) : 10;
+    const Shape ss[] = {{"layer2.0.conv1 s(1,2)", B, 64, 512, 64, 128, 3, 1, 2}, {"layer2.0.ds 1x1 s(1,2)", B, 64, 512, 64, 128, 1, 1, 2},
+                        {"layer3.0.conv1 s(1,2)", B, 64, 256, 128, 256, 3, 1, 2}, {"layer3.0.ds 1x1 s(1,2)", B, 64, 256, 128, 256, 1, 1, 2},
+                        {"layer4.0.conv1 s(2,2)", B, 64, 128, 256, 512, 3, 2, 2}, {"layer4.0.ds 1x1 s(2,2)", B, 64, 128, 256, 512, 1, 2, 2}};
+    for (int v = 0; v <= 7; ++v) {
+      g_ch_svariant = v;
+      printf("---- strided variant %d\n", v);
+      for (const auto& s : ss) time_shape(s, reps, gen, nullptr);
+    }
+    g_ch_svariant = 0;
+  }
   if (!strcmp(mode, "tune")) {
     const int reps = argc >= 3 && atoi(argv[2]) > 0 ? atoi(argv[2]) : 10;
     for (int v = 0; v <= 13; ++v) {
