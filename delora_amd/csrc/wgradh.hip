@@ -65,18 +65,21 @@ __global__ __launch_bounds__(64 * (BMK / 32) * 2, 2) void k_wgradh(WgradHArgs a)
   const int ch_begin = slab * a.chunks_per_slab;
   const int ch_end = min(ch_begin + a.chunks_per_slab, total_chunks);
 
-  // DMA pieces of this wave: chunk-invariant lane roles.  g: pixel (prow, pcol) of the chunk, 16-byte slot of its BMK channels
-  int g_pix[NGI_W], g_ch[NGI_W];
+  // DMA pieces of this wave: chunk-invariant lane roles.  g: pixel (prow, pcol) of the chunk, 16-byte slot of its BMK channels;
+  // g_rel = element offset of that slot relative to the chunk's first pixel
+  int g_pr[NGI_W], g_pc[NGI_W], g_rel[NGI_W];
 #pragma unroll
   for (int it = 0; it < NGI_W; ++it) {
     const int j = wave + it * NWV;
     const int q = j * 64 + lane;
     constexpr int PP = PG / 16;
     const int pix = q / PP, s16 = q % PP;
-    g_pix[it] = j < NGI ? pix : -1;
-    g_ch[it] = (((s16 >> 2) ^ ch_unit_swz<UG>(pix)) * 32 + (s16 & 3) * 8);
+    g_pr[it] = pix / PK; g_pc[it] = pix % PK;
+    g_rel[it] = (g_pr[it] * a.Wo + g_pc[it]) * a.K + (((s16 >> 2) ^ ch_unit_swz<UG>(pix)) * 32 + (s16 & 3) * 8);
   }
-  int x_row[NXI_W], x_col[NXI_W], x_ch[NXI_W];
+  // x: (row, column) of the staged window, element offset of the row and the slot; x_row < 0: a lane of the padding / of a stride
+  // phase a 1x1 layer never reads (it fetches zeros)
+  int x_row[NXI_W], x_col[NXI_W], x_rel[NXI_W];
 #pragma unroll
   for (int it = 0; it < NXI_W; ++it) {
     const int j = wave + it * NWV;
@@ -87,10 +90,10 @@ __global__ __launch_bounds__(64 * (BMK / 32) * 2, 2) void k_wgradh(WgradHArgs a)
     const int row = rp / SW, phase = rp % SW;
     const int col = colp * SW + phase;
     // a 1x1 strided layer reads only the pixels (SH i, SW j): the other rows / phases of the window are never used
-    const bool used = j < NXI && rp < NPLX && col < RWX && (KS == 3 || (phase == 0 && row % SH == 0));
+    const bool used = rp < NPLX && col < RWX && (KS == 3 || (phase == 0 && row % SH == 0));
     x_row[it] = used ? row : -1;
     x_col[it] = col;
-    x_ch[it] = (((s16 >> 2) ^ ch_unit_swz<UX>(pix)) * 32 + (s16 & 3) * 8);
+    x_rel[it] = row * a.W * a.C + (((s16 >> 2) ^ ch_unit_swz<UX>(pix)) * 32 + (s16 & 3) * 8);
   }
 
   // fragment addresses (bytes, relative to the buffer's g / x image).  Lane (h = half, gq = 16-lane group of the half,
@@ -108,7 +111,16 @@ __global__ __launch_bounds__(64 * (BMK / 32) * 2, 2) void k_wgradh(WgradHArgs a)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[tp][r] = 0.f;
 
+  // The operands of chunk ch+1 are fetched by the LDS DMA while chunk ch is multiplied.  The DMA is issued from inline assembly: the
+  // compiler guards every LDS read that follows a global_load_lds builtin with s_waitcnt vmcnt(0) (it cannot tell that the
+  // transposing reads touch the OTHER buffer), which put the whole fetch latency in front of every chunk's first MFMA (matrix pipe 35 %
+  // busy; round 4).  The one wait that is needed -- before the barrier that hands the buffer over -- is written out below.
+  // Addresses: wave-uniform 64-bit base of the sample + a 32-bit per-lane byte offset (the entry point keeps tensors below 2^30
+  // elements); lanes that must read zeros (gradient pixels beyond the image, rows above / below it, unused lanes) take the zero page.
   const char* zero = reinterpret_cast<const char*>(g_ch_zero_page);
+  const unsigned lds_base = (unsigned)(__SIZE_TYPE__)((__attribute__((address_space(3))) char*)lds);
+  const bool wide = a.W >= PK * SW + 4;                 // then a window column is off by less than one image width: no division
+#define WH_DMA(GP, LADDR) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(GP), "s"(LADDR) : "memory")
 #define WH_ISSUE(CH, BUFSEL)                                                                                          \
   {                                                                                                                   \
     int u_ = (CH);                                                                                                    \
@@ -116,22 +128,22 @@ __global__ __launch_bounds__(64 * (BMK / 32) * 2, 2) void k_wgradh(WgradHArgs a)
     const int rb_ = u_ % rows;                                                                                        \
     const int n_ = u_ / rows;                                                                                         \
     const int ho0_ = rb_ * PR, wo0_ = cb_ * PK;                                                                       \
-    const u16* gn_ = a.g + ((size_t)n_ * a.Ho * a.Wo) * a.K + k0;                                                     \
-    const u16* xn_ = a.x + ((size_t)n_ * a.H * a.W) * a.C + c0;                                                       \
-    const int lb_ = (BUFSEL) * BUF;                                                                                   \
-    _Pragma("unroll") for (int it = 0; it < NGI_W; ++it) if (g_pix[it] >= 0) {                                        \
-      const int pr_ = g_pix[it] / PK, pc_ = g_pix[it] % PK;                                                           \
+    const char* gn_ = reinterpret_cast<const char*>(a.g + ((size_t)n_ * a.Ho * a.Wo + (size_t)ho0_ * a.Wo + wo0_) * a.K + k0); \
+    const char* xn_ = reinterpret_cast<const char*>(a.x + ((size_t)n_ * a.H * a.W) * a.C + c0);                       \
+    const unsigned lb_ = lds_base + (BUFSEL) * BUF;                                                                   \
+    const int hrem_ = a.Ho - ho0_, wrem_ = a.Wo - wo0_, h0_ = ho0_ * SH - PAD, w0_ = wo0_ * SW - PAD;                 \
+    _Pragma("unroll") for (int it = 0; it < NGI_W; ++it) if (wave + it * NWV < NGI) {                                 \
       /* output pixels beyond the image contribute nothing: their gradient is read from the page of zeros */           \
-      const char* gsrc_ = (ho0_ + pr_ < a.Ho && wo0_ + pc_ < a.Wo)                                                    \
-          ? reinterpret_cast<const char*>(gn_ + ((size_t)(ho0_ + pr_) * a.Wo + wo0_ + pc_) * a.K + g_ch[it]) : zero;  \
-      CH_GLDS(gsrc_, lb_ + (wave + it * NWV) * 1024);                                                                 \
+      const char* gsrc_ = (g_pr[it] < hrem_ && g_pc[it] < wrem_) ? gn_ + 2u * (unsigned)g_rel[it] : zero;             \
+      WH_DMA(gsrc_, lb_ + (wave + it * NWV) * 1024);                                                                  \
     }                                                                                                                 \
-    _Pragma("unroll") for (int it = 0; it < NXI_W; ++it) if (x_row[it] >= 0) {                                        \
-      const int h_ = ho0_ * SH - PAD + x_row[it];                                                                     \
-      int w_ = (wo0_ * SW - PAD + x_col[it]) % a.W;                                                                   \
-      w_ = w_ < 0 ? w_ + a.W : w_;                                                                                    \
-      const char* src_ = (h_ >= 0 && h_ < a.H) ? reinterpret_cast<const char*>(xn_ + ((size_t)h_ * a.W + w_) * a.C + x_ch[it]) : zero; \
-      CH_GLDS(src_, lb_ + G_BYTES + (wave + it * NWV) * 1024);                                                        \
+    _Pragma("unroll") for (int it = 0; it < NXI_W; ++it) if (wave + it * NWV < NXI) {                                 \
+      const int h_ = h0_ + x_row[it];                                                                                 \
+      int w_ = w0_ + x_col[it];                                                                                       \
+      if (wide) { w_ = w_ < 0 ? w_ + a.W : w_; w_ = w_ >= a.W ? w_ - a.W : w_; }                                      \
+      else { w_ %= a.W; w_ = w_ < 0 ? w_ + a.W : w_; }                                                                \
+      const char* src_ = (x_row[it] >= 0 && h_ >= 0 && h_ < a.H) ? xn_ + 2u * (unsigned)(x_rel[it] + (h0_ * a.W + w_) * a.C) : zero; \
+      WH_DMA(src_, lb_ + G_BYTES + (wave + it * NWV) * 1024);                                                         \
     }                                                                                                                 \
   }
 
@@ -143,52 +155,82 @@ __global__ __launch_bounds__(64 * (BMK / 32) * 2, 2) void k_wgradh(WgradHArgs a)
     if (ch + 1 < ch_end) WH_ISSUE(ch + 1, cur ^ 1)
     const char* gb = lds + cur * BUF;
     const char* xb = gb + G_BYTES;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+#define WH_TR(PTR) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(PTR))
+    if constexpr (SW == 1 && KS == 3) {
+      // A: g[pixels i0 + 8 half ..+7][k subtile]; B per tap: x[the same output pixels shifted by the tap][c subtile].  The three taps
+      // of a row read the windows [s, s + 8) of the same pixel run: three transposing reads (12 pixels per lane, two per register)
+      // serve all of them -- s = 0 and s = 2 are register subsets, s = 1 is four 16-bit funnel shifts (9 LDS reads per 9 taps instead
+      // of 18).  The 11 reads of reduction step s+1 are issued BEFORE the nine MFMAs of step s (two register sets): the wave's
+      // matrix instructions then run back to back while its next fragments are in flight, instead of one LDS round trip per three.
+      constexpr int NSTEP = PR * (PK / 16);
+      s16x4 fa[2][2];
+      u32x2 fx[2][3][3];
+#define WH_LOAD(S, SET)                                                                                               \
+      {                                                                                                               \
+        constexpr int pr_ = (S) / (PK / 16), i0_ = ((S) % (PK / 16)) * 16, gpix_ = pr_ * PK + i0_;                    \
+        fa[SET][0] = WH_TR(gb + g_lane + gpix_ * PG);                                                                 \
+        fa[SET][1] = WH_TR(gb + g_lane + (gpix_ + 4) * PG);                                                           \
+        _Pragma("unroll") for (int r = 0; r < 3; ++r)                                                                 \
+          _Pragma("unroll") for (int q = 0; q < 3; ++q)                                                               \
+            fx[SET][r][q] = __builtin_bit_cast(u32x2, WH_TR(xb + x_lane[0] + ((pr_ * SH + r) * RWXP + i0_ + 4 * q) * PX)); \
+      }
+#define WH_MMA(SET)                                                                                                   \
+      {                                                                                                               \
+        const s16x8 af = __builtin_shufflevector(fa[SET][0], fa[SET][1], 0, 1, 2, 3, 4, 5, 6, 7);                     \
+        _Pragma("unroll") for (int r = 0; r < 3; ++r) {                                                               \
+          const u32x2 w01 = fx[SET][r][0], w23 = fx[SET][r][1], w45 = fx[SET][r][2];                                  \
+          const u32x4 f0 = {w01[0], w01[1], w23[0], w23[1]};                                                          \
+          const u32x4 f2 = {w01[1], w23[0], w23[1], w45[0]};                                                          \
+          const u32x4 f1 = {__builtin_amdgcn_alignbit(w01[1], w01[0], 16), __builtin_amdgcn_alignbit(w23[0], w01[1], 16), \
+                            __builtin_amdgcn_alignbit(w23[1], w23[0], 16), __builtin_amdgcn_alignbit(w45[0], w23[1], 16)}; \
+          acc[r * 3 + 0] = ch_mfma<F16>(af, __builtin_bit_cast(s16x8, f0), acc[r * 3 + 0]);                           \
+          acc[r * 3 + 1] = ch_mfma<F16>(af, __builtin_bit_cast(s16x8, f1), acc[r * 3 + 1]);                           \
+          acc[r * 3 + 2] = ch_mfma<F16>(af, __builtin_bit_cast(s16x8, f2), acc[r * 3 + 2]);                           \
+        }                                                                                                             \
+      }
+#define WH_STEP(S)                                                                                                    \
+      {                                                                                                               \
+        if constexpr ((S) + 1 < NSTEP) { WH_LOAD((S) + 1, ((S) + 1) & 1) }                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+        WH_MMA((S) & 1)                                                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                                            \
+      }
+      static_assert(NSTEP == 4 || NSTEP == 8, "reduction steps per chunk");
+      WH_LOAD(0, 0)
+      WH_STEP(0) WH_STEP(1) WH_STEP(2) WH_STEP(3)
+      if constexpr (NSTEP == 8) { WH_STEP(4) WH_STEP(5) WH_STEP(6) WH_STEP(7) }
+#undef WH_LOAD
+#undef WH_MMA
+#undef WH_STEP
+    } else {
 #pragma unroll
-    for (int pr = 0; pr < PR; ++pr)
+      for (int pr = 0; pr < PR; ++pr)
 #pragma unroll 2
-      for (int i0 = 0; i0 < PK; i0 += 16) {
-        // A: g[pixels i0 + 8 half ..+7][k subtile]; B per tap: x[the same output pixels shifted by the tap][c subtile]
-        const int gpix = pr * PK + i0;
-        const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(gb + g_lane + gpix * PG));
-        const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(gb + g_lane + (gpix + 4) * PG));
-        const s16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
-        if constexpr (SW == 1 && KS == 3) {
-          // the three taps of a row read the windows [s, s + 8) of the same pixel run: three transposing reads (12 pixels per lane,
-          // two per register) serve all of them -- s = 0 and s = 2 are register subsets, s = 1 is four 16-bit funnel shifts
-          // (9 LDS reads per 9 taps instead of 18: the kernel is LDS-read bound)
-#pragma unroll
-          for (int r = 0; r < 3; ++r) {
-            const int xpix = (pr * SH + r) * RWXP + i0;
-            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            u32x2 w01 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xb + x_lane[0] + xpix * PX)));
-            u32x2 w23 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xb + x_lane[0] + (xpix + 4) * PX)));
-            u32x2 w45 = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xb + x_lane[0] + (xpix + 8) * PX)));
-            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-            const u32x4 f0 = {w01[0], w01[1], w23[0], w23[1]};
-            const u32x4 f2 = {w01[1], w23[0], w23[1], w45[0]};
-            const u32x4 f1 = {__builtin_amdgcn_alignbit(w01[1], w01[0], 16), __builtin_amdgcn_alignbit(w23[0], w01[1], 16),
-                              __builtin_amdgcn_alignbit(w23[1], w23[0], 16), __builtin_amdgcn_alignbit(w45[0], w23[1], 16)};
-            acc[r * 3 + 0] = ch_mfma<F16>(af, __builtin_bit_cast(s16x8, f0), acc[r * 3 + 0]);
-            acc[r * 3 + 1] = ch_mfma<F16>(af, __builtin_bit_cast(s16x8, f1), acc[r * 3 + 1]);
-            acc[r * 3 + 2] = ch_mfma<F16>(af, __builtin_bit_cast(s16x8, f2), acc[r * 3 + 2]);
-          }
-        } else {
+        for (int i0 = 0; i0 < PK; i0 += 16) {
+          const int gpix = pr * PK + i0;
+          const s16x4 a0 = WH_TR(gb + g_lane + gpix * PG);
+          const s16x4 a1 = WH_TR(gb + g_lane + (gpix + 4) * PG);
+          const s16x8 af = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
 #pragma unroll
           for (int tp = 0; tp < TAPS; ++tp) {
             const int r = tp / KS, s = tp % KS;
             const int cs = s / SW, phase = s % SW;
             const int xpix = ((pr * SH + r) * SW + phase) * RWXP + i0;
-            const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xb + x_lane[cs] + xpix * PX));
-            const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(xb + x_lane[cs] + (xpix + 4) * PX));
+            const s16x4 b0 = WH_TR(xb + x_lane[cs] + xpix * PX);
+            const s16x4 b1 = WH_TR(xb + x_lane[cs] + (xpix + 4) * PX);
             const s16x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
             acc[tp] = ch_mfma<F16>(af, bf, acc[tp]);
           }
         }
-      }
+    }
+#undef WH_TR
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
   }
 #undef WH_ISSUE
+#undef WH_DMA
   // partial of this slab: part[slab][k][tap][c]; accumulator register r of lane (li, half) = row k = (r & 3) + 8 (r >> 2) + 4 half,
   // column c = li of the wave's 32x32 tile
   float* dst = a.part + (size_t)slab * a.K * TAPS * a.C;
