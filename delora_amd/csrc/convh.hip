@@ -30,6 +30,9 @@
 #include "conv_geom.h"
 #include "convh_common.h"
 
+// number of i in [0, n) with i % parts == part (DMA pieces a wave issues in one part of a chunk's input tile)
+constexpr int ch_count_parts(int n, int part, int parts) { int c = 0; for (int i = 0; i < n; ++i) c += (i % parts == part) ? 1 : 0; return c; }
+
 struct ConvHArgs {
   const u16* x;      // [N][H][W][C]
   const u16* w;      // [WTAPS][K][C]  prepared weights (k_wprep_h): rows = output channels of THIS pass, C = its reduction
@@ -45,8 +48,9 @@ struct ConvHArgs {
 };
 
 // BM = TH x TW output pixels, BN output channels, WGM x WGN waves (each (BM/WGM) x (BN/WGN)), G the geometry policy,
-// NG tap groups per channel chunk (3: one row of a 3x3 stencil per step; 1: all taps of the pass in one step).
-template <bool F16, int BM, int BN, int WGM, int WGN, int TW, class G, int NG>
+// NG tap groups per channel chunk (3: one row of a 3x3 stencil per step; 1: all taps of the pass in one step), WS weight buffers
+// (2: the operands of step s+1 are fetched during step s; 3 -- NG = 3 only: two steps ahead, see the main loop).
+template <bool F16, int BM, int BN, int WGM, int WGN, int TW, class G, int NG, int WS = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
   constexpr int NWV = WGM * WGN;
   constexpr int TH = BM / TW, SH = G::ISH, SW = G::ISW;
@@ -62,7 +66,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
   constexpr int WM = BM / 32 / WGM, WN = BN / 32 / WGN;
   constexpr int NCS = (G::EW - 1) / SW + 1;                          // distinct column shifts (in plane columns) of the taps
   constexpr int ES = WN * 32 + 4;                                    // epilogue staging: floats per pixel row
-  constexpr int MAIN_BYTES = 2 * IN_BYTES + 2 * W_BYTES, EPI_BYTES = NWV * 32 * ES * 4;
+  constexpr int MAIN_BYTES = 2 * IN_BYTES + WS * W_BYTES, EPI_BYTES = NWV * 32 * ES * 4;
+  static_assert(WS == 2 || (WS == 3 && NG == 3), "three weight buffers go with three tap groups per chunk");
   constexpr int LDS_BYTES = MAIN_BYTES > EPI_BYTES ? MAIN_BYTES : EPI_BYTES;
   static_assert(TW % 32 == 0 && BM % TW == 0 && BM % (32 * WGM) == 0 && BN % (32 * WGN) == 0 && BN % 16 == 0, "tile shape");
   static_assert(TAPS % NG == 0 && TAPS > 0, "tap groups");
@@ -90,12 +95,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
   const char* xn = reinterpret_cast<const char*>(a.x + (size_t)n * a.H * a.W * a.C);
   const char* wb = reinterpret_cast<const char*>(a.w);
 
-  // DMA pieces of this wave.  Input: piece j = wave + it * NWV, lane -> (pixel of the LDS image, 16-byte slot); byte offset
-  // of its source relative to xn, -1 = lane off (beyond the tile, or a zero row above / below the image).
+  // DMA pieces of this wave.  Input: piece j = wave + it * NWV (pieces beyond the tile repeat its last piece: every wave issues the
+  // same number of DMA instructions per step, which the counted waits below rely on), lane -> (pixel of the LDS image, 16-byte
+  // slot); byte offset of its source relative to xn, -1 = a pixel outside the image (a zero row above / below it, or a column
+  // beyond the edge of a pass that does not wrap): the lane fetches from the page of zeros.
   int in_off[NII_W], in_l[NII_W];
 #pragma unroll
   for (int it = 0; it < NII_W; ++it) {
-    const int j = wave + it * NWV;
+    const int j = min(wave + it * NWV, NII - 1);
     const int q = j * 64 + lane;
     const int pix = q >> 2, sslot = q & 3;
     const int rp = pix / RWP, colp = pix % RWP;
@@ -106,7 +113,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
     const bool col_in = w >= 0 && w < a.W;
     w %= a.W;                                        // (a full modulo: the surplus columns of an overhanging tile lie beyond 2W)
     w = w < 0 ? w + a.W : w;
-    const bool ok = j < NII && rp < NPL && col < RW && h >= 0 && h < a.H && (a.wrap || col_in);
+    const bool ok = rp < NPL && col < RW && h >= 0 && h < a.H && (a.wrap || col_in);
     in_off[it] = ok ? ((h * a.W + w) * a.C + ((sslot ^ ((colp >> 2) & 3)) * 8)) * 2 : -1;
     in_l[it] = j * 1024;
   }
@@ -114,11 +121,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
   int w_off[NWI_W], w_l[NWI_W];
 #pragma unroll
   for (int it = 0; it < NWI_W; ++it) {
-    const int j = wave + it * NWV;
+    const int j = min(wave + it * NWV, NWI - 1);
     const int q = j * 64 + lane;
     const int rowl = q >> 2, sslot = q & 3;
     const int tl = rowl / BN, nn = rowl % BN;
-    w_off[it] = j < NWI ? ((G::wt(tl) * a.K + k0 + nn) * a.C + ((sslot ^ ((rowl >> 2) & 3)) * 8)) * 2 : -1;
+    w_off[it] = ((G::wt(tl) * a.K + k0 + nn) * a.C + ((sslot ^ ((rowl >> 2) & 3)) * 8)) * 2;
     w_l[it] = W_BASE + j * 1024;
   }
   const int w_group_stride = TG * a.K * a.C * 2;       // bytes from one tap group's slabs to the next (NG > 1: wt(t) = t)
@@ -150,61 +157,95 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  // rows outside the image are never written by the DMA: zero both input buffers once if this tile touches the border
-  if (h_base < 0 || h_base + RH > a.H || !a.wrap) {
-    for (int i = tid * 16; i < 2 * IN_BYTES; i += 64 * NWV * 16) *reinterpret_cast<f32x4*>(lds + i) = (f32x4){0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
-  }
-
-#define CH_ISSUE_IN(CH, PART)                                                                                   \
+  const char* zero = reinterpret_cast<const char*>(g_ch_zero_page);
+  // input pieces `it` with it % PARTS == PART of chunk CH (PART < 0: all of them); weights of step STEP into weight buffer SLOT
+#define CH_ISSUE_IN(CH, PART, PARTS)                                                                            \
   {                                                                                                             \
     const int lb_ = ((CH) & 1) * IN_BYTES, go_ = (CH) * 64;                                                     \
     _Pragma("unroll") for (int it = 0; it < NII_W; ++it)                                                        \
-      if ((PART) < 0 || it % NG == (PART)) { if (in_off[it] >= 0) CH_GLDS(xn + in_off[it] + go_, lb_ + in_l[it]); } \
+      if ((PART) < 0 || it % (PARTS) == (PART)) CH_GLDS(in_off[it] >= 0 ? xn + in_off[it] + go_ : zero, lb_ + in_l[it]); \
   }
-#define CH_ISSUE_W(STEP)                                                                                        \
+#define CH_ISSUE_W(STEP, SLOT)                                                                                  \
   {                                                                                                             \
-    const int s_ = (STEP), lb_ = (s_ & 1) * W_BYTES, go_ = (s_ / NG) * 64 + (s_ % NG) * w_group_stride;         \
-    _Pragma("unroll") for (int it = 0; it < NWI_W; ++it)                                                        \
-      if (w_off[it] >= 0) CH_GLDS(wb + w_off[it] + go_, lb_ + w_l[it]);                                         \
+    const int s_ = (STEP), lb_ = (SLOT) * W_BYTES, go_ = (s_ / NG) * 64 + (s_ % NG) * w_group_stride;           \
+    _Pragma("unroll") for (int it = 0; it < NWI_W; ++it) CH_GLDS(wb + w_off[it] + go_, lb_ + w_l[it]);           \
   }
 
+  // Pipeline.  WS == 2: the weights of step s+1 and a third of the next chunk's input tile are requested at the start of step s and
+  // must have landed at its end (one wait for everything, one barrier).  WS == 3 (the big stride-1 tiles, one workgroup per CU: no
+  // neighbour to hide behind): everything is requested TWO steps ahead -- weights of step s+2 into a third buffer, the next chunk's
+  // input tile in the first two steps of the current chunk -- and the wait at the end of step s is COUNTED: every wave issues exactly
+  // the same DMA instructions per step (no lane-masked or skipped pieces, see above), they complete in order, so
+  // s_waitcnt vmcnt(<issued in this step>) means "everything older has landed".  A fetch then has two steps (~6 us) to arrive
+  // instead of one; with one step the matrix pipe idled while the waves waited for the L2 (waiting share 40 %, round-3 review).
   const int nchunks = a.C / 32, nsteps = nchunks * NG;
-  CH_ISSUE_IN(0, -1)
-  CH_ISSUE_W(0)
+  CH_ISSUE_IN(0, -1, 1)
+  CH_ISSUE_W(0, 0)
+  if constexpr (WS == 3) CH_ISSUE_W(min(1, nsteps - 1), 1)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  for (int ch = 0; ch < nchunks; ++ch) {
-    const int inb = (ch & 1) * IN_BYTES;
-#pragma unroll
-    for (int tg = 0; tg < NG; ++tg) {
+  int wslot = 0;                                        // weight buffer of the current step (step % WS)
+  // one step = one tap group of one channel chunk (the tap group is a compile-time constant: the counted wait needs an immediate)
+  auto step_body = [&](auto tg_c, int ch) {
+      constexpr int tg = decltype(tg_c)::value;
+      const int inb = (ch & 1) * IN_BYTES;
       const int step = ch * NG + tg;
-      const int wbb = W_BASE + (step & 1) * W_BYTES;
-      // next step's weights and this step's share of the next chunk's input tile: they have the whole step to land
-      if (step + 1 < nsteps) CH_ISSUE_W(step + 1)
-      if (ch + 1 < nchunks) CH_ISSUE_IN(ch + 1, tg)
-#pragma unroll
-      for (int tl = 0; tl < TG; ++tl) {
+      const int wbb = W_BASE + wslot * W_BYTES;
+      bool more_w, more_in;
+      if constexpr (WS == 2) {
+        // next step's weights and this step's share of the next chunk's input tile: they have the whole step to land
+        more_w = step + 1 < nsteps; more_in = ch + 1 < nchunks;
+        if (more_w) CH_ISSUE_W(step + 1, wslot ^ 1)
+        if (more_in) CH_ISSUE_IN(ch + 1, tg, NG)
+      } else {
+        more_w = step + 2 < nsteps; more_in = ch + 1 < nchunks && tg < 2;
+        if (more_w) CH_ISSUE_W(step + 2, wslot == 0 ? 2 : wslot - 1)
+        if (more_in) CH_ISSUE_IN(ch + 1, tg, 2)
+      }
+      // The fragments of reduction sub-step u+1 (one tap x 16 channels: WM + WN 16-byte LDS reads) are requested BEFORE the WM x WN
+      // MFMAs of sub-step u (two register sets): a wave's matrix instructions then issue back to back while its next operands are in
+      // flight -- read-then-use in one sub-step put an LDS round trip in front of every group of MFMAs (round 4).
+      s16x8 af[2][WM], bf[2][WN];
+      auto load_frags = [&](int u, int set) {
+        const int tl = u >> 1, ks = u & 1;
         const int tap = tg * TG + tl;
         const int dwv = G::dw(tap), cs = dwv / SW, phase = dwv % SW;
         const int tap_off = ((G::dh(tap) * SW + phase) * RWP) * 64;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-          s16x8 af[WM], bf[WN];
+        for (int mi = 0; mi < WM; ++mi) af[set][mi] = *reinterpret_cast<const s16x8*>(lds + inb + tap_off + (a_base[cs][mi] ^ (ks * 32)));
 #pragma unroll
-          for (int mi = 0; mi < WM; ++mi) af[mi] = *reinterpret_cast<const s16x8*>(lds + inb + tap_off + (a_base[cs][mi] ^ (ks * 32)));
+        for (int ni = 0; ni < WN; ++ni) bf[set][ni] = *reinterpret_cast<const s16x8*>(lds + wbb + tl * BN * 64 + (b_base[ni] ^ (ks * 32)));
+      };
+      load_frags(0, 0);
 #pragma unroll
-          for (int ni = 0; ni < WN; ++ni) bf[ni] = *reinterpret_cast<const s16x8*>(lds + wbb + tl * BN * 64 + (b_base[ni] ^ (ks * 32)));
+      for (int u = 0; u < 2 * TG; ++u) {
+        if (u + 1 < 2 * TG) load_frags(u + 1, (u + 1) & 1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int mi = 0; mi < WM; ++mi)
+        for (int mi = 0; mi < WM; ++mi)
 #pragma unroll
-            for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = ch_mfma<F16>(af[mi], bf[ni], acc[mi][ni]);
-        }
+          for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = ch_mfma<F16>(af[u & 1][mi], bf[u & 1][ni], acc[mi][ni]);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (WS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else {
+        constexpr int NIN = tg < 2 ? ch_count_parts(NII_W, tg, 2) : 0;
+        if (more_w && more_in) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NWI_W + NIN) : "memory");
+        else if (more_w) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NWI_W) : "memory");
+        else if (more_in) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NIN) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
       __builtin_amdgcn_s_barrier();
+      wslot = wslot + 1 == WS ? 0 : wslot + 1;
+  };
+  for (int ch = 0; ch < nchunks; ++ch) {
+    step_body(std::integral_constant<int, 0>{}, ch);
+    if constexpr (NG == 3) {
+      step_body(std::integral_constant<int, 1>{}, ch);
+      step_body(std::integral_constant<int, 2>{}, ch);
     }
   }
+  static_assert(NG == 1 || NG == 3, "tap groups per chunk");
 #undef CH_ISSUE_IN
 #undef CH_ISSUE_W
 
@@ -437,7 +478,7 @@ static double ch_eff(int Ho, int Wo, int TH, int TW) {
 }
 
 // launches unless the channels do not tile or the tile shape wastes more than 10 % more of the image than the best shape does
-template <bool F16, int BM, int BN, int WGM, int WGN, int TW, class G, int NG>
+template <bool F16, int BM, int BN, int WGM, int WGN, int TW, class G, int NG, int WS = 2>
 static int launch_convh(const ConvHArgs& a, hipStream_t st, double best_eff = 0.0) {
   constexpr int TH = BM / TW;
   if (a.K % BN || a.C % 32 || ch_eff(a.Ho, a.Wo, TH, TW) < 0.9 * best_eff) return 1;
@@ -445,7 +486,7 @@ static int launch_convh(const ConvHArgs& a, hipStream_t st, double best_eff = 0.
   const double px_ = (double)a.N * a.Ho * a.Wo;
   const DlProfTag tag{"k_convh", std::is_same<G, GeomConv<3, 1, 1>>::value ? "fwd" : (G::ISH * G::ISW > 1 || G::WTAPS == 1 ? "fwd-strided" : "dgrad"),
                       a.N, a.H, a.W, a.C, a.K, G::WTAPS == 9 ? 3 : 1, G::ISH * G::OSH, G::ISW * G::OSW, 2.0 * px_ * a.K * a.C * G::NT, 2.0 * ((double)a.N * a.H * a.W * a.C + px_ * a.K + (double)G::NT * a.K * a.C)};
-  DL_LAUNCH(tag, (k_convh<F16, BM, BN, WGM, WGN, TW, G, NG>), dim3(ntiles), dim3(64 * WGM * WGN), st, a);
+  DL_LAUNCH(tag, (k_convh<F16, BM, BN, WGM, WGN, TW, G, NG, WS>), dim3(ntiles), dim3(64 * WGM * WGN), st, a);
   return 0;
 }
 
@@ -492,6 +533,8 @@ static int dispatch_convh(const ConvHArgs& a, hipStream_t st) {
       case 11: return launch_convh<F16, 256, 256, 2, 2, 64, G, NG>(a, st);       // 128 x 128 per wave: half the LDS reads per MFMA
       case 12: return launch_convh<F16, 512, 128, 4, 1, 64, G, NG>(a, st);
       case 13: return launch_convh<F16, 256, 128, 2, 1, 64, G, NG>(a, st);
+      case 14: return launch_convh<F16, 512, 128, 4, 2, 64, G, NG, 3>(a, st);   // three weight buffers, counted waits
+      case 15: return launch_convh<F16, 256, 128, 4, 2, 64, G, NG, 3>(a, st);
       default: break;
     }
 #endif
@@ -502,8 +545,9 @@ static int dispatch_convh(const ConvHArgs& a, hipStream_t st) {
     const double e1 = ch_eff(a.Ho, a.Wo, 8, 64), e2 = ch_eff(a.Ho, a.Wo, 4, 64), e3 = ch_eff(a.Ho, a.Wo, 4, 32);
     const double best = e1 > e2 ? (e1 > e3 ? e1 : e3) : (e2 > e3 ? e2 : e3);
     if (a.C <= 128 && !launch_convh<F16, 256, 64, 4, 2, 64, G, NG>(a, st, best)) return 0;
-    if (a.K % 128 == 0 && pixels / 512 * (a.K / 128) >= 256 && !launch_convh<F16, 512, 128, 4, 2, 64, G, NG>(a, st, best)) return 0;
-    if (a.K % 128 == 0 && !launch_convh<F16, 256, 128, 4, 2, 64, G, NG>(a, st, best)) return 0;
+    // (these two run one workgroup per CU: three weight buffers, operands fetched two steps ahead)
+    if (a.K % 128 == 0 && pixels / 512 * (a.K / 128) >= 256 && !launch_convh<F16, 512, 128, 4, 2, 64, G, NG, 3>(a, st, best)) return 0;
+    if (a.K % 128 == 0 && !launch_convh<F16, 256, 128, 4, 2, 64, G, NG, 3>(a, st, best)) return 0;
     if (pixels / 512 >= 256 && !launch_convh<F16, 512, 64, 8, 1, 64, G, NG>(a, st, best)) return 0;
     if (!launch_convh<F16, 256, 64, 4, 2, 64, G, NG>(a, st, best)) return 0;
     if (a.K % 128 == 0 && !launch_convh<F16, 128, 128, 2, 2, 32, G, NG>(a, st, best)) return 0;

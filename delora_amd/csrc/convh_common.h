@@ -57,7 +57,18 @@ __device__ __forceinline__ int ch_xcd_swizzle(int id, int n) {
   return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
 }
 
-#define CH_GLDS(GPTR, LOFF)                                                                  \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(GPTR),   \
-                                   (__attribute__((address_space(3))) void*)(lds + (LOFF)), 16, 0, 0)
+// a page of zeros in device memory: the DMA source of lanes whose pixel lies outside the image (a DMA cannot write a constant)
+__device__ __attribute__((aligned(64))) const uint32_t g_ch_zero_page[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+
+// One LDS DMA piece: 64 lanes x 16 bytes from the per-lane global address GPTR to lds[LOFF + 16 lane] (LOFF wave-uniform).
+// Issued from inline assembly, not through __builtin_amdgcn_global_load_lds: hipcc's wait-count pass treats the builtin as a FLAT
+// access that may touch LDS, and while one is outstanding it (a) turns EVERY LDS wait into s_waitcnt lgkmcnt(0) -- a wave then drains
+// all its outstanding fragment reads in front of each group of MFMAs instead of waiting for the oldest ones -- and (b) may guard the
+// next LDS read with s_waitcnt vmcnt(0), i.e. wait for the prefetch it was meant to overlap (k_wgradh, round 4).  The kernels wait for
+// their DMA explicitly (s_waitcnt vmcnt(0) in front of the barrier that hands a buffer over), so nothing is lost.
+// Callers must NOT rely on __syncthreads() to wait for these loads: the compiler does not know they are in flight.
+#define CH_GLDS(GPTR, LOFF)                                                                                                  \
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off"                                             \
+               :: "v"(GPTR), "s"(__builtin_amdgcn_readfirstlane((int)(unsigned)(__SIZE_TYPE__)((__attribute__((address_space(3))) char*)lds) + (LOFF))) \
+               : "memory")
 

@@ -16,7 +16,6 @@
 // order by k_wgradh_reduce (deterministic, no float atomics).  Rows outside the image are read from a page of zeros.
 #include "convh_common.h"
 
-__device__ __attribute__((aligned(64))) const uint32_t g_ch_zero_page[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 
 struct WgradHArgs {
   const u16* x;     // [N][H][W][C]

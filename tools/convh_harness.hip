@@ -344,7 +344,7 @@ int main(int argc, char** argv) {
     printf("storage type: %s\n", g_dtype == DL_DTYPE_BF16 ? "bf16" : "f16");
     // every tile variant of the stride-1 kernel on a shape it tiles (variant 0 = the product's own choice)
     const Shape base = {"3x3 s1 2x16x128 64->128", 2, 16, 128, 64, 128, 3, 1, 1};
-    for (int v = 0; v <= 13; ++v) bad += check_shape(base, gen, v);
+    for (int v = 0; v <= 15; ++v) bad += check_shape(base, gen, v);
     const Shape small[] = {
         {"3x3 s1 2x8x128 64->64", 2, 8, 128, 64, 64, 3, 1, 1},     {"3x3 s1 1x4x64 128->128", 1, 4, 64, 128, 128, 3, 1, 1},
         {"3x3 s1 2x8x32 32->128", 2, 8, 32, 32, 128, 3, 1, 1},     {"3x3 s1 1x64x64 96->64", 1, 64, 64, 96, 64, 3, 1, 1},
@@ -384,7 +384,7 @@ int main(int argc, char** argv) {
   }
   if (!strcmp(mode, "tune")) {
     const int reps = argc >= 3 && atoi(argv[2]) > 0 ? atoi(argv[2]) : 10;
-    for (int v = 0; v <= 13; ++v) {
+    for (int v = 0; v <= 15; ++v) {
       g_ch_variant = v;
       printf("---- variant %d\n", v);
       for (const auto& s : s1) time_shape(s, reps, gen, nullptr);

@@ -18,4 +18,5 @@ for (k, grid, lds), v in sorted(agg.items()):
     w = m["SQ_WAVE_CYCLES"]
     print(f"{k} grid {grid}: kernel {cycles:.0f} cycles, MFMA busy {busy / cycles:.3f} of the kernel; waves: issuing {m['SQ_ACTIVE_INST_ANY'] / w:.2f}, "
           f"issue-stalled {m['SQ_WAIT_INST_ANY'] / w:.2f}, waiting {m['SQ_WAIT_ANY'] / w:.2f}; LDS conflict / LDS cycles "
-          f"{m['SQ_LDS_BANK_CONFLICT'] / max(m['SQ_LDS_IDX_ACTIVE'], 1):.2f}")
+          f"{m['SQ_LDS_BANK_CONFLICT'] / max(m['SQ_LDS_IDX_ACTIVE'], 1):.2f}; LDS index-active cycles per CU / kernel cycles "
+          f"{m['SQ_LDS_IDX_ACTIVE'] / 256 / cycles:.2f}")
