@@ -180,7 +180,7 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
 #pragma unroll
   for (int it = 0; it < NU_IT; ++it) {
     const int id = wave * NU_IT + it, xi = id >> 1, kk = (id & 1) * 32 + (lane >> 1), slot = lane & 1;
-    u_g[it] = (unsigned)((xi * a.K + kk) * 8 + ((slot ^ ((kk >> 3) & 1)) * 4));          // + k0 * 8 + chunk * 16 * K * 8
+    u_g[it] = 4u * (unsigned)((xi * a.K + kk) * 8 + ((slot ^ ((kk >> 3) & 1)) * 4));     // bytes; + k0 * 8 + chunk * 16 * K * 8 floats
     u_l[it] = 16 * WN_PLANE + xi * WN_PLANE + (id & 1) * 256;                // wave-uniform base (floats)
   }
   const int arow = mb * 32 + li, brow = nb * 32 + li;
@@ -215,18 +215,24 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
       int w_ = w_base_ + p_ % RW;                                                                                         \
       if (RAG) { w_ %= a.W; w_ = w_ < 0 ? w_ + a.W : w_; }       /* surplus columns of an overhanging group lie beyond 2W */ \
       else w_ = w_ < 0 ? w_ + a.W : (w_ >= a.W ? w_ - a.W : w_);                                                           \
-      raw_g[it] = (unsigned)((h_ * a.W + w_) * a.C + ((LN) & 1) * 4);                                                     \
+      raw_g[it] = 4u * (unsigned)((h_ * a.W + w_) * a.C + ((LN) & 1) * 4);          /* bytes */                             \
     }                                                                                                                     \
   }
 
-#define WN_GLDS(GPTR, LPTR)                                                                                               \
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(GPTR),                                 \
-                                   (__attribute__((address_space(3))) void*)(LPTR), 16, 0, 0);
+  // One LDS DMA piece: 64 lanes x 16 bytes from (wave-uniform base BASE) + (per-lane byte offset OFFB) to the LDS address LPTR + 16 lane.
+  // Issued from inline assembly (see CH_GLDS in convh_common.h): while a global_load_lds BUILTIN is outstanding the compiler turns every
+  // LDS wait into s_waitcnt lgkmcnt(0); hidden from it, the fragment / transform reads are waited for individually.  Every barrier that
+  // hands DMA-written data over is preceded by an explicit s_waitcnt vmcnt(0) -- __syncthreads() alone does NOT wait for these loads.
+  const unsigned lds_base = (unsigned)(__SIZE_TYPE__)((__attribute__((address_space(3))) char*)lds);
+#define WN_LDSADDR(LPTR) (lds_base + 4u * (unsigned)((LPTR) - lds))
+#define WN_GLDS(BASE, OFFB, LPTR)                                                                                         \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                           \
+               :: "v"(OFFB), "s"(BASE), "s"(__builtin_amdgcn_readfirstlane((int)WN_LDSADDR(LPTR))) : "memory");
 #define WN_U_PIECE_X(UG, IT, CH, BUFP) \
-  WN_GLDS((a.u + ((size_t)(CH) * 16 * a.K * 8 + k0 * 8)) + (size_t)(UG)[IT], (BUFP) + __builtin_amdgcn_readfirstlane(u_l[IT]))
+  WN_GLDS(a.u + ((size_t)(CH) * 16 * a.K * 8 + k0 * 8), (UG)[IT], (BUFP) + __builtin_amdgcn_readfirstlane(u_l[IT]))
 #define WN_U_PIECE(IT, CH, BUFP) WN_U_PIECE_X(u_g, IT, CH, BUFP)
 #define WN_RAW_PIECE(IT, CH) \
-  WN_GLDS((xn + (CH) * WN_CK) + (size_t)raw_g[IT], rawbase + ((CH) & 1) * RAWBUF + __builtin_amdgcn_readfirstlane(raw_l[IT]))
+  WN_GLDS(xn + (CH) * WN_CK, raw_g[IT], rawbase + ((CH) & 1) * RAWBUF + __builtin_amdgcn_readfirstlane(raw_l[IT]))
 #define WN_RAW_ALL(CH) { _Pragma("unroll") for (int it = 0; it < NR_IT; ++it) WN_RAW_PIECE(it, CH) }
 #define WN_U_ALL(CH, BUFP) { _Pragma("unroll") for (int it = 0; it < NU_IT; ++it) WN_U_PIECE(it, CH, BUFP) }
   // row I of T = d B for this thread's column: two 16-byte reads of the raw patch (issued ahead of their use: a read and its use in
@@ -274,6 +280,7 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   WN_RAW_ALL(0)
   WN_RAW_ALL(min(1, nchunks - 1))
   WN_U_ALL(0, WN_BUFOF(0))
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   WN_V0()
   for (;;) {
@@ -311,8 +318,9 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
       WN_M(0, 2, WN_U_PIECE(2, ch + 1, nxt) WN_U_PIECE(3, ch + 1, nxt))
       // raw(ch+2) overwrites raw(ch), which every wave finished reading before the last barrier
       WN_M(0, 3, if (ch + 2 < nchunks) WN_RAW_ALL(ch + 2))
-      // LDS traffic only in the first two slices of a plane, arithmetic in the last two: the compiler waits for ALL outstanding LDS
-      // operations (lgkmcnt(0)) in front of a plane's first MFMA, and with this layout everything it waits for is two slices old
+      // LDS traffic only in the first two slices of a plane, arithmetic in the last two: whatever a plane's first MFMA waits for is then
+      // two slices old.  (Laid out when the DMA was a builtin and every LDS wait a full drain, lgkmcnt(0); with the DMA in inline
+      // assembly the waits are counted and the layout costs nothing -- measured equal, kept.)
       WN_M(1, 0, WN_LOAD_FRAGS(2)) WN_M(1, 1, WN_TROW_LD(0, rb) WN_TROW_LD(1, rb)) WN_M(1, 2, ) WN_M(1, 3, WN_TROW_FIN(0) WN_TROW_FIN(1))
       WN_M(2, 0, WN_LOAD_FRAGS(3)) WN_M(2, 1, WN_TROW_LD(2, rb) WN_TROW_LD(3, rb)) WN_M(2, 2, ) WN_M(2, 3, WN_TROW_FIN(2) WN_TROW_FIN(3))
       WN_M(3, 0, WN_LOAD_FRAGS(4) *reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = tt[0] - tt[2];)
@@ -369,7 +377,7 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
 #pragma unroll
       for (int it = 0; it < NU_IT; ++it) {
         const int id = wave * NU_IT + it, xi = id >> 1, kk = (id & 1) * 32 + (lane_e >> 1), slot = lane_e & 1;
-        u_gn[it] = (unsigned)((xi * a.K + kk) * 8 + ((slot ^ ((kk >> 3) & 1)) * 4));
+        u_gn[it] = 4u * (unsigned)((xi * a.K + kk) * 8 + ((slot ^ ((kk >> 3) & 1)) * 4));
       }
 #pragma unroll
       for (int it = 0; it < NU_IT; ++it) WN_U_PIECE_X(u_gn, it, 0, WN_BUFOF(0))
@@ -464,6 +472,7 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
 #undef WN_BUFOF
 #undef WN_SETUP
 #undef WN_GLDS
+#undef WN_LDSADDR
 #undef WN_U_PIECE
 #undef WN_U_PIECE_X
 #undef WN_RAW_PIECE
@@ -630,26 +639,30 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
     dma_l[it] = piece * 256;
   }
   const int x_lane = c0 + (lane & 15) * 4;
+  // (LDS DMA from inline assembly, as in k_wino_conv: wave-uniform 64-bit base of the sample + per-lane 32-bit byte offset; the waits
+  // that hand the patches over are the explicit s_waitcnt vmcnt(0) in front of barrier E and in the prologue)
+  const unsigned ww_lds_base = (unsigned)(__SIZE_TYPE__)((__attribute__((address_space(3))) char*)lds);
+#define WW2_GLDS(BASE, OFFB, LOFF_FLOATS)                                                                                 \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                           \
+               :: "v"(OFFB), "s"(BASE), "s"(__builtin_amdgcn_readfirstlane((int)(ww_lds_base + 4u * (unsigned)(LOFF_FLOATS)))) : "memory");
 #define WW2_DMA(CH)                                                                                                       \
   {                                                                                                                       \
     int n_, ta_, b8_;                                                                                                     \
     chunk_pos((CH), n_, ta_, b8_);                                                                                        \
-    const float* xn_ = a.x + ((size_t)n_ * a.H * a.W) * a.C + x_lane;                                                     \
+    const float* xn_ = a.x + ((size_t)n_ * a.H * a.W) * a.C;                                                              \
     _Pragma("unroll") for (int it = 0; it < 3; ++it) {                                                                    \
       int row = 2 * ta_ - 1 + dma_pi[it];                                                                                 \
       row = row < 0 ? 0 : (row >= a.H ? a.H - 1 : row);                                                                   \
       int col = 16 * b8_ - 1 + dma_pj[it];                                                                                \
       if (RAG) { col %= a.W; col = col < 0 ? col + a.W : col; }                                                           \
       else col = col < 0 ? col + a.W : (col >= a.W ? col - a.W : col);                                                    \
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xn_ + (row * a.W + col) * a.C),    \
-                                       (__attribute__((address_space(3))) void*)(raw + dma_l[it]), 16, 0, 0);             \
+      WW2_GLDS(xn_, 4u * (unsigned)((row * a.W + col) * a.C + x_lane), (int)(raw - lds) + dma_l[it])                      \
     }                                                                                                                     \
     /* the output-gradient patch: wave w brings pixels 4w .. 4w+3 of the 2 x 16 (one 1 KiB piece; lane = pixel, channel quad) */ \
     /* (pixels outside the image: a clamped, valid address -- the transform zeroes them) */                              \
     const int grow_ = RAG ? min(2 * ta_ + g_p, a.H - 1) : 2 * ta_ + g_p, gcol_ = RAG ? min(16 * b8_ + g_px, a.W - 1) : 16 * b8_ + g_px; \
-    const float* gn_ = a.g + (((size_t)n_ * a.H + grow_) * a.W + gcol_) * a.K + k0 + (lane & 15) * 4;                     \
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gn_,                                  \
-                                     (__attribute__((address_space(3))) void*)(graw + wave * 256), 16, 0, 0);             \
+    const float* gn_ = a.g + ((size_t)n_ * a.H * a.W) * a.K;                                                              \
+    WW2_GLDS(gn_, 4u * (unsigned)((grow_ * a.W + gcol_) * a.K + k0 + (lane & 15) * 4), (int)(graw - lds) + wave * 256)    \
   }
   // the four gradient values of tile E of this thread's four: g[p][2 (4 tq + E) + q][k = r], two LDS reads of two rows each
   const int g_p = (wave * 4 + (lane >> 4)) >> 4, g_px = (wave * 4 + (lane >> 4)) & 15;     // DMA role: pixel of the 2 x 16 patch
@@ -783,6 +796,7 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
     WW2_M(7, 0, WW2_FR_FROM(0, nxt)) WW2_M(7, 1, ) WW2_M(7, 2, ) WW2_M(7, 3, )
   }
 #undef WW2_DMA
+#undef WW2_GLDS
 #undef WW2_TGL
 #undef WW2_TD
 #undef WW2_TDL
@@ -862,7 +876,8 @@ static int ww_slabs(int total_chunks, int tiles) {
 }
 
 static bool ww_supported(int N, int H, int W, int C, int K) {
-  return N > 0 && H > 0 && W >= 2 && C % 64 == 0 && K % 64 == 0 && (size_t)N * H * W * (C > K ? C : K) < ((size_t)1 << 31);
+  return N > 0 && H > 0 && W >= 2 && C % 64 == 0 && K % 64 == 0 && (size_t)N * H * W * (C > K ? C : K) < ((size_t)1 << 31) &&
+         (size_t)H * W * (C > K ? C : K) < ((size_t)1 << 30);      // (per-sample byte offsets are 32-bit)
 }
 static bool ww_exact(int H, int W) { return !(H & 1) && !(W & 1) && ((W / 2) % 8) == 0; }
 static int ww_chunks(int N, int H, int W) { return N * ((H + 1) / 2) * (((W + 1) / 2 + 7) / 8); }
@@ -904,7 +919,7 @@ extern "C" int dl_wino_conv3x3_nhwc_f32(const float* x, const float* u, float* y
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wino_conv3x3_nhwc_f32: bad argument");
   if (((epilogue & WN_EPI_ADD) && !add) || ((epilogue & WN_EPI_DACT) && !dsrc) || act < 0 || act > 2)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wino_conv3x3_nhwc_f32: epilogue operand missing / bad activation");
-  if (C % WN_CK || K % WN_KB || (size_t)N * H * W * (C > K ? C : K) >= ((size_t)1 << 31))
+  if (C % WN_CK || K % WN_KB || (size_t)N * H * W * (C > K ? C : K) >= ((size_t)1 << 31) || (size_t)H * W * C >= ((size_t)1 << 30))
     return dl_fail(DL_ERR_UNSUPPORTED, "dl_wino_conv3x3_nhwc_f32: shape N=%d H=%d W=%d C=%d K=%d not supported (C %% 8, K %% 64, < 2^31 elements)", N, H, W, C, K);
   WinoArgs a{x, u, y, add, dsrc, N, H, W, C, K, act, epilogue};
   hipStream_t st = (hipStream_t)stream;
