@@ -33,6 +33,13 @@
 // number of i in [0, n) with i % parts == part (DMA pieces a wave issues in one part of a chunk's input tile)
 constexpr int ch_count_parts(int n, int part, int parts) { int c = 0; for (int i = 0; i < n; ++i) c += (i % parts == part) ? 1 : 0; return c; }
 
+#ifdef CH_TUNE
+__device__ unsigned long long g_ch_t[4 * 4096];       // phase time stamps per workgroup (tools/convh_harness phases)
+#define CH_T(I) { if (threadIdx.x == 0 && blockIdx.x < 4096) g_ch_t[blockIdx.x * 4 + (I)] = clock64(); }
+#else
+#define CH_T(I)
+#endif
+
 struct ConvHArgs {
   const u16* x;      // [N][H][W][C]
   const u16* w;      // [WTAPS][K][C]  prepared weights (k_wprep_h): rows = output channels of THIS pass, C = its reduction
@@ -50,7 +57,8 @@ struct ConvHArgs {
 // BM = TH x TW output pixels, BN output channels, WGM x WGN waves (each (BM/WGM) x (BN/WGN)), G the geometry policy,
 // NG tap groups per channel chunk (3: one row of a 3x3 stencil per step; 1: all taps of the pass in one step), WS weight buffers
 // (2: the operands of step s+1 are fetched during step s; 3 -- NG = 3 only: two steps ahead, see the main loop).
-template <bool F16, int BM, int BN, int WGM, int WGN, int TW, class G, int NG, int WS = 2>
+// ABL (tuning build only): ablation -- 1: no DMA after the prologue, 2: no MFMAs (the fragments are still read), 4: no fragment reads
+template <bool F16, int BM, int BN, int WGM, int WGN, int TW, class G, int NG, int WS = 2, int ABL = 0>
 __global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
   constexpr int NWV = WGM * WGN;
   constexpr int TH = BM / TW, SH = G::ISH, SW = G::ISW;
@@ -179,11 +187,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
   // s_waitcnt vmcnt(<issued in this step>) means "everything older has landed".  A fetch then has two steps (~6 us) to arrive
   // instead of one; with one step the matrix pipe idled while the waves waited for the L2 (waiting share 40 %, round-3 review).
   const int nchunks = a.C / 32, nsteps = nchunks * NG;
+  CH_T(0)
   CH_ISSUE_IN(0, -1, 1)
   CH_ISSUE_W(0, 0)
   if constexpr (WS == 3) CH_ISSUE_W(min(1, nsteps - 1), 1)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
+  CH_T(1)
   int wslot = 0;                                        // weight buffer of the current step (step % WS)
   // one step = one tap group of one channel chunk (the tap group is a compile-time constant: the counted wait needs an immediate)
   auto step_body = [&](auto tg_c, int ch) {
@@ -195,10 +205,12 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
       if constexpr (WS == 2) {
         // next step's weights and this step's share of the next chunk's input tile: they have the whole step to land
         more_w = step + 1 < nsteps; more_in = ch + 1 < nchunks;
+        if (ABL & 1) more_w = more_in = false;
         if (more_w) CH_ISSUE_W(step + 1, wslot ^ 1)
         if (more_in) CH_ISSUE_IN(ch + 1, tg, NG)
       } else {
         more_w = step + 2 < nsteps; more_in = ch + 1 < nchunks && tg < 2;
+        if (ABL & 1) more_w = more_in = false;
         if (more_w) CH_ISSUE_W(step + 2, wslot == 0 ? 2 : wslot - 1)
         if (more_in) CH_ISSUE_IN(ch + 1, tg, 2)
       }
@@ -207,6 +219,13 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
       // flight -- read-then-use in one sub-step put an LDS round trip in front of every group of MFMAs (round 4).
       s16x8 af[2][WM], bf[2][WN];
       auto load_frags = [&](int u, int set) {
+        if constexpr ((ABL & 4) != 0) {
+#pragma unroll
+          for (int mi = 0; mi < WM; ++mi) asm volatile("" : "=v"(af[set][mi]));
+#pragma unroll
+          for (int ni = 0; ni < WN; ++ni) asm volatile("" : "=v"(bf[set][ni]));
+          return;
+        }
         const int tl = u >> 1, ks = u & 1;
         const int tap = tg * TG + tl;
         const int dwv = G::dw(tap), cs = dwv / SW, phase = dwv % SW;
@@ -221,10 +240,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
       for (int u = 0; u < 2 * TG; ++u) {
         if (u + 1 < 2 * TG) load_frags(u + 1, (u + 1) & 1);
         __builtin_amdgcn_sched_barrier(0);
+        if constexpr ((ABL & 2) != 0) {
 #pragma unroll
-        for (int mi = 0; mi < WM; ++mi)
+          for (int mi = 0; mi < WM; ++mi) asm volatile("" :: "v"(af[u & 1][mi]));
 #pragma unroll
-          for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = ch_mfma<F16>(af[u & 1][mi], bf[u & 1][ni], acc[mi][ni]);
+          for (int ni = 0; ni < WN; ++ni) asm volatile("" :: "v"(bf[u & 1][ni]));
+        } else {
+#pragma unroll
+          for (int mi = 0; mi < WM; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < WN; ++ni) acc[mi][ni] = ch_mfma<F16>(af[u & 1][mi], bf[u & 1][ni], acc[mi][ni]);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
       if constexpr (WS == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -246,6 +272,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
     }
   }
   static_assert(NG == 1 || NG == 3, "tap groups per chunk");
+  CH_T(2)
 #undef CH_ISSUE_IN
 #undef CH_ISSUE_W
 
@@ -294,8 +321,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
         for (int e = 0; e < 8; ++e) v[e] += ch_h2f<F16>(tv[e]);
       }
       if (f_act) {
+        if (a.act == 1) {                       // tanh: two elements per instruction
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = ch_act(v[e], a.act);
+          for (int e = 0; e < 8; e += 2) {
+            const f32x2 t2 = ch_tanh2((f32x2){v[e], v[e + 1]});
+            v[e] = t2[0]; v[e + 1] = t2[1];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = ch_act(v[e], a.act);
+        }
       }
       if (f_dact) {
         const u16x8 tv = *reinterpret_cast<const u16x8*>(a.dsrc + o);
@@ -308,6 +343,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void k_convh(ConvHArgs a) {
       *reinterpret_cast<u16x8*>(a.y + o) = ov;
     }
   }
+  CH_T(3)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -478,7 +514,7 @@ static double ch_eff(int Ho, int Wo, int TH, int TW) {
 }
 
 // launches unless the channels do not tile or the tile shape wastes more than 10 % more of the image than the best shape does
-template <bool F16, int BM, int BN, int WGM, int WGN, int TW, class G, int NG, int WS = 2>
+template <bool F16, int BM, int BN, int WGM, int WGN, int TW, class G, int NG, int WS = 2, int ABL = 0>
 static int launch_convh(const ConvHArgs& a, hipStream_t st, double best_eff = 0.0) {
   constexpr int TH = BM / TW;
   if (a.K % BN || a.C % 32 || ch_eff(a.Ho, a.Wo, TH, TW) < 0.9 * best_eff) return 1;
@@ -486,7 +522,7 @@ static int launch_convh(const ConvHArgs& a, hipStream_t st, double best_eff = 0.
   const double px_ = (double)a.N * a.Ho * a.Wo;
   const DlProfTag tag{"k_convh", std::is_same<G, GeomConv<3, 1, 1>>::value ? "fwd" : (G::ISH * G::ISW > 1 || G::WTAPS == 1 ? "fwd-strided" : "dgrad"),
                       a.N, a.H, a.W, a.C, a.K, G::WTAPS == 9 ? 3 : 1, G::ISH * G::OSH, G::ISW * G::OSW, 2.0 * px_ * a.K * a.C * G::NT, 2.0 * ((double)a.N * a.H * a.W * a.C + px_ * a.K + (double)G::NT * a.K * a.C)};
-  DL_LAUNCH(tag, (k_convh<F16, BM, BN, WGM, WGN, TW, G, NG, WS>), dim3(ntiles), dim3(64 * WGM * WGN), st, a);
+  DL_LAUNCH(tag, (k_convh<F16, BM, BN, WGM, WGN, TW, G, NG, WS, ABL>), dim3(ntiles), dim3(64 * WGM * WGN), st, a);
   return 0;
 }
 
@@ -535,6 +571,12 @@ static int dispatch_convh(const ConvHArgs& a, hipStream_t st) {
       case 13: return launch_convh<F16, 256, 128, 2, 1, 64, G, NG>(a, st);
       case 14: return launch_convh<F16, 512, 128, 4, 2, 64, G, NG, 3>(a, st);   // three weight buffers, counted waits
       case 15: return launch_convh<F16, 256, 128, 4, 2, 64, G, NG, 3>(a, st);
+      case 16: return launch_convh<F16, 512, 128, 4, 2, 64, G, NG, 2, 1>(a, st);   // ablations of the 512 x 128 tile: no DMA
+      case 17: return launch_convh<F16, 512, 128, 4, 2, 64, G, NG, 2, 2>(a, st);   // no MFMAs
+      case 18: return launch_convh<F16, 512, 128, 4, 2, 64, G, NG, 2, 4>(a, st);   // no fragment reads
+      case 19: return launch_convh<F16, 512, 128, 4, 2, 64, G, NG, 2, 5>(a, st);   // MFMAs only
+      case 20: return launch_convh<F16, 512, 128, 4, 2, 64, G, NG, 2, 0>(a, st);   // the two-buffer kernel
+      case 21: return launch_convh<F16, 512, 128, 4, 2, 64, G, NG, 2, 3>(a, st);   // fragment reads only
       default: break;
     }
 #endif

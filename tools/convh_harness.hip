@@ -369,6 +369,51 @@ int main(int argc, char** argv) {
     for (const auto& s : layers) time_shape(s, reps, gen, &total);
     printf("sum of the listed launches: %.1f us\n", total);
   }
+  if (!strcmp(mode, "phases")) {
+    // where a workgroup of the stride-1 kernel spends its life (clock64 stamps: start, operands of the first step landed, end of the
+    // reduction loop, end), averaged over the workgroups of one launch; variant = the product's choice
+    const Shape sa[] = {{"layer1 3x3 64->64", B, 64, 512, 64, 64, 3, 1, 1}, {"layer2 3x3 128->128", B, 64, 256, 128, 128, 3, 1, 1},
+                        {"layer3 3x3 256->256", B, 64, 128, 256, 256, 3, 1, 1}, {"layer4 3x3 512->512", B, 32, 64, 512, 512, 3, 1, 1}};
+    for (const auto& s : sa) {
+      const size_t nx = (size_t)s.N * s.H * s.W * s.C, nw = (size_t)s.K * 9 * s.C;
+      HalfTensor x = rnd_half(nx, gen, 1.f), w = rnd_half(nw, gen, 0.05f);
+      float* w32 = dev_f32(w.f);
+      uint16_t *wf, *wbk, *dy;
+      CK(hipMalloc(&wf, nw * 2)); CK(hipMalloc(&wbk, nw * 2)); CK(hipMalloc(&dy, nx / s.C * s.K * 2));
+      dl_conv_weights_h(w32, wf, wbk, s.K, 9, s.C, g_dtype, nullptr);
+      for (int mode2 = 0; mode2 < 2; ++mode2) {
+        for (int i = 0; i < 3; ++i)
+          dl_conv2d_nhwc_h(x.d, mode2 ? wbk : wf, dy, nullptr, mode2 ? x.d : nullptr, s.N, s.H, s.W, s.C, s.K, 3, 1, 1, mode2, g_dtype, 1, mode2 ? CH_EPI_DACT : CH_EPI_ACT, nullptr);
+        CK(hipDeviceSynchronize());
+        std::vector<unsigned long long> t(4 * 4096);
+        CK(hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_ch_t), t.size() * sizeof(unsigned long long)));
+        double d[3] = {0, 0, 0}; int cnt = 0; unsigned long long first = ~0ull, last = 0;
+        for (int g = 0; g < 4096; ++g) {
+          const unsigned long long* q = &t[g * 4];
+          if (!q[0] || q[3] < q[0]) continue;
+          for (int k = 0; k < 3; ++k) d[k] += (double)(q[k + 1] - q[k]);
+          first = std::min(first, q[0]); last = std::max(last, q[3]);
+          ++cnt;
+        }
+        printf("%-22s %s  workgroups (<= 4096 sampled) %d: first operands %6.0f  reduction loop %7.0f  epilogue %6.0f   first start -> last end %7.0f  (clock64 ticks)\n",
+               s.name, mode2 ? "dgrad" : "fwd  ", cnt, d[0] / cnt, d[1] / cnt, d[2] / cnt, (double)(last - first));
+      }
+      CK(hipFree(x.d)); CK(hipFree(w.d)); CK(hipFree(w32)); CK(hipFree(wf)); CK(hipFree(wbk)); CK(hipFree(dy));
+    }
+  }
+  if (!strcmp(mode, "ablate")) {
+    // what bounds the 512 x 128 stride-1 kernel: the same launch with parts of the loop removed (results are garbage)
+    const int reps = argc >= 3 && atoi(argv[2]) > 0 ? atoi(argv[2]) : 10;
+    const Shape sa[] = {{"layer3 3x3 256->256", B, 64, 128, 256, 256, 3, 1, 1}, {"layer4 3x3 512->512", B, 32, 64, 512, 512, 3, 1, 1}};
+    const char* what[] = {"full (3 buffers)", "no DMA in the loop", "no MFMAs", "no fragment reads", "MFMAs only", "full (2 buffers)", "fragment reads only"};
+    const int vs[] = {14, 16, 17, 18, 19, 20, 21};
+    for (int i = 0; i < 7; ++i) {
+      g_ch_variant = vs[i];
+      printf("---- %s\n", what[i]);
+      for (const auto& s : sa) time_shape(s, reps, gen, nullptr);
+    }
+    g_ch_variant = 0;
+  }
   if (!strcmp(mode, "tune-s")) {
     // the strided 3x3 / 1x1 layers and their input-gradient phases with every tile variant of the tuning build (0 = the product's choice)
     const int reps = argc >= 3 && atoi(argv[2]) > 0 ? atoi(argv[2]) : 10;

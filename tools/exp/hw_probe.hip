@@ -3,6 +3,7 @@
 //   2. global_load_lds (16 bytes per lane) under a partial EXEC mask: inactive lanes must leave their LDS slot untouched;
 //   3. v_mfma_f32_32x32x16_bf16 operand layout: lane l holds A[i = l & 31][k = 8 (l >> 5) .. + 7], B[k][j = l & 31].
 // Build: hipcc -O2 --offload-arch=gfx950 tools/exp/hw_probe.hip -o tools/bin/hw_probe
+#include <cstring>
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
@@ -52,7 +53,49 @@ __global__ void k_mfma(int probe_i, int probe_k, float* out) {
   for (int r = 0; r < 16; ++r) out[((r & 3) + 8 * (r >> 2) + 4 * (l >> 5)) * 32 + i] = c[r];
 }
 
-int main() {
+// --- 4: sustained rate of the bf16 matrix instruction: independent v_mfma_f32_32x32x16_bf16 back to back, registers only
+typedef __bf16 pk_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float pk_f32x16 __attribute__((ext_vector_type(16)));
+template <int NACC>
+__global__ __launch_bounds__(512) void k_mfma_peak_bf16(float* out, int iters) {
+  pk_f32x16 acc[NACC];
+  for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = (float)i;
+  pk_bf16x8 x, y;
+  for (int e = 0; e < 8; ++e) { x[e] = (__bf16)(threadIdx.x * 1e-3f + e); y[e] = (__bf16)(blockIdx.x * 1e-3f - e); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < NACC; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+template <int NACC>
+static void mfma_peak_bf16(int threads, int wg_per_cu) {
+  const int grid = 256 * wg_per_cu, iters = 2000;
+  float* out; hipMalloc(&out, (size_t)grid * threads * 4);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  hipLaunchKernelGGL(k_mfma_peak_bf16<NACC>, dim3(grid), dim3(threads), 0, 0, out, 50);
+  hipDeviceSynchronize();
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(a);
+    hipLaunchKernelGGL(k_mfma_peak_bf16<NACC>, dim3(grid), dim3(threads), 0, 0, out, iters);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    best = ms < best ? ms : best;
+  }
+  const double flop = (double)grid * (threads / 64) * NACC * (double)iters * 32768.0;
+  printf("bf16 MFMA sustained: %d waves/CU, %d independent accumulators per wave: %.0f us  %.0f TFLOP/s (%.2f of the 2500 TFLOP/s datasheet rate)\n",
+         wg_per_cu * threads / 64, NACC, best * 1e3, flop / best * 1e-9, flop / best * 1e-9 / 2500.0);
+  hipFree(out);
+}
+
+int main(int argc, char** argv) {
+  if (argc >= 2 && !strcmp(argv[1], "peak")) {
+    mfma_peak_bf16<8>(256, 1); mfma_peak_bf16<8>(512, 1); mfma_peak_bf16<4>(512, 1); mfma_peak_bf16<8>(512, 2);
+    return 0;
+  }
   // --- 1
   int* d_addr; short* d_out;
   hipMalloc(&d_addr, 64 * 4); hipMalloc(&d_out, 64 * 4 * 2);
