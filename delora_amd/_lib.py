@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdelora_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class DeloraHipError(RuntimeError):
@@ -86,6 +86,8 @@ SIGNATURES = {
     "dl_mean_hw_bwd_act_h": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "dl_conv2d_wgrad_h_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "dl_conv2d_wgrad_nhwc_h": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dl_conv2d_wgrad_batch_h_workspace_bytes": (_sz, [_vp, _i32]),
+    "dl_conv2d_wgrad_batch_nhwc_h": (_i32, [_vp, _i32, _vp, _i32, _vp]),
     "dl_profile_begin": (_i32, [_i32, ctypes.c_char_p]),
     "dl_profile_end": (_i32, [_vp, _i32, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]),
     "dl_profile_pause": (_i32, [_i32]),
@@ -112,6 +114,16 @@ class ConvHLayer(ctypes.Structure):
 
 
 CONVH_BATCH = 32
+
+
+class WgradHLayer(ctypes.Structure):
+    """``dl_wgrad_h_layer`` of include/delora_hip.h."""
+    _fields_ = [("x", ctypes.c_void_p), ("g", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("N", ctypes.c_int32), ("H", ctypes.c_int32),
+                ("W", ctypes.c_int32), ("C", ctypes.c_int32), ("K", ctypes.c_int32), ("ksize", ctypes.c_int32),
+                ("stride_h", ctypes.c_int32), ("stride_w", ctypes.c_int32)]
+
+
+WGRAD_BATCH = 24
 
 
 class ProfileRow(ctypes.Structure):

@@ -32,8 +32,10 @@ __device__ __forceinline__ int ch_unit_swz(int p) {
   else return 0;
 }
 
+// The body of the kernel for workgroup `blk` of one layer's launch (k_wgradh: blk = blockIdx.x; k_wgradh_batch: several layers in
+// one launch, blk = the workgroup's index inside its layer)
 template <bool F16, int BMK, int PK, int PR, int SH, int SW, int KS>
-__global__ __launch_bounds__(64 * (BMK / 32) * 2, 2) void k_wgradh(WgradHArgs a) {
+__device__ __forceinline__ void wgradh_body(const WgradHArgs& a, const int blk) {
   constexpr int BNC = 64;
   constexpr int NWV = (BMK / 32) * 2;                       // wave = (k subtile, c subtile)
   constexpr int PAD = (KS - 1) / 2, TAPS = KS * KS;
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(64 * (BMK / 32) * 2, 2) void k_wgradh(WgradHArgs a)
   const int li = lane & 31, half = lane >> 5;
   const int ksub = wave >> 1, csub = wave & 1;
   const int KT = a.K / BMK, CT = a.C / BNC;
-  int t = blockIdx.x;
+  int t = blk;
   const int ct = t % CT; t /= CT;
   const int kt = t % KT; t /= KT;
   const int slab = t;
@@ -242,9 +244,34 @@ __global__ __launch_bounds__(64 * (BMK / 32) * 2, 2) void k_wgradh(WgradHArgs a)
     }
 }
 
+template <bool F16, int BMK, int PK, int PR, int SH, int SW, int KS>
+__global__ __launch_bounds__(64 * (BMK / 32) * 2, 2) void k_wgradh(WgradHArgs a) {
+  wgradh_body<F16, BMK, PK, PR, SH, SW, KS>(a, blockIdx.x);
+}
+
+// Several layers in ONE launch (dl_conv2d_wgrad_batch_nhwc_h).  A single layer has 2-64 output tiles, so filling 256 CUs takes
+// 4-128 pixel slabs per tile, and every slab writes a full fp32 copy of its tile: 75 MB of partials per layer whatever its size,
+// written and read back (~0.5 ms of a 4.6 ms bf16 step, round 4).  The weight gradients of a run of layers do not depend on each
+// other, so their launches are deferred to the end of the run and merged: with 9 layers sharing the chip a tile needs 1-8 slabs
+// (layer4: one -- its workgroups write dw itself), the partial traffic drops ~8x, and eight launch ramps / tails disappear.
+// The layer table travels in the kernel arguments; layers are ordered by decreasing work per workgroup (the big units start first).
+struct WgradHBatchArgs {
+  WgradHArgs layer[DL_WGRAD_BATCH];
+  int first_wg[DL_WGRAD_BATCH + 1];
+  int n;
+};
+template <bool F16, int BMK, int PK, int PR, int SH, int SW, int KS>
+__global__ __launch_bounds__(64 * (BMK / 32) * 2, 2) void k_wgradh_batch(WgradHBatchArgs b) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < DL_WGRAD_BATCH; ++i)
+    if (i < b.n && (int)blockIdx.x >= b.first_wg[i]) l = i;
+  const WgradHArgs a = b.layer[l];
+  wgradh_body<F16, BMK, PK, PR, SH, SW, KS>(a, (int)blockIdx.x - b.first_wg[l]);
+}
+
 // dw = sum of the slab partials in a fixed order (slab 0, 1, 2, ...), eight 16-byte loads in flight per lane
-__global__ __launch_bounds__(256) void k_wgradh_reduce(const float* __restrict__ part, int nslabs, size_t count, float* __restrict__ dw) {
-  const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+__device__ __forceinline__ void wgradh_reduce_body(const float* __restrict__ part, int nslabs, size_t count, float* __restrict__ dw, size_t i) {
   if (i >= count) return;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   int k = 0;
@@ -257,6 +284,24 @@ __global__ __launch_bounds__(256) void k_wgradh_reduce(const float* __restrict__
   }
   for (; k < nslabs; ++k) s += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(part + (size_t)k * count + i));
   *reinterpret_cast<f32x4*>(dw + i) = s;
+}
+struct WgradHReduceBatchArgs {
+  const float* part[DL_WGRAD_BATCH];
+  float* dw[DL_WGRAD_BATCH];
+  unsigned count[DL_WGRAD_BATCH];
+  int nslabs[DL_WGRAD_BATCH];
+  int first_block[DL_WGRAD_BATCH + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void k_wgradh_reduce_batch(WgradHReduceBatchArgs b) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < DL_WGRAD_BATCH; ++i)
+    if (i < b.n && (int)blockIdx.x >= b.first_block[i]) l = i;
+  wgradh_reduce_body(b.part[l], b.nslabs[l], b.count[l], b.dw[l], ((size_t)((int)blockIdx.x - b.first_block[l]) * 256 + threadIdx.x) * 4);
+}
+__global__ __launch_bounds__(256) void k_wgradh_reduce(const float* __restrict__ part, int nslabs, size_t count, float* __restrict__ dw) {
+  wgradh_reduce_body(part, nslabs, count, dw, ((size_t)blockIdx.x * 256 + threadIdx.x) * 4);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -348,4 +393,149 @@ extern "C" int dl_conv2d_wgrad_nhwc_h(const void* x, const void* g, float* dw, v
   const size_t count = (size_t)K * ksize * ksize * C;
   hipLaunchKernelGGL(k_wgradh_reduce, dim3((unsigned)((count / 4 + 255) / 256)), dim3(256), 0, st, (const float*)workspace, p.nslabs, count, dw);
   return dl_check_launch("dl_conv2d_wgrad_nhwc_h");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Several layers in one call (see k_wgradh_batch).  Layers that share a kernel instantiation form a group = one launch; the slab
+// count of every layer follows from the group's total work: a workgroup should reduce about total / (one workgroup per CU) chunks.
+#include <algorithm>
+#include <vector>
+
+namespace {
+struct WgradHItem {
+  WgradHArgs a;
+  WgradHPlan p;
+  float* dw;
+  size_t count;            // elements of dw
+  int key, ks, sh, sw;     // kernel instantiation
+  double flop, bytes;
+};
+
+int wgradh_key(const WgradHPlan& p, int ks, int sh, int sw) { return (((p.bmk == 128 ? 1 : 0) * 2 + (p.pk == 64 ? 1 : 0)) * 4 + (sh - 1) * 2 + (sw - 1)) * 2 + (ks == 3 ? 1 : 0); }
+
+// fills items (validated, planned per group); returns an error code
+int wgradh_batch_plan(const dl_wgrad_h_layer* L, int n, std::vector<WgradHItem>& items) {
+  if (!L || n <= 0 || n > DL_WGRAD_BATCH) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_wgrad_batch_nhwc_h: 1..%d layers per call", DL_WGRAD_BATCH);
+  items.resize(n);
+  for (int i = 0; i < n; ++i) {
+    const dl_wgrad_h_layer& l = L[i];
+    WgradHItem& it = items[i];
+    if (!wgradh_plan(l.N, l.H, l.W, l.C, l.K, l.ksize, l.stride_h, l.stride_w, &it.p))
+      return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_wgrad_batch_nhwc_h: layer %d: N=%d H=%d W=%d C=%d K=%d kernel %d stride (%d,%d) is not supported (C, K %% 64)",
+                     i, l.N, l.H, l.W, l.C, l.K, l.ksize, l.stride_h, l.stride_w);
+    const int Ho = (l.H + l.stride_h - 1) / l.stride_h, Wo = (l.W + l.stride_w - 1) / l.stride_w;
+    if ((size_t)l.N * l.H * l.W * l.C >= ((size_t)1 << 30) || (size_t)l.N * Ho * Wo * l.K >= ((size_t)1 << 30))
+      return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_wgrad_batch_nhwc_h: layer %d: tensors beyond 2^30 elements are not supported", i);
+    it.a = WgradHArgs{(const u16*)l.x, (const u16*)l.g, nullptr, l.N, l.H, l.W, l.C, l.K, Ho, Wo, 0, 0};
+    it.dw = l.dw;
+    it.count = (size_t)l.K * l.ksize * l.ksize * l.C;
+    it.ks = l.ksize; it.sh = l.stride_h; it.sw = l.stride_w;
+    it.key = wgradh_key(it.p, l.ksize, l.stride_h, l.stride_w);
+    it.flop = 2.0 * l.N * Ho * Wo * (double)l.K * l.C * l.ksize * l.ksize;
+    it.bytes = 2.0 * ((double)l.N * l.H * l.W * l.C + (double)l.N * Ho * Wo * l.K) + 4.0 * it.count;
+  }
+  // slab counts per group
+  std::vector<int> keys;
+  for (const auto& it : items) if (std::find(keys.begin(), keys.end(), it.key) == keys.end()) keys.push_back(it.key);
+  for (int key : keys) {
+    double total = 0;
+    for (const auto& it : items) if (it.key == key) total += (double)it.p.tiles * it.p.total_chunks;
+    long target = (long)((total + g_wh_want - 1) / g_wh_want);
+    if (target < 1) target = 1;
+    for (auto& it : items) if (it.key == key) {
+      int ns = (int)((it.p.total_chunks + target - 1) / target);
+      if (ns < 1) ns = 1;
+      it.p.chunks_per_slab = (it.p.total_chunks + ns - 1) / ns;
+      it.p.nslabs = (it.p.total_chunks + it.p.chunks_per_slab - 1) / it.p.chunks_per_slab;
+      it.a.chunks_per_slab = it.p.chunks_per_slab; it.a.nslabs = it.p.nslabs;
+    }
+  }
+  return DL_OK;
+}
+
+template <bool F16, int BMK, int PK, int SH, int SW, int KS>
+void launch_wgradh_batch(const WgradHBatchArgs& b, int wgs, const DlProfTag& tag, hipStream_t st) {
+  DL_LAUNCH(tag, (k_wgradh_batch<F16, BMK, PK, 2, SH, SW, KS>), dim3(wgs), dim3(64 * (BMK / 32) * 2), st, b);
+}
+template <bool F16, int SH, int SW, int KS>
+int wgradh_batch_geom(const WgradHBatchArgs& b, int wgs, int bmk, int pk, const DlProfTag& tag, hipStream_t st) {
+  if constexpr (SH == 1 && SW == 1) {
+    if (pk == 64 && bmk == 128) { launch_wgradh_batch<F16, 128, 64, SH, SW, KS>(b, wgs, tag, st); return 0; }
+  }
+  if (pk != 32) return 1;
+  if (bmk == 128) launch_wgradh_batch<F16, 128, 32, SH, SW, KS>(b, wgs, tag, st);
+  else launch_wgradh_batch<F16, 64, 32, SH, SW, KS>(b, wgs, tag, st);
+  return 0;
+}
+template <bool F16>
+int wgradh_batch_dispatch(const WgradHBatchArgs& b, int wgs, int bmk, int pk, int ks, int sh, int sw, const DlProfTag& tag, hipStream_t st) {
+  if (ks == 3 && sh == 1 && sw == 1) return wgradh_batch_geom<F16, 1, 1, 3>(b, wgs, bmk, pk, tag, st);
+  if (ks == 3 && sh == 1 && sw == 2) return wgradh_batch_geom<F16, 1, 2, 3>(b, wgs, bmk, pk, tag, st);
+  if (ks == 3 && sh == 2 && sw == 2) return wgradh_batch_geom<F16, 2, 2, 3>(b, wgs, bmk, pk, tag, st);
+  if (ks == 1 && sh == 1 && sw == 2) return wgradh_batch_geom<F16, 1, 2, 1>(b, wgs, bmk, pk, tag, st);
+  if (ks == 1 && sh == 2 && sw == 2) return wgradh_batch_geom<F16, 2, 2, 1>(b, wgs, bmk, pk, tag, st);
+  return 1;
+}
+}  // namespace
+
+/* see include/delora_hip.h */
+extern "C" size_t dl_conv2d_wgrad_batch_h_workspace_bytes(const dl_wgrad_h_layer* layers, int32_t n) {
+  std::vector<WgradHItem> items;
+  if (wgradh_batch_plan(layers, n, items)) return 0;
+  size_t floats = 4;                                  // (never zero: 0 means "not supported")
+  for (const auto& it : items) if (it.p.nslabs > 1) floats += (size_t)it.p.nslabs * it.count;
+  return floats * sizeof(float);
+}
+
+extern "C" int dl_conv2d_wgrad_batch_nhwc_h(const dl_wgrad_h_layer* layers, int32_t n, void* workspace, int32_t dtype, dl_stream stream) {
+  if (!workspace) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_wgrad_batch_nhwc_h: null workspace");
+  if (dtype != DL_DTYPE_F16 && dtype != DL_DTYPE_BF16) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_wgrad_batch_nhwc_h: dtype must be DL_DTYPE_F16 or DL_DTYPE_BF16");
+  std::vector<WgradHItem> items;
+  const int rc0 = wgradh_batch_plan(layers, n, items);
+  if (rc0) return rc0;
+  for (int i = 0; i < n; ++i)
+    if (!layers[i].x || !layers[i].g || !layers[i].dw) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_wgrad_batch_nhwc_h: layer %d: null pointer", i);
+  hipStream_t st = (hipStream_t)stream;
+  // partial buffers: a layer with one slab writes its gradient directly
+  float* wsf = (float*)workspace;
+  for (auto& it : items) {
+    if (it.p.nslabs > 1) { it.a.part = wsf; wsf += (size_t)it.p.nslabs * it.count; }
+    else it.a.part = it.dw;
+  }
+  std::vector<int> keys;
+  for (const auto& it : items) if (std::find(keys.begin(), keys.end(), it.key) == keys.end()) keys.push_back(it.key);
+  for (int key : keys) {
+    std::vector<const WgradHItem*> grp;
+    for (const auto& it : items) if (it.key == key) grp.push_back(&it);
+    std::stable_sort(grp.begin(), grp.end(), [](const WgradHItem* x, const WgradHItem* y) { return x->p.chunks_per_slab > y->p.chunks_per_slab; });
+    WgradHBatchArgs b{};
+    b.n = (int)grp.size();
+    int wgs = 0;
+    double flop = 0, bytes = 0;
+    for (int i = 0; i < b.n; ++i) {
+      b.layer[i] = grp[i]->a;
+      b.first_wg[i] = wgs;
+      wgs += grp[i]->p.tiles * grp[i]->p.nslabs;
+      flop += grp[i]->flop; bytes += grp[i]->bytes;
+    }
+    b.first_wg[b.n] = wgs;
+    const WgradHItem& f = *grp[0];
+    // (profile row: the first layer's shape, the group's summed work)
+    const DlProfTag tag{"k_wgradh", b.n > 1 ? "wgrad-batch" : "wgrad", f.a.N, f.a.H, f.a.W, f.a.C, f.a.K, f.ks, f.sh, f.sw, flop, bytes};
+    const int rc = dtype == DL_DTYPE_F16 ? wgradh_batch_dispatch<true>(b, wgs, f.p.bmk, f.p.pk, f.ks, f.sh, f.sw, tag, st)
+                                         : wgradh_batch_dispatch<false>(b, wgs, f.p.bmk, f.p.pk, f.ks, f.sh, f.sw, tag, st);
+    if (rc) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_wgrad_batch_nhwc_h: no kernel for a layer group");
+  }
+  // one reduction launch for every layer that was split
+  WgradHReduceBatchArgs r{};
+  int blocks = 0;
+  for (const auto& it : items) if (it.p.nslabs > 1) {
+    r.part[r.n] = it.a.part; r.dw[r.n] = it.dw; r.count[r.n] = (unsigned)it.count; r.nslabs[r.n] = it.p.nslabs;
+    r.first_block[r.n] = blocks;
+    blocks += (int)((it.count / 4 + 255) / 256);
+    ++r.n;
+  }
+  r.first_block[r.n] = blocks;
+  if (r.n) hipLaunchKernelGGL(k_wgradh_reduce_batch, dim3(blocks), dim3(256), 0, st, r);
+  return dl_check_launch("dl_conv2d_wgrad_batch_nhwc_h");
 }

@@ -19,6 +19,7 @@ The strided layers' input gradients run one pass per stride phase with exactly t
 (``dgrad_strided``); no library convolution is left in the trunk.
 """
 import ctypes
+import os
 
 import torch
 
@@ -314,6 +315,8 @@ class RingStem(torch.autograd.Function):
 #            rest of the backward runs -- what deploy/trainer.py selects under DDP
 #   "block"  one Function per residual block
 TRUNK_SEGMENTS = "mono"
+# Weight gradients of a segment in merged launches at its end (wgrad_batch_h) instead of one launch per layer inside the chain
+WGRAD_BATCHED = os.environ.get("DELORA_WGRAD_BATCHED", "1") != "0"      # (0: one launch per layer, for A/B measurements)
 # Order in which the segment Functions finished their backward passes in this process (tests: DDP overlap) -- appended to when a list
 BACKWARD_TRACE = None
 
@@ -551,6 +554,33 @@ def wgrad_nhwc_h(x, g, ks, stride=(1, 1)):
     return dw
 
 
+def wgrad_batch_h(items):
+    """The weight gradients of several layers in one call (``dl_conv2d_wgrad_batch_nhwc_h``): ``items`` = list of (x, g, ks, stride) with
+    half-precision channels-last x / g; returns the fp32 ``dW [K,k,k,C]`` of every item.  Layers that share a kernel run in ONE launch
+    and need far fewer pixel slabs each than a launch of their own would (include/delora_hip.h); the caller keeps x and g alive until
+    the call -- ``RingSegmentH.backward`` defers the gradients of a whole segment to its end."""
+    lib = _lib.load()
+    out = [None] * len(items)
+    for i0 in range(0, len(items), _lib.WGRAD_BATCH):
+        part = items[i0:i0 + _lib.WGRAD_BATCH]
+        arr = (_lib.WgradHLayer * len(part))()
+        for j, (x, g, ks, stride) in enumerate(part):
+            N, H, W, C = x.shape
+            K = g.shape[3]
+            dw = torch.empty((K, ks, ks, C), dtype=torch.float32, device=x.device)
+            out[i0 + j] = dw
+            arr[j].x, arr[j].g, arr[j].dw = x.data_ptr(), g.data_ptr(), dw.data_ptr()
+            arr[j].N, arr[j].H, arr[j].W, arr[j].C, arr[j].K = N, H, W, C, K
+            arr[j].ksize, arr[j].stride_h, arr[j].stride_w = ks, stride[0], stride[1]
+        ap = ctypes.cast(arr, ctypes.c_void_p)
+        nbytes = lib.dl_conv2d_wgrad_batch_h_workspace_bytes(ap, len(part))
+        if not nbytes:
+            raise _lib.DeloraHipError("dl_conv2d_wgrad_batch_nhwc_h: " + (lib.dl_last_error() or b"").decode())
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=part[0][0].device)
+        _lib.check(lib.dl_conv2d_wgrad_batch_nhwc_h(ap, len(part), _ptr(ws), DTYPE_CODE[part[0][0].dtype], _stream()), "dl_conv2d_wgrad_batch_nhwc_h")
+    return out
+
+
 def supported_h(x_shape, blocks):
     """Whether the half-precision HIP trunk can run these shapes: as ``supported`` (channel counts multiples of 64, any image size:
     tiles hang over the edges of feature maps that do not divide)."""
@@ -614,23 +644,32 @@ class RingSegmentH(torch.autograd.Function):
             elif act == ACT["relu"]:
                 g2 = g2 * (y_last > 0).to(g2.dtype)
         wi = ctx.n_w
+        # The weight gradients do not feed the chain of input gradients: they are collected (x, g kept alive) and computed together
+        # at the end of the segment -- merged launches need far fewer slab partials than one launch per layer (wgrad_batch_h)
+        pending = []
         for b in range(nb - 1, -1, -1):
             cin, cout, stride, has_ds = blocks[b]
             wi -= 3 if has_ds else 2
             w1b, w2b = wbs[wi], wbs[wi + 1]
             x, y1 = acts[2 * b], acts[2 * b + 1]
             first = ctx.first and b == 0
-            grads[wi + 1] = grad_for(wgrad_nhwc_h(y1, g2, 3), ctx.w_meta[wi + 1])
+            pending.append((wi + 1, (y1, g2, 3, (1, 1))))
             g1 = conv_nhwc_h(g2, w2b, 3, act=act, epilogue=EPI_DACT, dsrc=y1, transposed=True)
-            grads[wi] = grad_for(wgrad_nhwc_h(x, g1, 3, stride=stride), ctx.w_meta[wi])
+            pending.append((wi, (x, g1, 3, stride)))
             if not has_ds:
                 epi = EPI_ADD if first else (EPI_ADD | EPI_DACT)
                 g2 = conv_nhwc_h(g1, w1b, 3, act=act, epilogue=epi, add=g2, dsrc=None if first else x, transposed=True)
             else:
-                grads[wi + 2] = grad_for(wgrad_nhwc_h(x, g2, 1, stride=stride), ctx.w_meta[wi + 2])
+                pending.append((wi + 2, (x, g2, 1, stride)))
                 dxb = dgrad_strided_h(g2, wbs[wi + 2], 1, stride, x.shape[1:3], dense=True)
                 epi = EPI_ADD_GRID if first else (EPI_ADD_GRID | EPI_DACT)
                 g2 = dgrad_strided_h(g1, w1b, 3, stride, x.shape[1:3], act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)
+        if WGRAD_BATCHED:
+            for (gi, _), dw in zip(pending, wgrad_batch_h([it for _, it in pending])):
+                grads[gi] = grad_for(dw, ctx.w_meta[gi])
+        else:
+            for gi, (xx, gg, ks, st) in pending:
+                grads[gi] = grad_for(wgrad_nhwc_h(xx, gg, ks, stride=st), ctx.w_meta[gi])
         if BACKWARD_TRACE is not None:
             BACKWARD_TRACE.append(("segment", blocks[0][0], blocks[-1][1], nb))
         return (g2, None, None, None, None, *grads)

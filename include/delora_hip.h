@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 4   /* 4: free image sizes in the convolution family (the strided input gradients take the INPUT image size and a seam workspace); 3: half-precision convolutions, launch profiler */
+#define DL_ABI_VERSION 5   /* 5: batched weight gradients (dl_conv2d_wgrad_batch_*); 4: free image sizes in the convolution family (the strided input gradients take the INPUT image size and a seam workspace); 3: half-precision convolutions, launch profiler */
 
 typedef void* dl_stream;
 
@@ -371,6 +371,21 @@ size_t dl_conv2d_wgrad_h_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_
                                          int32_t stride_w);
 int dl_conv2d_wgrad_nhwc_h(const void* x, const void* g, float* dw, void* workspace, int32_t N, int32_t H, int32_t W, int32_t C,
                            int32_t K, int32_t ksize, int32_t stride_h, int32_t stride_w, int32_t dtype, dl_stream stream);
+
+/* The weight gradients of up to DL_WGRAD_BATCH layers in one call: layers that share a kernel instantiation run in ONE launch, which
+ * needs far fewer pixel slabs per layer to fill the chip than a launch per layer does (a slab = one fp32 copy of an output tile that
+ * is written and read back); one reduction launch for all layers that were split, layers that were not write dw directly.  The
+ * gradients do not depend on each other: the trunk defers them to the end of a run of layers (delora_amd/models/ring_conv.py).
+ * Results are identical to dl_conv2d_wgrad_nhwc_h up to the summation order of the slabs (fixed for a given set of layers). */
+#define DL_WGRAD_BATCH 24
+typedef struct dl_wgrad_h_layer {
+  const void* x;        /* [N][H][W][C] half */
+  const void* g;        /* [N][ceil(H/stride_h)][ceil(W/stride_w)][K] half */
+  float* dw;            /* [K][ksize][ksize][C] fp32 */
+  int32_t N, H, W, C, K, ksize, stride_h, stride_w;
+} dl_wgrad_h_layer;
+size_t dl_conv2d_wgrad_batch_h_workspace_bytes(const dl_wgrad_h_layer* layers, int32_t n);      /* 0 = a layer is not supported */
+int dl_conv2d_wgrad_batch_nhwc_h(const dl_wgrad_h_layer* layers, int32_t n, void* workspace, int32_t dtype, dl_stream stream);
 
 /*
  * The stem's max-pooling on channels-last activations (reference src/models/resnet_modified.py:100-102: F.pad(circular) +

@@ -112,6 +112,31 @@ def test_half_conv_forward_and_both_gradients_against_torch(shape, dtype):
                       _worst(dx, dref[:, ::stride[0], ::stride[1]], eps, abs_tol), bound=1.0)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_batched_weight_gradients_equal_the_single_launches(dtype):
+    """dl_conv2d_wgrad_batch_nhwc_h (the gradients of a run of layers in merged launches, fewer pixel slabs per layer) against
+    dl_conv2d_wgrad_nhwc_h layer by layer: the same products, only the slab boundaries of the fp32 sums differ -- agreement to a few
+    fp32 roundings of the largest partial sum.  All kernel groups at once: 3x3 stride 1 (wide and narrow output blocks), strided 3x3,
+    1x1, images that do not divide into chunks; and a batch of one, which must reproduce the single launch bit for bit."""
+    from delora_amd.models import ring_conv as rc
+    dev = _dev()
+    g = torch.Generator().manual_seed(12)
+    shapes = [(2, 16, 128, 64, 128, 3, (1, 1)), (2, 8, 64, 128, 128, 3, (1, 1)), (1, 8, 32, 256, 256, 3, (1, 1)), (2, 16, 128, 64, 64, 3, (1, 1)),
+              (2, 8, 256, 64, 128, 3, (1, 2)), (2, 16, 128, 128, 256, 3, (2, 2)), (2, 8, 128, 64, 128, 1, (1, 2)), (2, 8, 64, 128, 256, 1, (2, 2)),
+              (2, 8, 180, 64, 64, 3, (1, 1)), (1, 6, 90, 128, 128, 3, (1, 1)), (2, 5, 45, 64, 128, 3, (1, 1)), (2, 8, 45, 64, 128, 3, (2, 2))]
+    items = []
+    for (N, H, W, C, K, ks, st) in shapes:
+        x = torch.randn((N, H, W, C), generator=g).to(dev).to(dtype)
+        gy = torch.randn((N, rc.out_size(H, st[0]), rc.out_size(W, st[1]), K), generator=g).to(dev).to(dtype)
+        items.append((x, gy, ks, st))
+    batched = rc.wgrad_batch_h(items)
+    for (x, gy, ks, st), dw_b, shp in zip(items, batched, shapes):
+        dw_1 = rc.wgrad_nhwc_h(x, gy, ks, stride=st)
+        scale = float(dw_1.abs().max())
+        util.measured(f"batched vs single weight gradient {shp} {dtype}: max |diff| / max |dw|", float((dw_b - dw_1).abs().max()) / scale, bound=2e-6)
+        assert torch.equal(rc.wgrad_batch_h([(x, gy, ks, st)])[0], dw_1), shp
+
+
 def test_half_conv_rejects_bad_arguments():
     from delora_amd import _lib
     from delora_amd.models import ring_conv as rc
