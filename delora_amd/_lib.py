@@ -86,6 +86,10 @@ SIGNATURES = {
     "dl_mean_hw_bwd_act_h": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "dl_conv2d_wgrad_h_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "dl_conv2d_wgrad_nhwc_h": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dl_wino_wgrad3x3_batch_workspace_bytes": (_sz, [_vp, _i32]),
+    "dl_wino_wgrad3x3_batch_nhwc_f32": (_i32, [_vp, _i32, _vp, _vp]),
+    "dl_conv2d_wgrad_batch_workspace_bytes": (_sz, [_vp, _i32]),
+    "dl_conv2d_wgrad_batch_nhwc_f32": (_i32, [_vp, _i32, _vp, _vp]),
     "dl_conv2d_wgrad_batch_h_workspace_bytes": (_sz, [_vp, _i32]),
     "dl_conv2d_wgrad_batch_nhwc_h": (_i32, [_vp, _i32, _vp, _i32, _vp]),
     "dl_profile_begin": (_i32, [_i32, ctypes.c_char_p]),
@@ -116,13 +120,14 @@ class ConvHLayer(ctypes.Structure):
 CONVH_BATCH = 32
 
 
-class WgradHLayer(ctypes.Structure):
-    """``dl_wgrad_h_layer`` of include/delora_hip.h."""
+class WgradLayer(ctypes.Structure):
+    """``dl_wgrad_layer`` (= ``dl_wgrad_h_layer``) of include/delora_hip.h."""
     _fields_ = [("x", ctypes.c_void_p), ("g", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("N", ctypes.c_int32), ("H", ctypes.c_int32),
                 ("W", ctypes.c_int32), ("C", ctypes.c_int32), ("K", ctypes.c_int32), ("ksize", ctypes.c_int32),
                 ("stride_h", ctypes.c_int32), ("stride_w", ctypes.c_int32)]
 
 
+WgradHLayer = WgradLayer
 WGRAD_BATCH = 24
 
 

@@ -47,6 +47,76 @@ int dl_fill_words(void* p, uint32_t value, size_t n_words, hipStream_t st) {
   return DL_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// see common.h
+#include <algorithm>
+#include <queue>
+namespace {
+double dl_batch_cost(const int* tiles, const int* chunks, int n, int machines, int partial_cost, long unit, int* nslabs) {
+  // units of layer i: tiles[i] * ns of size ceil(chunks / ns); dispatched by decreasing size to the first free machine
+  std::vector<std::pair<long, long>> runs;                    // (size, count)
+  double partials = 0;
+  for (int i = 0; i < n; ++i) {
+    long ns = (chunks[i] + unit - 1) / unit;
+    if (ns < 1) ns = 1;
+    nslabs[i] = (int)ns;
+    const long cps = (chunks[i] + ns - 1) / ns;
+    runs.push_back({cps, (long)tiles[i] * ns});
+    if (ns > 1) partials += (double)tiles[i] * ns;
+  }
+  std::sort(runs.begin(), runs.end(), [](const std::pair<long, long>& a, const std::pair<long, long>& b) { return a.first > b.first; });
+  std::priority_queue<long, std::vector<long>, std::greater<long>> free_at;
+  for (int m = 0; m < machines; ++m) free_at.push(0);
+  long makespan = 0;
+  for (const auto& r : runs)
+    for (long u = 0; u < r.second; ++u) {
+      const long t = free_at.top() + r.first;
+      free_at.pop();
+      free_at.push(t);
+      makespan = std::max(makespan, t);
+    }
+  return (double)makespan + (double)partial_cost * partials / machines;
+}
+std::mutex g_plan_mu;
+std::map<std::vector<int>, std::vector<int>> g_plan_cache;
+}  // namespace
+
+void dl_plan_batch(const int* tiles, const int* chunks, int n, int machines, int partial_cost, int* nslabs) {
+  std::vector<int> key;
+  key.reserve(2 * n + 2);
+  key.push_back(machines); key.push_back(partial_cost);
+  for (int i = 0; i < n; ++i) { key.push_back(tiles[i]); key.push_back(chunks[i]); }
+  {
+    std::lock_guard<std::mutex> lk(g_plan_mu);
+    auto it = g_plan_cache.find(key);
+    if (it != g_plan_cache.end()) { std::copy(it->second.begin(), it->second.end(), nslabs); return; }
+  }
+  double total = 0;
+  for (int i = 0; i < n; ++i) total += (double)tiles[i] * chunks[i];
+  const long target = std::max<long>(1, (long)((total + machines - 1) / machines));
+  // candidate unit sizes: the even share, and every way of cutting a layer's chunks into equal slabs of [share / 4, 2 share] chunks
+  std::vector<long> cand{target};
+  const long u_lo = std::max<long>(1, target / 4), u_hi = 2 * target;
+  for (int i = 0; i < n; ++i) {
+    const long k_lo = std::max<long>(1, chunks[i] / u_hi), k_hi = std::min<long>(chunks[i], chunks[i] / u_lo + 1);
+    for (long k = k_lo; k <= k_hi; ++k) {
+      const long u = (chunks[i] + k - 1) / k;
+      if (u >= u_lo && u <= u_hi) cand.push_back(u);
+    }
+  }
+  std::sort(cand.begin(), cand.end());
+  cand.erase(std::unique(cand.begin(), cand.end()), cand.end());
+  std::vector<int> best(n, 1), cur(n, 1);
+  double best_cost = -1;
+  for (long u : cand) {
+    const double c = dl_batch_cost(tiles, chunks, n, machines, partial_cost, u, cur.data());
+    if (best_cost < 0 || c < best_cost) { best_cost = c; best = cur; }
+  }
+  std::copy(best.begin(), best.end(), nslabs);
+  std::lock_guard<std::mutex> lk(g_plan_mu);
+  if (g_plan_cache.size() < 4096) g_plan_cache[key] = best;
+}
+
 extern "C" int dl_abi_version(void) { return DL_ABI_VERSION; }
 extern "C" const char* dl_last_error(void) { return g_dl_err; }
 

@@ -99,6 +99,11 @@ __device__ __forceinline__ float dl_tanh(float x) {
 extern thread_local char g_dl_err[256];
 int dl_fail(int code, const char* fmt, ...);
 int dl_check_launch(const char* what);
+// Slab plan of a merged weight-gradient launch (abi.hip): layer i has tiles[i] output tiles and chunks[i] equal-cost pixel chunks per
+// tile; `machines` workgroups run at a time.  Fills nslabs[i] (pixel slabs per tile; every slab beyond a tile's only one costs a
+// partial copy of the tile, `partial_cost` chunks' worth of time) so that the makespan of the launch -- workgroups dispatched in
+// order of decreasing slab size, each to the first free slot -- plus the partial traffic is smallest.  Memoised per shape set.
+void dl_plan_batch(const int* tiles, const int* chunks, int n, int machines, int partial_cost, int* nslabs);
 int dl_fill_words(void* p, uint32_t value, size_t n_words, hipStream_t st);   // abi.hip: memset as a kernel (graph-safe)
 
 // Launch profiler (abi.hip; dl_profile_begin / dl_profile_end of the C ABI): while a profile is open, every launch that goes

@@ -343,10 +343,16 @@ __global__ __launch_bounds__(CV_THREADS, CV_MINWAVES) void k_conv_f32(ConvArgs a
 // fixed order (deterministic, no float atomics).  g[p][k] and x[p][c] both have the reduction index as the slow axis, so
 // fragments are ds_read_b32 with lanes along k / c (consecutive addresses, conflict-free) -- one read per MFMA operand,
 // which the 64-cycle fp32 MFMA hides easily.
+struct WgArgs {
+  const float* x;    // [N][H][W][C]
+  const float* g;    // [N][Ho][Wo][K]
+  float* part;       // [nslabs][K][taps][C]
+  int N, H, W, C, K, Ho, Wo, chunks_per_slab, nslabs;
+};
+// (the body of the kernel for workgroup `blk` of one layer: k_wgrad_f32 runs one layer per launch, k_wgrad_f32_batch several)
 template <int BMK, int BNC, int PK, int SH, int SW, int KS>
-__global__ __launch_bounds__(CV_THREADS, 2) void k_wgrad_f32(const float* __restrict__ x, const float* __restrict__ g,
-                                                             float* __restrict__ part, int N, int H, int W, int C, int K,
-                                                             int Ho, int Wo, int chunks_per_slab, int nslabs) {
+__device__ __forceinline__ void wgrad_f32_body(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ part, int N, int H,
+                                               int W, int C, int K, int Ho, int Wo, int chunks_per_slab, int nslabs, const int blk) {
   // pixel chunk: PK consecutive output columns of one output row; a slab is a run of consecutive chunks
   constexpr int PAD = (KS - 1) / 2;
   constexpr int TAPS = KS * KS;
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void k_wgrad_f32(const float* __rest
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, half = lane >> 5;
   const int KT = K / BMK, CT = C / BNC;
-  int t = blockIdx.x;
+  int t = blk;
   const int ct = t % CT; t /= CT;
   const int kt = t % KT; t /= KT;
   const int slab = t;
@@ -488,11 +494,53 @@ __global__ __launch_bounds__(CV_THREADS, 2) void k_wgrad_f32(const float* __rest
   }
 }
 
+template <int BMK, int BNC, int PK, int SH, int SW, int KS>
+__global__ __launch_bounds__(CV_THREADS, 2) void k_wgrad_f32(const float* __restrict__ x, const float* __restrict__ g,
+                                                             float* __restrict__ part, int N, int H, int W, int C, int K,
+                                                             int Ho, int Wo, int chunks_per_slab, int nslabs) {
+  wgrad_f32_body<BMK, BNC, PK, SH, SW, KS>(x, g, part, N, H, W, C, K, Ho, Wo, chunks_per_slab, nslabs, blockIdx.x);
+}
+
+// Several layers in one launch (dl_conv2d_wgrad_batch_nhwc_f32, see include/delora_hip.h): layer table in the kernel arguments,
+// layers ordered by decreasing work per workgroup
+struct WgBatchArgs {
+  WgArgs layer[DL_WGRAD_BATCH];
+  int first_wg[DL_WGRAD_BATCH + 1];
+  int n;
+};
+template <int BMK, int BNC, int PK, int SH, int SW, int KS>
+__global__ __launch_bounds__(CV_THREADS, 2) void k_wgrad_f32_batch(WgBatchArgs b) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < DL_WGRAD_BATCH; ++i)
+    if (i < b.n && (int)blockIdx.x >= b.first_wg[i]) l = i;
+  const WgArgs a = b.layer[l];
+  wgrad_f32_body<BMK, BNC, PK, SH, SW, KS>(a.x, a.g, a.part, a.N, a.H, a.W, a.C, a.K, a.Ho, a.Wo, a.chunks_per_slab, a.nslabs, (int)blockIdx.x - b.first_wg[l]);
+}
+
 // Sum of the slab partials in a fixed order (slab 0, 1, 2, ... per element: deterministic).  Eight slabs are loaded per
 // trip so that eight independent 16-byte loads are in flight per lane -- the one-load-per-trip form ran at 1.7 TB/s.
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, int nslabs, size_t count, float* __restrict__ dw, size_t i);
+struct WgReduceBatchArgs {
+  const float* part[DL_WGRAD_BATCH];
+  float* dw[DL_WGRAD_BATCH];
+  unsigned count[DL_WGRAD_BATCH];
+  int nslabs[DL_WGRAD_BATCH];
+  int first_block[DL_WGRAD_BATCH + 1];
+  int n;
+};
+__global__ __launch_bounds__(CV_THREADS) void k_wgrad_reduce_batch(WgReduceBatchArgs b) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < DL_WGRAD_BATCH; ++i)
+    if (i < b.n && (int)blockIdx.x >= b.first_block[i]) l = i;
+  wgrad_reduce_body(b.part[l], b.nslabs[l], b.count[l], b.dw[l], ((size_t)((int)blockIdx.x - b.first_block[l]) * CV_THREADS + threadIdx.x) * 4);
+}
 __global__ __launch_bounds__(CV_THREADS) void k_wgrad_reduce(const float* __restrict__ part, int nslabs, size_t count,
                                                              float* __restrict__ dw) {
-  const size_t i = ((size_t)blockIdx.x * CV_THREADS + threadIdx.x) * 4;
+  wgrad_reduce_body(part, nslabs, count, dw, ((size_t)blockIdx.x * CV_THREADS + threadIdx.x) * 4);
+}
+__device__ __forceinline__ void wgrad_reduce_body(const float* __restrict__ part, int nslabs, size_t count, float* __restrict__ dw, size_t i) {
   if (i >= count) return;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   int k = 0;
@@ -838,4 +886,118 @@ extern "C" int dl_conv2d_wgrad_nhwc_f32(const float* x, const float* g, float* d
   else return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_wgrad_nhwc_f32: kernel %d stride (%d,%d) is not built", ksize, stride_h, stride_w);
   if (rc) return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_wgrad_nhwc_f32: shape N=%d H=%d W=%d C=%d K=%d does not tile", N, H, W, C, K);
   return dl_check_launch("dl_conv2d_wgrad_nhwc_f32");
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradients of several layers in one call (include/delora_hip.h: dl_wgrad_layer)
+#include <algorithm>
+#include <vector>
+namespace {
+struct WgItem {
+  WgArgs a;
+  float* dw;
+  size_t count;
+  int tiles, total_chunks, key, ks, sh, sw;
+  double flop, bytes;
+};
+int wg_batch_plan(const dl_wgrad_layer* L, int n, std::vector<WgItem>& items) {
+  if (!L || n <= 0 || n > DL_WGRAD_BATCH) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_wgrad_batch_nhwc_f32: 1..%d layers per call", DL_WGRAD_BATCH);
+  items.resize(n);
+  for (int i = 0; i < n; ++i) {
+    const dl_wgrad_layer& l = L[i];
+    const bool geom = (l.ksize == 3 && l.stride_h == 1 && (l.stride_w == 1 || l.stride_w == 2)) || (l.ksize == 3 && l.stride_h == 2 && l.stride_w == 2) ||
+                      (l.ksize == 1 && l.stride_h == 1 && l.stride_w == 2) || (l.ksize == 1 && l.stride_h == 2 && l.stride_w == 2);
+    if (!geom || l.N <= 0 || l.H <= 0 || l.W <= 0 || l.C <= 0 || l.K <= 0 || l.C % 64 || l.K % 64)
+      return dl_fail(DL_ERR_UNSUPPORTED, "dl_conv2d_wgrad_batch_nhwc_f32: layer %d: N=%d H=%d W=%d C=%d K=%d kernel %d stride (%d,%d) is not built / does not tile",
+                     i, l.N, l.H, l.W, l.C, l.K, l.ksize, l.stride_h, l.stride_w);
+    WgItem& it = items[i];
+    const int Ho = (l.H + l.stride_h - 1) / l.stride_h, Wo = (l.W + l.stride_w - 1) / l.stride_w;
+    const int pk = wg_pk(l.stride_w, l.ksize);
+    it.a = WgArgs{(const float*)l.x, (const float*)l.g, nullptr, l.N, l.H, l.W, l.C, l.K, Ho, Wo, 0, 0};
+    it.dw = l.dw;
+    it.count = (size_t)l.K * l.ksize * l.ksize * l.C;
+    it.tiles = (l.K / 64) * (l.C / 64);
+    it.total_chunks = l.N * Ho * ((Wo + pk - 1) / pk);
+    it.ks = l.ksize; it.sh = l.stride_h; it.sw = l.stride_w;
+    it.key = (l.ksize == 3 ? 4 : 0) + (l.stride_h - 1) * 2 + (l.stride_w - 1);
+    it.flop = 2.0 * l.N * Ho * Wo * (double)l.K * l.C * l.ksize * l.ksize;
+    it.bytes = 4.0 * ((double)l.N * l.H * l.W * l.C + (double)l.N * Ho * Wo * l.K + (double)it.count);
+  }
+  for (int key = 0; key < 8; ++key) {
+    std::vector<int> tl, ch, idx;
+    for (int i = 0; i < n; ++i) if (items[i].key == key) { tl.push_back(items[i].tiles); ch.push_back(items[i].total_chunks); idx.push_back(i); }
+    if (idx.empty()) continue;
+    std::vector<int> ns(idx.size());
+    dl_plan_batch(tl.data(), ch.data(), (int)idx.size(), g_wg_want, 20, ns.data());   // two 256-thread workgroups per CU
+    for (size_t j = 0; j < idx.size(); ++j) {
+      WgItem& it = items[idx[j]];
+      it.a.chunks_per_slab = (it.total_chunks + ns[j] - 1) / ns[j];
+      it.a.nslabs = (it.total_chunks + it.a.chunks_per_slab - 1) / it.a.chunks_per_slab;
+    }
+  }
+  return DL_OK;
+}
+template <int SH, int SW, int KS>
+void launch_wgrad_batch(const WgBatchArgs& b, int wgs, const DlProfTag& tag, hipStream_t st) {
+  DL_LAUNCH(tag, (k_wgrad_f32_batch<64, 64, wg_pk(SW, KS), SH, SW, KS>), dim3(wgs), dim3(CV_THREADS), st, b);
+}
+}  // namespace
+
+/* see include/delora_hip.h */
+extern "C" size_t dl_conv2d_wgrad_batch_workspace_bytes(const dl_wgrad_layer* layers, int32_t n) {
+  std::vector<WgItem> items;
+  if (wg_batch_plan(layers, n, items)) return 0;
+  size_t floats = 4;
+  for (const auto& it : items) if (it.a.nslabs > 1) floats += (size_t)it.a.nslabs * it.count;
+  return floats * sizeof(float);
+}
+
+extern "C" int dl_conv2d_wgrad_batch_nhwc_f32(const dl_wgrad_layer* layers, int32_t n, void* workspace, dl_stream stream) {
+  if (!workspace) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_wgrad_batch_nhwc_f32: null workspace");
+  std::vector<WgItem> items;
+  const int rc0 = wg_batch_plan(layers, n, items);
+  if (rc0) return rc0;
+  for (int i = 0; i < n; ++i)
+    if (!layers[i].x || !layers[i].g || !layers[i].dw) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_conv2d_wgrad_batch_nhwc_f32: layer %d: null pointer", i);
+  hipStream_t st = (hipStream_t)stream;
+  float* wsf = (float*)workspace;
+  for (auto& it : items) {
+    if (it.a.nslabs > 1) { it.a.part = wsf; wsf += (size_t)it.a.nslabs * it.count; }
+    else it.a.part = it.dw;                               // a single slab is the gradient itself
+  }
+  for (int key = 0; key < 8; ++key) {
+    std::vector<const WgItem*> grp;
+    for (const auto& it : items) if (it.key == key) grp.push_back(&it);
+    if (grp.empty()) continue;
+    std::stable_sort(grp.begin(), grp.end(), [](const WgItem* x, const WgItem* y) { return x->a.chunks_per_slab > y->a.chunks_per_slab; });
+    WgBatchArgs b{};
+    b.n = (int)grp.size();
+    int wgs = 0;
+    double flop = 0, bytes = 0;
+    for (int i = 0; i < b.n; ++i) {
+      b.layer[i] = grp[i]->a;
+      b.first_wg[i] = wgs;
+      wgs += grp[i]->tiles * grp[i]->a.nslabs;
+      flop += grp[i]->flop; bytes += grp[i]->bytes;
+    }
+    b.first_wg[b.n] = wgs;
+    const WgItem& f = *grp[0];
+    const DlProfTag tag{"k_wgrad_f32", b.n > 1 ? "wgrad-batch" : "wgrad", f.a.N, f.a.H, f.a.W, f.a.C, f.a.K, f.ks, f.sh, f.sw, flop, bytes};
+    if (f.ks == 3 && f.sh == 1 && f.sw == 1) launch_wgrad_batch<1, 1, 3>(b, wgs, tag, st);
+    else if (f.ks == 3 && f.sh == 1 && f.sw == 2) launch_wgrad_batch<1, 2, 3>(b, wgs, tag, st);
+    else if (f.ks == 3 && f.sh == 2 && f.sw == 2) launch_wgrad_batch<2, 2, 3>(b, wgs, tag, st);
+    else if (f.ks == 1 && f.sh == 1 && f.sw == 2) launch_wgrad_batch<1, 2, 1>(b, wgs, tag, st);
+    else launch_wgrad_batch<2, 2, 1>(b, wgs, tag, st);
+  }
+  WgReduceBatchArgs r{};
+  int blocks = 0;
+  for (const auto& it : items) if (it.a.nslabs > 1) {
+    r.part[r.n] = it.a.part; r.dw[r.n] = it.dw; r.count[r.n] = (unsigned)it.count; r.nslabs[r.n] = it.a.nslabs;
+    r.first_block[r.n] = blocks;
+    blocks += (int)((it.count / 4 + CV_THREADS - 1) / CV_THREADS);
+    ++r.n;
+  }
+  r.first_block[r.n] = blocks;
+  if (r.n) hipLaunchKernelGGL(k_wgrad_reduce_batch, dim3(blocks), dim3(CV_THREADS), 0, st, r);
+  return dl_check_launch("dl_conv2d_wgrad_batch_nhwc_f32");
 }

@@ -438,14 +438,13 @@ int wgradh_batch_plan(const dl_wgrad_h_layer* L, int n, std::vector<WgradHItem>&
   std::vector<int> keys;
   for (const auto& it : items) if (std::find(keys.begin(), keys.end(), it.key) == keys.end()) keys.push_back(it.key);
   for (int key : keys) {
-    double total = 0;
-    for (const auto& it : items) if (it.key == key) total += (double)it.p.tiles * it.p.total_chunks;
-    long target = (long)((total + g_wh_want - 1) / g_wh_want);
-    if (target < 1) target = 1;
-    for (auto& it : items) if (it.key == key) {
-      int ns = (int)((it.p.total_chunks + target - 1) / target);
-      if (ns < 1) ns = 1;
-      it.p.chunks_per_slab = (it.p.total_chunks + ns - 1) / ns;
+    std::vector<int> tl, ch, idx;
+    for (int i = 0; i < n; ++i) if (items[i].key == key) { tl.push_back(items[i].p.tiles); ch.push_back(items[i].p.total_chunks); idx.push_back(i); }
+    std::vector<int> ns(idx.size());
+    dl_plan_batch(tl.data(), ch.data(), (int)idx.size(), g_wh_want, 10, ns.data());
+    for (size_t j = 0; j < idx.size(); ++j) {
+      WgradHItem& it = items[idx[j]];
+      it.p.chunks_per_slab = (it.p.total_chunks + ns[j] - 1) / ns[j];
       it.p.nslabs = (it.p.total_chunks + it.p.chunks_per_slab - 1) / it.p.chunks_per_slab;
       it.a.chunks_per_slab = it.p.chunks_per_slab; it.a.nslabs = it.p.nslabs;
     }

@@ -597,7 +597,7 @@ struct WWArgs {
 // output-gradient values of pixels outside the image are zeroed in the transform (their tiles then contribute nothing, whatever the
 // wrapped input patch holds), and an odd height masks the input row below the image as well.
 template <bool RAG>
-__global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
+__device__ __forceinline__ void wino_wgrad_body(const WWArgs& a, const int blk) {
   static_assert((2 * WW_BUF + WW_RAW + WW_GRAW) * 4 <= 163840, "LDS budget");
   __shared__ __attribute__((aligned(16))) float lds[2 * WW_BUF + WW_RAW + WW_GRAW];
   float* raw = lds + 2 * WW_BUF;
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
   const int li = lane & 31, half = lane >> 5;
   const int mb = wave & 1, nb = (wave >> 1) & 1, xh = wave >> 2;
   const int CT = a.C / 64;
-  int t = blockIdx.x;
+  int t = blk;
   const int slab = t % a.nslabs; t /= a.nslabs;
   const int ct = t % CT;
   const int kt = t / CT;
@@ -820,18 +820,69 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
   }
 }
 
+template <bool RAG>
+__global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
+  wino_wgrad_body<RAG>(a, blockIdx.x);
+}
+
+// Several layers in one launch (dl_wino_wgrad3x3_batch_nhwc_f32, see include/delora_hip.h): the layer table travels in the kernel
+// arguments, layers ordered by decreasing work per workgroup
+struct WWBatchArgs {
+  WWArgs layer[DL_WGRAD_BATCH];
+  int first_wg[DL_WGRAD_BATCH + 1];
+  int n;
+};
+template <bool RAG>
+__global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad_batch(WWBatchArgs b) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < DL_WGRAD_BATCH; ++i)
+    if (i < b.n && (int)blockIdx.x >= b.first_wg[i]) l = i;
+  const WWArgs a = b.layer[l];
+  wino_wgrad_body<RAG>(a, (int)blockIdx.x - b.first_wg[l]);
+}
+
 // U[xi][k][c] = sum over slabs of ws[slab][xi][k][c] in a fixed order (deterministic), four channels per thread
-__global__ __launch_bounds__(256) void k_wino_wgrad_sum(const float* __restrict__ ws, int nslabs, size_t count4, float* __restrict__ u) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void wino_wgrad_sum_body(const float* __restrict__ ws, int nslabs, size_t count4, float* __restrict__ u, size_t i) {
   if (i >= count4) return;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   for (int sl = 0; sl < nslabs; ++sl) s += reinterpret_cast<const f32x4*>(ws)[(size_t)sl * count4 + i];
   reinterpret_cast<f32x4*>(u)[i] = s;
 }
+__global__ __launch_bounds__(256) void k_wino_wgrad_sum(const float* __restrict__ ws, int nslabs, size_t count4, float* __restrict__ u) {
+  wino_wgrad_sum_body(ws, nslabs, count4, u, (size_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+__device__ __forceinline__ void wino_wgrad_out_body(const float* __restrict__ uu, int K, int C, float* __restrict__ dw, size_t i);
+__global__ __launch_bounds__(256) void k_wino_wgrad_out(const float* __restrict__ uu, int K, int C, float* __restrict__ dw) {
+  wino_wgrad_out_body(uu, K, C, dw, (size_t)blockIdx.x * 256 + threadIdx.x);
+}
+
+// the two small passes for a table of layers in one launch each
+struct WWPostArgs {
+  const float* src[DL_WGRAD_BATCH];      // sum: slab partials; out: the summed Winograd-domain gradient
+  float* dst[DL_WGRAD_BATCH];            // sum: the summed gradient; out: dw
+  int K[DL_WGRAD_BATCH], C[DL_WGRAD_BATCH], nslabs[DL_WGRAD_BATCH];
+  int first_block[DL_WGRAD_BATCH + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void k_wino_wgrad_sum_batch(WWPostArgs b) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < DL_WGRAD_BATCH; ++i)
+    if (i < b.n && (int)blockIdx.x >= b.first_block[i]) l = i;
+  wino_wgrad_sum_body(b.src[l], b.nslabs[l], (size_t)16 * b.K[l] * b.C[l] / 4, b.dst[l], (size_t)((int)blockIdx.x - b.first_block[l]) * 256 + threadIdx.x);
+}
+__global__ __launch_bounds__(256) void k_wino_wgrad_out_batch(WWPostArgs b) {
+  int l = 0;
+#pragma unroll
+  for (int i = 1; i < DL_WGRAD_BATCH; ++i)
+    if (i < b.n && (int)blockIdx.x >= b.first_block[i]) l = i;
+  wino_wgrad_out_body(b.src[l], b.K[l], b.C[l], b.dst[l], (size_t)((int)blockIdx.x - b.first_block[l]) * 256 + threadIdx.x);
+}
 
 // dw[k][r][s][c] = (G^T U G)[r][s]
-__global__ __launch_bounds__(256) void k_wino_wgrad_out(const float* __restrict__ uu, int K, int C, float* __restrict__ dw) {
-  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void wino_wgrad_out_body(const float* __restrict__ uu, int K, int C, float* __restrict__ dw, size_t i) {
   if (i >= (size_t)K * C) return;
   const int k = (int)(i / C), c = (int)(i % C);
   float u[4][4];
@@ -910,6 +961,114 @@ extern "C" int dl_wino_wgrad3x3_nhwc_f32(const float* x, const float* g, float* 
   hipLaunchKernelGGL(k_wino_wgrad_sum, dim3((unsigned)((count4 + 255) / 256)), dim3(256), 0, st, (const float*)ws, nslabs, count4, usum);
   hipLaunchKernelGGL(k_wino_wgrad_out, dim3((unsigned)(((size_t)K * C + 255) / 256)), dim3(256), 0, st, (const float*)usum, K, C, dw);
   return dl_check_launch("dl_wino_wgrad3x3_nhwc_f32");
+}
+
+// ---- several layers in one call
+#include <algorithm>
+#include <vector>
+namespace {
+struct WWItem {
+  WWArgs a;
+  float* dw;
+  float* usum;
+  int tiles, total_chunks, rag;
+  double flop, bytes;
+};
+int ww_batch_plan(const dl_wgrad_layer* L, int n, std::vector<WWItem>& items) {
+  if (!L || n <= 0 || n > DL_WGRAD_BATCH) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wino_wgrad3x3_batch_nhwc_f32: 1..%d layers per call", DL_WGRAD_BATCH);
+  items.resize(n);
+  for (int i = 0; i < n; ++i) {
+    const dl_wgrad_layer& l = L[i];
+    if (l.ksize != 3 || l.stride_h != 1 || l.stride_w != 1 || !ww_supported(l.N, l.H, l.W, l.C, l.K))
+      return dl_fail(DL_ERR_UNSUPPORTED, "dl_wino_wgrad3x3_batch_nhwc_f32: layer %d: N=%d H=%d W=%d C=%d K=%d kernel %d stride (%d,%d) not supported "
+                     "(3x3 stride 1, C, K %% 64, < 2^31 elements)", i, l.N, l.H, l.W, l.C, l.K, l.ksize, l.stride_h, l.stride_w);
+    WWItem& it = items[i];
+    it.a = WWArgs{(const float*)l.x, (const float*)l.g, nullptr, l.N, l.H, l.W, l.C, l.K, 0, 0};
+    it.dw = l.dw;
+    it.tiles = (l.K / 64) * (l.C / 64);
+    it.total_chunks = ww_chunks(l.N, l.H, l.W);
+    it.rag = ww_exact(l.H, l.W) ? 0 : 1;
+    it.flop = 2.0 * 16.0 * (double)l.N * ((l.H + 1) / 2) * ((l.W + 1) / 2) * (double)l.C * l.K;
+    it.bytes = 4.0 * ((double)l.N * l.H * l.W * (l.C + l.K) + 9.0 * l.C * l.K);
+  }
+  for (int rag = 0; rag < 2; ++rag) {
+    std::vector<int> tl, ch, idx;
+    for (int i = 0; i < n; ++i) if (items[i].rag == rag) { tl.push_back(items[i].tiles); ch.push_back(items[i].total_chunks); idx.push_back(i); }
+    if (idx.empty()) continue;
+    std::vector<int> ns(idx.size());
+    dl_plan_batch(tl.data(), ch.data(), (int)idx.size(), 256, 10, ns.data());         // one 512-thread workgroup per CU
+    for (size_t j = 0; j < idx.size(); ++j) {
+      WWItem& it = items[idx[j]];
+      it.a.chunks_per_slab = (it.total_chunks + ns[j] - 1) / ns[j];
+      it.a.nslabs = (it.total_chunks + it.a.chunks_per_slab - 1) / it.a.chunks_per_slab;
+    }
+  }
+  return DL_OK;
+}
+}  // namespace
+
+/* see include/delora_hip.h */
+extern "C" size_t dl_wino_wgrad3x3_batch_workspace_bytes(const dl_wgrad_layer* layers, int32_t n) {
+  std::vector<WWItem> items;
+  if (ww_batch_plan(layers, n, items)) return 0;
+  size_t floats = 0;
+  for (const auto& it : items) floats += ((size_t)(it.a.nslabs > 1 ? it.a.nslabs : 0) + 1) * 16 * it.a.K * it.a.C;
+  return floats * sizeof(float);
+}
+
+extern "C" int dl_wino_wgrad3x3_batch_nhwc_f32(const dl_wgrad_layer* layers, int32_t n, void* workspace, dl_stream stream) {
+  if (!workspace) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wino_wgrad3x3_batch_nhwc_f32: null workspace");
+  std::vector<WWItem> items;
+  const int rc0 = ww_batch_plan(layers, n, items);
+  if (rc0) return rc0;
+  for (int i = 0; i < n; ++i)
+    if (!layers[i].x || !layers[i].g || !layers[i].dw) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wino_wgrad3x3_batch_nhwc_f32: layer %d: null pointer", i);
+  hipStream_t st = (hipStream_t)stream;
+  float* wsf = (float*)workspace;
+  for (auto& it : items) {                               // [slab partials (only when split)] [their sum]
+    const size_t plane = (size_t)16 * it.a.K * it.a.C;
+    if (it.a.nslabs > 1) { it.a.ws = wsf; wsf += (size_t)it.a.nslabs * plane; it.usum = wsf; wsf += plane; }
+    else { it.a.ws = wsf; it.usum = wsf; wsf += plane; }  // a single slab IS the sum
+  }
+  for (int rag = 0; rag < 2; ++rag) {
+    std::vector<const WWItem*> grp;
+    for (const auto& it : items) if (it.rag == rag) grp.push_back(&it);
+    if (grp.empty()) continue;
+    std::stable_sort(grp.begin(), grp.end(), [](const WWItem* x, const WWItem* y) { return x->a.chunks_per_slab > y->a.chunks_per_slab; });
+    WWBatchArgs b{};
+    b.n = (int)grp.size();
+    int wgs = 0;
+    double flop = 0, bytes = 0;
+    for (int i = 0; i < b.n; ++i) {
+      b.layer[i] = grp[i]->a;
+      b.first_wg[i] = wgs;
+      wgs += grp[i]->tiles * grp[i]->a.nslabs;
+      flop += grp[i]->flop; bytes += grp[i]->bytes;
+    }
+    b.first_wg[b.n] = wgs;
+    const WWArgs& f = grp[0]->a;
+    const DlProfTag tag{"k_wino_wgrad", b.n > 1 ? "wgrad-batch" : "wgrad", f.N, f.H, f.W, f.C, f.K, 3, 1, 1, flop, bytes};
+    if (rag) DL_LAUNCH(tag, k_wino_wgrad_batch<true>, dim3(wgs), dim3(WW_THREADS), st, b);
+    else DL_LAUNCH(tag, k_wino_wgrad_batch<false>, dim3(wgs), dim3(WW_THREADS), st, b);
+  }
+  WWPostArgs sum{}, out{};
+  int sum_blocks = 0, out_blocks = 0;
+  for (const auto& it : items) {
+    if (it.a.nslabs > 1) {
+      sum.src[sum.n] = it.a.ws; sum.dst[sum.n] = it.usum; sum.K[sum.n] = it.a.K; sum.C[sum.n] = it.a.C; sum.nslabs[sum.n] = it.a.nslabs;
+      sum.first_block[sum.n] = sum_blocks;
+      sum_blocks += (int)(((size_t)16 * it.a.K * it.a.C / 4 + 255) / 256);
+      ++sum.n;
+    }
+    out.src[out.n] = it.usum; out.dst[out.n] = it.dw; out.K[out.n] = it.a.K; out.C[out.n] = it.a.C;
+    out.first_block[out.n] = out_blocks;
+    out_blocks += (int)(((size_t)it.a.K * it.a.C + 255) / 256);
+    ++out.n;
+  }
+  sum.first_block[sum.n] = sum_blocks; out.first_block[out.n] = out_blocks;
+  if (sum.n) hipLaunchKernelGGL(k_wino_wgrad_sum_batch, dim3(sum_blocks), dim3(256), 0, st, sum);
+  hipLaunchKernelGGL(k_wino_wgrad_out_batch, dim3(out_blocks), dim3(256), 0, st, out);
+  return dl_check_launch("dl_wino_wgrad3x3_batch_nhwc_f32");
 }
 
 extern "C" int dl_wino_conv3x3_nhwc_f32(const float* x, const float* u, float* y, const float* add, const float* dsrc,

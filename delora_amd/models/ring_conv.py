@@ -119,6 +119,62 @@ def wgrad_nhwc(x, g, ks, stride=(1, 1)):
     return dw
 
 
+def _wgrad_layer_table(part):
+    """ctypes table of ``dl_wgrad_layer`` for (x, g, ks, stride) items + the freshly allocated fp32 ``dW [K,k,k,C]`` of each."""
+    arr = (_lib.WgradLayer * len(part))()
+    dws = []
+    for j, (x, g, ks, stride) in enumerate(part):
+        N, H, W, C = x.shape
+        K = g.shape[3]
+        dw = torch.empty((K, ks, ks, C), dtype=torch.float32, device=x.device)
+        dws.append(dw)
+        arr[j].x, arr[j].g, arr[j].dw = x.data_ptr(), g.data_ptr(), dw.data_ptr()
+        arr[j].N, arr[j].H, arr[j].W, arr[j].C, arr[j].K = N, H, W, C, K
+        arr[j].ksize, arr[j].stride_h, arr[j].stride_w = ks, stride[0], stride[1]
+    return arr, dws
+
+
+def _wgrad_batch_call(items, size_fn, run_fn, what, *extra):
+    lib = _lib.load()
+    out = []
+    for i0 in range(0, len(items), _lib.WGRAD_BATCH):
+        part = items[i0:i0 + _lib.WGRAD_BATCH]
+        arr, dws = _wgrad_layer_table(part)
+        ap = ctypes.cast(arr, ctypes.c_void_p)
+        nbytes = getattr(lib, size_fn)(ap, len(part))
+        if not nbytes:
+            raise _lib.DeloraHipError(what + ": " + (lib.dl_last_error() or b"").decode())
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=part[0][0].device)
+        _lib.check(getattr(lib, run_fn)(ap, len(part), _ptr(ws), *extra, _stream()), what)
+        out += dws
+    return out
+
+
+def wgrad_batch(items):
+    """The fp32 weight gradients of several layers in merged launches (include/delora_hip.h: ``dl_wgrad_layer``): ``items`` = list of
+    (x, g, ks, stride); returns ``dW [K,k,k,C]`` per item.  Stride-1 3x3 layers with at least 128 input channels take the Winograd-domain
+    kernel (as ``wgrad_nhwc`` decides), the rest the direct one; within each family the layers that share a kernel run in ONE launch
+    with far fewer pixel slabs (fp32 partial copies of the gradient) per layer than a launch of their own needs."""
+    lib = _lib.load()
+    wino, direct = [], []
+    for i, (x, g, ks, stride) in enumerate(items):
+        N, H, W, C = x.shape
+        if (USE_WINOGRAD_WGRAD and ks == 3 and tuple(stride) == (1, 1) and C >= 128 and lib.dl_wino_wgrad_workspace_bytes(N, H, W, C, g.shape[3])):
+            wino.append(i)
+        else:
+            direct.append(i)
+    out = [None] * len(items)
+    if wino:
+        for i, dw in zip(wino, _wgrad_batch_call([items[i] for i in wino], "dl_wino_wgrad3x3_batch_workspace_bytes", "dl_wino_wgrad3x3_batch_nhwc_f32",
+                                                 "dl_wino_wgrad3x3_batch_nhwc_f32")):
+            out[i] = dw
+    if direct:
+        for i, dw in zip(direct, _wgrad_batch_call([items[i] for i in direct], "dl_conv2d_wgrad_batch_workspace_bytes", "dl_conv2d_wgrad_batch_nhwc_f32",
+                                                   "dl_conv2d_wgrad_batch_nhwc_f32")):
+            out[i] = dw
+    return out
+
+
 def wino_ok(H, W, C, K):
     """Whether the fused Winograd F(2x2,3x3) kernel (csrc/wino.hip) takes a stride-1 3x3 layer of this shape: any image size (groups
     of 64 tiles hang over the edge of images that do not divide; odd sizes end in partial tiles), channel counts that tile."""
@@ -413,19 +469,22 @@ class RingSegment(torch.autograd.Function):
             elif act == ACT["relu"]:
                 g2 = g2 * (y_last > 0).to(g2.dtype)
         wi = len(weights)
+        # The weight gradients do not feed the chain of input gradients: they are collected (x, g stay alive) and computed together at
+        # the end of the segment -- merged launches need far fewer slab partials than one launch per layer (wgrad_batch)
+        pending = []
         for b in range(nb - 1, -1, -1):
             cin, cout, stride, has_ds = blocks[b]
             wi -= 3 if has_ds else 2
             w1p, w2p = weights[wi], weights[wi + 1]
             x, y1 = acts[2 * b], acts[2 * b + 1]
             first = ctx.first and b == 0                    # x0 is the pooled stem output: its act' belongs to the stem
-            grads[wi + 1] = grad_for(wgrad_nhwc(y1, g2, 3), w2p)
+            pending.append((wi + 1, (y1, g2, 3, (1, 1))))
             ub1, ub2 = ubwd[2 * b], ubwd[2 * b + 1]
             if ub2 is not None:
                 g1 = wino_conv(g2, ub2, cout, act=act, epilogue=EPI_DACT, dsrc=y1)
             else:
                 g1 = conv_nhwc(g2, weight_storage(w2p), act=act, epilogue=EPI_DACT, dsrc=y1, transposed=True)
-            grads[wi] = grad_for(wgrad_nhwc(x, g1, 3, stride=stride), w1p)
+            pending.append((wi, (x, g1, 3, stride)))
             if not has_ds:
                 epi = EPI_ADD if first else (EPI_ADD | EPI_DACT)
                 if ub1 is not None:
@@ -434,11 +493,17 @@ class RingSegment(torch.autograd.Function):
                     g2 = conv_nhwc(g1, weight_storage(w1p), act=act, epilogue=epi, add=g2, dsrc=None if first else x, transposed=True)
             else:
                 wdp = weights[wi + 2]
-                grads[wi + 2] = grad_for(wgrad_nhwc(x, g2, 1, stride=stride), wdp)
+                pending.append((wi + 2, (x, g2, 1, stride)))
                 # down-sampling branch on the grid, then one pass per stride phase of the 3x3 layer with it and act'(x) fused
                 dxb = dgrad_strided(g2, weight_storage(wdp), stride, x.shape[1:3], dense=True)
                 epi = EPI_ADD_GRID if first else (EPI_ADD_GRID | EPI_DACT)
                 g2 = dgrad_strided(g1, weight_storage(w1p), stride, x.shape[1:3], act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)
+        if WGRAD_BATCHED:
+            for (gi, _), dw in zip(pending, wgrad_batch([it for _, it in pending])):
+                grads[gi] = grad_for(dw, weights[gi])
+        else:
+            for gi, (xx, gg, ks, st) in pending:
+                grads[gi] = grad_for(wgrad_nhwc(xx, gg, ks, stride=st), weights[gi])
         if BACKWARD_TRACE is not None:
             BACKWARD_TRACE.append(("segment", blocks[0][0], blocks[-1][1], nb))
         return (g2, None, None, None, None, *grads)
@@ -559,26 +624,8 @@ def wgrad_batch_h(items):
     half-precision channels-last x / g; returns the fp32 ``dW [K,k,k,C]`` of every item.  Layers that share a kernel run in ONE launch
     and need far fewer pixel slabs each than a launch of their own would (include/delora_hip.h); the caller keeps x and g alive until
     the call -- ``RingSegmentH.backward`` defers the gradients of a whole segment to its end."""
-    lib = _lib.load()
-    out = [None] * len(items)
-    for i0 in range(0, len(items), _lib.WGRAD_BATCH):
-        part = items[i0:i0 + _lib.WGRAD_BATCH]
-        arr = (_lib.WgradHLayer * len(part))()
-        for j, (x, g, ks, stride) in enumerate(part):
-            N, H, W, C = x.shape
-            K = g.shape[3]
-            dw = torch.empty((K, ks, ks, C), dtype=torch.float32, device=x.device)
-            out[i0 + j] = dw
-            arr[j].x, arr[j].g, arr[j].dw = x.data_ptr(), g.data_ptr(), dw.data_ptr()
-            arr[j].N, arr[j].H, arr[j].W, arr[j].C, arr[j].K = N, H, W, C, K
-            arr[j].ksize, arr[j].stride_h, arr[j].stride_w = ks, stride[0], stride[1]
-        ap = ctypes.cast(arr, ctypes.c_void_p)
-        nbytes = lib.dl_conv2d_wgrad_batch_h_workspace_bytes(ap, len(part))
-        if not nbytes:
-            raise _lib.DeloraHipError("dl_conv2d_wgrad_batch_nhwc_h: " + (lib.dl_last_error() or b"").decode())
-        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=part[0][0].device)
-        _lib.check(lib.dl_conv2d_wgrad_batch_nhwc_h(ap, len(part), _ptr(ws), DTYPE_CODE[part[0][0].dtype], _stream()), "dl_conv2d_wgrad_batch_nhwc_h")
-    return out
+    return _wgrad_batch_call(items, "dl_conv2d_wgrad_batch_h_workspace_bytes", "dl_conv2d_wgrad_batch_nhwc_h", "dl_conv2d_wgrad_batch_nhwc_h",
+                             DTYPE_CODE[items[0][0].dtype])
 
 
 def supported_h(x_shape, blocks):

