@@ -155,11 +155,13 @@ def wgrad_batch(items):
     (x, g, ks, stride); returns ``dW [K,k,k,C]`` per item.  Stride-1 3x3 layers with at least 128 input channels take the Winograd-domain
     kernel (as ``wgrad_nhwc`` decides), the rest the direct one; within each family the layers that share a kernel run in ONE launch
     with far fewer pixel slabs (fp32 partial copies of the gradient) per layer than a launch of their own needs."""
-    lib = _lib.load()
     wino, direct = [], []
     for i, (x, g, ks, stride) in enumerate(items):
         N, H, W, C = x.shape
-        if (USE_WINOGRAD_WGRAD and ks == 3 and tuple(stride) == (1, 1) and C >= 128 and lib.dl_wino_wgrad_workspace_bytes(N, H, W, C, g.shape[3])):
+        K = g.shape[3]
+        # (the shape rule of dl_wino_wgrad_workspace_bytes, restated here: one library call per layer and step is host time)
+        if (USE_WINOGRAD_WGRAD and ks == 3 and tuple(stride) == (1, 1) and C >= 128 and C % 64 == 0 and K % 64 == 0 and W >= 2
+                and N * H * W * max(C, K) < 2 ** 31 and H * W * max(C, K) < 2 ** 30):
             wino.append(i)
         else:
             direct.append(i)
