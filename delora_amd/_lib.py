@@ -86,6 +86,7 @@ SIGNATURES = {
     "dl_mean_hw_bwd_act_h": (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "dl_conv2d_wgrad_h_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "dl_conv2d_wgrad_nhwc_h": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "dl_wgrad_batch_plan": (_i64, [_vp, _vp, _i32, _i32, _i32, _vp]),
     "dl_wino_wgrad3x3_batch_workspace_bytes": (_sz, [_vp, _i32]),
     "dl_wino_wgrad3x3_batch_nhwc_f32": (_i32, [_vp, _i32, _vp, _vp]),
     "dl_conv2d_wgrad_batch_workspace_bytes": (_sz, [_vp, _i32]),

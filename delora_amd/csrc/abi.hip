@@ -117,6 +117,29 @@ void dl_plan_batch(const int* tiles, const int* chunks, int n, int machines, int
   if (g_plan_cache.size() < 4096) g_plan_cache[key] = best;
 }
 
+/* see include/delora_hip.h */
+extern "C" int64_t dl_wgrad_batch_plan(const int32_t* tiles, const int32_t* chunks, int32_t n, int32_t slots, int32_t partial_cost, int32_t* nslabs) {
+  if (!tiles || !chunks || !nslabs || n <= 0 || n > DL_WGRAD_BATCH || slots <= 0 || partial_cost < 0)
+    return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wgrad_batch_plan: bad argument (1..%d layers)", DL_WGRAD_BATCH);
+  for (int i = 0; i < n; ++i)
+    if (tiles[i] <= 0 || chunks[i] <= 0) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wgrad_batch_plan: layer %d: tiles and chunks must be positive", i);
+  dl_plan_batch(tiles, chunks, n, slots, partial_cost, nslabs);
+  // the makespan of the chosen plan (same simulation as the planner's, without the partial term)
+  std::vector<std::pair<long, long>> runs;
+  for (int i = 0; i < n; ++i) runs.push_back({((long)chunks[i] + nslabs[i] - 1) / nslabs[i], (long)tiles[i] * nslabs[i]});
+  std::sort(runs.begin(), runs.end(), [](const std::pair<long, long>& a, const std::pair<long, long>& b) { return a.first > b.first; });
+  std::priority_queue<long, std::vector<long>, std::greater<long>> free_at;
+  for (int m = 0; m < slots; ++m) free_at.push(0);
+  long makespan = 0;
+  for (const auto& r : runs)
+    for (long u = 0; u < r.second; ++u) {
+      const long t = free_at.top() + r.first;
+      free_at.pop(); free_at.push(t);
+      makespan = std::max(makespan, t);
+    }
+  return makespan;
+}
+
 extern "C" int dl_abi_version(void) { return DL_ABI_VERSION; }
 extern "C" const char* dl_last_error(void) { return g_dl_err; }
 

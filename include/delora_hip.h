@@ -346,6 +346,11 @@ typedef struct dl_wgrad_layer {
   float* dw;            /* [K][ksize][ksize][C] fp32 */
   int32_t N, H, W, C, K, ksize, stride_h, stride_w;
 } dl_wgrad_layer;
+/* The slab plan of such a merged launch, for inspection and tests (host only, no GPU needed): n layers with tiles[i] output tiles and
+ * chunks[i] equal-cost pixel chunks per tile, `slots` workgroups running at a time, every slab beyond a tile's only one costing
+ * `partial_cost` chunks' worth of time -> nslabs[i]; returns the simulated makespan in chunks (workgroups dispatched by decreasing
+ * slab size, each to the first free slot), or a negative status. */
+int64_t dl_wgrad_batch_plan(const int32_t* tiles, const int32_t* chunks, int32_t n, int32_t slots, int32_t partial_cost, int32_t* nslabs);
 size_t dl_wino_wgrad3x3_batch_workspace_bytes(const dl_wgrad_layer* layers, int32_t n);
 int dl_wino_wgrad3x3_batch_nhwc_f32(const dl_wgrad_layer* layers, int32_t n, void* workspace, dl_stream stream);
 size_t dl_conv2d_wgrad_batch_workspace_bytes(const dl_wgrad_layer* layers, int32_t n);

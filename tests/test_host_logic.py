@@ -725,3 +725,37 @@ def test_graphed_step_runs_the_eager_step_when_capture_is_not_possible(blocker):
     assert all(isinstance(b, list) and not isinstance(b, step_geometry.PackedBatch) for b in tr.seen)
     with pytest.raises(ValueError):
         g(None)
+
+
+def test_slab_plan_of_the_merged_weight_gradient_launches():
+    """dl_wgrad_batch_plan (host only): the slab counts the merged weight-gradient launches use.  For the layer groups of
+    the network at 64x2048, batch 8: every layer gets between 1 and `chunks` slabs, the simulated makespan stays within 10 % of the even
+    share, far fewer slabs than one launch per layer needs, and the plan is reproducible (memoised)."""
+    import ctypes
+    from delora_amd import _lib
+    lib = _lib.load()
+
+    def plan(tiles, chunks, slots, cost):
+        n = len(tiles)
+        t, c, ns = (ctypes.c_int32 * n)(*tiles), (ctypes.c_int32 * n)(*chunks), (ctypes.c_int32 * n)()
+        mk = lib.dl_wgrad_batch_plan(ctypes.cast(t, ctypes.c_void_p), ctypes.cast(c, ctypes.c_void_p), n, slots, cost, ctypes.cast(ns, ctypes.c_void_p))
+        assert mk > 0, lib.dl_last_error()
+        return list(ns), mk
+
+    groups = {  # name: (tiles, chunks, slots, partial cost)
+        "fp32 Winograd-domain, layer2-4": ([4] * 3 + [16] * 3 + [64] * 3, [4096] * 3 + [2048] * 3 + [512] * 3, 256, 10),
+        "bf16 stride-1 >= 128 channels": ([2] * 3 + [8] * 3 + [32] * 3, [1024] * 3 + [512] * 3 + [128] * 3, 256, 10),
+        "fp32 direct, layer1": ([1] * 4, [8192] * 4, 512, 20),
+        "fp32 direct, stride (1,2)": ([2, 8], [8192, 4096], 512, 20),
+    }
+    for name, (tiles, chunks, slots, cost) in groups.items():
+        ns, mk = plan(tiles, chunks, slots, cost)
+        share = sum(t * c for t, c in zip(tiles, chunks)) / slots
+        assert all(1 <= a <= c for a, c in zip(ns, chunks)), (name, ns)
+        assert mk <= 1.10 * share, (name, ns, mk, share)
+        alone = [max(1, min(c, -(-slots // t))) for t, c in zip(tiles, chunks)]       # slabs of a launch per layer
+        assert sum(t * a for t, a in zip(tiles, ns)) <= 0.6 * sum(t * a for t, a in zip(tiles, alone)), (name, ns, alone)
+        assert plan(tiles, chunks, slots, cost) == (ns, mk)
+    assert plan([4] * 3 + [16] * 3 + [64] * 3, [4096] * 3 + [2048] * 3 + [512] * 3, 256, 10)[0] == [4, 4, 4, 2, 2, 2, 1, 1, 1]
+    n1 = (ctypes.c_int32 * 1)(0)
+    assert lib.dl_wgrad_batch_plan(ctypes.cast(n1, ctypes.c_void_p), ctypes.cast(n1, ctypes.c_void_p), 1, 256, 10, ctypes.cast(n1, ctypes.c_void_p)) < 0
