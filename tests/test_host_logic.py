@@ -759,3 +759,32 @@ def test_slab_plan_of_the_merged_weight_gradient_launches():
     assert plan([4] * 3 + [16] * 3 + [64] * 3, [4096] * 3 + [2048] * 3 + [512] * 3, 256, 10)[0] == [4, 4, 4, 2, 2, 2, 1, 1, 1]
     n1 = (ctypes.c_int32 * 1)(0)
     assert lib.dl_wgrad_batch_plan(ctypes.cast(n1, ctypes.c_void_p), ctypes.cast(n1, ctypes.c_void_p), 1, 256, 10, ctypes.cast(n1, ctypes.c_void_p)) < 0
+
+
+def test_merged_weight_gradients_are_routed_like_the_single_launches(monkeypatch):
+    """ring_conv.wgrad_batch (host logic, no GPU): stride-1 3x3 layers with at least 128 input channels go to the Winograd-domain batch,
+    everything else to the direct batch -- the rule of wgrad_nhwc --, results come back in the order of the items, and with
+    USE_WINOGRAD_WGRAD off everything takes the direct kernel."""
+    import torch
+    from delora_amd.models import ring_conv as rc
+    calls = []
+
+    def fake(items, size_fn, run_fn, what, *extra):
+        calls.append((run_fn, [tuple(x.shape) + (ks,) + tuple(st) for x, g, ks, st in items]))
+        return [("dw", run_fn, tuple(x.shape), ks, tuple(st)) for x, g, ks, st in items]
+
+    monkeypatch.setattr(rc, "_wgrad_batch_call", fake)
+    shapes = [(2, 8, 64, 128, 128, 3, (1, 1)), (2, 8, 64, 64, 64, 3, (1, 1)), (2, 8, 64, 128, 256, 3, (1, 2)), (2, 8, 64, 256, 256, 3, (1, 1)),
+              (2, 8, 64, 128, 256, 1, (1, 2)), (2, 8, 64, 64, 128, 3, (1, 1))]
+    items = [(torch.empty((N, H, W, C)), torch.empty((N, rc.out_size(H, st[0]), rc.out_size(W, st[1]), K)), ks, st) for (N, H, W, C, K, ks, st) in shapes]
+    out = rc.wgrad_batch(items)
+    by_fn = dict(calls)
+    assert [s[3] for s in by_fn["dl_wino_wgrad3x3_batch_nhwc_f32"]] == [128, 256]                       # input channels of the two Winograd layers
+    assert len(by_fn["dl_conv2d_wgrad_batch_nhwc_f32"]) == 4
+    for (N, H, W, C, K, ks, st), o in zip(shapes, out):
+        wino = ks == 3 and st == (1, 1) and C >= 128
+        assert o == ("dw", "dl_wino_wgrad3x3_batch_nhwc_f32" if wino else "dl_conv2d_wgrad_batch_nhwc_f32", (N, H, W, C), ks, st)
+    calls.clear()
+    monkeypatch.setattr(rc, "USE_WINOGRAD_WGRAD", False)
+    rc.wgrad_batch(items)
+    assert [fn for fn, _ in calls] == ["dl_conv2d_wgrad_batch_nhwc_f32"] and len(calls[0][1]) == 6
