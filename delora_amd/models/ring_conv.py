@@ -160,7 +160,7 @@ def wgrad_batch(items):
         N, H, W, C = x.shape
         K = g.shape[3]
         # (the shape rule of dl_wino_wgrad_workspace_bytes, restated here: one library call per layer and step is host time)
-        if (USE_WINOGRAD_WGRAD and ks == 3 and tuple(stride) == (1, 1) and C >= 128 and C % 64 == 0 and K % 64 == 0 and W >= 2
+        if (USE_WINOGRAD_WGRAD and ks == 3 and tuple(stride) == (1, 1) and C >= WINO_WGRAD_MIN_C_BATCHED and C % 64 == 0 and K % 64 == 0 and W >= 2
                 and N * H * W * max(C, K) < 2 ** 31 and H * W * max(C, K) < 2 ** 30):
             wino.append(i)
         else:
@@ -373,6 +373,10 @@ class RingStem(torch.autograd.Function):
 #            rest of the backward runs -- what deploy/trainer.py selects under DDP
 #   "block"  one Function per residual block
 TRUNK_SEGMENTS = "mono"
+# Fewest input channels of a stride-1 3x3 layer whose weight gradient takes the Winograd-domain kernel inside a merged launch.  A single
+# launch keeps 128 (wgrad_nhwc): a 64-channel layer has ONE output tile, i.e. 256 slab partials of 262 KB each -- the direct kernel won.
+# Merged with the other layers of the segment it needs 64 slabs, and 2.25x fewer multiplications decide (A/B in DESIGN.md 4.6).
+WINO_WGRAD_MIN_C_BATCHED = int(os.environ.get("DELORA_WINO_WGRAD_MIN_C", "64"))
 # Weight gradients of a segment in merged launches at its end (wgrad_batch_h) instead of one launch per layer inside the chain
 WGRAD_BATCHED = os.environ.get("DELORA_WGRAD_BATCHED", "1") != "0"      # (0: one launch per layer, for A/B measurements)
 # Order in which the segment Functions finished their backward passes in this process (tests: DDP overlap) -- appended to when a list

@@ -762,8 +762,8 @@ def test_slab_plan_of_the_merged_weight_gradient_launches():
 
 
 def test_merged_weight_gradients_are_routed_like_the_single_launches(monkeypatch):
-    """ring_conv.wgrad_batch (host logic, no GPU): stride-1 3x3 layers with at least 128 input channels go to the Winograd-domain batch,
-    everything else to the direct batch -- the rule of wgrad_nhwc --, results come back in the order of the items, and with
+    """ring_conv.wgrad_batch (host logic, no GPU): stride-1 3x3 layers go to the Winograd-domain batch (from 64 input channels on: the rule
+    of wgrad_nhwc is 128, a merged launch lowers it), everything else to the direct batch, results come back in the order of the items, and with
     USE_WINOGRAD_WGRAD off everything takes the direct kernel."""
     import torch
     from delora_amd.models import ring_conv as rc
@@ -779,10 +779,11 @@ def test_merged_weight_gradients_are_routed_like_the_single_launches(monkeypatch
     items = [(torch.empty((N, H, W, C)), torch.empty((N, rc.out_size(H, st[0]), rc.out_size(W, st[1]), K)), ks, st) for (N, H, W, C, K, ks, st) in shapes]
     out = rc.wgrad_batch(items)
     by_fn = dict(calls)
-    assert [s[3] for s in by_fn["dl_wino_wgrad3x3_batch_nhwc_f32"]] == [128, 256]                       # input channels of the two Winograd layers
-    assert len(by_fn["dl_conv2d_wgrad_batch_nhwc_f32"]) == 4
+    assert rc.WINO_WGRAD_MIN_C_BATCHED == 64        # (inside a merged launch the 64-channel layers take the Winograd-domain kernel too)
+    assert [s[3] for s in by_fn["dl_wino_wgrad3x3_batch_nhwc_f32"]] == [128, 64, 256, 64]               # input channels of the Winograd layers
+    assert len(by_fn["dl_conv2d_wgrad_batch_nhwc_f32"]) == 2
     for (N, H, W, C, K, ks, st), o in zip(shapes, out):
-        wino = ks == 3 and st == (1, 1) and C >= 128
+        wino = ks == 3 and st == (1, 1) and C >= 64
         assert o == ("dw", "dl_wino_wgrad3x3_batch_nhwc_f32" if wino else "dl_conv2d_wgrad_batch_nhwc_f32", (N, H, W, C), ks, st)
     calls.clear()
     monkeypatch.setattr(rc, "USE_WINOGRAD_WGRAD", False)
