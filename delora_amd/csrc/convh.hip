@@ -11,7 +11,8 @@
 //  * operands reach LDS by DMA only (global_load_lds, 16 bytes per lane, no registers, no staging instructions); the image
 //    in LDS is linear in the lane id as the instruction requires, every layout decision -- wrap-around column, stride phase
 //    planes, the XOR swizzle that makes the fragment reads bank-conflict free -- is made on the per-lane SOURCE address;
-//    rows above / below the image are lanes switched off (the DMA leaves their LDS bytes untouched: zeroed once);
+//    rows above / below the image (and the columns beyond the edge of a pass that does not wrap) are lanes whose source address is a
+//    page of zeros -- every lane of every DMA instruction is active, so a wave issues the same number of them in every step;
 //  * forward / input gradient (k_convh): a workgroup owns BM = TH x TW output pixels x BN output channels and walks the
 //    reduction in steps of (32 input channels) x (one row of taps): per step 41 KB of DMA against 384 MFMAs (BM 512, BN 128);
 //    the input halo tile of a channel chunk is staged ONCE for all nine taps (taps read it at shifted pixel offsets), the
