@@ -299,14 +299,15 @@ def disk_feed_leg(args, cfg, device, tree, run_step, timed_region, resident_pair
             while True:
                 for b in pf:
                     yield b
+        # the yardstick: the same step on the same data, resident -- one epoch of the feed's batches kept on the device (taken BEFORE the
+        # endless iterator starts: a feed serves one consumer at a time)
+        kept = [b for b in pf]
         it = epochs()
 
         def fed_step():
             return run_step(next(it))
         for _ in range(max(3, 2 * len(pf))):                     # workers up, page cache and allocator primed with this data's sizes
             fed_step()
-        # the yardstick: the same step on the same data, resident -- one epoch of the feed's batches kept on the device
-        kept = [b for b in pf]
         k = {"i": 0}
 
         def resident_step():

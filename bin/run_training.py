@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Training entry point with the reference's command line (bin/run_training.py:14-21):
 
-    python bin/run_training.py --training_run_name NAME [--experiment_name EXP] [--checkpoint FILE]
+    python bin/run_training.py --training_run_name NAME [--experiment_name EXP] [--checkpoint FILE] [--max_epochs N]
 
 reads config/*.yaml relative to the working directory.  Multi-GPU: launch the same command through
 ``python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 bin/run_training.py ...``
@@ -25,8 +25,11 @@ import deploy.trainer  # noqa: E402
               help="The name under which the run can be found afterwards.")
 @click.option("--experiment_name", help="High-level training sequence name for clustering in MLFlow.", default="")
 @click.option("--checkpoint", help="Path to the saved checkpoint. Leave empty if none.", default="")
-def config(training_run_name, experiment_name, checkpoint):
+@click.option("--max_epochs", type=int, default=10000, show_default=True,
+              help="Stop after this many epochs (the reference trains its 10000 epochs until interrupted, src/deploy/trainer.py:93).")
+def config(training_run_name, experiment_name, checkpoint, max_epochs):
     cfg = delora_amd.config.training_config(training_run_name, experiment_name, checkpoint)
+    cfg["max_epochs"] = int(max_epochs)
     print("----------------------------------")
     print("Configuration for this run: ")
     print(cfg)
@@ -40,5 +43,4 @@ if __name__ == "__main__":
         torch.distributed.init_process_group(backend="nccl")
     cfg = config(standalone_mode=False)
     trainer = deploy.trainer.Trainer(config=cfg)
-    # the reference trains until it is interrupted (src/deploy/trainer.py:93-186: 10000 epochs); DELORA_MAX_EPOCHS bounds a run (tests, CI)
-    trainer.train(max_epochs=int(os.environ.get("DELORA_MAX_EPOCHS", "10000")))
+    trainer.train(max_epochs=cfg.pop("max_epochs"))

@@ -10,7 +10,7 @@ _SUBMODULES = {
     "deploy": ("deployer", "trainer", "tester", "step_geometry"), "utility": ("projection", "poses"), "losses": ("icp_losses",),
     "models": ("model", "model_parts", "resnet_modified"), "preprocessing": ("normal_computation", "preprocesser"),
     "data": ("dataset", "synthetic", "feed", "kitti_scans"),
-    "ros_utils": ("odometry",),            # odometry_publisher needs ROS and is imported on demand
+    "ros_utils": ("odometry",),            # the ROS-free inference core only: the ROS node itself is out of scope and not built
 }
 
 for _name in _NAMES:

@@ -102,7 +102,8 @@ def testing_config(testing_run_name, experiment_name="testing", checkpoint="", c
 
 
 def rosnode_config(checkpoint, dataset, lidar_topic, lidar_frame, integrate_odometry=True, config_dir="config"):
-    """The dict ``bin/run_rosnode.py`` hands to ``OdometryPublisher`` (reference bin/run_rosnode.py:27-71)."""
+    """The dict the reference's ``bin/run_rosnode.py`` (:27-71) builds; here it configures ``ros_utils.odometry.ScanToScanOdometry``, the
+    ROS-free core of that node.  The ROS node itself (publishers, TF, message conversion) is out of scope and not built."""
     cfg = load_yaml_config(config_dir)
     cfg["mode"] = "training"
     if cfg["use_dropout"]:

@@ -45,7 +45,17 @@ class PreprocessedPointCloudDataset(torch.utils.data.Dataset):
                 scans = sorted(glob.glob(os.path.join(root, "scans/", "*.npy")))
                 normals = sorted(glob.glob(os.path.join(root, "normals/", "*.npy"))) if self.load_normals else []
                 if self.load_normals and not normals and not os.path.isdir(os.path.join(root, "normals")):
-                    self.load_normals = False                                   # an xyz-only tree
+                    # an xyz-only tree.  The mode holds for the WHOLE dataset and is decided by the first sequence: a later sequence
+                    # without normals/ next to earlier ones that have them would silently drop stored normals (advisor, round 4)
+                    if table:
+                        raise Exception("The sequence " + root + " has no normals/ directory but earlier sequences do: mixed trees are "
+                                        "not supported (set load_normal_lists: false to train every sequence with online normals).")
+                    self.load_normals = False
+                    print("Dataset: " + root + " holds no stored normal lists -- xyz-only mode, normals are estimated online for every sequence.")
+                if not self.load_normals and bool(config.get("load_normal_lists", True)) and os.path.isdir(os.path.join(root, "normals")) \
+                        and glob.glob(os.path.join(root, "normals/", "*.npy")):
+                    raise Exception("The sequence " + root + " holds stored normal lists but an earlier sequence does not: mixed trees "
+                                    "are not supported (set load_normal_lists: false to ignore them).")
                 if self.load_normals and len(normals) != len(scans):
                     raise Exception("The sequence " + root + " holds " + str(len(scans)) + " scans but " + str(len(normals)) + " normal lists.")
                 scans_seq.append(scans)

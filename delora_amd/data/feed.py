@@ -143,6 +143,7 @@ class PackedFeed:
         self.host_seconds = {"wait_for_workers": 0.0, "upload_enqueue": 0.0, "reclaim": 0.0}      # where the consumer's time goes
         self._outstanding = 0                       # tasks handed to the workers whose result has not been received yet
         self._uploads = []                          # (event, slot): copies of an abandoned epoch still in flight
+        self._generation = 0                        # one consumer at a time: starting an epoch invalidates the iterators before it
 
     def __len__(self):
         return len(self.batch_sampler)
@@ -202,6 +203,11 @@ class PackedFeed:
         self._uploads = []
 
     def __iter__(self):
+        """One epoch.  SINGLE consumer: the worker queues, the slots and the uploads in flight belong to the feed, not to the iterator, so
+        starting a new epoch while an earlier iterator is still suspended takes them over -- the earlier iterator raises on its next
+        ``next()`` instead of waiting for batches that were drained (advisor, round 4)."""
+        self._generation += 1
+        generation = self._generation
         self._drain()
         batches = iter(self.batch_sampler)
         free = list(range(len(self.slots)))
@@ -240,6 +246,9 @@ class PackedFeed:
 
         def next_uploaded():
             nonlocal consumed
+            if generation != self._generation:
+                raise RuntimeError("PackedFeed: this iterator was abandoned -- a later iter() of the same feed took over its workers "
+                                   "and slots (one consumer at a time)")
             if consumed >= issued:
                 return None
             t0 = _time.perf_counter()

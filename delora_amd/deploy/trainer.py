@@ -46,6 +46,8 @@ class Trainer(deployer.Deployer):
             print("Model weights loaded from " + config["checkpoint"])
             self.optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
             print("Optimizer parameters loaded from " + config["checkpoint"])
+            if self.grad_scaler is not None and checkpoint.get("grad_scaler_state_dict"):
+                self.grad_scaler.load_state_dict(checkpoint["grad_scaler_state_dict"])     # float16: resume at the scale the run had reached
             config["unsupervised_at_start"] = True      # a pretrained model continues unsupervised (trainer.py:35-36)
         if config["inference_only"]:
             print("Config error: Inference only does not make sense during training. Changing to inference_only=False.")
@@ -77,6 +79,63 @@ class Trainer(deployer.Deployer):
                     d[key] = value.to(self.device, non_blocking=True)
         return preprocessed_dicts
 
+    # ------------------------------------------------------------------------------------------ eager step or replayed graph
+    def graph_policy(self):
+        """config ``hip_graph``: ``true`` -> every eligible step is replayed as one captured HIP graph, ``false`` -> eager, ``"auto"``
+        (the default, also when the key is absent -- the reference's YAML does not have it) -> MEASURE: the first eager steps of a
+        training phase are timed, and the step is captured when the host needs as long to enqueue it as the GPU needs to run it.
+        That is the reference's own default operating point -- ``batch_size: 1`` on 64x720 images (config/hyperparameters.yaml:3,
+        config_datasets.yaml:21): ~100 launches for ~1 ms of GPU work -- and not BASELINE's 64x2048, batch 8 (GPU-bound: capture
+        buys nothing there and stays off)."""
+        from .graph_step import GraphedStep
+        if getattr(self.device, "type", "cpu") != "cuda" or not GraphedStep.config_eligible(self):
+            return "off"
+        v = self.config.get("hip_graph", "auto")
+        if isinstance(v, str):
+            v = v.strip().lower()
+        if v in (True, 1, "true", "on", "yes"):
+            return "on"
+        if v in (False, 0, None, "false", "off", "no"):
+            return "off"
+        return "auto"
+
+    PROBE_SKIP, PROBE_STEPS, PROBE_HOST_BOUND = 3, 8, 0.8
+
+    def _probe_step(self, phase, run_eager):
+        """One eager step of the ``auto`` policy's measurement.  Returns the step's result.  After PROBE_SKIP untimed steps (allocator,
+        first-call set-up), PROBE_STEPS steps are bracketed by a pair of events on the stream and by the host clock around their
+        enqueue: when the host is the bottleneck the GPU finishes each step right behind its last launch (event time ~ enqueue
+        time); when the GPU is, the queue fills up and the events measure pure GPU time, longer than the enqueue."""
+        import time
+        st = self._graph_probe.setdefault(phase, {"n": 0, "host": 0.0, "events": []})
+        timed = st["n"] >= self.PROBE_SKIP
+        if timed:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            t0 = time.perf_counter()
+        out = run_eager()
+        if timed:
+            st["host"] += time.perf_counter() - t0
+            b.record()
+            st["events"].append((a, b))
+        st["n"] += 1
+        if len(st["events"]) >= self.PROBE_STEPS:
+            st["events"][-1][1].synchronize()
+            gpu = sum(x.elapsed_time(y) for x, y in st["events"]) * 1e-3
+            ratio = st["host"] / max(gpu, 1e-9)
+            decision = "graph" if ratio >= float(self.config.get("hip_graph_auto_threshold", self.PROBE_HOST_BOUND)) else "eager"
+            self._graph_decision[phase] = decision
+            self.graph_probe_result[phase] = {"host_enqueue_ms": round(1e3 * st["host"] / self.PROBE_STEPS, 3),
+                                              "stream_ms": round(1e3 * gpu / self.PROBE_STEPS, 3), "ratio": round(ratio, 3),
+                                              "decision": decision}
+            if self.rank == 0:
+                print(f"[delora_amd] hip_graph auto ({'unsupervised' if phase else 'identity'} phase): host enqueue "
+                      f"{1e3 * st['host'] / self.PROBE_STEPS:.2f} ms vs {1e3 * gpu / self.PROBE_STEPS:.2f} ms on the stream per step -> "
+                      + ("the step is host-bound: replaying it as ONE captured HIP graph" if decision == "graph"
+                         else "the step is GPU-bound: staying eager"))
+            del self._graph_probe[phase]
+        return out
+
     def train_epoch(self, epoch, dataloader):
         epoch_losses = self.new_epoch_losses()
         # next batch is copied while this step runs (a PackedFeed does that itself and yields device-resident PackedBatch objects)
@@ -85,33 +144,61 @@ class Trainer(deployer.Deployer):
         if show:
             iterator = qqdm.qqdm(iterator, desc=qqdm.format_str("blue", "Epoch " + str(epoch)))
         every = max(1, int(self.config.get("progress_every", 50)))
-        use_graph = (bool(self.config.get("hip_graph", False)) and self.world_size == 1
-                     and getattr(self.device, "type", "cpu") == "cuda")
+        policy = self.graph_policy()
+        if not hasattr(self, "_graph_decision"):
+            self._graph_decision, self._graph_probe, self.graph_probe_result = {}, {}, {}
+        self.graph_steps = getattr(self, "graph_steps", 0)
+        if getattr(self, "_graphed", None) is not None:
+            self._graphed.take_epoch_sums()             # (steps replayed outside an epoch, e.g. by a caller's own loop)
         for counter, preprocessed_dicts in enumerate(iterator):
-            if use_graph:
+            phase = bool(self.config["unsupervised_at_start"])
+            mode = "eager" if policy == "off" else ("graph" if policy == "on" else self._graph_decision.get(phase, "probe"))
+            if mode == "graph":
                 epoch_losses = self._graphed_step(preprocessed_dicts, epoch_losses)
                 continue
-            self.optimizer.zero_grad(set_to_none=True)
-            epoch_losses, _ = self.step(preprocessed_dicts=preprocessed_dicts, epoch_losses=epoch_losses,
-                                        log_images_bool=False)
+
+            def run_eager(batch=preprocessed_dicts, ep=epoch_losses):
+                self.optimizer.zero_grad(set_to_none=True)
+                return self.step(preprocessed_dicts=batch, epoch_losses=ep, log_images_bool=False)[0]
+            epoch_losses = self._probe_step(phase, run_eager) if mode == "probe" else run_eager()
             if show and counter % every == 0:          # one host sync per `every` steps instead of one per step
                 iterator.set_infos({"loss": f'{float(epoch_losses["loss_epoch"]) / (counter + 1):.6f}',
                                     "loss_po2pl": f'{float(epoch_losses["loss_po2pl_epoch"]) / (counter + 1):.6f}',
                                     "loss_pl2pl": f'{float(epoch_losses["loss_pl2pl_epoch"]) / (counter + 1):.6f}'})
-        return epoch_losses
+        return self._fold_graph_sums(epoch_losses)
 
     def _graphed_step(self, preprocessed_dicts, epoch_losses):
-        """config ``hip_graph: true``: the step replayed as one captured HIP graph (deploy/graph_step.py; ragged batches go
-        through static buffers of ``graph_max_points`` points per scan).  Re-captured when the training phase changes."""
+        """The step replayed as one captured HIP graph (deploy/graph_step.py; ragged batches go through static buffers of
+        ``graph_max_points`` points per scan -- by default the packed feed's own slot capacity, else the example's longest scan + 15 %).
+        Re-captured when the training phase changes.  A batch the capture cannot take (or a failed capture) runs eagerly."""
         from .graph_step import GraphedStep
         phase = bool(self.config["unsupervised_at_start"])
         g = getattr(self, "_graphed", None)
         if g is None or self._graphed_phase != phase:
-            g = self._graphed = GraphedStep(self, preprocessed_dicts, max_points=self.config.get("graph_max_points"))
+            if g is not None:
+                del self._graphed                       # the old capture's private memory pool goes before the new one is built
+                g = None
+            cap = self.config.get("graph_max_points") or getattr(self, "_feed_points_per_scan", None)
+            g = self._graphed = GraphedStep(self, preprocessed_dicts, max_points=cap)
             self._graphed_phase = phase
+            if self.rank == 0:
+                print(f"[delora_amd] training step captured as a HIP graph: {g.captured} ({'unsupervised' if phase else 'identity'} phase, "
+                      f"{g.capacity} points per scan)")
+        before = g.replayed_steps
         ep, _ = g(preprocessed_dicts)
-        for k, v in ep.items():                      # the graph's outputs are static tensors: add their VALUES to the epoch sums
+        replayed = g.replayed_steps - before
+        self.graph_steps += replayed
+        if replayed and g.acc is not None:
+            return epoch_losses                      # the replay added its metrics to the graph's own accumulator (folded in per epoch)
+        for k, v in ep.items():                      # eager fallback / no accumulator: the outputs are (static) tensors, add their VALUES
             if torch.is_tensor(v):
+                epoch_losses[k] = epoch_losses[k] + v
+        return epoch_losses
+
+    def _fold_graph_sums(self, epoch_losses):
+        g = getattr(self, "_graphed", None)
+        if g is not None:
+            for k, v in g.take_epoch_sums().items():
                 epoch_losses[k] = epoch_losses[k] + v
         return epoch_losses
 
@@ -130,9 +217,11 @@ class Trainer(deployer.Deployer):
         return dict(zip(keys, vals))
 
     def save_checkpoint(self, path, epoch, loss):
-        torch.save({"epoch": epoch, "model_state_dict": self.raw_model.state_dict(),
-                    "optimizer_state_dict": self.optimizer.state_dict(), "loss": float(loss),
-                    "parameters": self.config}, path)
+        ck = {"epoch": epoch, "model_state_dict": self.raw_model.state_dict(),
+              "optimizer_state_dict": self.optimizer.state_dict(), "loss": float(loss), "parameters": self.config}
+        if self.grad_scaler is not None:            # an optional sixth key (float16 autocast only): the reference's five stay as they are
+            ck["grad_scaler_state_dict"] = self.grad_scaler.state_dict()
+        torch.save(ck, path)
 
     def make_dataloader(self):
         sampler = None
@@ -140,10 +229,13 @@ class Trainer(deployer.Deployer):
             sampler = torch.utils.data.distributed.DistributedSampler(self.dataset, num_replicas=self.world_size,
                                                                       rank=self.rank, shuffle=True, drop_last=True)
         shuffle = bool(self.config.get("shuffle_training_data", True))          # the reference always shuffles (trainer.py:95-101)
-        if feed.packed_feed_applicable(self.dataset, self.config, self.device) and not self.config.get("hip_graph", False):
+        if feed.packed_feed_applicable(self.dataset, self.config, self.device):
             # the reference's on-disk training set with worker processes: batches are decoded straight into page-locked shared memory
-            # in the layout of the step's first kernel and reach the GPU as ONE copy per batch (data/feed.py: PackedFeed)
-            return feed.make_packed_feed(self.dataset, self.config, self.device, self.batch_size, sampler=sampler, shuffle=shuffle), sampler
+            # in the layout of the step's first kernel and reach the GPU as ONE copy per batch (data/feed.py: PackedFeed); a captured
+            # step takes such a batch with one device-side copy into its static buffers, sized for the feed's slots
+            pf = feed.make_packed_feed(self.dataset, self.config, self.device, self.batch_size, sampler=sampler, shuffle=shuffle)
+            self._feed_points_per_scan = pf.capacity // (2 * self.batch_size)
+            return pf, sampler
         workers = int(self.config["num_dataloader_workers"])
         # worker processes decode whole batches ahead of the step (np.load + the [M,3] -> [1,3,M] transposition: ~3 ms per pair) and
         # stay alive between epochs; the loader's pinning thread copies each batch into page-locked memory, from where the
@@ -179,7 +271,8 @@ class Trainer(deployer.Deployer):
                 if self.rank == 0:
                     print("--------------------------")
                     print("Epoch Summary: " + format(epoch, "05d") + ", loss: " + str(metrics["loss_epoch"]) +
-                          ", unsupervised: " + str(self.config["unsupervised_at_start"]))
+                          ", unsupervised: " + str(self.config["unsupervised_at_start"]) +
+                          ", steps replayed as a HIP graph so far: " + str(getattr(self, "graph_steps", 0)))
                     names = {"loss": "loss_epoch", "loss point cloud": "loss_point_cloud_epoch", "loss po2po": "loss_po2po_epoch",
                              "loss po2pl": "loss_po2pl_epoch", "loss pl2pl": "loss_pl2pl_epoch", "visible pixels": "visible_pixels_epoch"}
                     if mlflow is not None:

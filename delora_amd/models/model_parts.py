@@ -116,8 +116,12 @@ class FusedHeads(torch.autograd.Function):
         dev = x.device
         a1 = torch.empty((B, R), dtype=torch.float32, device=dev)
         a2 = torch.empty((B, 2, Hd), dtype=torch.float32, device=dev)
-        small = torch.empty((B * 11 + 1,), dtype=torch.float32, device=dev)         # rot_raw [B,4] | translation [B,3] | rotation [B,4] | norm
-        rot_raw, translation, rotation, norm = small[:4 * B].view(B, 4), small[4 * B:7 * B].view(B, 3), small[7 * B:11 * B].view(B, 4), small[11 * B:]
+        # the two outputs are tensors of their own: views of one scratch buffer that is also saved for the backward would share a
+        # version counter with a saved tensor, and an in-place op of a caller on either output would trip autograd (advisor, round 4)
+        small = torch.empty((B * 4 + 1,), dtype=torch.float32, device=dev)           # rot_raw [B,4] | norm: what the backward needs
+        rot_raw, norm = small[:4 * B].view(B, 4), small[4 * B:]
+        translation = torch.empty((B, 3), dtype=torch.float32, device=dev)
+        rotation = torch.empty((B, 4), dtype=torch.float32, device=dev)
         st = FusedHeads._struct(params)
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         vp = lambda t: ctypes.c_void_p(t.data_ptr())                                  # noqa: E731
@@ -135,7 +139,7 @@ class FusedHeads(torch.autograd.Function):
         x, a1, a2, small, *params = ctx.saved_tensors
         B, F = x.shape
         R, Hd = params[0].shape[0], params[2].shape[0]
-        rot_raw, norm = small[:4 * B], small[11 * B:]
+        rot_raw, norm = small[:4 * B], small[4 * B:]
         dev = x.device
         gt = (g_translation if g_translation is not None else torch.zeros((B, 3), device=dev)).contiguous().float()
         gr = (g_rotation if g_rotation is not None else torch.zeros((B, 4), device=dev)).contiguous().float()

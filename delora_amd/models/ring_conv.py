@@ -238,11 +238,21 @@ def supported(x_shape, blocks):
     """Whether the HIP trunk can run these shapes: channel counts multiples of 64.  The image size is free: tiles hang over the edge
     of feature maps that do not divide, odd widths / heights included -- the reference's shipped 64x720 image (feature maps 180, 90,
     45 and 23 pixels wide, config/config_datasets.yaml:21) and 64x512 (layer4: 32x16, :47) run here like BASELINE's 64x2048."""
+    return _supported(x_shape, blocks, 1 << 31)
+
+
+def _supported(x_shape, blocks, max_elements):
+    """``max_elements``: the C side indexes a tensor with 32-bit element (fp32) / byte (half) offsets and rejects N*H*W*max(C,K) at or
+    above 2^31 (conv.hip, wino.hip) resp. 2^30 (convh.hip, wgradh.hip); the Winograd kernels additionally keep a sample's H*W*C below
+    2^30.  The same bounds here let cnn_impl 'auto' fall back to the module path instead of raising from the C side."""
     N, H, W, C = x_shape
     if C % 64 or H < 1 or W < 1:
         return False
     for (cin, cout, stride, _) in blocks:
         if cin % 64 or cout % 64 or stride[0] not in (1, 2) or stride[1] not in (1, 2) or (stride[0] == 2 and stride[1] == 1):
+            return False
+        wide = max(cin, cout)
+        if N * H * W * wide >= max_elements or H * W * wide >= (1 << 30):
             return False
         H, W = out_size(H, stride[0]), out_size(W, stride[1])
     return True
@@ -379,6 +389,40 @@ TRUNK_SEGMENTS = "mono"
 WINO_WGRAD_MIN_C_BATCHED = int(os.environ.get("DELORA_WINO_WGRAD_MIN_C", "64"))
 # Weight gradients of a segment in merged launches at its end (wgrad_batch_h) instead of one launch per layer inside the chain
 WGRAD_BATCHED = os.environ.get("DELORA_WGRAD_BATCHED", "1") != "0"      # (0: one launch per layer, for A/B measurements)
+# Deferring a segment's weight gradients keeps every inter-layer GRADIENT map of the segment alive until they are computed (the
+# activations are saved tensors and alive anyway).  At B=8, 64x2048 that is ~1 GB for the 19 layers of a mono trunk; above this many
+# bytes the collected layers are flushed early (one more merged launch), so that peak memory stays bounded for large batches / tall
+# images (advisor, round 4).
+WGRAD_PENDING_MAX_BYTES = int(os.environ.get("DELORA_WGRAD_PENDING_MAX_BYTES", str(2 << 30)))
+
+
+class _PendingWgrads:
+    """(gradient slot, (x, g, filter size, stride)) items of a segment's backward, flushed into ``grads`` through ``batch_fn`` (merged
+    launches) or ``single_fn`` at the end of the segment -- or earlier, once the gradient maps they keep alive pass
+    ``WGRAD_PENDING_MAX_BYTES``."""
+
+    def __init__(self, grads, meta, batch_fn, single_fn):
+        self.grads, self.meta, self.batch_fn, self.single_fn = grads, meta, batch_fn, single_fn
+        self.items, self.bytes, self.flushes = [], 0, 0
+
+    def append(self, item):
+        self.items.append(item)
+        g = item[1][1]
+        self.bytes += g.numel() * g.element_size()
+        if self.bytes > WGRAD_PENDING_MAX_BYTES:
+            self.flush()
+
+    def flush(self):
+        if not self.items:
+            return
+        if WGRAD_BATCHED:
+            for (gi, _), dw in zip(self.items, self.batch_fn([it for _, it in self.items])):
+                self.grads[gi] = grad_for(dw, self.meta[gi])
+        else:
+            for gi, (xx, gg, ks, st) in self.items:
+                self.grads[gi] = grad_for(self.single_fn(xx, gg, ks, stride=st), self.meta[gi])
+        self.items, self.bytes = [], 0
+        self.flushes += 1
 # Order in which the segment Functions finished their backward passes in this process (tests: DDP overlap) -- appended to when a list
 BACKWARD_TRACE = None
 
@@ -477,7 +521,7 @@ class RingSegment(torch.autograd.Function):
         wi = len(weights)
         # The weight gradients do not feed the chain of input gradients: they are collected (x, g stay alive) and computed together at
         # the end of the segment -- merged launches need far fewer slab partials than one launch per layer (wgrad_batch)
-        pending = []
+        pending = _PendingWgrads(grads, weights, wgrad_batch, wgrad_nhwc)
         for b in range(nb - 1, -1, -1):
             cin, cout, stride, has_ds = blocks[b]
             wi -= 3 if has_ds else 2
@@ -504,12 +548,7 @@ class RingSegment(torch.autograd.Function):
                 dxb = dgrad_strided(g2, weight_storage(wdp), stride, x.shape[1:3], dense=True)
                 epi = EPI_ADD_GRID if first else (EPI_ADD_GRID | EPI_DACT)
                 g2 = dgrad_strided(g1, weight_storage(w1p), stride, x.shape[1:3], act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)
-        if WGRAD_BATCHED:
-            for (gi, _), dw in zip(pending, wgrad_batch([it for _, it in pending])):
-                grads[gi] = grad_for(dw, weights[gi])
-        else:
-            for gi, (xx, gg, ks, st) in pending:
-                grads[gi] = grad_for(wgrad_nhwc(xx, gg, ks, stride=st), weights[gi])
+        pending.flush()
         if BACKWARD_TRACE is not None:
             BACKWARD_TRACE.append(("segment", blocks[0][0], blocks[-1][1], nb))
         return (g2, None, None, None, None, *grads)
@@ -637,7 +676,7 @@ def wgrad_batch_h(items):
 def supported_h(x_shape, blocks):
     """Whether the half-precision HIP trunk can run these shapes: as ``supported`` (channel counts multiples of 64, any image size:
     tiles hang over the edges of feature maps that do not divide)."""
-    return supported(x_shape, blocks)
+    return _supported(x_shape, blocks, 1 << 30)
 
 
 class CastToHalf(torch.autograd.Function):
@@ -699,7 +738,7 @@ class RingSegmentH(torch.autograd.Function):
         wi = ctx.n_w
         # The weight gradients do not feed the chain of input gradients: they are collected (x, g kept alive) and computed together
         # at the end of the segment -- merged launches need far fewer slab partials than one launch per layer (wgrad_batch_h)
-        pending = []
+        pending = _PendingWgrads(grads, ctx.w_meta, wgrad_batch_h, wgrad_nhwc_h)
         for b in range(nb - 1, -1, -1):
             cin, cout, stride, has_ds = blocks[b]
             wi -= 3 if has_ds else 2
@@ -717,12 +756,7 @@ class RingSegmentH(torch.autograd.Function):
                 dxb = dgrad_strided_h(g2, wbs[wi + 2], 1, stride, x.shape[1:3], dense=True)
                 epi = EPI_ADD_GRID if first else (EPI_ADD_GRID | EPI_DACT)
                 g2 = dgrad_strided_h(g1, w1b, 3, stride, x.shape[1:3], act=act, epilogue=epi, add_grid=dxb, dsrc=None if first else x)
-        if WGRAD_BATCHED:
-            for (gi, _), dw in zip(pending, wgrad_batch_h([it for _, it in pending])):
-                grads[gi] = grad_for(dw, ctx.w_meta[gi])
-        else:
-            for gi, (xx, gg, ks, st) in pending:
-                grads[gi] = grad_for(wgrad_nhwc_h(xx, gg, ks, stride=st), ctx.w_meta[gi])
+        pending.flush()
         if BACKWARD_TRACE is not None:
             BACKWARD_TRACE.append(("segment", blocks[0][0], blocks[-1][1], nb))
         return (g2, None, None, None, None, *grads)

@@ -3,7 +3,7 @@
 ``ScanToScanOdometry`` is what ``OdometryPublisher.subscriber_callback`` / ``predict_and_publish`` do between receiving
 a PointCloud2 message and filling the Odometry message (reference src/ros_utils/odometry_publisher.py:93-172), and
 ``TrajectoryIntegrator`` is ``OdometryIntegrator.update_transformation`` (src/ros_utils/odometry_integrator.py:79-93);
-the ROS plumbing around them lives in ``odometry_publisher.py``.  Both scans of a pair are projected by ONE launch of the
+the ROS plumbing around them (publishers, TF, message conversion) is out of scope and not built.  Both scans of a pair are projected by ONE launch of the
 HIP projection (``geometry.project``), the network runs on the stacked pair, nothing else touches the points.
 
 ``quaternion_from_matrix`` / ``quaternion_matrix`` restate the two ``tf.transformations`` functions the node calls

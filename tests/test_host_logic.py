@@ -226,6 +226,16 @@ def test_xyz_only_tree_and_consecutive_pair_reuse(tmp_path, monkeypatch):
     with pytest.raises(Exception):
         dsmod.PreprocessedPointCloudDataset(cfg)
     assert not dsmod.PreprocessedPointCloudDataset(dict(cfg, load_normal_lists=False)).load_normals
+    # mixed trees -- one sequence with stored normals, one without -- are rejected in either order instead of silently dropping the
+    # stored normals of the sequences scanned first (advisor, round 4); load_normal_lists: false trains all of them xyz-only
+    synthetic.write_tree(str(tmp_path / "m"), scans[:3], sequence=0, normals=[-s for s in scans[:3]])
+    synthetic.write_tree(str(tmp_path / "m"), scans[3:6], sequence=1)
+    cfg["kitti"]["preprocessed_path"] = str(tmp_path / "m")
+    for order in ([0, 1], [1, 0]):
+        cfg["kitti"]["data_identifiers"] = order
+        with pytest.raises(Exception, match="mixed trees"):
+            dsmod.PreprocessedPointCloudDataset(cfg)
+    assert len(dsmod.PreprocessedPointCloudDataset(dict(cfg, load_normal_lists=False))) == 4
 
 
 @pytest.mark.parametrize("with_normals", [False, True])
@@ -265,6 +275,13 @@ def test_packed_feed_delivers_the_batches_of_the_sampler_in_the_steps_layout(tmp
         del it
         again = list(pf)
         assert [b.offs.tolist() for b in again] == [b.offs.tolist() for b in got]
+        # one consumer at a time: an iterator that is still alive when a later epoch starts is stale and says so (it used to wait
+        # 120 s for batches the later epoch had drained)
+        stale = iter(pf)
+        next(stale)
+        assert len(list(pf)) == len(order)
+        with pytest.raises(RuntimeError, match="abandoned"):
+            next(stale)
         # a batch beyond the slot capacity is an error of the feed, not a silent truncation
         small = feed.PackedFeed(ds, [[0, 1]], 2, torch.device("cpu"), workers=1, points_per_scan=20)
         with pytest.raises(RuntimeError):
