@@ -61,6 +61,12 @@ def parse(argv=None):
     ap.add_argument("--disk-workers", type=int, default=2, help="DataLoader worker processes of the `feed_disk` leg")
     ap.add_argument("--variant-steps", type=int, default=10, help="timed steps of the extra fp32 legs `shipped_image` (64x720, the reference's "
                     "default KITTI image) and `untrained_network` (randomly initialised heads: whole-image search) (0 = skip); N=1 only")
+    ap.add_argument("--point-order", default="raster", choices=("raster", "firing", "shuffled"),
+                    help="order of the points inside a raw scan: raster = ring after ring, the order of the reference's stored point lists "
+                         "(src/preprocessing/preprocesser.py:60-67; the default since round 5), firing = the order a spinning sensor delivers, "
+                         "shuffled = a random permutation (rounds 1-4: the worst case of the projection's vote; still a row of `kernels`)")
+    ap.add_argument("--shipped-steps", type=int, default=200, help="timed batch-1 steps of the `shipped_config` leg: the reference's default operating "
+                    "point (unmodified YAML: 64x720, batch 1, stored lists), eager / graph / product loop from disk (0 = skip); N=1 only")
     ap.add_argument("--amp", default="", help="optional autocast dtype for the CNN (bfloat16/float16); default fp32 = parity mode")
     ap.add_argument("--channels-last", action="store_true")
     ap.add_argument("--cnn", default="", help="CNN implementation override (config key cnn_impl)")
@@ -97,7 +103,7 @@ def make_batch(args, rank, device=None):
     from delora_amd.data import synthetic
     samples = []
     for j in range(args.batch):
-        s1, s2, T = synthetic.make_pair(2000 + rank * args.batch + j, rings=args.height, azimuth_steps=2250)
+        s1, s2, T = synthetic.make_pair(2000 + rank * args.batch + j, rings=args.height, azimuth_steps=2250, point_order=args.point_order)
         d = {"dataset": "kitti", "scan_1": torch.from_numpy(s1).unsqueeze(0), "scan_2": torch.from_numpy(s2).unsqueeze(0),
              "normal_list_1": None, "normal_list_2": None}
         if device is not None:
@@ -106,11 +112,11 @@ def make_batch(args, rank, device=None):
     return samples
 
 
-def derived_batches(base, count, rank):
+def derived_batches(base, count, rank, shuffled=False):
     """`count` distinct host batches from one ray-cast batch (ray casting costs ~0.4 s per pair): batch 0 is `base`, batch k
     is the same scenes seen under a different heading -- both scans of a pair rotated about the vertical axis by the same
     angle, which moves every point to another pixel column and keeps the pair's relative motion small -- with a different
-    random 0-3 % of the points dropped (ragged scan lengths) and the points shuffled."""
+    random 0-3 % of the points dropped (ragged scan lengths); the remaining points keep their order (``shuffled``: re-permuted)."""
     out = [[{k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()} for d in base]]
     for k in range(1, count):
         rng = np.random.default_rng(77000 + 100 * rank + k)
@@ -123,7 +129,8 @@ def derived_batches(base, count, rank):
             for name in ("scan_1", "scan_2"):
                 pts = d[name][0]
                 n = pts.shape[1]
-                keep = torch.from_numpy(rng.permutation(n)[: n - int(rng.integers(0, max(1, int(0.03 * n))))])
+                keep = rng.permutation(n)[: n - int(rng.integers(0, max(1, int(0.03 * n))))]
+                keep = torch.from_numpy(keep if shuffled else np.sort(keep))     # dropped points leave the order of the others alone
                 e[name] = (R @ pts[:, keep]).unsqueeze(0).contiguous()
             batch.append(e)
         out.append(batch)
@@ -272,7 +279,7 @@ def make_disk_tree(args):
     from delora_amd.data import synthetic
     tmp = tempfile.mkdtemp(prefix="delora_feed_")
     t0 = time.perf_counter()
-    scans, _ = synthetic.make_sequence(4000, args.disk_pairs + 1, rings=args.height, azimuth_steps=2250)
+    scans, _ = synthetic.make_sequence(4000, args.disk_pairs + 1, rings=args.height, azimuth_steps=2250, point_order=args.point_order)
     synthetic.write_tree(tmp, scans, sequence=0)
     nbytes = sum(os.path.getsize(os.path.join(tmp, "00", "scans", f)) for f in os.listdir(os.path.join(tmp, "00", "scans")))
     return {"path": tmp, "bytes": nbytes, "generation_s": round(time.perf_counter() - t0, 1)}
@@ -338,6 +345,174 @@ def disk_feed_leg(args, cfg, device, tree, run_step, timed_region, resident_pair
                         "epoch, as a training set that fits in RAM does"}
     finally:
         pf.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The reference's DEFAULT operating point: config/*.yaml unmodified -- 64x720 images, batch_size 1, stored point + normal lists read
+# from <preprocessed_path>/<seq>/{scans,normals}/ (config/hyperparameters.yaml:3, config_datasets.yaml:21, src/deploy/trainer.py:43-91).
+# ~100 launches for ~1 ms of GPU work: the eager step is bound by the host's enqueue time, which is what `hip_graph: auto` removes.
+def shipped_tree(device, n_pairs, seed=4100):
+    """A synthetic sequence through the OFFLINE PREPROCESSING of the reference (projection at horizontal_cells_preprocessing = 2250 +
+    normals, src/preprocessing/preprocesser.py:52-68: raster-ordered [M,3] point and normal lists) into a temporary tree."""
+    import tempfile
+    from delora_amd import config as cfgmod
+    from delora_amd.data import synthetic
+    from delora_amd.preprocessing.preprocesser import Preprocesser
+    tmp = tempfile.mkdtemp(prefix="delora_shipped_")
+    t0 = time.perf_counter()
+    scans, poses = synthetic.make_sequence(seed, n_pairs + 1, rings=64, azimuth_steps=2250, point_order="firing")    # raw scans as a driver delivers them
+    cfg = cfgmod.load_yaml_config(os.path.join(ROOT, "config"))
+    cfgmod.degrees_to_radians(cfg)
+    cfg["device"] = device
+    cfg["kitti"]["preprocessed_path"] = tmp
+    Preprocesser(cfg).preprocess_scans(scans, "kitti", 0)
+    torch.cuda.synchronize()
+    nbytes = sum(os.path.getsize(os.path.join(dp, f)) for dp, _, fs in os.walk(tmp) for f in fs)
+    return {"path": tmp, "pairs": n_pairs, "bytes": nbytes, "generation_s": round(time.perf_counter() - t0, 1), "poses": poses}
+
+
+def shipped_trainer(device, tree_path, batch, workers=0, hip_graph="auto", amp=""):
+    """A Trainer on this repository's YAML as it is, plus what a user has to set anyway (where the data are) and the leg's variables."""
+    from delora_amd import config as cfgmod
+    from delora_amd.deploy.trainer import Trainer
+    cfg = cfgmod.load_yaml_config(os.path.join(ROOT, "config"))
+    cfgmod.degrees_to_radians(cfg)
+    cfg["kitti"]["preprocessed_path"] = tree_path
+    cfg["kitti"]["data_identifiers"] = [0]
+    cfg.update(device=device, batch_size=batch, unsupervised_at_start=True, inference_only=False, checkpoint=None, mode="training",
+               training_run_name="bench_shipped", run_name="bench_shipped", num_dataloader_workers=workers, hip_graph=hip_graph)
+    if amp:
+        cfg["amp_dtype"] = amp
+    torch.manual_seed(1234)
+    trainer = Trainer(cfg)
+    identity_pretrained_state(trainer.raw_model)
+    return trainer
+
+
+def shipped_resident_batches(trainer, count):
+    """`count` batches of the trainer's dataset, on the device, as the lists of sample dicts the DataLoader would deliver."""
+    B = trainer.batch_size
+    n = len(trainer.dataset)
+    return [trainer.to_device([trainer.dataset[(k * B + j) % n] for j in range(B)]) for k in range(count)]
+
+
+def shipped_config_leg(args, device, timed_region, enqueue, steps_b1=200, steps_b8=40, pairs=32):
+    """Every way the reference's default operating point can run here, B = 1 (the YAML's value) and B = 8: the eager step and the
+    replayed graph on HBM-resident batches (rotating), and the PRODUCT LOOP -- `Trainer.train_epoch` with `hip_graph: auto`, which
+    measures and decides by itself -- fed from the on-disk tree through `PackedFeed` (2 workers) and through the YAML's literal
+    `num_dataloader_workers: 0` (in-process DataLoader + DevicePrefetcher).  Each entry carries the host's enqueue time per step."""
+    import gc, shutil
+    from delora_amd.deploy.graph_step import GraphedStep
+    tree = shipped_tree(device, pairs)
+    out = {"image": "64x720", "data": f"{pairs} consecutive pairs of one synthetic sequence, preprocessed offline at 64x2250 (stored point + "
+                                       f"normal lists, raster order, {tree['bytes'] / 1e6:.0f} MB on disk)",
+           "reference": "config/hyperparameters.yaml:3 (batch_size 1), config/config_datasets.yaml:21 (64x720), src/deploy/trainer.py:43-91"}
+    try:
+        for B, steps in ((1, steps_b1), (8, steps_b8)):
+            leg = {}
+            trainer = shipped_trainer(device, tree["path"], B, workers=0, hip_graph="off")
+            batches = shipped_resident_batches(trainer, 8 if B == 1 else 4)
+            k = {"i": 0}
+
+            def eager_step():
+                k["i"] += 1
+                trainer.optimizer.zero_grad(set_to_none=True)
+                return trainer.step(preprocessed_dicts=[dict(d) for d in batches[k["i"] % len(batches)]], epoch_losses=trainer.new_epoch_losses())[0]
+            for _ in range(len(batches) + 3):
+                eager_step()
+            gc.collect()
+            el, ep = timed_region(steps, eager_step)
+            leg["eager_resident"] = {"ms_per_step": round(1e3 * el / steps, 4), "value": round(B * steps / el, 2),
+                                     "host_enqueue_ms_per_step": round(enqueue["ms_per_step"], 4), "final_loss": float(ep["loss_epoch"])}
+            graphed = GraphedStep(trainer, batches[0])
+            if graphed.captured:
+                def graph_step():
+                    k["i"] += 1
+                    return graphed(batches[k["i"] % len(batches)])[0]
+                for _ in range(5):
+                    graph_step()
+                el, ep = timed_region(steps, graph_step)
+                leg["graph_resident"] = {"ms_per_step": round(1e3 * el / steps, 4), "value": round(B * steps / el, 2),
+                                         "host_enqueue_ms_per_step": round(enqueue["ms_per_step"], 4), "final_loss": float(ep["loss_epoch"]),
+                                         "eager_fallback_steps": graphed.fallback_steps}
+                # the GPU's own time for one replay: the same batch replayed back to back (no packing, the host far ahead)
+                for _ in range(3):
+                    graphed(None)
+                el, _ = timed_region(steps, lambda: graphed(None)[0])
+                leg["graph_replay_only_ms"] = round(1e3 * el / steps, 4)
+            del graphed, batches, trainer
+            gc.collect()
+            torch.cuda.empty_cache()
+            for name, workers in (("product_loop_packed_feed_2_workers", 2), ("product_loop_yaml_default_0_workers", 0)):
+                trainer = shipped_trainer(device, tree["path"], B, workers=workers, hip_graph="auto")
+                loader, _ = trainer.make_dataloader()
+                per_epoch = len(loader)
+                try:
+                    for e in range(max(2, -(-16 // per_epoch))):        # the probe of `auto` (11 steps), capture, page cache, workers up
+                        trainer.train_epoch(e, loader)
+                    n_ep = max(1, steps // per_epoch)
+                    count = {"e": 100}
+
+                    def epoch_step():
+                        count["e"] += 1
+                        return trainer.train_epoch(count["e"], loader)
+                    before = trainer.graph_steps
+                    el, ep = timed_region(n_ep, epoch_step)
+                    n = n_ep * per_epoch
+                    leg[name] = {"ms_per_step": round(1e3 * el / n, 4), "value": round(B * n / el, 2), "steps": n,
+                                 "host_ms_per_step": round(enqueue["ms_per_step"] / per_epoch, 4),
+                                 "hip_graph_auto": trainer.graph_probe_result.get(True), "graph_replayed_steps": trainer.graph_steps - before,
+                                 "feed": type(loader).__name__}
+                finally:
+                    if hasattr(loader, "close"):
+                        loader.close()
+                    del loader, trainer
+                    gc.collect()
+                    torch.cuda.empty_cache()
+            out[f"batch_{B}"] = leg
+    finally:
+        shutil.rmtree(tree["path"], ignore_errors=True)
+    return out
+
+
+def live_kernel_sum(batch, mode="graph", steps=40, timeout_s=300):
+    """Summed kernel time of ONE step of the default operating point, measured by this run: a rocprofv3 --kernel-trace child over
+    tools/shipped_step.py (the resident step, eager or replayed); the trace is cut at the projection's first kernel, the median
+    steady-state step gives `kernel_sum_ms` (sum of kernel durations) and `step_wall_ms` (start of a step to start of the next)."""
+    import csv, glob, shutil, subprocess, tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None or any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
+    tmp = tempfile.mkdtemp(prefix="bench_ksum_", dir="/tmp")
+    try:
+        cmd = [exe, "--kernel-trace", "--output-format", "csv", "-d", tmp, "-o", "k", "--", sys.executable,
+               os.path.join(ROOT, "tools", "shipped_step.py"), str(batch), mode, str(steps)]
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout_s)
+        files = glob.glob(os.path.join(tmp, "**", "*kernel_trace.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            return None
+        rows = sorted(csv.DictReader(open(files[0])), key=lambda r_: int(r_["Start_Timestamp"]))
+        return kernel_sum_of_trace(rows, steps)
+    except (OSError, subprocess.SubprocessError, ValueError, KeyError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def kernel_sum_of_trace(rows, steps):
+    """Median over the last `steps` - 1 steps of a kernel trace (rows sorted by start time; a step starts at `k_fill_words` followed by
+    `k_project_scatter`, i.e. at the projection): (sum of kernel durations, start-to-start wall time, kernels per step)."""
+    starts = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("k_project_scatter")]
+    if len(starts) < 4:
+        return None
+    starts = starts[-min(len(starts), steps):]
+    busy, wall, count = [], [], []
+    for a, b in zip(starts[:-1], starts[1:]):
+        busy.append(sum(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in rows[a:b]))
+        wall.append(int(rows[b]["Start_Timestamp"]) - int(rows[a]["Start_Timestamp"]))
+        count.append(b - a)
+    return {"kernel_sum_ms": round(float(np.median(busy)) * 1e-6, 4), "step_wall_ms": round(float(np.median(wall)) * 1e-6, 4),
+            "kernels_per_step": int(np.median(count)), "steps_in_trace": len(busy)}
 
 
 def conv_table(args, device, reps=10):
@@ -559,16 +734,15 @@ def kernel_table(trainer, batch, reps):
                      "bound": bound, "note": note})
 
     row("dl_project", timed(lambda: G.project(pts, offs, max(lengths), sensor, want_kept=False)), 12 * n_pts + 36 * 2 * B * HW, "hbm",
-        f"{2 * B} scans, {n_pts} points -> {2 * B}x{sensor.H}x{sensor.W}; 12 B/point + 36 B/pixel (planar + packed image, map)")
-    # the same points in raster order, as the reference's stored scans are (its preprocessing saves the projected point list,
-    # src/preprocessing/preprocesser.py:60-67): the votes of neighbouring points share cache lines of the key plane
-    uv = G.project(pts, offs, max(lengths), sensor, want_kept=False, want_uv=True)["uv"]
-    scan_id = torch.repeat_interleave(torch.arange(len(lengths), device=pts.device), torch.tensor(lengths, device=pts.device))
-    pix = (torch.round(uv[1]).clamp(0, sensor.H - 1) * sensor.W + torch.round(uv[0]).clamp(0, sensor.W - 1)).long()
-    pts_raster = pts[:, torch.argsort(scan_id * HW + pix)].contiguous()
-    row("dl_project/raster-order", timed(lambda: G.project(pts_raster, offs, max(lengths), sensor, want_kept=False)), 12 * n_pts + 36 * 2 * B * HW,
-        "hbm", "the same points sorted by pixel (the order of the reference's preprocessed scans); the bench feeds randomly permuted points")
-    del uv, scan_id, pix, pts_raster
+        f"{2 * B} scans, {n_pts} points -> {2 * B}x{sensor.H}x{sensor.W}; 12 B/point + 36 B/pixel (planar + packed image, map); points in the "
+        f"bench's order (--point-order, default raster: ring after ring, as the reference's stored lists, src/preprocessing/preprocesser.py:60-67)")
+    # the same points randomly permuted inside every scan (the input order of rounds 1-4): every vote touches another line of the key plane
+    g_perm = torch.Generator(device="cpu").manual_seed(11)
+    perm = torch.cat([o + torch.randperm(n, generator=g_perm) for o, n in zip(np.cumsum([0] + lengths[:-1]).tolist(), lengths)]).to(pts.device)
+    pts_shuffled = pts[:, perm].contiguous()
+    row("dl_project/shuffled-points", timed(lambda: G.project(pts_shuffled, offs, max(lengths), sensor, want_kept=False)), 12 * n_pts + 36 * 2 * B * HW,
+        "hbm", "the same points randomly permuted inside every scan (rounds 1-4 fed the bench this order): the worst case of the vote's atomics")
+    del perm, pts_shuffled
     row("dl_normals", timed(lambda: G.normals(prepared["stacked"].view(2 * B, 4, sensor.H, sensor.W), want_packed=True)), 40 * 2 * B * HW, "valu",
         "7x11 stencil + 3x3 eigen solve; 40 B/pixel (read xyz, write planar + packed normals)")
     row("dl_nn_correspond", timed(lambda: G.nn_correspond(img[:, 1], nrm[:, 1], tgt_pk, tgt_n_pk, T_small, sensor)), 28 * B * HW + 12 * B * HW, "l2+valu",
@@ -761,7 +935,7 @@ def main():
         from delora_amd.models import ring_conv
         ring_conv.ALLOC_SKEW = args.alloc_skew
     torch.manual_seed(1234)
-    host_batches = pin_batches(derived_batches(make_batch(args, rank), max(1, args.rotate), rank))
+    host_batches = pin_batches(derived_batches(make_batch(args, rank), max(1, args.rotate), rank, shuffled=args.point_order == "shuffled"))
     batches = [to_device(b, device) for b in host_batches]
     trainer = Trainer(cfg, dataset=ListDataset([d for b in host_batches for d in b]))
     identity_pretrained_state(trainer.raw_model)
@@ -888,7 +1062,7 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if not args.amp else args.amp,
         "data": "synthetic",
-        "config": {"workload": f"KITTI-shaped {args.height}x{args.width}, batch={args.batch} pairs/GPU, raw scans of ~141k points (ragged), "
+        "config": {"workload": f"KITTI-shaped {args.height}x{args.width}, batch={args.batch} pairs/GPU, raw scans of ~141k points (ragged, {args.point_order} order), "
                                f"steps rotate over {len(batches)} distinct HBM-resident batches, online normals, ResNet pose CNN (11.9M params, "
                                f"identity-pretrained state), Adam; BASELINE configs[1]",
                    "global_batch": world * args.batch, "parallelism": f"dp{world}", "cnn": "fp32" if not args.amp else "autocast " + args.amp,
@@ -1007,6 +1181,21 @@ def main():
                 result["untrained_network"]["note"] = ("the headline workload with the network as torch initialises it (a run from scratch with "
                                                        "unsupervised_at_start: True): random poses, so the exact search walks the whole image for "
                                                        "every query; the headline uses the state the reference's identity pre-training leaves")
+            if not args.amp and args.shipped_steps > 0 and (graphed is None or not graphed.captured):
+                try:
+                    sc = shipped_config_leg(args, device, timed_region, enqueue, steps_b1=args.shipped_steps, steps_b8=max(8, args.shipped_steps // 5))
+                    ks = None if args.no_live_pmc else live_kernel_sum(1, "graph")
+                    if ks:
+                        b1 = sc["batch_1"]
+                        ks["product_loop_vs_kernel_sum"] = round(b1["product_loop_packed_feed_2_workers"]["ms_per_step"] / ks["kernel_sum_ms"], 3)
+                        if "graph_resident" in b1:
+                            ks["graph_resident_vs_kernel_sum"] = round(b1["graph_resident"]["ms_per_step"] / ks["kernel_sum_ms"], 3)
+                        ks["note"] = ("rocprofv3 --kernel-trace child over tools/shipped_step.py 1 graph: sum of the kernel durations of one "
+                                      "replayed batch-1 step (median steady-state step) and its start-to-start time inside the trace")
+                    sc["batch_1"]["kernel_sum"] = ks
+                    result["shipped_config"] = sc
+                except Exception as e:                               # noqa: BLE001 -- the leg is informative
+                    result["shipped_config"] = {"error": f"{type(e).__name__}: {e}"}
             if not args.no_cpu_baseline:
                 result["cpu_baseline"], result["cpu_baseline_online_normals"] = cpu_baseline(args, cfg)
         print(json.dumps(result))

@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdelora_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class DeloraHipError(RuntimeError):
@@ -30,8 +30,8 @@ _SP = ctypes.POINTER(SensorStruct)
 SIGNATURES = {
     "dl_abi_version": (_i32, []),
     "dl_last_error": (ctypes.c_char_p, []),
-    "dl_project_workspace_bytes": (_sz, [_i32, _i32, _i32]),
-    "dl_project": (_i32, [_vp, _i64, _vp, _i32, _i32, _i32, _SP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dl_project_workspace_bytes": (_sz, [_i32, _i32, _i32, _i64, _i32]),
+    "dl_project": (_i32, [_vp, _i64, _i64, _vp, _i32, _i32, _i32, _SP, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dl_normals": (_i32, [_vp, _i64, _i32, _i32, _i32, _i32, _i32, _f32, _i32, _vp, _vp, _vp]),
     "dl_nn_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "dl_nn_correspond": (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _i32, _SP, _i32, _vp, _vp, _vp, _vp, _vp]),

@@ -62,8 +62,12 @@ class Scene:
 
 
 def scan_scene(scene, rng, rings=64, azimuth_steps=2250, vfov_deg=(-24.5, 2.0), pose=None,
-               noise=0.01, min_range=1.0, max_range=80.0, dropout=0.02):
-    """One revolution: ``rings`` x ``azimuth_steps`` rays, returns ``[3,N]`` fp32 in the sensor frame."""
+               noise=0.01, min_range=1.0, max_range=80.0, dropout=0.02, point_order="shuffled"):
+    """One revolution: ``rings`` x ``azimuth_steps`` rays, returns ``[3,N]`` fp32 in the sensor frame.  ``point_order``:
+    "shuffled" (default: a random permutation -- the hardest order for the projection's vote, and what every committed fixture was
+    generated with), "raster" (ring after ring, azimuth ascending: the order of the reference's stored point lists,
+    src/preprocessing/preprocesser.py:60-67) or "firing" (azimuth step after azimuth step, all rings of a step together: the order
+    a spinning sensor's driver delivers).  The same random numbers are drawn in every mode, so the SET of points is the same."""
     R, t = (np.eye(3), np.zeros(3)) if pose is None else pose
     el = np.deg2rad(np.linspace(vfov_deg[0], vfov_deg[1], rings))
     el = el + rng.normal(0, 2e-4, size=rings)
@@ -75,7 +79,14 @@ def scan_scene(scene, rng, rings=64, azimuth_steps=2250, vfov_deg=(-24.5, 2.0), 
     dist = dist + rng.normal(0, noise, size=dist.shape)
     ok = np.isfinite(dist) & (dist > min_range) & (dist < max_range) & (rng.uniform(size=dist.shape) > dropout)
     pts = d[ok] * dist[ok, None]
-    order = rng.permutation(pts.shape[0])        # raw driver order is not range- or ring-sorted
+    order = rng.permutation(pts.shape[0])        # drawn in every mode (keeps the random stream of later scans identical)
+    if point_order == "raster":
+        order = np.arange(pts.shape[0])
+    elif point_order == "firing":
+        ring, step = np.divmod(np.nonzero(ok)[0], azimuth_steps)
+        order = np.lexsort((ring, step))
+    elif point_order != "shuffled":
+        raise ValueError(f"point_order {point_order!r}: shuffled, raster or firing")
     return np.ascontiguousarray(pts[order].T.astype(np.float32))
 
 

@@ -179,6 +179,8 @@ class Trainer(deployer.Deployer):
                 del self._graphed                       # the old capture's private memory pool goes before the new one is built
                 g = None
             cap = self.config.get("graph_max_points") or getattr(self, "_feed_points_per_scan", None)
+            if not cap and hasattr(self.dataset, "max_points_per_scan") and len(self.config["datasets"]) == 1:
+                cap = self.dataset.max_points_per_scan()          # stored lists: at most one point per pixel of the preprocessing image
             g = self._graphed = GraphedStep(self, preprocessed_dicts, max_points=cap)
             self._graphed_phase = phase
             if self.rank == 0:
@@ -263,11 +265,13 @@ class Trainer(deployer.Deployer):
             import gc
             gc.collect()
             gc.freeze()
+        self.history = []                           # per epoch: the reduced metrics + the phase they were computed in
         try:
             for epoch in range(max_epochs):
                 if sampler is not None:
                     sampler.set_epoch(epoch)
                 metrics = self._reduce_metrics(self.train_epoch(epoch=epoch, dataloader=dataloader))
+                self.history.append(dict(metrics, epoch=epoch, unsupervised=bool(self.config["unsupervised_at_start"])))
                 if self.rank == 0:
                     print("--------------------------")
                     print("Epoch Summary: " + format(epoch, "05d") + ", loss: " + str(metrics["loss_epoch"]) +
@@ -280,13 +284,17 @@ class Trainer(deployer.Deployer):
                             mlflow.log_metric(shown, float(metrics[key]), step=epoch)
                     else:
                         print({shown: metrics[key] for shown, key in names.items()})
+                    # the reference writes the latest checkpoint every epoch (trainer.py:155-162) and keeps a copy every 5 (:164-173);
+                    # `checkpoint_every` / `checkpoint_keep_every` (0 = never) thin that out for runs whose epochs take a second
+                    every, keep = int(self.config.get("checkpoint_every", 1)), int(self.config.get("checkpoint_keep_every", 5))
                     latest = os.path.join(out_dir, self.config["training_run_name"] + "_latest_checkpoint.pth")
-                    self.save_checkpoint(latest, epoch, metrics["loss_epoch"])            # every epoch (trainer.py:155-162)
-                    if not epoch % 5:                                                       # and a kept copy every 5 (:164-173)
+                    if (every > 0 and not epoch % every) or epoch == max_epochs - 1:
+                        self.save_checkpoint(latest, epoch, metrics["loss_epoch"])
+                        if mlflow is not None:
+                            mlflow.log_artifact(latest)
+                    if keep > 0 and not epoch % keep:
                         self.save_checkpoint(os.path.join(out_dir, self.config["training_run_name"] + "_checkpoint_epoch_" + str(epoch) + ".pth"),
                                              epoch, metrics["loss_epoch"])
-                    if mlflow is not None:
-                        mlflow.log_artifact(latest)
                 # identity pre-training ends once its loss is small (trainer.py:184-186); all ranks see the same reduced value
                 if not self.config["unsupervised_at_start"] and metrics["loss_epoch"] < 1e-2:
                     self.config["unsupervised_at_start"] = True
@@ -295,3 +303,6 @@ class Trainer(deployer.Deployer):
         finally:
             if run is not None:
                 mlflow.end_run()
+            if hasattr(dataloader, "close"):
+                dataloader.close()                  # PackedFeed: worker processes and page-locked slots
+        return self.history

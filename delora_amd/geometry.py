@@ -76,13 +76,14 @@ def project(points, offsets, max_points, sensor, want_uv=False, want_kept=True, 
     packed_aux = torch.empty((S, H, W, 4), dtype=torch.float32, device=dev) if (want_packed and C >= 6) else None
     pix2pt = torch.empty((S, H, W), dtype=torch.int32, device=dev)
     kept = torch.empty((S,), dtype=torch.int32, device=dev) if want_kept else None
-    keys = torch.empty((lib.dl_project_workspace_bytes(S, H, W) // 8,), dtype=torch.int64, device=dev)
+    n_cols = points.shape[1]
+    ws = torch.empty((lib.dl_project_workspace_bytes(S, H, W, n_cols, C) // 8,), dtype=torch.int64, device=dev)
     uv = torch.empty((3, points.shape[1]), dtype=torch.float32, device=dev) if want_uv else None
     if uv is not None and points.stride(0) != uv.stride(0):
         raise ValueError("want_uv needs a dense points buffer")
-    _lib.check(lib.dl_project(_ptr(points), points.stride(0), _ptr(offsets), S, C, int(max_points),
+    _lib.check(lib.dl_project(_ptr(points), points.stride(0), n_cols, _ptr(offsets), S, C, int(max_points),
                               ctypes.byref(sensor.struct), _ptr(image4), _ptr(aux), _ptr(packed), _ptr(packed_aux),
-                              _ptr(pix2pt), _ptr(keys), _ptr(kept), _ptr(uv), _stream()), "dl_project")
+                              _ptr(pix2pt), _ptr(ws), _ptr(kept), _ptr(uv), _stream()), "dl_project")
     return {"image4": image4, "aux": aux, "packed": packed, "packed_aux": packed_aux, "pix2pt": pix2pt, "kept": kept,
             "uv": uv}
 

@@ -32,6 +32,24 @@ class Preprocesser:
         np.save(os.path.join(self.normals_name, format(int(index), "06d") + ".npy"), normals.cpu().numpy())
         np.save(os.path.join(self.scans_name, format(int(index), "06d") + ".npy"), point_list.cpu().numpy())
 
+    def preprocess_scans(self, scans, dataset_name, data_identifier=0):
+        """The preprocessing step over raw scans that are already in memory (an iterable of ``[3|4,N]`` arrays / tensors): writes
+        ``<preprocessed_path>/<data_identifier:02d>/{scans,normals}/<idx:06d>.npy`` exactly as ``preprocess_data`` does for a KITTI
+        directory (synthetic sequences of the bench, the tests and the convergence run go through the same code as real scans)."""
+        import torch
+        block = self.config[dataset_name]
+        self.config["dataset"] = dataset_name
+        block["horizontal_cells"] = block["horizontal_cells_preprocessing"]                # preprocesser.py:73-74
+        self.normals_computer = normal_computation.NormalsComputer(config=self.config, dataset_name=dataset_name)
+        name = os.path.join(block["preprocessed_path"], format(int(data_identifier), "02d") + "/")
+        self.normals_name, self.scans_name = os.path.join(name, "normals/"), os.path.join(name, "scans/")
+        self.ensure_dir(self.normals_name)
+        self.ensure_dir(self.scans_name)
+        for index, scan in enumerate(scans):
+            scan = torch.as_tensor(np.ascontiguousarray(scan) if isinstance(scan, np.ndarray) else scan)
+            self.apply_preprocessing_step(scan=scan.reshape(1, scan.shape[-2], scan.shape[-1]).to(self.config["device"]), index=index)
+        return name
+
     def preprocess_data(self):
         for dataset_name in self.config["datasets"]:
             block = self.config[dataset_name]

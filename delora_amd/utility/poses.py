@@ -42,3 +42,39 @@ def write_poses_to_text_file(file_name, poses):
         writer = csv.writer(f, delimiter=" ")
         for pose in poses:
             writer.writerow(np.asarray(pose).reshape(16)[:12])
+
+
+def relative_pose_errors(poses_estimated, poses_ground_truth, lengths_m=(100.0, 200.0, 300.0, 400.0, 500.0, 600.0, 700.0, 800.0), step=10):
+    """Relative pose error of an integrated trajectory in the style of the KITTI odometry benchmark, the protocol the reference's
+    results are quoted in (the reference itself only writes the KITTI pose file, src/utility/poses.py:67-74, and leaves the scoring
+    to the benchmark's development kit, which is third party and absent here; restated from its published definition): for every
+    ``step``-th start frame i and every segment length L, j is the first frame whose travelled ground-truth distance from i reaches
+    L; the error transform is ``inv(inv(E_i) E_j) @ (inv(G_i) G_j)``; its translation norm / L is the translation error (a
+    fraction: x100 = percent) and its rotation angle / L the rotation error (rad/m).  Returns ``{"translation": mean fraction,
+    "rotation_rad_per_m": mean, "rotation_deg_per_100m": ..., "segments": count, "per_length": {L: (t, r, n)}}``; the means run over
+    all segments, as the development kit's do.  ``lengths_m`` is free because synthetic sequences are tens of metres long."""
+    E = np.asarray(poses_estimated, dtype=np.float64).reshape(-1, 4, 4)
+    G = np.asarray(poses_ground_truth, dtype=np.float64).reshape(-1, 4, 4)
+    if E.shape != G.shape:
+        raise ValueError(f"trajectories differ in length: {E.shape[0]} vs {G.shape[0]} poses")
+    dist = np.concatenate(([0.0], np.cumsum(np.linalg.norm(np.diff(G[:, :3, 3], axis=0), axis=1))))
+    per_length, t_all, r_all = {}, [], []
+    for L in lengths_m:
+        t_err, r_err = [], []
+        for i in range(0, len(G), max(1, int(step))):
+            j = int(np.searchsorted(dist, dist[i] + L, side="left"))
+            if j >= len(G):
+                break
+            err = np.linalg.inv(np.linalg.inv(E[i]) @ E[j]) @ (np.linalg.inv(G[i]) @ G[j])
+            cos = max(-1.0, min(1.0, 0.5 * (np.trace(err[:3, :3]) - 1.0)))
+            t_err.append(np.linalg.norm(err[:3, 3]) / L)
+            r_err.append(np.arccos(cos) / L)
+        if t_err:
+            per_length[float(L)] = (float(np.mean(t_err)), float(np.mean(r_err)), len(t_err))
+            t_all += t_err
+            r_all += r_err
+    if not t_all:
+        return {"translation": float("nan"), "rotation_rad_per_m": float("nan"), "rotation_deg_per_100m": float("nan"), "segments": 0,
+                "per_length": {}}
+    return {"translation": float(np.mean(t_all)), "rotation_rad_per_m": float(np.mean(r_all)),
+            "rotation_deg_per_100m": float(np.degrees(np.mean(r_all)) * 100.0), "segments": len(t_all), "per_length": per_length}

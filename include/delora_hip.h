@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 5   /* 5: batched weight gradients (dl_conv2d_wgrad_batch_*); 4: free image sizes in the convolution family (the strided input gradients take the INPUT image size and a seam workspace); 3: half-precision convolutions, launch profiler */
+#define DL_ABI_VERSION 6   /* 6: dl_project takes n_cols and ONE workspace (key plane + staging records of the vote); 5: batched weight gradients (dl_conv2d_wgrad_batch_*); 4: free image sizes in the convolution family (the strided input gradients take the INPUT image size and a seam workspace); 3: half-precision convolutions, launch profiler */
 
 typedef void* dl_stream;
 
@@ -66,29 +66,32 @@ typedef struct {
 int dl_abi_version(void);
 const char* dl_last_error(void);
 
-/* Bytes of the uint64 key workspace dl_project needs for S scans of H x W pixels. */
-size_t dl_project_workspace_bytes(int32_t S, int32_t H, int32_t W);
+/* Bytes of scratch dl_project needs for S scans of H x W pixels whose points lie in columns [0, n_cols) of a C-channel buffer:
+ * the uint64 key plane [S][H*W] followed by one 16-byte staging record per column (two when C > 3). */
+size_t dl_project_workspace_bytes(int32_t S, int32_t H, int32_t W, int64_t n_cols, int32_t C);
 
 /*
  * Spherical projection of S scans into range images, nearest point per pixel.
  * Replaces ImageProjectionLayer.project_to_img (src/utility/projection.py:48-106): range channel
  * (:55-60), argsort by range + sequential first-wins dedup on the host (:63-67, :34-43, :80-91)
  * and the index scatter (:98-103) become one atomicMin pass over (range_bits << 32 | point_index)
- * keys plus one resolve pass; u,v follow compute_2D_coordinates (:21-31) with round-half-even.
+ * keys -- which also leaves (x,y,z,range) of every point behind as one 16-byte record -- plus one resolve pass
+ * (one 16-byte gather per occupied pixel); u,v follow compute_2D_coordinates (:21-31) with round-half-even.
  *   pts      [C][pts_cs]   planar fp32, channels 0..2 = x,y,z; scan s owns columns offs[s]..offs[s+1)
+ *   n_cols                 number of columns in use (offs[S] <= n_cols <= pts_cs): sizes the staging records
  *   offs     [S+1]         int32 CSR offsets (device); max_n = largest scan length (host value)
  *   image4   [S][4][H][W]  out: x,y,z,range of the winning point, zeros elsewhere
  *   aux      [S][C-3][H][W] out (may be NULL when C == 3): the remaining channels of the winner
  *   packed   [S][H][W][4]  out (may be NULL): x,y,z,range of the winner, pixel-interleaved
  *   packed_aux [S][H][W][4] out (may be NULL; needs C >= 6): channels 3..5 of the winner + 0 (stored normals)
  *   pix2pt   [S][H][W]     out: index of the winning point relative to its scan start, -1 if empty
- *   keys_ws  dl_project_workspace_bytes(S,H,W) bytes of scratch
+ *   workspace dl_project_workspace_bytes(S,H,W,n_cols,C) bytes of scratch, 16-byte aligned
  *   kept     [S]           out (may be NULL): number of occupied pixels per scan
  *   uvr      [3][pts_cs]   out (may be NULL): fp32 u, v and range of EVERY input point, input order
  */
-int dl_project(const float* pts, int64_t pts_cs, const int32_t* offs, int32_t S, int32_t C,
+int dl_project(const float* pts, int64_t pts_cs, int64_t n_cols, const int32_t* offs, int32_t S, int32_t C,
                int32_t max_n, const dl_sensor* sensor, float* image4, float* aux, float* packed,
-               float* packed_aux, int32_t* pix2pt, uint64_t* keys_ws, int32_t* kept, float* uvr,
+               float* packed_aux, int32_t* pix2pt, void* workspace, int32_t* kept, float* uvr,
                dl_stream stream);
 
 /*

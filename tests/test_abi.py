@@ -31,7 +31,9 @@ def test_library_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), name
         assert name in _lib.SIGNATURES, f"{name} has no ctypes signature"
     assert lib.dl_abi_version() == _lib.ABI_VERSION
-    assert lib.dl_project_workspace_bytes(2, 64, 2048) == 2 * 64 * 2048 * 8
+    assert lib.dl_project_workspace_bytes(2, 64, 2048, 0, 3) == 2 * 64 * 2048 * 8                       # the key plane alone
+    assert lib.dl_project_workspace_bytes(2, 64, 2048, 1000, 3) == 2 * 64 * 2048 * 8 + 1000 * 16          # + (x,y,z,range) per point
+    assert lib.dl_project_workspace_bytes(2, 64, 2048, 1000, 6) == 2 * 64 * 2048 * 8 + 1000 * 32          # + the stored normals
     assert lib.dl_nn_workspace_bytes(1, 4, 8) >= 4 * 8 * 16
     assert lib.dl_icp_loss_workspace_bytes(8, 64, 2048) > 0
 

@@ -171,3 +171,20 @@ def test_weight_gradient_takes_the_parameters_strides():
             g = grad_for(dw, ref)
             assert g.shape == w.shape and g.stride() == w.stride() and g.data_ptr() == dw.data_ptr()
             assert torch.equal(g, dw.permute(0, 3, 1, 2))
+
+
+def test_kernel_sum_of_trace_cuts_steps_at_the_projection():
+    """bench.kernel_sum_of_trace: a kernel trace is cut into steps at `k_project_scatter`; the median step's summed kernel time and
+    start-to-start time are what `shipped_config.batch_1.kernel_sum` reports."""
+    import bench
+    rows, t = [], 1000
+    for step in range(6):
+        for name, dur, gap in (("k_fill_words", 2000, 500), ("k_project_scatter(float const*)", 10000, 500), ("k_other", 30000 + 1000 * (step == 2), 1500)):
+            if name == "k_fill_words":
+                pass
+            rows.append({"Kernel_Name": name, "Start_Timestamp": str(t), "End_Timestamp": str(t + dur)})
+            t += dur + gap
+    out = bench.kernel_sum_of_trace(rows, steps=5)
+    assert out["kernels_per_step"] == 3 and out["steps_in_trace"] == 4
+    assert abs(out["kernel_sum_ms"] - 42000e-6) < 1e-9 and abs(out["step_wall_ms"] - 44500e-6) < 1e-9
+    assert bench.kernel_sum_of_trace(rows[:5], steps=5) is None

@@ -598,7 +598,7 @@ def test_quaternion_kernel_against_the_references_own_quat2mat():
 
 
 @pytest.mark.parametrize("workers", [0, 2])
-def test_run_training_cli_with_the_unmodified_yaml_takes_the_hip_path(tmp_path, workers):
+def test_run_training_cli_with_the_unmodified_yaml_takes_the_hip_path_and_the_graph(tmp_path, workers):
     """The drop-in claim end to end (review item 2): `bin/run_training.py` with this repo's config/*.yaml UNMODIFIED -- the reference's
     shipped KITTI setup, 64x720 images, batch 1, identity pre-training first -- on a tree in the reference's on-disk format under the
     YAML's own relative path.  The CNN must run on the HIP stem + trunk (no "MODULE path" line), epochs must complete and a checkpoint
@@ -627,6 +627,14 @@ def test_run_training_cli_with_the_unmodified_yaml_takes_the_hip_path(tmp_path, 
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "MODULE path" not in r.stdout, "the unmodified YAML (64x720) must run on the HIP stem + trunk"
     assert r.stdout.count("Epoch Summary") == 2 and "nan" not in r.stdout.lower()
+    # the default operating point (batch 1, ~100 launches for a millisecond of GPU work) is host-bound when run eagerly: `hip_graph: auto`
+    # (the key is absent from the YAML) must have measured that, captured the step and replayed the rest of the two epochs -- from the
+    # DataLoader's lists of dicts (workers 0) and from the packed feed's batches (workers 2)
+    assert "the step is host-bound: replaying it as ONE captured HIP graph" in r.stdout, r.stdout[-3000:]
+    assert "training step captured as a HIP graph: True" in r.stdout, r.stdout[-3000:]
+    import re
+    replayed = [int(x) for x in re.findall(r"steps replayed as a HIP graph so far: (\d+)", r.stdout)]
+    assert len(replayed) == 2 and replayed[-1] >= 14, replayed      # 36 steps - 11 probe steps (twice, should the phase change after epoch 0)
     ck = torch.load("/tmp/dropin_latest_checkpoint.pth", map_location="cpu", weights_only=False)
     assert ck["epoch"] == 1 and ck["parameters"]["kitti"]["horizontal_cells"] == 720 and len(ck["model_state_dict"]) == 30
     for name in ("dropin_latest_checkpoint.pth", "dropin_checkpoint_epoch_0.pth"):

@@ -806,3 +806,55 @@ def test_merged_weight_gradients_are_routed_like_the_single_launches(monkeypatch
     monkeypatch.setattr(rc, "USE_WINOGRAD_WGRAD", False)
     rc.wgrad_batch(items)
     assert [fn for fn, _ in calls] == ["dl_conv2d_wgrad_batch_nhwc_f32"] and len(calls[0][1]) == 6
+
+
+def test_relative_pose_errors_known_answers():
+    """utility/poses.relative_pose_errors (KITTI-benchmark-style relative error; the metric of the convergence evidence): a 10 % scale
+    error of a straight trajectory is a 10 % translation error and no rotation error; a constant yaw-rate error of 0.01 rad per metre is
+    that rotation error; identical trajectories have none; segments longer than the trajectory are skipped."""
+    from delora_amd.utility import poses as P
+
+    def chain(steps):
+        out = [np.eye(4)]
+        for T in steps:
+            out.append(out[-1] @ T)
+        return np.stack(out)
+
+    def step(dz, yaw=0.0):
+        T = np.eye(4)
+        T[2, 3] = dz
+        c, s_ = np.cos(yaw), np.sin(yaw)
+        T[:3, :3] = np.array([[c, 0, s_], [0, 1, 0], [-s_, 0, c]])          # yaw about the camera frame's y axis
+        return T
+
+    gt = chain([step(1.0)] * 60)
+    r = P.relative_pose_errors(chain([step(1.1)] * 60), gt, lengths_m=(5.0, 10.0, 1000.0), step=1)
+    assert abs(r["translation"] - 0.1) < 1e-12 and r["rotation_rad_per_m"] < 1e-7 and set(r["per_length"]) == {5.0, 10.0}
+    assert r["segments"] == (61 - 5) + (61 - 10)
+    r = P.relative_pose_errors(chain([step(1.0, 0.01)] * 60), gt, lengths_m=(5.0,), step=1)
+    assert abs(r["rotation_rad_per_m"] - 0.01) < 1e-9 and abs(r["rotation_deg_per_100m"] - np.degrees(1.0)) < 1e-6
+    r = P.relative_pose_errors(gt, gt, lengths_m=(5.0,))
+    assert r["translation"] < 1e-15 and r["segments"] == 6
+    assert P.relative_pose_errors(gt, gt, lengths_m=(100.0,))["segments"] == 0
+    with pytest.raises(ValueError):
+        P.relative_pose_errors(gt[:-1], gt)
+
+
+def test_graph_policy_reads_the_config_key():
+    """Trainer.graph_policy: `hip_graph` absent = "auto" (measure and decide), true / false force it, and a configuration a capture
+    cannot serve (augmentation, range normalisation, several ranks, fp16 loss scaling) or a CPU run is always eager."""
+    from delora_amd.deploy.trainer import Trainer
+
+    class T(Trainer):
+        def __init__(self, config, device="cuda", world=1, scaler=None):            # noqa: super().__init__ not called on purpose
+            self.config, self.device, self.world_size, self.grad_scaler = config, torch.device(device), world, scaler
+
+    base = {"normalization_scaling": False, "random_point_cloud_rotations": False, "use_jit": False}
+    assert T(dict(base)).graph_policy() == "auto"
+    for v, want in ((True, "on"), ("true", "on"), (False, "off"), ("off", "off"), ("auto", "auto"), ("Auto", "auto")):
+        assert T(dict(base, hip_graph=v)).graph_policy() == want, v
+    assert T(dict(base, hip_graph=True), device="cpu").graph_policy() == "off"
+    assert T(dict(base, hip_graph=True), world=2).graph_policy() == "off"
+    assert T(dict(base, hip_graph=True, normalization_scaling=True)).graph_policy() == "off"
+    assert T(dict(base, hip_graph=True, random_point_cloud_rotations=True)).graph_policy() == "off"
+    assert T(dict(base, hip_graph=True), scaler=object()).graph_policy() == "off"
