@@ -65,6 +65,8 @@ def parse(argv=None):
                     help="order of the points inside a raw scan: raster = ring after ring, the order of the reference's stored point lists "
                          "(src/preprocessing/preprocesser.py:60-67; the default since round 5), firing = the order a spinning sensor delivers, "
                          "shuffled = a random permutation (rounds 1-4: the worst case of the projection's vote; still a row of `kernels`)")
+    ap.add_argument("--ddp-steps", type=int, default=20, help="timed steps of the `ddp_rank` leg: one rank wrapped in DistributedDataParallel over a "
+                    "one-rank RCCL group, fp32 and bf16, against the unwrapped step (0 = skip); N=1 only")
     ap.add_argument("--shipped-steps", type=int, default=200, help="timed batch-1 steps of the `shipped_config` leg: the reference's default operating "
                     "point (unmodified YAML: 64x720, batch 1, stored lists), eager / graph / product loop from disk (0 = skip); N=1 only")
     ap.add_argument("--amp", default="", help="optional autocast dtype for the CNN (bfloat16/float16); default fp32 = parity mode")
@@ -513,6 +515,60 @@ def kernel_sum_of_trace(rows, steps):
         count.append(b - a)
     return {"kernel_sum_ms": round(float(np.median(busy)) * 1e-6, 4), "step_wall_ms": round(float(np.median(wall)) * 1e-6, 4),
             "kernels_per_step": int(np.median(count)), "steps_in_trace": len(busy)}
+
+
+def ddp_rank_leg(args, device, host_batches, batches, timed_region, enqueue, steps=20):
+    """What DistributedDataParallel adds to ONE rank, measured without a second GPU: a process group of one rank over RCCL
+    (backend "nccl"), the model wrapped exactly as `Trainer._wrap_ddp` wraps it on an 8-GPU node (trunk cut into three autograd
+    Functions, 5 MB buckets as gradient views, one all-reduce launch per bucket -- RCCL's single-rank kernels), against the same steps
+    unwrapped, fp32 and bf16.  The step time tells what the reducer costs the GPU side, `host_enqueue_ms_per_step` whether a DDP rank's
+    HOST keeps up with its GPU (a rank whose enqueue time exceeds its GPU step is host-bound before the network is even involved)."""
+    import argparse, gc
+    from delora_amd.deploy.trainer import Trainer
+    from delora_amd.data.dataset import ListDataset
+    from delora_amd.models import ring_conv
+    own_group = not torch.distributed.is_initialized()
+    if own_group:
+        torch.distributed.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=device)
+    out = {"process_group": "1 rank, backend nccl (RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version()) + ")"}
+    segments = ring_conv.TRUNK_SEGMENTS
+    try:
+        for amp in ("", "bfloat16"):
+            leg = {}
+            for wrapped in (False, True):
+                a2 = argparse.Namespace(**vars(args))
+                a2.amp = amp
+                cfg = build_config(a2, device)
+                ring_conv.TRUNK_SEGMENTS = segments
+                torch.manual_seed(1234)
+                trainer = Trainer(cfg, dataset=ListDataset([d for b in host_batches for d in b]))
+                identity_pretrained_state(trainer.raw_model)
+                if wrapped:
+                    trainer.model = trainer._wrap_ddp(trainer.raw_model)
+                k = {"i": 0}
+
+                def step():
+                    k["i"] += 1
+                    trainer.optimizer.zero_grad(set_to_none=True)
+                    return trainer.step(preprocessed_dicts=[dict(d) for d in batches[k["i"] % len(batches)]], epoch_losses=trainer.new_epoch_losses())[0]
+                for _ in range(len(batches) + 2):
+                    step()
+                el, ep = timed_region(steps, step)
+                leg["ddp" if wrapped else "plain"] = {"ms_per_step": round(1e3 * el / steps, 3), "host_enqueue_ms_per_step": round(enqueue["ms_per_step"], 3),
+                                                     "final_loss": float(ep["loss_epoch"])}
+                del trainer
+                gc.collect()
+                torch.cuda.empty_cache()
+            leg["ddp_host_bound"] = bool(leg["ddp"]["host_enqueue_ms_per_step"] > leg["plain"]["ms_per_step"])
+            leg["ddp_step_overhead_ms"] = round(leg["ddp"]["ms_per_step"] - leg["plain"]["ms_per_step"], 3)
+            out["fp32" if not amp else "bf16"] = leg
+    finally:
+        ring_conv.TRUNK_SEGMENTS = segments
+        if own_group:
+            torch.distributed.destroy_process_group()
+    out["note"] = ("ddp_host_bound = the wrapped rank's host needs longer to enqueue a step than the unwrapped step takes on the GPU; the all-reduce "
+                   "itself moves no data here (one rank) -- its xGMI time is arithmetic in DESIGN.md, not a measurement")
+    return out
 
 
 def conv_table(args, device, reps=10):
@@ -1196,6 +1252,11 @@ def main():
                     result["shipped_config"] = sc
                 except Exception as e:                               # noqa: BLE001 -- the leg is informative
                     result["shipped_config"] = {"error": f"{type(e).__name__}: {e}"}
+            if not args.amp and args.ddp_steps > 0 and (graphed is None or not graphed.captured):
+                try:
+                    result["ddp_rank"] = ddp_rank_leg(args, device, host_batches, batches, timed_region, enqueue, steps=args.ddp_steps)
+                except Exception as e:                               # noqa: BLE001 -- the leg is informative
+                    result["ddp_rank"] = {"error": f"{type(e).__name__}: {e}"}
             if not args.no_cpu_baseline:
                 result["cpu_baseline"], result["cpu_baseline_online_normals"] = cpu_baseline(args, cfg)
         print(json.dumps(result))

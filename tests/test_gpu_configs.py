@@ -183,7 +183,7 @@ def _bench_setup(batch, dev, rotate=1):
     args = bench.parse(["--batch", str(batch), "--rotate", str(rotate)])
     cfg = bench.build_config(args, dev)
     torch.manual_seed(1234)
-    host = bench.derived_batches(bench.make_batch(args, 0), rotate, 0)
+    host = bench.derived_batches(bench.make_batch(args, 0), rotate, 0, shuffled=args.point_order == "shuffled")
     batches = [bench.to_device(b, dev) for b in host]
     trainer = _trainer(cfg, [d for b in host for d in b])
     bench.identity_pretrained_state(trainer.raw_model)
@@ -291,7 +291,7 @@ def test_bench_final_loss_reproduces():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "3", "--warmup", "0", "--no-cpu-baseline",
                         "--kernel-reps", "2", "--feed-steps", "0", "--long-steps", "0", "--no-live-pmc", "--variant-steps", "2",
-                        "--autocast-steps", "0"], capture_output=True, text=True, timeout=900)
+                        "--autocast-steps", "0", "--shipped-steps", "8", "--ddp-steps", "2"], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
     line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
     j = json.loads(line)
@@ -301,6 +301,23 @@ def test_bench_final_loss_reproduces():
     # the reference's shipped image size runs on the HIP stem + trunk too (overhanging tiles), and a run from scratch has a number
     assert j["shipped_image"]["image"] == "64x720" and "hip trunk" in j["shipped_image"]["cnn_impl"] and j["shipped_image"]["value"] > 0
     assert "random" in j["untrained_network"]["network_state"] and j["untrained_network"]["value"] > 0 and np.isfinite(j["untrained_network"]["final_loss"])
+    # the reference's default operating point (unmodified YAML: 64x720, batch 1, stored lists): eager, replayed, and the product loop,
+    # whose `hip_graph: auto` must have found the batch-1 step host-bound and replayed it -- from the packed feed and from the DataLoader
+    sc = j["shipped_config"]
+    assert "error" not in sc, sc
+    b1 = sc["batch_1"]
+    for leg in ("eager_resident", "graph_resident", "product_loop_packed_feed_2_workers", "product_loop_yaml_default_0_workers"):
+        assert b1[leg]["ms_per_step"] > 0 and b1[leg]["value"] > 0, leg
+    assert b1["graph_resident"]["eager_fallback_steps"] == 0
+    for leg in ("product_loop_packed_feed_2_workers", "product_loop_yaml_default_0_workers"):
+        assert b1[leg]["hip_graph_auto"]["decision"] == "graph" and b1[leg]["graph_replayed_steps"] == b1[leg]["steps"], (leg, b1[leg])
+    assert b1["product_loop_packed_feed_2_workers"]["feed"] == "PackedFeed" and sc["batch_8"]["eager_resident"]["value"] > 0
+    util.measured("default operating point (64x720, batch 1): graph replay / eager step time", b1["graph_resident"]["ms_per_step"] / b1["eager_resident"]["ms_per_step"], bound=1.0)
+    # one rank under DistributedDataParallel over a one-rank RCCL group, fp32 and bf16
+    dd = j["ddp_rank"]
+    assert "error" not in dd, dd
+    for prec in ("fp32", "bf16"):
+        assert dd[prec]["ddp"]["ms_per_step"] > 0 and np.isfinite(dd[prec]["ddp"]["final_loss"]) and isinstance(dd[prec]["ddp_host_bound"], bool)
 
 
 def test_bench_measures_the_convolution_traffic_itself():
@@ -377,6 +394,29 @@ def test_config4_mixed_sensor_batch_against_oracle(amp):
 
 
 # ------------------------------------------------------------------------------------------- config 2 (multi-GPU readiness)
+def test_bench_eight_ranks_dry_run_on_one_gpu():
+    """`python bench.py --gpus 8` end to end on a 1-GPU box: the script re-launches itself as EIGHT ranks (torch.distributed.run), all
+    sharing the GPU over gloo (test hooks), at a tiny size (64x256 images, one pair per rank).  One JSON line, n_gpus = rccl_ranks = 8,
+    a global batch of 8, eight per-rank step times, a finite loss -- the launch / barrier / max-over-ranks / gather path of BASELINE
+    configs[2] with its real world size (no scaling number can come from one GPU)."""
+    _dev()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DELORA_BENCH_SHARE_GPU="1", DELORA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--batch", "1", "--width", "256",
+           "--rotate", "2", "--kernel-reps", "2", "--no-live-pmc", "--no-profile"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints exactly one JSON line"
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 8 and j["rccl_ranks"] == 8 and j["config"]["global_batch"] == 8 and j["config"]["parallelism"] == "dp8"
+    rk = j["rank_ms_per_step"]
+    assert len(rk["per_rank"]) == 8 and 0 < rk["min"] <= rk["max"] <= j["ms_per_step"] * 1.001 + 1e-3
+    assert j["scaling"] == "weak" and j["steps"] == 3 and np.isfinite(j["final_loss"]) and j["value"] > 0
+    assert "cpu_baseline" not in j and "shipped_config" not in j and "hip trunk" in j["config"]["cnn_impl"]
+
+
 @pytest.mark.parametrize("launcher", ["torchrun", "plain"])
 def test_bench_two_ranks_on_one_gpu_through_torchrun(launcher):
     """BASELINE config 2's launch path on a 1-GPU box: `python -m torch.distributed.run --nproc-per-node 2 bench.py --gpus 2`

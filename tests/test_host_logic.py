@@ -596,8 +596,11 @@ def _ddp_worker_n(rank, world, per_rank, port, identity_phase, return_dict):
         tr.optimizer.zero_grad()
         mine = _synthetic_samples(world * per_rank)[rank * per_rank:(rank + 1) * per_rank]
         ep, T = tr.step(preprocessed_dicts=mine, epoch_losses=ep)
+        tr.steps_per_epoch_effective = 1
         return_dict[rank] = {"T": T.detach().clone(), "grads": {k: p.grad.clone() for k, p in tr.raw_model.named_parameters()},
-                             "loss": float(ep["loss_epoch"]), "loss_pc": float(ep["loss_point_cloud_epoch"])}
+                             "loss": float(ep["loss_epoch"]), "loss_pc": float(ep["loss_point_cloud_epoch"]),
+                             "visible_local": float(ep["visible_pixels_epoch"]), "reduced": tr._reduce_metrics(ep),
+                             "after": {k: v.clone() for k, v in tr.raw_model.state_dict().items()}}
     finally:
         torch.distributed.destroy_process_group()
 
@@ -625,6 +628,41 @@ def test_three_ranks_times_two_samples_equal_one_batch_of_six(identity_phase):
             assert torch.allclose(a, b, rtol=2e-3, atol=3e-4 * float(b.abs().max()) + 1e-12), k
     assert np.isclose(sum(ret[r]["loss"] for r in range(world)), float(ep["loss_epoch"]), rtol=1e-5)
     assert np.isclose(sum(ret[r]["loss_pc"] for r in range(world)), float(ep["loss_point_cloud_epoch"]), rtol=1e-5)
+
+
+@pytest.mark.parametrize("identity_phase", [False, True])
+def test_eight_ranks_times_one_sample_equal_one_batch_of_eight(identity_phase):
+    """BASELINE configs[2] in miniature: 8 ranks x B=1 (gloo) == 1 process x B=8, in both training phases -- poses, the (Bg - j)/Bg
+    weights of the global sample index, the identity loss of the LAST rank's sample only, the averaged gradients, the Adam update,
+    and the epoch metrics after the all-reduce (the loss terms are sums over ranks; `visible_pixels` is the last sample's count,
+    contributed by the last rank alone)."""
+    from delora_amd.deploy.trainer import Trainer
+    world, per_rank = 8, 1
+    cfg, sd = _small_cfg(16, 128, world * per_rank, unsupervised_at_start=not identity_phase)
+    tr = Trainer(cfg, dataset=util.ListDataset([]), geometry_backend=util.OracleStepGeometry())
+    tr.raw_model.load_state_dict(sd)
+    ep = tr.new_epoch_losses()
+    tr.optimizer.zero_grad()
+    ep, T = tr.step(preprocessed_dicts=_synthetic_samples(world * per_rank), epoch_losses=ep)
+    single = {k: p.grad.clone() for k, p in tr.raw_model.named_parameters()}
+    single_after = {k: v.clone() for k, v in tr.raw_model.state_dict().items()}
+    ret = mp.Manager().dict()
+    mp.spawn(_ddp_worker_n, args=(world, per_rank, 33500 + (os.getpid() % 2000), identity_phase, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert torch.allclose(ret[r]["T"], T[r:r + 1].detach(), atol=2e-6)
+        for k, b in single.items():
+            assert torch.allclose(ret[r]["grads"][k], b, rtol=2e-3, atol=3e-4 * float(b.abs().max()) + 1e-12), k
+        for k, b in single_after.items():
+            # Adam's first step moves every weight by +-lr: only weights whose gradient is ~0 may move differently
+            off = (ret[r]["after"][k] - b).abs() > 2e-7
+            assert float(off.float().mean()) < 0.01, k
+        # every rank holds the same reduced metrics, and they are the single process' epoch sums
+        for key in ("loss_epoch", "loss_point_cloud_epoch", "loss_po2pl_epoch", "loss_pl2pl_epoch", "visible_pixels_epoch"):
+            assert np.isclose(ret[r]["reduced"][key], float(ep[key]), rtol=1e-5, atol=1e-9), (r, key)
+    if identity_phase:                                  # only the last rank's sample is fitted to the identity (deployer.py:324-338)
+        assert all(ret[r]["loss"] == 0.0 for r in range(world - 1)) and ret[world - 1]["loss"] > 0.0
+    assert np.isclose(sum(ret[r]["loss"] for r in range(world)), float(ep["loss_epoch"]), rtol=1e-5)
+    assert ret[world - 1]["visible_local"] == float(ep["visible_pixels_epoch"]) > 0
 
 
 def test_rotation_head_gradient_does_not_depend_on_which_rows_share_the_batch_norm():
@@ -858,3 +896,18 @@ def test_graph_policy_reads_the_config_key():
     assert T(dict(base, hip_graph=True, normalization_scaling=True)).graph_policy() == "off"
     assert T(dict(base, hip_graph=True, random_point_cloud_rotations=True)).graph_policy() == "off"
     assert T(dict(base, hip_graph=True), scaler=object()).graph_policy() == "off"
+
+
+def test_packed_feed_of_eight_ranks_with_two_workers_each_on_one_host():
+    """BASELINE configs[2]'s feed in miniature (tools/feed_ranks.py): 8 rank processes x (1 consumer + 2 workers) = 24 processes on
+    this host, each rank reading its DistributedSampler shard of one tree through its own PackedFeed.  Every rank must get every
+    batch of its shard in every epoch; the aggregate rate is recorded (the full-size run is tools/feed_ranks.py on the GPU box)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))              # (importable by name: the rank processes are spawned, not forked)
+    try:
+        import feed_ranks as mod
+        out = mod.run(ranks=8, workers=2, batch=1, scans=17, epochs=3, rings=16, cells=200)
+    finally:
+        sys.path.pop(0)
+    assert out["processes"] == 24 and out["batches_per_rank"] == 3 * (16 // 8) and out["pairs_per_s_per_rank_min"] > 0
+    print(out)
