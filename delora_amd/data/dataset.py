@@ -134,8 +134,16 @@ class PreprocessedPointCloudDataset(torch.utils.data.Dataset):
         return hit
 
     def load_pair_arrays(self, index):
-        """[(xyz [M,3], normals [M,3] | None) of scan k, the same of scan k+1] as stored on disk (no transposition, no tensors)."""
+        """[(xyz, normals | None) of scan k, the same of scan k+1] without tensors: ``[M,3]`` arrays as stored on disk, or -- with
+        ``store_dataset_in_RAM`` -- the ``[3,M]`` planar views of the tensors held in RAM (``PackedFeed`` tells the two layouts apart by
+        their shape and copies either into the planar batch slot)."""
         i_ds, i_seq, k = int(self.indices_dataset[index]), int(self.indices_sequence[index]), int(self.indices_scan[index])
+        if self.store_dataset_in_RAM:
+            out = []
+            for kk in (k, k + 1):
+                normals, scan = self._ram[(i_ds, i_seq, kk)]
+                out.append((scan[0].numpy(), normals[0].numpy() if normals is not None else None))
+            return out
         return [self._arrays(i_ds, i_seq, k), self._arrays(i_ds, i_seq, k + 1)]
 
     def max_points_per_scan(self):

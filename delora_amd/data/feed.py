@@ -74,35 +74,41 @@ import multiprocessing as _mp
 import queue as _queue
 
 
-def _feed_worker(dataset, slots, tasks, done, rows, capacity):
-    """Worker loop: (batch id, sample indices, slot) -> the slot filled as ``[rows][capacity]`` planar fp32 (row c holds coordinate c of
-    the batch's scans back to back) + the scan lengths."""
-    torch.set_num_threads(1)
+def _fill_slot(dataset, out, indices, rows, capacity):
+    """The scans of the samples ``indices`` into ``out [rows][capacity]`` (planar fp32: row c holds coordinate c of the batch's scans back
+    to back; rows 3..5 the stored normals).  Returns (scan lengths, (seconds reading, seconds copying))."""
     import time as _t
+    lengths, o, t_read, t_copy = [], 0, 0.0, 0.0
+    planar = bool(getattr(dataset, "store_dataset_in_RAM", False))   # RAM: the [3,M] rows of the stored tensors; disk: [M,3] files
+    for i in indices:
+        t0 = _t.perf_counter()
+        pair = dataset.load_pair_arrays(int(i))                      # [(xyz, normals | None)] x 2: [M,3] from disk, [3,M] from RAM
+        t1 = _t.perf_counter()
+        for xyz, nrm in pair:
+            n = xyz.shape[1] if planar else xyz.shape[0]
+            if o + n > capacity:
+                raise ValueError(f"batch exceeds the slot capacity of {capacity} points (config feed_points_per_scan)")
+            out[:3, o:o + n] = xyz[:3] if planar else xyz[:, :3].T       # decode -> planar slot in one pass
+            if rows == 6:
+                out[3:6, o:o + n] = nrm if planar else nrm.T
+            lengths.append(n)
+            o += n
+        t_read += t1 - t0
+        t_copy += _t.perf_counter() - t1
+    return lengths, (t_read, t_copy)
+
+
+def _feed_worker(dataset, slots, tasks, done, rows, capacity):
+    """Worker loop: (batch id, sample indices, slot) -> the slot filled by ``_fill_slot`` + the scan lengths."""
+    torch.set_num_threads(1)
     while True:
         task = tasks.get()
         if task is None:
             return
         bid, indices, slot = task
         try:
-            out = slots[slot].numpy().reshape(rows, capacity)
-            lengths, o, t_read, t_copy = [], 0, 0.0, 0.0
-            for i in indices:
-                t0 = _t.perf_counter()
-                pair = dataset.load_pair_arrays(int(i))                  # [(xyz [M,3], normals [M,3] | None)] x 2, scan reuse inside
-                t1 = _t.perf_counter()
-                for xyz, nrm in pair:
-                    n = xyz.shape[0]
-                    if o + n > capacity:
-                        raise ValueError(f"batch exceeds the slot capacity of {capacity} points (config feed_points_per_scan)")
-                    out[:3, o:o + n] = xyz[:, :3].T                       # decode -> planar slot in one pass
-                    if rows == 6:
-                        out[3:6, o:o + n] = nrm.T
-                    lengths.append(n)
-                    o += n
-                t_read += t1 - t0
-                t_copy += _t.perf_counter() - t1
-            done.put((bid, slot, lengths, (t_read, t_copy), None))
+            lengths, spent = _fill_slot(dataset, slots[slot].numpy().reshape(rows, capacity), indices, rows, capacity)
+            done.put((bid, slot, lengths, spent, None))
         except Exception as e:                                       # noqa: BLE001 -- reported to the consumer, which raises
             done.put((bid, slot, None, None, f"{type(e).__name__}: {e}"))
 
@@ -110,9 +116,11 @@ def _feed_worker(dataset, slots, tasks, done, rows, capacity):
 class PackedFeed:
     """Iterable over the batches of one epoch as ``PackedBatch`` objects on ``device`` (see the block comment above).
 
-    ``dataset``: a ``PreprocessedPointCloudDataset`` over ONE dataset block (one sensor); ``batch_sampler``: an iterable of index
-    lists per epoch (torch's BatchSampler); ``workers`` >= 1 processes; ``points_per_scan``: upper bound of a stored list's length
-    (the slot capacity is 2 * batch_size * that many points)."""
+    ``dataset``: a ``PreprocessedPointCloudDataset`` over ONE dataset block (one sensor), on disk or held in RAM; ``batch_sampler``: an
+    iterable of index lists per epoch (torch's BatchSampler); ``workers`` processes -- **0 = no processes at all**: the consumer
+    itself decodes the next batch into a page-locked slot (the reference's ``num_dataloader_workers: 0`` taken literally; what it saves
+    over the DataLoader is the per-tensor pinning and the 4-32 separate copies per batch: measured 44 ms -> see bench.py
+    ``shipped_config``); ``points_per_scan``: upper bound of a stored list's length (the slot capacity is 2 * batch_size * that)."""
 
     def __init__(self, dataset, batch_sampler, batch_size, device, workers=4, points_per_scan=None, slots=None, ahead=None):
         from ..deploy.step_geometry import PackedBatch
@@ -121,7 +129,7 @@ class PackedFeed:
         self.cuda = getattr(device, "type", str(device)) == "cuda"
         self.rows = 6 if dataset.load_normals else 3
         self.dataset_name = dataset.config["datasets"][0]
-        self.workers = max(1, int(workers))
+        self.workers = max(0, int(workers))
         self.ahead = int(ahead) if ahead else self.workers + 2            # batches in flight
         n_slots = int(slots) if slots else self.ahead + 2
         cap = int(points_per_scan or dataset.max_points_per_scan())
@@ -155,15 +163,18 @@ class PackedFeed:
             p.join(timeout=2)
             if p.is_alive():
                 p.terminate()
-        if self.cuda and self.pinned:
+        if self.cuda and self.pinned and self.slots:
+            for ev, _ in self._uploads:                 # a copy still in flight reads the slot it is about to lose
+                if ev is not None:
+                    ev.synchronize()
             rt = torch.cuda.cudart()
             for s in self.slots:
                 rt.cudaHostUnregister(s.data_ptr())
-        self.procs, self.slots = [], []
+        self.procs, self.slots, self._uploads = [], [], []
 
     def __del__(self):
         try:
-            if self.procs:
+            if self.procs or self.slots:
                 self.close()
         except Exception:                                            # noqa: BLE001 -- interpreter shutdown
             pass
@@ -234,14 +245,25 @@ class PackedFeed:
 
         def issue():
             nonlocal issued, exhausted
-            while not exhausted and free and issued - consumed < self.ahead:
+            while not exhausted and free and issued - consumed < (self.ahead if self.workers else 1):
                 try:
                     idx = next(batches)
                 except StopIteration:
                     exhausted = True
                     return
-                self.tasks.put((issued, [int(i) for i in idx], free.pop(0)))
-                self._outstanding += 1
+                slot = free.pop(0)
+                if self.workers:
+                    self.tasks.put((issued, [int(i) for i in idx], slot))
+                    self._outstanding += 1
+                else:                                                    # no worker processes: decode here, now
+                    try:
+                        lengths, spent = _fill_slot(self.dataset, self.slots[slot].numpy().reshape(self.rows, self.capacity),
+                                                    [int(i) for i in idx], self.rows, self.capacity)
+                    except Exception as e:                               # noqa: BLE001 -- same error type as a worker's report
+                        raise RuntimeError(f"PackedFeed worker: {type(e).__name__}: {e}")
+                    self.host_seconds["worker_read_files"] = self.host_seconds.get("worker_read_files", 0.0) + spent[0]
+                    self.host_seconds["worker_transpose_into_slot"] = self.host_seconds.get("worker_transpose_into_slot", 0.0) + spent[1]
+                    arrived[issued] = (slot, lengths)
                 issued += 1
 
         def next_uploaded():
@@ -288,12 +310,13 @@ class PackedFeed:
 
 
 def packed_feed_applicable(dataset, config, device):
-    """Whether the training set can go through ``PackedFeed``: worker processes requested, a CUDA device, the reference's on-disk
-    dataset over ONE dataset block (one sensor per batch), no per-sample host preprocessing (augmentation / range normalisation work
-    on the sample dicts)."""
+    """Whether the training set can go through ``PackedFeed``: a CUDA device, the reference's dataset (on disk or in RAM) over ONE
+    dataset block (one sensor per batch), no per-sample host preprocessing (augmentation / range normalisation work on the sample
+    dicts).  Any worker count, 0 included (the consumer then decodes in-process): the DataLoader path re-pins every tensor of every
+    batch and costs the host tens of milliseconds per step -- it remains for what the packed layout cannot express."""
     from .dataset import PreprocessedPointCloudDataset
-    return (isinstance(dataset, PreprocessedPointCloudDataset) and not dataset.store_dataset_in_RAM and len(config["datasets"]) == 1
-            and int(config.get("num_dataloader_workers", 0)) > 0 and bool(config.get("packed_feed", True))
+    return (isinstance(dataset, PreprocessedPointCloudDataset) and len(config["datasets"]) == 1
+            and int(config.get("num_dataloader_workers", 0)) >= 0 and bool(config.get("packed_feed", True))
             and not config.get("normalization_scaling") and not config.get("random_point_cloud_rotations")
             and getattr(device, "type", str(device)) == "cuda")
 

@@ -37,11 +37,18 @@ class HipStepGeometry:
             offs = [0]
             for n in lengths:
                 offs.append(offs[-1] + n)
-            t = torch.tensor(offs, dtype=torch.int32, device=device)
+            host = torch.tensor(offs, dtype=torch.int32)
+            if getattr(device, "type", str(device)) == "cuda":
+                # through page-locked memory, asynchronously: a copy from pageable memory makes the host wait for everything queued on
+                # the stream -- with ragged batches (every step a new key) the host could never run ahead of the GPU
+                host = host.pin_memory()
+                t = (host.to(device, non_blocking=True), host)            # (the staging vector lives as long as the cache entry)
+            else:
+                t = (host.to(device), None)
             if len(self._offsets) > 64:
                 self._offsets.clear()
             self._offsets[key] = t
-        return t
+        return t[0]
 
     def prepare(self, samples, sensor, normal_params):
         """samples: list of dicts with ``scan_1``/``scan_2`` ``[1,3,N]`` on the GPU and optional ``normal_list_*``.

@@ -99,20 +99,25 @@ class Trainer(deployer.Deployer):
             return "off"
         return "auto"
 
-    PROBE_SKIP, PROBE_STEPS, PROBE_HOST_BOUND = 3, 8, 0.8
+    PROBE_SKIP, PROBE_STEPS, PROBE_HOST_BOUND = 8, 8, 0.8
 
     def _probe_step(self, phase, run_eager):
-        """One eager step of the ``auto`` policy's measurement.  Returns the step's result.  After PROBE_SKIP untimed steps (allocator,
-        first-call set-up), PROBE_STEPS steps are bracketed by a pair of events on the stream and by the host clock around their
-        enqueue: when the host is the bottleneck the GPU finishes each step right behind its last launch (event time ~ enqueue
-        time); when the GPU is, the queue fills up and the events measure pure GPU time, longer than the enqueue."""
+        """One eager step of the ``auto`` policy's measurement.  Returns the step's result.  After PROBE_SKIP untimed steps (first-call
+        set-up, the caching allocator meeting the sizes of ragged batches), PROBE_STEPS steps are bracketed by a pair of events on the
+        stream; the host clock measures the loop's PERIOD (step start to step start: the loader's time included) and the enqueue time
+        of the step alone.  When the host is the bottleneck the GPU finishes each step right behind its last launch and idles until
+        the next one arrives (period >= stream time); when the GPU is, the queue fills up, the events measure pure GPU time and the
+        host's period is shorter."""
         import time
-        st = self._graph_probe.setdefault(phase, {"n": 0, "host": 0.0, "events": []})
+        st = self._graph_probe.setdefault(phase, {"n": 0, "host": 0.0, "events": [], "t_first": None, "t_last": None})
         timed = st["n"] >= self.PROBE_SKIP
         if timed:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             t0 = time.perf_counter()
+            if st["t_first"] is None:
+                st["t_first"] = t0
+            st["t_last"] = t0
         out = run_eager()
         if timed:
             st["host"] += time.perf_counter() - t0
@@ -121,16 +126,18 @@ class Trainer(deployer.Deployer):
         st["n"] += 1
         if len(st["events"]) >= self.PROBE_STEPS:
             st["events"][-1][1].synchronize()
-            gpu = sum(x.elapsed_time(y) for x, y in st["events"]) * 1e-3
-            ratio = st["host"] / max(gpu, 1e-9)
+            k = len(st["events"])
+            gpu = sum(x.elapsed_time(y) for x, y in st["events"]) * 1e-3 / k
+            enqueue = st["host"] / k
+            period = (st["t_last"] - st["t_first"]) / max(1, k - 1)       # start of the first timed step to the start of the last
+            ratio = max(period, enqueue) / max(gpu, 1e-9)
             decision = "graph" if ratio >= float(self.config.get("hip_graph_auto_threshold", self.PROBE_HOST_BOUND)) else "eager"
             self._graph_decision[phase] = decision
-            self.graph_probe_result[phase] = {"host_enqueue_ms": round(1e3 * st["host"] / self.PROBE_STEPS, 3),
-                                              "stream_ms": round(1e3 * gpu / self.PROBE_STEPS, 3), "ratio": round(ratio, 3),
-                                              "decision": decision}
+            self.graph_probe_result[phase] = {"host_enqueue_ms": round(1e3 * enqueue, 3), "host_period_ms": round(1e3 * period, 3),
+                                              "stream_ms": round(1e3 * gpu, 3), "ratio": round(ratio, 3), "decision": decision}
             if self.rank == 0:
-                print(f"[delora_amd] hip_graph auto ({'unsupervised' if phase else 'identity'} phase): host enqueue "
-                      f"{1e3 * st['host'] / self.PROBE_STEPS:.2f} ms vs {1e3 * gpu / self.PROBE_STEPS:.2f} ms on the stream per step -> "
+                print(f"[delora_amd] hip_graph auto ({'unsupervised' if phase else 'identity'} phase): the host needs {1e3 * period:.2f} ms per "
+                      f"step ({1e3 * enqueue:.2f} ms of it to enqueue the step), the stream {1e3 * gpu:.2f} ms -> "
                       + ("the step is host-bound: replaying it as ONE captured HIP graph" if decision == "graph"
                          else "the step is GPU-bound: staying eager"))
             del self._graph_probe[phase]

@@ -282,6 +282,15 @@ def test_packed_feed_delivers_the_batches_of_the_sampler_in_the_steps_layout(tmp
         assert len(list(pf)) == len(order)
         with pytest.raises(RuntimeError, match="abandoned"):
             next(stale)
+        # no worker processes at all (num_dataloader_workers: 0 taken literally: the consumer decodes in-process) and a dataset held in
+        # RAM ([3,M] tensors instead of [M,3] files) deliver the same batches
+        for ram in (False, True):
+            ds0 = dsmod.PreprocessedPointCloudDataset(dict(cfg, store_dataset_in_RAM=ram))
+            inproc = feed.PackedFeed(ds0, order, 2, torch.device("cpu"), workers=0, points_per_scan=200, slots=2)
+            assert inproc.procs == []
+            same = list(inproc)
+            assert [b.offs.tolist() for b in same] == [b.offs.tolist() for b in got] and all(torch.equal(a.pts, b.pts) for a, b in zip(same, got))
+            inproc.close()
         # a batch beyond the slot capacity is an error of the feed, not a silent truncation
         small = feed.PackedFeed(ds, [[0, 1]], 2, torch.device("cpu"), workers=1, points_per_scan=20)
         with pytest.raises(RuntimeError):
