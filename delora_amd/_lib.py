@@ -63,7 +63,8 @@ SIGNATURES = {
     "dl_wino_weights_floats": (_sz, [_i32, _i32]),
     "dl_wino_weights_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
     "dl_wino_weights_batch_f32": (_i32, [_vp, _i32, _vp]),
-    "dl_wino_conv3x3_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _u32, _vp]),
+    "dl_wino_conv3x3_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    "dl_wino_conv3x3_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _u32, _vp, _vp]),
     "dl_wino_wgrad_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
     "dl_wino_wgrad3x3_nhwc_f32": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "dl_pool3x3s12_nhwc_fwd": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),

@@ -47,6 +47,8 @@ struct WinoArgs {
   int N, H, W, C, K;
   int act;
   unsigned epi;
+  int splits;          // k_wino_conv<.., .., true> only: the input channels are cut into this many ranges, one workgroup each; y then is
+                       // the partial-sum workspace [splits][N][H][W][K] and k_wino_split_sum adds the ranges up and runs the epilogue
 };
 
 __device__ __forceinline__ float wn_act(float v, int act) {
@@ -134,7 +136,13 @@ __device__ unsigned long long g_wn_t[8 * 8192];       // phase time stamps per g
 // RAG: the image does not divide into groups of TR x TC tiles (or has an odd width / height): the last group of a row / column
 // hangs over the edge.  Its surplus tiles transform wrapped (valid) addresses and multiply like the others; only the epilogue
 // differs -- surplus output pixels are neither fetched from the epilogue operands nor stored.
-template <int TC, bool RAG>
+// SPLIT: split-K for SMALL problems.  A workgroup walks ALL input channels of its 64 tiles x 64 output channels: 8 ... 64 chunks of
+// ~5400 cycles each, whatever the batch size -- at the reference's default batch size 1 (64x720: 24 ... 48 tile groups for 256 CUs) a
+// layer4 launch was 170 us of ONE workgroup's serial chain with 90 % of the chip idle.  With SPLIT the group index also selects one of
+// `splits` channel ranges; the workgroup accumulates that range only and stores its raw partial sums (no epilogue) to
+// y + split * N*H*W*K; k_wino_split_sum adds the ranges in a fixed order and applies the epilogue.  SPLIT = false compiles to the
+// code of round 4 (the split index and the chunk base are compile-time zeros).
+template <int TC, bool RAG, bool SPLIT = false>
 __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   constexpr int TR = WN_TILES / TC;
   constexpr int RH = 2 * TR + 2, RW = 2 * TC + 2;
@@ -156,8 +164,9 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   const int KT = a.K / WN_KB;
   const int tiles_w = RAG ? ((a.W + 1) / 2 + TC - 1) / TC : (a.W / 2) / TC;
   const int tiles_h = RAG ? ((a.H + 1) / 2 + TR - 1) / TR : (a.H / 2) / TR;
-  const int ngroups = a.N * tiles_h * tiles_w * KT;
-  const int nchunks = a.C / WN_CK;
+  const int nsplit = SPLIT ? a.splits : 1;
+  const int ngroups = a.N * tiles_h * tiles_w * KT * nsplit;
+  const int nchunks = a.C / WN_CK / nsplit;                           // chunks per workgroup (the launcher makes the split exact)
 
   // transform role of this thread: tile, channel quad, column b of the 4x4 domain
   const int tb = tid & 3, tc4 = (tid >> 2) & 1, ttile = tid >> 3;
@@ -191,12 +200,15 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   // 512-thread workgroup fits a CU) and every workgroup walks its share of the groups, fetching the first operands of its NEXT
   // group while the epilogue of the current one runs
   int n, k0, gh, gw;
+  int cb = 0;                                                           // first chunk of this workgroup's channel range (SPLIT)
+  float* ysp = a.y;                                                     // where this group's result goes (SPLIT: its range's partial plane)
   const float* xn;
   int rowmask[4];                                                     // zero rows above / below the image
   unsigned raw_g[NR_IT];
 #define WN_SETUP(G, LN)                                                                                                   \
   {                                                                                                                       \
     int t_ = wn_xcd_swizzle((G), ngroups);                                                                                \
+    if (SPLIT) { cb = (t_ % nsplit) * nchunks; t_ /= nsplit; }       /* the ranges of one (tiles, channels) block are neighbours */ \
     const int kt_ = t_ % KT; t_ /= KT;                                                                                    \
     gw = t_ % tiles_w; t_ /= tiles_w;                                                                                     \
     gh = t_ % tiles_h;                                                                                                    \
@@ -229,10 +241,10 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                           \
                :: "v"(OFFB), "s"(BASE), "s"(__builtin_amdgcn_readfirstlane((int)WN_LDSADDR(LPTR))) : "memory");
 #define WN_U_PIECE_X(UG, IT, CH, BUFP) \
-  WN_GLDS(a.u + ((size_t)(CH) * 16 * a.K * 8 + k0 * 8), (UG)[IT], (BUFP) + __builtin_amdgcn_readfirstlane(u_l[IT]))
+  WN_GLDS(a.u + ((size_t)((CH) + cb) * 16 * a.K * 8 + k0 * 8), (UG)[IT], (BUFP) + __builtin_amdgcn_readfirstlane(u_l[IT]))
 #define WN_U_PIECE(IT, CH, BUFP) WN_U_PIECE_X(u_g, IT, CH, BUFP)
 #define WN_RAW_PIECE(IT, CH) \
-  WN_GLDS(xn + (CH) * WN_CK, raw_g[IT], rawbase + ((CH) & 1) * RAWBUF + __builtin_amdgcn_readfirstlane(raw_l[IT]))
+  WN_GLDS(xn + ((CH) + cb) * WN_CK, raw_g[IT], rawbase + ((CH) & 1) * RAWBUF + __builtin_amdgcn_readfirstlane(raw_l[IT]))
 #define WN_RAW_ALL(CH) { _Pragma("unroll") for (int it = 0; it < NR_IT; ++it) WN_RAW_PIECE(it, CH) }
 #define WN_U_ALL(CH, BUFP) { _Pragma("unroll") for (int it = 0; it < NU_IT; ++it) WN_U_PIECE(it, CH, BUFP) }
   // row I of T = d B for this thread's column: two 16-byte reads of the raw patch (issued ahead of their use: a read and its use in
@@ -365,6 +377,7 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
       ooff[it] = (unsigned)(((n * a.H + oh) * a.W + ow) * a.K + k0 + nb * 32 + c4 * 4);
       if (RAG && (oh >= a.H || ow >= a.W)) ooff[it] = 0xffffffffu;       // a surplus pixel (offsets are below 2^31)
     }
+    if (SPLIT) ysp = a.y + (size_t)(cb / nchunks) * ((size_t)a.N * a.H * a.W * a.K);
     // The first operands of the NEXT group are requested now: raw(0), raw(1) into the raw buffers, U(0) into the upper (V, U) buffer --
     // none of them is touched by the epilogue below, whose duration covers their latency.
     const int nextg = grp + gridDim.x;
@@ -463,7 +476,7 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
         if (tanh_act) v *= 1.f - sv * sv;
         else { v[0] *= wn_dact(sv[0], a.act); v[1] *= wn_dact(sv[1], a.act); v[2] *= wn_dact(sv[2], a.act); v[3] *= wn_dact(sv[3], a.act); }
       }
-      *reinterpret_cast<f32x4*>(a.y + ooff[it]) = v;
+      *reinterpret_cast<f32x4*>(ysp + ooff[it]) = v;
     }
     WN_T(4)
     if (!more) break;
@@ -1071,16 +1084,76 @@ extern "C" int dl_wino_wgrad3x3_batch_nhwc_f32(const dl_wgrad_layer* layers, int
   return dl_check_launch("dl_wino_wgrad3x3_batch_nhwc_f32");
 }
 
+// Sum of the channel ranges of a split launch + the layer's epilogue (as in k_wino_conv: shortcut add, activation, activation
+// derivative of the saved forward activation), four channels per thread, ranges added in index order (deterministic).
+__global__ __launch_bounds__(256) void k_wino_split_sum(const float* __restrict__ part, int splits, size_t count4, float* __restrict__ y,
+                                                         const float* __restrict__ add, const float* __restrict__ dsrc, int act, unsigned epi) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= count4) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(part) + i;
+  f32x4 v = p[0];
+  for (int s = 1; s < splits; ++s) v += p[(size_t)s * count4];
+  if (epi & WN_EPI_ADD) v += reinterpret_cast<const f32x4*>(add)[i];
+  if (epi & WN_EPI_ACT) {
+    if (act == 1) { v[0] = dl_tanh(v[0]); v[1] = dl_tanh(v[1]); v[2] = dl_tanh(v[2]); v[3] = dl_tanh(v[3]); }
+    else { v[0] = wn_act(v[0], act); v[1] = wn_act(v[1], act); v[2] = wn_act(v[2], act); v[3] = wn_act(v[3], act); }
+  }
+  if (epi & WN_EPI_DACT) {
+    const f32x4 sv = reinterpret_cast<const f32x4*>(dsrc)[i];
+    if (act == 1) v *= 1.f - sv * sv;
+    else { v[0] *= wn_dact(sv[0], act); v[1] *= wn_dact(sv[1], act); v[2] *= wn_dact(sv[2], act); v[3] *= wn_dact(sv[3], act); }
+  }
+  reinterpret_cast<f32x4*>(y)[i] = v;
+}
+
+// (tile-group shape, number of groups) of a launch: images that divide take 2 x 32 or 4 x 16 tiles per group (the two shapes the
+// network's BASELINE images need); every other image -- the reference's shipped 64x720 (feature maps 180 / 90 / 45 / 23 wide) and
+// 64x512 (layer4: 32x16) -- takes the shape that wastes the fewest tiles, with overhanging groups at the right / lower edge.
+struct WinoPlan { int tc; bool rag; int groups; int splits; };
+static WinoPlan wino_plan(int N, int H, int W, int C, int K, int cap) {
+  const int tw = (W + 1) / 2, th = (H + 1) / 2;                     // 2x2 output tiles (the last one of an odd row / column is partial)
+  const bool even = !(H & 1) && !(W & 1);
+  WinoPlan p{32, false, 0, 1};
+  if (even && tw % 32 == 0 && th % 2 == 0) { p.tc = 32; p.groups = N * (th / 2) * (tw / 32) * (K / WN_KB); }
+  else if (even && tw % 16 == 0 && th % 4 == 0) { p.tc = 16; p.groups = N * (th / 4) * (tw / 16) * (K / WN_KB); }
+  else {
+    int best_tc = 0;
+    long best_tiles = 0;
+    for (int tc = 32; tc >= 4; tc >>= 1) {
+      const int tr = WN_TILES / tc;
+      const long tiles = (long)((tw + tc - 1) / tc) * tc * (long)((th + tr - 1) / tr) * tr;
+      if (!best_tc || tiles < best_tiles) { best_tc = tc; best_tiles = tiles; }
+    }
+    const int tr = WN_TILES / best_tc;
+    p.tc = best_tc; p.rag = true;
+    p.groups = N * ((th + tr - 1) / tr) * ((tw + best_tc - 1) / best_tc) * (K / WN_KB);
+  }
+  // Split-K when the launch leaves most of the chip idle: double the number of channel ranges while all workgroups still fit one
+  // round of the CUs and a range keeps at least 4 chunks (32 channels: below that the fixed cost of a group -- prologue, output
+  // transform, stores, ~2 chunks' worth -- and the partial-sum traffic eat the gain).  DL_WINO_SPLIT=0 turns it off (A/B).
+  static const bool allow = [] { const char* e = getenv("DL_WINO_SPLIT"); return !(e && e[0] == '0'); }();
+  const int nchunks = C / WN_CK;
+  if (allow && cap > 0)
+    while (p.groups * p.splits * 2 <= cap && nchunks % (p.splits * 2) == 0 && nchunks / (p.splits * 2) >= 4) p.splits *= 2;
+  return p;
+}
+
+extern "C" size_t dl_wino_conv3x3_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0 || C % WN_CK || K % WN_KB) return 0;
+  const WinoPlan p = wino_plan(N, H, W, C, K, wn_cu_count());
+  return p.splits > 1 ? (size_t)p.splits * N * H * W * K * sizeof(float) : 0;
+}
+
 extern "C" int dl_wino_conv3x3_nhwc_f32(const float* x, const float* u, float* y, const float* add, const float* dsrc,
                                         int32_t N, int32_t H, int32_t W, int32_t C, int32_t K, int32_t act,
-                                        uint32_t epilogue, dl_stream stream) {
+                                        uint32_t epilogue, void* workspace, dl_stream stream) {
   if (!x || !u || !y || N <= 0 || H <= 0 || W <= 0 || C <= 0 || K <= 0)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wino_conv3x3_nhwc_f32: bad argument");
   if (((epilogue & WN_EPI_ADD) && !add) || ((epilogue & WN_EPI_DACT) && !dsrc) || act < 0 || act > 2)
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_wino_conv3x3_nhwc_f32: epilogue operand missing / bad activation");
   if (C % WN_CK || K % WN_KB || (size_t)N * H * W * (C > K ? C : K) >= ((size_t)1 << 31) || (size_t)H * W * C >= ((size_t)1 << 30))
     return dl_fail(DL_ERR_UNSUPPORTED, "dl_wino_conv3x3_nhwc_f32: shape N=%d H=%d W=%d C=%d K=%d not supported (C %% 8, K %% 64, < 2^31 elements)", N, H, W, C, K);
-  WinoArgs a{x, u, y, add, dsrc, N, H, W, C, K, act, epilogue};
+  WinoArgs a{x, u, y, add, dsrc, N, H, W, C, K, act, epilogue, 1};
   hipStream_t st = (hipStream_t)stream;
   const int tw = (W + 1) / 2, th = (H + 1) / 2;                     // 2x2 output tiles (the last one of an odd row / column is partial)
   // what the algorithm asks of the matrix cores: 16 multiply-adds per 2x2 output tile and (c, k) pair (a direct convolution: 36)
@@ -1091,33 +1164,34 @@ extern "C" int dl_wino_conv3x3_nhwc_f32(const float* x, const float* u, float* y
 #ifdef CV_TUNE
   if (const char* e = getenv("DL_WN_GRID")) cap = atoi(e);
 #endif
-  // A workgroup takes 64 tiles as TR rows x TC columns.  Images that divide take 2 x 32 or 4 x 16 (the two shapes the network's
-  // BASELINE images need); every other image -- the reference's shipped 64x720 (feature maps 180 / 90 / 45 / 23 wide) and 64x512
-  // (layer4: 32x16) -- takes the shape that wastes the fewest tiles, with overhanging groups at the right / lower edge.
-  const bool even = !(H & 1) && !(W & 1);
-  if (even && tw % 32 == 0 && th % 2 == 0) {
-    const int groups = N * (th / 2) * (tw / 32) * (K / WN_KB);
-    DL_LAUNCH(tag, (k_wino_conv<32, false>), dim3(cap > 0 && groups > cap ? cap : groups), dim3(WN_THREADS), st, a);
-  } else if (even && tw % 16 == 0 && th % 4 == 0) {
-    const int groups = N * (th / 4) * (tw / 16) * (K / WN_KB);
-    DL_LAUNCH(tag, (k_wino_conv<16, false>), dim3(cap > 0 && groups > cap ? cap : groups), dim3(WN_THREADS), st, a);
-  } else {
-    int best_tc = 0;
-    long best_tiles = 0;
-    for (int tc = 32; tc >= 4; tc >>= 1) {
-      const int tr = WN_TILES / tc;
-      const long tiles = (long)((tw + tc - 1) / tc) * tc * (long)((th + tr - 1) / tr) * tr;
-      if (!best_tc || tiles < best_tiles) { best_tc = tc; best_tiles = tiles; }
+  WinoPlan p = wino_plan(N, H, W, C, K, cap);
+  if (p.splits > 1 && (!workspace || (size_t)p.splits * N * H * W * K >= ((size_t)1 << 31))) p.splits = 1;   // no scratch given: one range
+  if (p.splits > 1) {
+    // the channel ranges of a SMALL launch on otherwise idle CUs; partial sums + epilogue in a second, elementwise launch
+    a.y = (float*)workspace; a.add = nullptr; a.dsrc = nullptr; a.act = 0; a.epi = 0; a.splits = p.splits;
+    const dim3 grid(p.groups * p.splits);             // <= cap by construction
+    if (!p.rag && p.tc == 32) DL_LAUNCH(tag, (k_wino_conv<32, false, true>), grid, dim3(WN_THREADS), st, a);
+    else if (!p.rag) DL_LAUNCH(tag, (k_wino_conv<16, false, true>), grid, dim3(WN_THREADS), st, a);
+    else switch (p.tc) {
+      case 32: DL_LAUNCH(tag, (k_wino_conv<32, true, true>), grid, dim3(WN_THREADS), st, a); break;
+      case 16: DL_LAUNCH(tag, (k_wino_conv<16, true, true>), grid, dim3(WN_THREADS), st, a); break;
+      case 8: DL_LAUNCH(tag, (k_wino_conv<8, true, true>), grid, dim3(WN_THREADS), st, a); break;
+      default: DL_LAUNCH(tag, (k_wino_conv<4, true, true>), grid, dim3(WN_THREADS), st, a); break;
     }
-    const int tr = WN_TILES / best_tc;
-    const int groups = N * ((th + tr - 1) / tr) * ((tw + best_tc - 1) / best_tc) * (K / WN_KB);
-    const dim3 grid(cap > 0 && groups > cap ? cap : groups);
-    switch (best_tc) {
-      case 32: DL_LAUNCH(tag, (k_wino_conv<32, true>), grid, dim3(WN_THREADS), st, a); break;
-      case 16: DL_LAUNCH(tag, (k_wino_conv<16, true>), grid, dim3(WN_THREADS), st, a); break;
-      case 8: DL_LAUNCH(tag, (k_wino_conv<8, true>), grid, dim3(WN_THREADS), st, a); break;
-      default: DL_LAUNCH(tag, (k_wino_conv<4, true>), grid, dim3(WN_THREADS), st, a); break;
-    }
+    const size_t count4 = (size_t)N * H * W * K / 4;
+    const DlProfTag tag2{"k_wino_split_sum", "conv", N, H, W, C, K, 3, 1, 1, 0.0, 4.0 * (double)N * H * W * K * (p.splits + 1)};
+    DL_LAUNCH(tag2, k_wino_split_sum, dim3((unsigned)((count4 + 255) / 256)), dim3(256), st, (const float*)workspace, p.splits, count4, y, add,
+              dsrc, act, epilogue);
+    return dl_check_launch("dl_wino_conv3x3_nhwc_f32");
+  }
+  const dim3 grid(cap > 0 && p.groups > cap ? cap : p.groups);
+  if (!p.rag && p.tc == 32) DL_LAUNCH(tag, (k_wino_conv<32, false>), grid, dim3(WN_THREADS), st, a);
+  else if (!p.rag) DL_LAUNCH(tag, (k_wino_conv<16, false>), grid, dim3(WN_THREADS), st, a);
+  else switch (p.tc) {
+    case 32: DL_LAUNCH(tag, (k_wino_conv<32, true>), grid, dim3(WN_THREADS), st, a); break;
+    case 16: DL_LAUNCH(tag, (k_wino_conv<16, true>), grid, dim3(WN_THREADS), st, a); break;
+    case 8: DL_LAUNCH(tag, (k_wino_conv<8, true>), grid, dim3(WN_THREADS), st, a); break;
+    default: DL_LAUNCH(tag, (k_wino_conv<4, true>), grid, dim3(WN_THREADS), st, a); break;
   }
   return dl_check_launch("dl_wino_conv3x3_nhwc_f32");
 }

@@ -229,9 +229,18 @@ def wino_conv(x, u, K, act=0, epilogue=0, add=None, dsrc=None):
     lib = _lib.load()
     N, H, W, C = x.shape
     y = _empty((N, H, W, K), torch.float32, x.device)
+    # a launch with few tile groups (batch 1) splits its input channels over otherwise idle CUs and needs scratch for the partial sums
+    key = (N, H, W, C, K)
+    nbytes = _WINO_WS_BYTES.get(key)
+    if nbytes is None:
+        nbytes = _WINO_WS_BYTES[key] = int(lib.dl_wino_conv3x3_workspace_bytes(N, H, W, C, K))
+    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device) if nbytes else None
     _lib.check(lib.dl_wino_conv3x3_nhwc_f32(_ptr(x), _ptr(u), _ptr(y), _ptr(add), _ptr(dsrc), N, H, W, C, K, int(act),
-                                            int(epilogue), _stream()), "dl_wino_conv3x3_nhwc_f32")
+                                            int(epilogue), _ptr(ws), _stream()), "dl_wino_conv3x3_nhwc_f32")
     return y
+
+
+_WINO_WS_BYTES = {}
 
 
 def supported(x_shape, blocks):

@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 6   /* 6: dl_project takes n_cols and ONE workspace (key plane + staging records of the vote); 5: batched weight gradients (dl_conv2d_wgrad_batch_*); 4: free image sizes in the convolution family (the strided input gradients take the INPUT image size and a seam workspace); 3: half-precision convolutions, launch profiler */
+#define DL_ABI_VERSION 6   /* 6: dl_project takes n_cols and ONE workspace (key plane + staging records of the vote), dl_wino_conv3x3_nhwc_f32 an optional split-K workspace; 5: batched weight gradients (dl_conv2d_wgrad_batch_*); 4: free image sizes in the convolution family (the strided input gradients take the INPUT image size and a seam workspace); 3: half-precision convolutions, launch profiler */
 
 typedef void* dl_stream;
 
@@ -317,8 +317,13 @@ typedef struct {
   int32_t K, C;
 } dl_wino_layer;
 int dl_wino_weights_batch_f32(const dl_wino_layer* layers, int32_t n, dl_stream stream);
+/* Scratch of dl_wino_conv3x3_nhwc_f32: 0 for launches that fill the chip; for SMALL launches (few tile groups: the reference's
+ * default batch size 1) the bytes of the partial sums of a split over the input channels -- the launch then runs its channel ranges on
+ * otherwise idle CUs and a second, elementwise launch adds them up and applies the epilogue.  workspace may be NULL (no split). */
+size_t dl_wino_conv3x3_workspace_bytes(int32_t N, int32_t H, int32_t W, int32_t C, int32_t K);
 int dl_wino_conv3x3_nhwc_f32(const float* x, const float* u, float* y, const float* add, const float* dsrc, int32_t N,
-                             int32_t H, int32_t W, int32_t C, int32_t K, int32_t act, uint32_t epilogue, dl_stream stream);
+                             int32_t H, int32_t W, int32_t C, int32_t K, int32_t act, uint32_t epilogue, void* workspace,
+                             dl_stream stream);
 
 /*
  * Weight gradient of a stride-1 3x3 layer in the Winograd domain (2.25x fewer multiplications than

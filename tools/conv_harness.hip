@@ -279,7 +279,7 @@ static int check_wino(const Shape& s, std::mt19937& gen) {
   CK(hipMalloc(&uf, 16 * nw / 9 * sizeof(float))); CK(hipMalloc(&ub, 16 * nw / 9 * sizeof(float)));
   int bad = 0;
   int rc = dl_wino_weights_f32(dw, uf, ub, s.K, s.C, nullptr);
-  if (!rc) rc = dl_wino_conv3x3_nhwc_f32(dx, uf, dy, dadd, nullptr, s.N, s.H, s.W, s.C, s.K, 1, 3, nullptr);
+  if (!rc) rc = dl_wino_conv3x3_nhwc_f32(dx, uf, dy, dadd, nullptr, s.N, s.H, s.W, s.C, s.K, 1, 3, nullptr, nullptr);
   if (rc) { printf("  %s wino fwd: rc %d %s\n", s.name, rc, dl_last_error()); return 1; }
   CK(hipDeviceSynchronize());
   std::vector<float> y(ny), gi(nx);
@@ -295,7 +295,7 @@ static int check_wino(const Shape& s, std::mt19937& gen) {
   }
   printf("  %-28s wino fwd(add+tanh) max abs err %.3e\n", s.name, worst);
   if (!(worst < 5e-5)) bad++;
-  rc = dl_wino_conv3x3_nhwc_f32(dg, ub, dgi, nullptr, dds, s.N, s.H, s.W, s.K, s.C, 1, 4, nullptr);
+  rc = dl_wino_conv3x3_nhwc_f32(dg, ub, dgi, nullptr, dds, s.N, s.H, s.W, s.K, s.C, 1, 4, nullptr, nullptr);
   if (rc) { printf("  %s wino dgrad: rc %d %s\n", s.name, rc, dl_last_error()); return bad + 1; }
   CK(hipDeviceSynchronize());
   CK(hipMemcpy(gi.data(), dgi, nx * sizeof(float), hipMemcpyDeviceToHost));
@@ -337,8 +337,8 @@ static void time_wino(const Shape& s, int reps, std::mt19937& gen) {
     printf("%-26s %-10s %9.1f us  %7.1f TFLOP/s direct-equivalent\n", s.name, what, us, flop / us * 1e-6);
   };
   run("wino-wts", [&] { return dl_wino_weights_f32(dw, uf, ub, s.K, s.C, nullptr); });
-  run("wino-fwd", [&] { return dl_wino_conv3x3_nhwc_f32(dx, uf, dy, nullptr, nullptr, s.N, s.H, s.W, s.C, s.K, 1, 2, nullptr); });
-  run("wino-dgrad", [&] { return dl_wino_conv3x3_nhwc_f32(dg, ub, dgi, nullptr, dx, s.N, s.H, s.W, s.K, s.C, 1, 4, nullptr); });
+  run("wino-fwd", [&] { return dl_wino_conv3x3_nhwc_f32(dx, uf, dy, nullptr, nullptr, s.N, s.H, s.W, s.C, s.K, 1, 2, nullptr, nullptr); });
+  run("wino-dgrad", [&] { return dl_wino_conv3x3_nhwc_f32(dg, ub, dgi, nullptr, dx, s.N, s.H, s.W, s.K, s.C, 1, 4, nullptr, nullptr); });
   CK(hipFree(dx)); CK(hipFree(dw)); CK(hipFree(dg)); CK(hipFree(dy)); CK(hipFree(dgi)); CK(hipFree(uf)); CK(hipFree(ub));
 }
 
@@ -452,7 +452,7 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&uf, 16 * nw / 9 * sizeof(float))); CK(hipMalloc(&ub, 16 * nw / 9 * sizeof(float)));
         dl_wino_weights_f32(dw, uf, ub, s.K, s.C, nullptr);
         for (int mode = 0; mode < 2; ++mode) {
-          for (int i = 0; i < 3; ++i) dl_wino_conv3x3_nhwc_f32(dx, uf, dy, nullptr, mode ? dx : nullptr, s.N, s.H, s.W, s.C, s.K, 1, mode ? 4 : 2, nullptr);
+          for (int i = 0; i < 3; ++i) dl_wino_conv3x3_nhwc_f32(dx, uf, dy, nullptr, mode ? dx : nullptr, s.N, s.H, s.W, s.C, s.K, 1, mode ? 4 : 2, nullptr, nullptr);
           CK(hipDeviceSynchronize());
           std::vector<unsigned long long> t(8 * 8192);
           CK(hipMemcpyFromSymbol(t.data(), HIP_SYMBOL(g_wn_t), t.size() * sizeof(unsigned long long)));

@@ -40,9 +40,18 @@ def main():
                 nonlocal i
                 i += 1
                 g(batches[i % len(batches)])
-        for _ in range(steps + 2):
+        import time
+        for _ in range(2):
             run()
         torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        host = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        print(f"shipped_step B={B} {mode} {amp or 'float32'}: {1e3 * el / steps:.3f} ms/step ({B * steps / el:.1f} pairs/s), host enqueue {1e3 * host / steps:.3f} ms/step, "
+              f"DL_WINO_SPLIT={os.environ.get('DL_WINO_SPLIT', '1')}")
     finally:
         import shutil
         shutil.rmtree(tree["path"], ignore_errors=True)
