@@ -450,7 +450,7 @@ def shipped_config_leg(args, device, timed_region, enqueue, steps_b1=200, steps_
                 loader, _ = trainer.make_dataloader()
                 per_epoch = len(loader)
                 try:
-                    for e in range(max(2, -(-16 // per_epoch))):        # the probe of `auto` (11 steps), capture, page cache, workers up
+                    for e in range(max(2, -(-32 // per_epoch))):        # the probe of `auto` (16 eager steps + 9 replayed ones), page cache, workers up
                         trainer.train_epoch(e, loader)
                     n_ep = max(1, steps // per_epoch)
                     count = {"e": 100}
@@ -967,6 +967,11 @@ def main():
         raise SystemExit(subprocess.run(cmd, env=env).returncode)
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
+    t_start = time.perf_counter()
+
+    def trace(what):                                    # DELORA_BENCH_TRACE=1: milestones of every rank on stderr (where does a run spend / lose its time)
+        if os.environ.get("DELORA_BENCH_TRACE"):
+            print(f"[bench rank {rank}/{world} +{time.perf_counter() - t_start:7.2f}s] {what}", file=sys.stderr, flush=True)
     # test hooks (never set in production): run all ranks on one GPU over gloo to exercise the N>1 code path on a 1-GPU box
     if os.environ.get("DELORA_BENCH_SHARE_GPU") == "1":
         local = 0
@@ -978,6 +983,7 @@ def main():
             torch.distributed.init_process_group(backend="nccl", device_id=device)
         else:
             torch.distributed.init_process_group(backend=backend)
+    trace("process group up")
     from delora_amd.deploy.trainer import Trainer
     from delora_amd.data.dataset import ListDataset
     from delora_amd.data.feed import DevicePrefetcher
@@ -993,8 +999,10 @@ def main():
     torch.manual_seed(1234)
     host_batches = pin_batches(derived_batches(make_batch(args, rank), max(1, args.rotate), rank, shuffled=args.point_order == "shuffled"))
     batches = [to_device(b, device) for b in host_batches]
+    trace("batches generated")
     trainer = Trainer(cfg, dataset=ListDataset([d for b in host_batches for d in b]))
     identity_pretrained_state(trainer.raw_model)
+    trace("trainer built")
     counter = {"i": 0}
 
     def run_step(batch=None):
@@ -1012,6 +1020,7 @@ def main():
     # synchronisation): with W = 5 < 8 batches the first timed steps were such visits (autocast step: 11 ms instead of 5 ms of enqueue)
     for b in batches:
         run_step(b)
+        trace("priming step enqueued")
     # As Trainer.train does after its set-up: everything alive now (batches, datasets, module trees) moves to the collector's permanent
     # generation.  A generation-2 pass over that heap stalled the host for ~0.1 s at random steps -- invisible behind a 14.6 ms GPU-bound
     # step, 5 ms per step of a 20-step autocast region (1500 pairs/s read as 750).
@@ -1020,6 +1029,7 @@ def main():
     gc.freeze()
     for _ in range(args.warmup):
         run_step()
+    trace("warm-up enqueued")
     graphed = None
     if args.graph and world == 1:
         from delora_amd.deploy.graph_step import GraphedStep
@@ -1100,6 +1110,7 @@ def main():
     elapsed, ep = timed_region(args.steps, run_step_sampled if in_timed and (can_profile or loss_timed) else run_step)
     host_enqueue_ms = enqueue["ms_per_step"]
     rank_ms = enqueue.get("rank_ms_per_step")
+    trace("timed region done")
     roofline_pass = f"every {EVENT_EVERY}th of the K timed steps ({evented['steps']} steps)"
     if not in_timed and (can_profile or loss_timed):
         counter["i"] = 0
@@ -1260,6 +1271,7 @@ def main():
             if not args.no_cpu_baseline:
                 result["cpu_baseline"], result["cpu_baseline_online_normals"] = cpu_baseline(args, cfg)
         print(json.dumps(result))
+    trace("at the final barrier")
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

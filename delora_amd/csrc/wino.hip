@@ -1130,10 +1130,12 @@ static WinoPlan wino_plan(int N, int H, int W, int C, int K, int cap) {
   }
   // Split-K when the launch leaves most of the chip idle: double the number of channel ranges while all workgroups still fit one
   // round of the CUs and a range keeps at least 4 chunks (32 channels: below that the fixed cost of a group -- prologue, output
-  // transform, stores, ~2 chunks' worth -- and the partial-sum traffic eat the gain).  DL_WINO_SPLIT=0 turns it off (A/B).
+  // transform, stores, ~2 chunks' worth -- and the partial-sum traffic eat the gain).  Layers with fewer than 128 input channels are
+  // left alone: their chain is 8 chunks, a split saves ~10 us of GPU time and costs a second launch (~18 us of host time in a step
+  // that is host-bound at batch 1).  DL_WINO_SPLIT=0 turns it off (A/B).
   static const bool allow = [] { const char* e = getenv("DL_WINO_SPLIT"); return !(e && e[0] == '0'); }();
   const int nchunks = C / WN_CK;
-  if (allow && cap > 0)
+  if (allow && cap > 0 && nchunks >= 16)
     while (p.groups * p.splits * 2 <= cap && nchunks % (p.splits * 2) == 0 && nchunks / (p.splits * 2) >= 4) p.splits *= 2;
   return p;
 }

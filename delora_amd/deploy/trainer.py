@@ -190,13 +190,21 @@ class Trainer(deployer.Deployer):
                 cap = self.dataset.max_points_per_scan()          # stored lists: at most one point per pixel of the preprocessing image
             g = self._graphed = GraphedStep(self, preprocessed_dicts, max_points=cap)
             self._graphed_phase = phase
+            if self.graph_policy() == "auto" and g.captured:
+                self.__dict__.setdefault("_graph_trial", {})[phase] = []      # start times of the first replayed steps (_judge_replay)
             if self.rank == 0:
                 print(f"[delora_amd] training step captured as a HIP graph: {g.captured} ({'unsupervised' if phase else 'identity'} phase, "
                       f"{g.capacity} points per scan)")
         before = g.replayed_steps
+        trial = self._graph_trial.get(phase) if hasattr(self, "_graph_trial") else None
+        if trial is not None:
+            import time
+            trial.append(time.perf_counter())
         ep, _ = g(preprocessed_dicts)
         replayed = g.replayed_steps - before
         self.graph_steps += replayed
+        if trial is not None and len(trial) > self.PROBE_STEPS:
+            self._judge_replay(phase, trial)
         if replayed and g.acc is not None:
             return epoch_losses                      # the replay added its metrics to the graph's own accumulator (folded in per epoch)
         for k, v in ep.items():                      # eager fallback / no accumulator: the outputs are (static) tensors, add their VALUES
@@ -204,7 +212,33 @@ class Trainer(deployer.Deployer):
                 epoch_losses[k] = epoch_losses[k] + v
         return epoch_losses
 
+    def _judge_replay(self, phase, starts):
+        """`auto` only: the host's period over the first replayed steps against the eager period the probe measured.  hipGraphLaunch
+        of this ROCm release enqueues a captured step node by node, at about the cost of the eager enqueue -- measured on the
+        reference's default batch-1 step: 2.22 ms to replay 130 kernel nodes against 2.33 ms to enqueue them eagerly -- so a replay
+        that does not shorten the host's period by at least 3 % is dropped again (config ``hip_graph_keep_if_slower`` keeps it)."""
+        del self._graph_trial[phase]
+        res = self.graph_probe_result.get(phase, {})
+        period = (starts[-1] - starts[0]) / (len(starts) - 1)
+        res["replay_host_period_ms"] = round(1e3 * period, 3)
+        eager = res.get("host_period_ms")
+        keep = eager is None or 1e3 * period < 0.97 * max(eager, res.get("host_enqueue_ms", 0.0)) or bool(self.config.get("hip_graph_keep_if_slower", False))
+        res["decision"] = "graph" if keep else "eager (replay measured, not faster)"
+        if not keep:
+            self._graph_decision[phase] = "eager"
+            self._fold_pending = self._graphed.take_epoch_sums()      # metrics of the replayed steps: folded into the running epoch
+            del self._graphed
+            self._graphed = None
+        if self.rank == 0:
+            print(f"[delora_amd] hip_graph auto: replaying costs the host {1e3 * period:.2f} ms per step -> "
+                  + ("keeping the captured graph" if keep else "no gain over the eager enqueue on this stack: back to the eager step"))
+
     def _fold_graph_sums(self, epoch_losses):
+        pending = getattr(self, "_fold_pending", None)
+        if pending:
+            for k, v in pending.items():
+                epoch_losses[k] = epoch_losses[k] + v
+            self._fold_pending = None
         g = getattr(self, "_graphed", None)
         if g is not None:
             for k, v in g.take_epoch_sums().items():

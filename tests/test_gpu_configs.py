@@ -311,7 +311,7 @@ def test_bench_final_loss_reproduces():
     assert b1["graph_resident"]["eager_fallback_steps"] == 0
     for leg in ("product_loop_packed_feed_2_workers", "product_loop_yaml_default_0_workers"):
         auto = b1[leg]["hip_graph_auto"]
-        assert auto["decision"] in ("graph", "eager") and auto["stream_ms"] > 0, (leg, b1[leg])
+        assert auto["decision"].split(" ")[0] in ("graph", "eager") and auto["stream_ms"] > 0, (leg, b1[leg])
         assert b1[leg]["graph_replayed_steps"] == (b1[leg]["steps"] if auto["decision"] == "graph" else 0), (leg, b1[leg])
         assert b1[leg]["feed"] == "PackedFeed"          # 0 workers included: the consumer decodes in-process into page-locked slots
         util.measured(f"default operating point (64x720, batch 1), {leg}: step time / eager step on resident batches",
@@ -410,7 +410,15 @@ def test_bench_eight_ranks_dry_run_on_one_gpu():
     env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
     cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1", "--batch", "1", "--width", "256",
            "--rotate", "2", "--kernel-reps", "2", "--no-live-pmc", "--no-profile"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env, cwd=root)
+    # (a bounded wait: eight processes time-slicing one GPU are slow, not stuck -- but a stuck run must cost minutes, not the session)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=root, start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=420)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, 9)
+        out, err = proc.communicate()
+        pytest.fail("bench.py --gpus 8 on one shared GPU did not finish in 420 s:\n" + err[-3000:])
+    r = subprocess.CompletedProcess(cmd, proc.returncode, out, err)
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [x for x in r.stdout.splitlines() if x.startswith("{")]
     assert len(lines) == 1, "rank 0 prints exactly one JSON line"

@@ -305,38 +305,45 @@ def test_training_from_the_on_disk_format_through_the_packed_feed(tmp_path, with
             normals.append(n / np.linalg.norm(n, axis=0, keepdims=True))
     synthetic.write_tree(str(tmp_path / "data"), scans, sequence=0, normals=normals)
     results = []
-    for workers in (0, 2):
+    # the plain DataLoader (config packed_feed: false), the packed feed without worker processes (num_dataloader_workers: 0, the YAML's
+    # default: the consumer decodes in-process), with two worker processes, and over a dataset held in RAM
+    for workers, packed, ram in ((0, False, False), (0, True, False), (2, True, False), (0, True, True)):
         cfg = util.repo_config(16, 128, device="cuda:0", factor_fewer_resnet_channels=8, resnet_outputs=64, batch_size=2,
                                unsupervised_at_start=True, inference_only=False, checkpoint_dir=str(tmp_path), learning_rate=1e-4,
-                               num_dataloader_workers=workers, store_dataset_in_RAM=False, shuffle_training_data=False)
+                               num_dataloader_workers=workers, store_dataset_in_RAM=ram, shuffle_training_data=False, packed_feed=packed,
+                               hip_graph=False)
         cfg["kitti"]["preprocessed_path"] = str(tmp_path / "data")
         cfg["kitti"]["data_identifiers"] = cfg["kitti"]["training_identifiers"] = [0]
         torch.manual_seed(7)
         tr = Trainer(cfg, dataset=PreprocessedPointCloudDataset(cfg))
         loader, sampler = tr.make_dataloader()
-        assert isinstance(loader, feed.PackedFeed) == (workers > 0)
-        if workers:
+        assert isinstance(loader, feed.PackedFeed) == packed
+        if packed:
             assert loader.pinned, "the slots of the feed must be page-locked (hipHostRegister) on a GPU box"
+            assert len(loader.procs) == workers
         tr.steps_per_epoch_effective = len(loader)
         metrics = tr._reduce_metrics(tr.train_epoch(epoch=0, dataloader=loader))
         results.append((metrics, [p.detach().clone() for p in tr.raw_model.parameters()]))
-        if workers:
+        if packed:
             loader.close()
-    (m0, p0), (m1, p1) = results
+    m0, p0 = results[0]
     assert len(tr.dataset) == 6 and np.isfinite(m0["loss_epoch"]) and m0["loss_epoch"] > 0
-    for k in m0:
-        assert np.isclose(m0[k], m1[k], rtol=1e-6, atol=1e-9), (k, m0[k], m1[k])
-    util.measured(f"packed feed vs DataLoader ({'stored normals' if with_normals else 'xyz only'}): largest parameter difference after one epoch",
-                  max(float((a - b).abs().max()) for a, b in zip(p0, p1)), bound=1e-7)
+    for name, (m1, p1) in zip(("in-process", "2 workers", "in-process, dataset in RAM"), results[1:]):
+        for k in m0:
+            assert np.isclose(m0[k], m1[k], rtol=1e-6, atol=1e-9), (name, k, m0[k], m1[k])
+        util.measured(f"packed feed ({name}) vs DataLoader ({'stored normals' if with_normals else 'xyz only'}): largest parameter difference after one epoch",
+                      max(float((a - b).abs().max()) for a, b in zip(p0, p1)), bound=1e-7)
 
 
-@pytest.mark.parametrize("workers", [0, 2])
-def test_product_loop_switches_to_graph_replay_and_keeps_the_trajectory(tmp_path, workers):
+@pytest.mark.parametrize("feed_kind", ["dataloader", "packed-in-process", "packed-2-workers"])
+def test_product_loop_switches_to_graph_replay_and_keeps_the_trajectory(tmp_path, feed_kind):
     """`hip_graph: auto` (the default) in the product loop, on the reference's default batch size 1 with the full-width network on the HIP
     path: `Trainer.train_epoch` times its first eager steps, decides (forced here by `hip_graph_auto_threshold: 0`), captures the step
     in the MIDDLE of an epoch -- the capture's warm-up steps are rolled back -- and replays every later batch, from the DataLoader
-    (workers 0: lists of dicts packed scan by scan) and from the packed feed (workers 2: a PackedBatch, one device copy into the static
-    buffers).  Epoch metrics and final weights must equal those of the eager run (`hip_graph: false`) on the same samples."""
+    (`packed_feed: false`: lists of dicts packed scan by scan) and from the packed feed (in-process and with two workers: a
+    PackedBatch, one device copy into the static buffers).  Epoch metrics and final weights must equal those of the eager run
+    (`hip_graph: false`) on the same samples."""
+    workers = 2 if feed_kind == "packed-2-workers" else 0
     from delora_amd.data import feed, synthetic
     from delora_amd.data.dataset import PreprocessedPointCloudDataset
     from delora_amd.deploy.trainer import Trainer
@@ -352,19 +359,20 @@ def test_product_loop_switches_to_graph_replay_and_keeps_the_trajectory(tmp_path
     for mode in (False, "auto"):
         cfg = util.repo_config(16, 128, device="cuda:0", batch_size=1, unsupervised_at_start=True, inference_only=False,
                                checkpoint_dir=str(tmp_path), learning_rate=1e-5, num_dataloader_workers=workers, store_dataset_in_RAM=False,
-                               shuffle_training_data=False, hip_graph=mode, hip_graph_auto_threshold=0.0)
+                               shuffle_training_data=False, hip_graph=mode, hip_graph_auto_threshold=0.0, hip_graph_keep_if_slower=True,
+                               packed_feed=feed_kind != "dataloader")
         cfg["kitti"]["preprocessed_path"] = str(tmp_path / "data")
         cfg["kitti"]["data_identifiers"] = cfg["kitti"]["training_identifiers"] = [0]
         torch.manual_seed(7)
         tr = Trainer(cfg, dataset=PreprocessedPointCloudDataset(cfg))
         assert tr.graph_policy() == ("off" if mode is False else "auto")
         loader, _ = tr.make_dataloader()
-        assert isinstance(loader, feed.PackedFeed) == (workers > 0)
+        assert isinstance(loader, feed.PackedFeed) == (feed_kind != "dataloader")
         tr.steps_per_epoch_effective = len(loader)
         metrics = [tr._reduce_metrics(tr.train_epoch(epoch=e, dataloader=loader)) for e in range(3)]
         torch.cuda.synchronize()
         runs[mode] = (metrics, [p.detach().clone() for p in tr.raw_model.parameters()], tr)
-        if workers:
+        if hasattr(loader, "close"):
             loader.close()
     tr = runs["auto"][2]
     probe = tr.PROBE_SKIP + tr.PROBE_STEPS
@@ -375,9 +383,9 @@ def test_product_loop_switches_to_graph_replay_and_keeps_the_trajectory(tmp_path
     for m_e, m_g in zip(runs[False][0], runs["auto"][0]):
         for k in m_e:
             worst = max(worst, abs(m_e[k] - m_g[k]) / max(abs(m_e[k]), 1e-12))
-    util.measured(f"product loop, graph replay vs eager ({'packed feed' if workers else 'DataLoader'}): worst relative difference of an epoch metric "
+    util.measured(f"product loop, graph replay vs eager ({feed_kind}): worst relative difference of an epoch metric "
                   "over three epochs", worst, bound=1e-5)
-    util.measured(f"product loop, graph replay vs eager ({'packed feed' if workers else 'DataLoader'}): largest parameter difference after 36 steps",
+    util.measured(f"product loop, graph replay vs eager ({feed_kind}): largest parameter difference after 36 steps",
                   max(float((a - b).abs().max()) for a, b in zip(runs[False][1], runs["auto"][1])), bound=2e-6)
 
 
