@@ -1144,16 +1144,17 @@ def main():
     }
     if rank == 0:
         rows, counts = kernel_table(trainer, batches[0], args.kernel_reps)
-        if timers.used == 0:                                   # graph mode: measure the same launch right after the timed region
+        if timers.used == 0 and world == 1:                    # graph mode: measure the same launch right after the timed region
+            # (one process only: under DDP a training step is a collective -- rank 0 stepping alone would wait for the others forever)
             G.LOSS_TIMER_FACTORY = timers.new
             for _ in range(5):
                 trainer.optimizer.zero_grad(set_to_none=True)
                 trainer.step(preprocessed_dicts=[dict(s) for s in batches[0]], epoch_losses=trainer.new_epoch_losses())
             torch.cuda.synchronize()
             G.LOSS_TIMER_FACTORY = None
-        loss_ms = float(np.mean(timers.elapsed_ms()))
-        timers.close()
         alg = next(r for r in rows if r["kernel"] == "dl_icp_loss_fwd")
+        loss_ms = float(np.mean(timers.elapsed_ms())) if timers.used else float(alg["ms"])     # (no in-step timer: the back-to-back figure)
+        timers.close()
         live_bytes = 52 * counts["M"]
         warm = live_bytes / loss_ms / 1e6
         cold = live_bytes / counts["loss_cold_ms"] / 1e6

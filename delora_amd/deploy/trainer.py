@@ -344,6 +344,11 @@ class Trainer(deployer.Deployer):
         finally:
             if run is not None:
                 mlflow.end_run()
+            if isinstance(dataloader, feed.PackedFeed) and self.rank == 0:
+                steps = max(1, len(self.history) * len(dataloader))
+                self.feed_report = {"page_locked_slots": bool(dataloader.pinned), "workers": dataloader.workers,
+                                    "consumer_host_ms_per_step": {k: round(1e3 * v / steps, 3) for k, v in dataloader.host_seconds.items()}}
+                print("[delora_amd] packed feed: " + str(self.feed_report))
             if hasattr(dataloader, "close"):
                 dataloader.close()                  # PackedFeed: worker processes and page-locked slots
         return self.history

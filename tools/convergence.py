@@ -122,7 +122,7 @@ def train_and_test(device, tree, truth, precision, epochs, lr, batch, seed, out_
     result = {"precision": precision, "epochs": len(history), "steps": len(history) * steps_per_epoch, "steps_per_epoch": steps_per_epoch,
               "identity_epochs": identity_epochs, "unsupervised_epochs": len(unsup), "train_wall_s": round(wall, 2),
               "ms_per_step_incl_feed_and_checkpoints": round(1e3 * wall / max(1, len(history) * steps_per_epoch), 3),
-              "graph_replayed_steps": getattr(trainer, "graph_steps", 0), "hip_graph_auto": {str(k): v for k, v in getattr(trainer, "graph_probe_result", {}).items()},
+              "graph_replayed_steps": getattr(trainer, "graph_steps", 0), "feed": getattr(trainer, "feed_report", None), "hip_graph_auto": {str(k): v for k, v in getattr(trainer, "graph_probe_result", {}).items()},
               "identity_loss_per_epoch": [round(h["loss_epoch"], 6) for h in history if not h["unsupervised"]],
               "unsupervised_loss_per_epoch": curve,
               "loss_po2pl_per_epoch": [round(h["loss_po2pl_epoch"], 6) for h in unsup], "loss_pl2pl_per_epoch": [round(h["loss_pl2pl_epoch"], 6) for h in unsup]}
@@ -147,6 +147,8 @@ def main(argv=None):
     ap.add_argument("--scans", type=int, default=41, help="scans per sequence")
     ap.add_argument("--precisions", default="float32,bfloat16,float16")
     ap.add_argument("--seed", type=int, default=11)
+    ap.add_argument("--on-disk", action="store_true", help="store_dataset_in_RAM: false (the YAML's default) instead of the RAM-resident dataset")
+    ap.add_argument("--workers", type=int, default=0)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "convergence.json"))
     args = ap.parse_args(argv)
     device = torch.device("cuda", 0)
@@ -161,7 +163,8 @@ def main(argv=None):
               "segment_lengths_m": [2.0, 5.0, 10.0, 15.0], "runs": {}}
     try:
         for precision in args.precisions.split(","):
-            report["runs"][precision] = train_and_test(device, tree, truth, precision, args.epochs, args.lr, args.batch, args.seed, out_dir)
+            report["runs"][precision] = train_and_test(device, tree, truth, precision, args.epochs, args.lr, args.batch, args.seed, out_dir,
+                                                       extra={"store_dataset_in_RAM": not args.on_disk, "num_dataloader_workers": args.workers})
             r = report["runs"][precision]
             print(precision, "steps", r["steps"], "loss", r.get("loss_first_epochs_mean"), "->", r.get("loss_plateau_last_epochs_mean"),
                   "held-out", r["held_out_sequence"]["translation_error_percent"], "%", r["held_out_sequence"]["rotation_error_deg_per_m"], "deg/m", flush=True)
