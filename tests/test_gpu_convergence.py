@@ -1,0 +1,68 @@
+"""Training-quality evidence (-m gpu): the product's own Trainer.train() -> Tester.test() pipeline on a synthetic dataset with known
+ego-motion, in every precision the bench advertises, scored the way the reference's results are scored (KITTI-style relative
+trajectory errors).  The same run as tools/convergence.py (300 epochs = 6000 steps per precision, ~2.5 minutes on the GPU); its report
+is written to gpurun_out/convergence.json and committed as profiles/r05_convergence.json.
+
+What it establishes -- and what it does not: the three precisions start from the same weights and see the same samples in the same
+order, reach the SAME loss plateau and the SAME trajectory error (so bf16 / fp16 storage with fp32 accumulation and fp32 master weights
+trains like fp32).  The absolute error stays far above KITTI figures: the synthetic scenes are corridors (walls and ground parallel to
+the motion), where the point-to-plane loss leaves the forward translation almost unconstrained -- a property of the scenes."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from tests import util
+from tests.conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_every_precision_trains_to_the_same_plateau_and_trajectory_error(tmp_path):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import convergence as cv
+    finally:
+        sys.path.pop(0)
+    device = torch.device("cuda", 0)
+    tree, truth = cv.build_dataset(device, train_sequences=4, scans_per_sequence=41, workdir=str(tmp_path / "tree"))
+    out_dir = str(tmp_path / "out")
+    os.makedirs(out_dir)
+    # (the middle of the three loss curves is chaotic -- at epoch 150 they differ by 30 % -- and all three settle on the same plateau
+    # from epoch ~240 on: 0.9855 / 0.9861 / 0.9861 in the first long run; hence the full 300 epochs)
+    runs = {p: cv.train_and_test(device, tree, truth, p, epochs=300, lr=1e-4, batch=8, seed=11, out_dir=out_dir)
+            for p in ("float32", "bfloat16", "float16")}
+    base = runs["float32"]
+    curve = np.asarray(base["unsupervised_loss_per_epoch"])
+    assert base["identity_epochs"] >= 1 and len(curve) >= 280, "identity pre-training must hand over to the unsupervised phase"
+    first, last, before_last = curve[:8].mean(), curve[-16:].mean(), curve[-32:-16].mean()
+    util.measured("fp32 training: mean unsupervised loss of the last 16 epochs / of the first 8", last / first, bound=0.85)
+    util.measured("fp32 training: the plateau -- |last 16 epochs - the 16 before| / last", abs(last - before_last) / last, bound=0.08)
+    held = base["held_out_sequence"]
+    util.measured("fp32 training: held-out relative translation error / the error of a predictor that says 'no motion'",
+                  held["translation_error_percent"] / held["yardstick_no_motion_percent"], bound=0.6)
+    for p in ("bfloat16", "float16"):
+        r = runs[p]
+        c = np.asarray(r["unsupervised_loss_per_epoch"])
+        assert np.isfinite(c).all() and len(c) == len(curve)
+        util.measured(f"{p} training: loss plateau (last 16 epochs) / fp32's", c[-16:].mean() / last, bound=1.05)
+        util.measured(f"{p} training: held-out relative translation error / fp32's",
+                      r["held_out_sequence"]["translation_error_percent"] / held["translation_error_percent"], bound=1.2)
+        util.measured(f"{p} training: held-out per-step rotation error (deg) / fp32's",
+                      r["held_out_sequence"]["per_step_rotation_error_deg_mean"] / held["per_step_rotation_error_deg_mean"], bound=1.2)
+    import json
+    report = {"what": "identity pre-training -> unsupervised training -> Tester -> KITTI-style relative errors, per precision, same seed "
+                      "(tests/test_gpu_convergence.py; tools/convergence.py is the same run as a script)",
+              "image": "64x720", "batch": 8, "learning_rate": 1e-4, "reference_learning_rate": 1e-5, "epochs": 300, "segment_lengths_m": [2.0, 5.0, 10.0, 15.0],
+              "dataset": "4 training sequences + 1 held out, 41 scans each (synthetic scenes, ~0.45 m and <=1.5 deg yaw per scan), preprocessed offline at 64x2250",
+              "runs": runs}
+    for p in ("bfloat16", "float16"):
+        runs[p]["vs_float32"] = {"plateau_loss_ratio": float(np.asarray(runs[p]["unsupervised_loss_per_epoch"])[-16:].mean() / last),
+                                 "held_out_translation_error_ratio": runs[p]["held_out_sequence"]["translation_error_percent"] / held["translation_error_percent"]}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "convergence.json"), "w") as f:
+        json.dump(report, f, indent=1)
