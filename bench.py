@@ -105,7 +105,8 @@ def make_batch(args, rank, device=None):
     from delora_amd.data import synthetic
     samples = []
     for j in range(args.batch):
-        s1, s2, T = synthetic.make_pair(2000 + rank * args.batch + j, rings=args.height, azimuth_steps=2250, point_order=args.point_order)
+        s1, s2, T = synthetic.make_pair(2000 + rank * args.batch + j, rings=args.height, azimuth_steps=2250,
+                                        point_order=getattr(args, "point_order", "raster"))       # (the tools pass ad-hoc argument objects)
         d = {"dataset": "kitti", "scan_1": torch.from_numpy(s1).unsqueeze(0), "scan_2": torch.from_numpy(s2).unsqueeze(0),
              "normal_list_1": None, "normal_list_2": None}
         if device is not None:

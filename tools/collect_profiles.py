@@ -21,7 +21,9 @@ if NEW:
             json.dump(last_json(os.path.join(src, a)), open(os.path.join(dst, f"{R}_{a}"), "w"), indent=1)
     for name in ("bench_kernel_stats_f32.csv", "bench_kernel_stats_bf16.csv", "step_breakdown_f32.txt", "step_breakdown_bf16.txt",
                  "geometry_kernel_stats.csv", "loss_calibration.txt", "loss_warm.txt", "loss_cold.txt", "conv_harness.txt", "convh_harness.txt",
-                 "conv_layers_float32.txt", "conv_layers_bfloat16.txt", "conv_pmc.txt", "convh_pmc.txt", "scatter_probe.txt"):
+                 "conv_layers_float32.txt", "conv_layers_bfloat16.txt", "conv_pmc.txt", "convh_pmc.txt", "scatter_probe.txt",
+                 "step_breakdown_64x720_b1_f32.txt", "step_breakdown_64x720_b1_bf16.txt", "step_breakdown_64x720_b8_f32.txt",
+                 "shipped_step_b1_ab.txt", "feed_ranks.json"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{R}_{name}"))
     merged = {"launches": {}}
@@ -54,19 +56,30 @@ def counter(path, name):
     return {k: statistics.mean(v) for k, v in vals.items()}
 
 
-fetch = counter(os.path.join(src, "geo_fetch", "geo_counter_collection.csv"), "FETCH_SIZE")
-write = counter(os.path.join(src, "geo_write", "geo_counter_collection.csv"), "WRITE_SIZE")
-pmc = {"workload": "tools/geo_bench.py 5 0.4: bench batch B=8, 64x2048, residual motion 0.4 m; rocprofv3 --kernel-trace --pmc FETCH_SIZE / "
-                   "--pmc WRITE_SIZE in separate passes",
-       "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read (MI355X_MICROARCH.md, HBM section) -> read "
-                     "bytes = FETCH_SIZE*1024*2; WRITE_SIZE*1024 uncorrected; exact for streaming kernels (k_icp_loss), an upper bound for "
-                     "gather-heavy kernels",
-       "kernels": {}}
-for k in OWN:
-    if k in fetch and k in write:
-        rd, wr = fetch[k] * 1024 * 2, write[k] * 1024
-        pmc["kernels"][k] = {"FETCH_SIZE_KB_raw": fetch[k], "WRITE_SIZE_KB_raw": write[k], "read_bytes_corrected_x2": rd, "write_bytes": wr,
-                             "hbm_bytes_per_launch": rd + wr}
+def geometry_pmc(tag, order):
+    fetch = counter(os.path.join(src, "geo_fetch" + tag, "geo_counter_collection.csv"), "FETCH_SIZE")
+    write = counter(os.path.join(src, "geo_write" + tag, "geo_counter_collection.csv"), "WRITE_SIZE")
+    pmc = {"workload": f"tools/geo_bench.py 5 0.4 {order}: bench batch B=8, 64x2048, points in {order} order, residual motion 0.4 m; rocprofv3 "
+                       "--kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes",
+           "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request of a wide coalesced read (MI355X_MICROARCH.md, HBM section) -> read "
+                         "bytes = FETCH_SIZE*1024*2; WRITE_SIZE*1024 uncorrected; exact for streaming kernels (k_icp_loss), an upper bound for "
+                         "gather-heavy kernels",
+           "kernels": {}}
+    for k in OWN:
+        if k in fetch and k in write:
+            rd, wr = fetch[k] * 1024 * 2, write[k] * 1024
+            pmc["kernels"][k] = {"FETCH_SIZE_KB_raw": fetch[k], "WRITE_SIZE_KB_raw": write[k], "read_bytes_corrected_x2": rd, "write_bytes": wr,
+                                 "hbm_bytes_per_launch": rd + wr}
+    if "k_project_scatter" in pmc["kernels"] and "k_project_resolve" in pmc["kernels"]:
+        total = pmc["kernels"]["k_project_scatter"]["hbm_bytes_per_launch"] + pmc["kernels"]["k_project_resolve"]["hbm_bytes_per_launch"]
+        pmc["dl_project"] = {"hbm_bytes_per_launch_vote_plus_resolve": total,
+                             "note": "against the algorithmic 12 B/point + 36 B/pixel of the same batch (bench.py kernels: dl_project, ~102.6 MB)"}
+    return pmc
+
+
+if os.path.exists(os.path.join(src, "geo_fetch_shuffled", "geo_counter_collection.csv")):
+    json.dump(geometry_pmc("_shuffled", "shuffled"), open(os.path.join(dst, f"{R}_geometry_pmc_shuffled.json"), "w"), indent=1)
+pmc = geometry_pmc("", "raster")
 json.dump(pmc, open(os.path.join(dst, f"{R}_geometry_pmc.json"), "w"), indent=1)
 if not NEW:
     trace = os.path.join(src, "bench_trace", "bench_kernel_trace.csv")

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the geometry kernels on the bench batch (B=8, 64x2048); meant to run under rocprofv3.
-usage: python tools/geo_bench.py [reps] [shift_m]"""
+usage: python tools/geo_bench.py [reps] [shift_m] [point_order]"""
 import os, sys, time
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
@@ -8,9 +8,9 @@ import bench
 from delora_amd import geometry as G
 from delora_amd.deploy.step_geometry import HipStepGeometry
 
-class A: batch=8; height=64; width=2048
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 shift = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0
+class A: batch=8; height=64; width=2048; point_order = sys.argv[3] if len(sys.argv) > 3 else "raster"   # raster (bench default) | shuffled | firing
 dev = torch.device("cuda:0")
 args = A()
 cfg = bench.build_config(argparse_like := type("X", (), dict(height=64, width=2048, batch=8, amp="", channels_last=False))(), dev)

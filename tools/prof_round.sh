@@ -4,7 +4,7 @@
 # launch table + FETCH_SIZE / WRITE_SIZE per layer (tools/conv_layers.py), matrix-core counters of the Winograd and the
 # half-precision kernels.  Counters are collected in their own runs, with --kernel-trace only.
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 out=gpurun_out/profiles_$R; rm -rf $out; mkdir -p $out
 T=/tmp/prof_$R; rm -rf $T; mkdir -p $T
 python bench.py > $out/bench.json 2> $out/bench.err; tail -1 $out/bench.json | cut -c1-300
@@ -16,15 +16,28 @@ for m in f32 bf16; do
   python tools/step_breakdown.py $(find $T/bench_$m -name "*kernel_trace.csv" | head -1) 20 200 > $out/step_breakdown_$m.txt 2>&1
   cp $(find $T/bench_$m -name "*kernel_stats.csv" | head -1) $out/bench_kernel_stats_$m.csv
 done
+# the reference's default operating point (64x720, stored lists): one steady-state step at batch 1 (fp32, bf16) and batch 8, eager
+for v in "1 f32" "1 bf16" "8 f32"; do
+  set -- $v; a=""; [ $2 = bf16 ] && a=bfloat16
+  rocprofv3 --kernel-trace --output-format csv -d $T/ship_$1_$2 -o t -- python tools/shipped_step.py $1 eager 30 $a > $out/shipped_step_b$1_$2.txt 2>/dev/null
+  python tools/step_breakdown.py $(find $T/ship_$1_$2 -name "*kernel_trace.csv" | head -1) 20 60 > $out/step_breakdown_64x720_b$1_$2.txt 2>&1
+done
+(for sp in 1 0; do DL_WINO_SPLIT=$sp python tools/shipped_step.py 1 eager 100 2>/dev/null | grep shipped_step; done; python tools/shipped_step.py 1 graph 100 2>/dev/null | grep shipped_step) > $out/shipped_step_b1_ab.txt
+timeout 300 python tools/feed_ranks.py --out $out/feed_ranks.json > /dev/null 2>&1
 # geometry kernels alone + their HBM counters
 rocprofv3 --kernel-trace --stats --output-format csv -d $T/geo_trace -o geo -- python tools/geo_bench.py 30 0.4 > /dev/null 2>&1
 cp $(find $T/geo_trace -name "*kernel_stats.csv" | head -1) $out/geometry_kernel_stats.csv
 python tools/loss_calibration.py $(find $T/geo_trace -name "*kernel_trace.csv" | head -1) 30 > $out/loss_calibration.txt 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $T/geo_fetch -o geo -- python tools/geo_bench.py 5 0.4 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $T/geo_write -o geo -- python tools/geo_bench.py 5 0.4 > /dev/null 2>&1
-mkdir -p $out/geo_fetch $out/geo_write
+mkdir -p $out/geo_fetch $out/geo_write $out/geo_fetch_shuffled $out/geo_write_shuffled
 cp $(find $T/geo_fetch -name "*counter_collection.csv" | head -1) $out/geo_fetch/geo_counter_collection.csv
 cp $(find $T/geo_write -name "*counter_collection.csv" | head -1) $out/geo_write/geo_counter_collection.csv
+# (the same counters with the points of every scan randomly permuted: the input order of rounds 1-4)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $T/geo_fetch_s -o geo -- python tools/geo_bench.py 5 0.4 shuffled > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $T/geo_write_s -o geo -- python tools/geo_bench.py 5 0.4 shuffled > /dev/null 2>&1
+cp $(find $T/geo_fetch_s -name "*counter_collection.csv" | head -1) $out/geo_fetch_shuffled/geo_counter_collection.csv
+cp $(find $T/geo_write_s -name "*counter_collection.csv" | head -1) $out/geo_write_shuffled/geo_counter_collection.csv
 python tools/loss_warm.py 50 > $out/loss_warm.txt 2>/dev/null
 python tools/exp/loss_cold.py 2>/dev/null | grep '^B=' > $out/loss_cold.txt
 # convolution kernels: stand-alone harnesses (host-checked correctness + per-layer times)
