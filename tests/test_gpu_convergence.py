@@ -32,37 +32,36 @@ def test_every_precision_trains_to_the_same_plateau_and_trajectory_error(tmp_pat
     tree, truth = cv.build_dataset(device, train_sequences=4, scans_per_sequence=41, workdir=str(tmp_path / "tree"))
     out_dir = str(tmp_path / "out")
     os.makedirs(out_dir)
-    # (the middle of the three loss curves is chaotic -- at epoch 150 they differ by 30 % -- and all three settle on the same plateau
-    # from epoch ~240 on: 0.9855 / 0.9861 / 0.9861 in the first long run; hence the full 300 epochs)
+    # (at a constant 1e-4 the loss curves keep spiking -- three precisions then end wherever their last spike left them: 0.986 / 0.986 /
+    # 0.986 in one run, 1.00 / 1.16 / ... in the next -- hence the last third at the reference's own 1e-5, resumed from the checkpoint)
     runs = {p: cv.train_and_test(device, tree, truth, p, epochs=300, lr=1e-4, batch=8, seed=11, out_dir=out_dir)
             for p in ("float32", "bfloat16", "float16")}
     base = runs["float32"]
     curve = np.asarray(base["unsupervised_loss_per_epoch"])
-    assert base["identity_epochs"] >= 1 and len(curve) >= 280, "identity pre-training must hand over to the unsupervised phase"
-    first, last, before_last = curve[:8].mean(), curve[-16:].mean(), curve[-32:-16].mean()
-    util.measured("fp32 training: mean unsupervised loss of the last 16 epochs / of the first 8", last / first, bound=0.85)
-    util.measured("fp32 training: the plateau -- |last 16 epochs - the 16 before| / last", abs(last - before_last) / last, bound=0.08)
     held = base["held_out_sequence"]
-    util.measured("fp32 training: held-out relative translation error / the error of a predictor that says 'no motion'",
-                  held["translation_error_percent"] / held["yardstick_no_motion_percent"], bound=0.6)
+    last = curve[-20:].mean()
     for p in ("bfloat16", "float16"):
-        r = runs[p]
-        c = np.asarray(r["unsupervised_loss_per_epoch"])
-        assert np.isfinite(c).all() and len(c) == len(curve)
-        util.measured(f"{p} training: loss plateau (last 16 epochs) / fp32's", c[-16:].mean() / last, bound=1.05)
-        util.measured(f"{p} training: held-out relative translation error / fp32's",
-                      r["held_out_sequence"]["translation_error_percent"] / held["translation_error_percent"], bound=1.2)
-        util.measured(f"{p} training: held-out per-step rotation error (deg) / fp32's",
-                      r["held_out_sequence"]["per_step_rotation_error_deg_mean"] / held["per_step_rotation_error_deg_mean"], bound=1.2)
+        runs[p]["vs_float32"] = {"plateau_loss_ratio": float(np.asarray(runs[p]["unsupervised_loss_per_epoch"])[-20:].mean() / last),
+                                 "held_out_translation_error_ratio": runs[p]["held_out_sequence"]["translation_error_percent"] / held["translation_error_percent"],
+                                 "held_out_per_step_rotation_error_ratio": runs[p]["held_out_sequence"]["per_step_rotation_error_deg_mean"] / held["per_step_rotation_error_deg_mean"]}
     import json
-    report = {"what": "identity pre-training -> unsupervised training -> Tester -> KITTI-style relative errors, per precision, same seed "
-                      "(tests/test_gpu_convergence.py; tools/convergence.py is the same run as a script)",
+    report = {"what": "identity pre-training -> unsupervised training (200 epochs at lr 1e-4, 100 more at 1e-5 resumed from the checkpoint) -> Tester -> "
+                      "KITTI-style relative errors, per precision, same seed (tests/test_gpu_convergence.py; tools/convergence.py is the same run as a script)",
               "image": "64x720", "batch": 8, "learning_rate": 1e-4, "reference_learning_rate": 1e-5, "epochs": 300, "segment_lengths_m": [2.0, 5.0, 10.0, 15.0],
               "dataset": "4 training sequences + 1 held out, 41 scans each (synthetic scenes, ~0.45 m and <=1.5 deg yaw per scan), preprocessed offline at 64x2250",
               "runs": runs}
-    for p in ("bfloat16", "float16"):
-        runs[p]["vs_float32"] = {"plateau_loss_ratio": float(np.asarray(runs[p]["unsupervised_loss_per_epoch"])[-16:].mean() / last),
-                                 "held_out_translation_error_ratio": runs[p]["held_out_sequence"]["translation_error_percent"] / held["translation_error_percent"]}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "convergence.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "convergence.json"), "w") as f:                    # (before the assertions: a failing run leaves its curves behind)
         json.dump(report, f, indent=1)
+    assert base["identity_epochs"] >= 1 and len(curve) >= 280, "identity pre-training must hand over to the unsupervised phase"
+    first, before_last = curve[:8].mean(), curve[-40:-20].mean()
+    util.measured("fp32 training: mean unsupervised loss of the last 20 epochs / of the first 8", last / first, bound=0.85)
+    util.measured("fp32 training: the plateau -- |last 20 epochs - the 20 before| / last", abs(last - before_last) / last, bound=0.05)
+    util.measured("fp32 training: held-out relative translation error / the error of a predictor that says 'no motion'",
+                  held["translation_error_percent"] / held["yardstick_no_motion_percent"], bound=0.6)
+    for p in ("bfloat16", "float16"):
+        c = np.asarray(runs[p]["unsupervised_loss_per_epoch"])
+        assert np.isfinite(c).all() and len(c) == len(curve)
+        util.measured(f"{p} training: loss plateau (last 20 epochs) / fp32's", runs[p]["vs_float32"]["plateau_loss_ratio"], bound=1.05)
+        util.measured(f"{p} training: held-out relative translation error / fp32's", runs[p]["vs_float32"]["held_out_translation_error_ratio"], bound=1.2)
+        util.measured(f"{p} training: held-out per-step rotation error (deg) / fp32's", runs[p]["vs_float32"]["held_out_per_step_rotation_error_ratio"], bound=1.2)
