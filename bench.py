@@ -969,6 +969,12 @@ def main():
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     t_start = time.perf_counter()
+    # The contract is ONE JSON line on stdout.  Libraries print there too -- the dataset's and the trainer's progress lines, and RCCL's
+    # version banner (a C-level printf at communicator set-up that lands BEHIND the JSON line once Python's buffer is flushed) -- so for
+    # the whole run file descriptor 1 is pointed at stderr, and the result goes to a private duplicate of the real stdout.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     def trace(what):                                    # DELORA_BENCH_TRACE=1: milestones of every rank on stderr (where does a run spend / lose its time)
         if os.environ.get("DELORA_BENCH_TRACE"):
@@ -1272,7 +1278,7 @@ def main():
                     result["ddp_rank"] = {"error": f"{type(e).__name__}: {e}"}
             if not args.no_cpu_baseline:
                 result["cpu_baseline"], result["cpu_baseline_online_normals"] = cpu_baseline(args, cfg)
-        print(json.dumps(result))
+        os.write(json_fd, (json.dumps(result) + "\n").encode())
     trace("at the final barrier")
     if world > 1:
         torch.distributed.barrier()

@@ -34,7 +34,11 @@ def test_every_precision_trains_to_the_same_plateau_and_trajectory_error(tmp_pat
     os.makedirs(out_dir)
     # (at a constant 1e-4 the loss curves keep spiking -- three precisions then end wherever their last spike left them: 0.986 / 0.986 /
     # 0.986 in one run, 1.00 / 1.16 / ... in the next -- hence the last third at the reference's own 1e-5, resumed from the checkpoint)
-    runs = {p: cv.train_and_test(device, tree, truth, p, epochs=300, lr=1e-4, batch=8, seed=11, out_dir=out_dir)
+    # `hip_graph: false` for all three: a replayed step runs torch's capturable Adam, whose bias corrections are computed on the device --
+    # one ulp away from the eager ones, which is enough to send a chaotic trajectory elsewhere; `auto` decides by the host's speed, i.e.
+    # per box.  Eager steps make the run the same on every box.
+    runs = {p: cv.train_and_test(device, tree, truth, p, epochs=360, lr=1e-4, batch=8, seed=11, out_dir=out_dir, anneal_fraction=1.0 / 6.0,
+                                 extra={"hip_graph": False})
             for p in ("float32", "bfloat16", "float16")}
     base = runs["float32"]
     curve = np.asarray(base["unsupervised_loss_per_epoch"])
@@ -45,15 +49,15 @@ def test_every_precision_trains_to_the_same_plateau_and_trajectory_error(tmp_pat
                                  "held_out_translation_error_ratio": runs[p]["held_out_sequence"]["translation_error_percent"] / held["translation_error_percent"],
                                  "held_out_per_step_rotation_error_ratio": runs[p]["held_out_sequence"]["per_step_rotation_error_deg_mean"] / held["per_step_rotation_error_deg_mean"]}
     import json
-    report = {"what": "identity pre-training -> unsupervised training (200 epochs at lr 1e-4, 100 more at 1e-5 resumed from the checkpoint) -> Tester -> "
-                      "KITTI-style relative errors, per precision, same seed (tests/test_gpu_convergence.py; tools/convergence.py is the same run as a script)",
-              "image": "64x720", "batch": 8, "learning_rate": 1e-4, "reference_learning_rate": 1e-5, "epochs": 300, "segment_lengths_m": [2.0, 5.0, 10.0, 15.0],
+    report = {"what": "identity pre-training -> unsupervised training (300 epochs at lr 1e-4, 60 more at 1e-5 resumed from the checkpoint; eager steps) -> Tester -> "
+                      "KITTI-style relative errors, per precision, same seed (tests/test_gpu_zz_convergence.py; tools/convergence.py is the same run as a script)",
+              "image": "64x720", "batch": 8, "learning_rate": 1e-4, "reference_learning_rate": 1e-5, "epochs": 360, "segment_lengths_m": [2.0, 5.0, 10.0, 15.0],
               "dataset": "4 training sequences + 1 held out, 41 scans each (synthetic scenes, ~0.45 m and <=1.5 deg yaw per scan), preprocessed offline at 64x2250",
               "runs": runs}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", "convergence.json"), "w") as f:                    # (before the assertions: a failing run leaves its curves behind)
         json.dump(report, f, indent=1)
-    assert base["identity_epochs"] >= 1 and len(curve) >= 280, "identity pre-training must hand over to the unsupervised phase"
+    assert base["identity_epochs"] >= 1 and len(curve) >= 340, "identity pre-training must hand over to the unsupervised phase"
     first, before_last = curve[:8].mean(), curve[-40:-20].mean()
     util.measured("fp32 training: mean unsupervised loss of the last 20 epochs / of the first 8", last / first, bound=0.85)
     util.measured("fp32 training: the plateau -- |last 20 epochs - the 20 before| / last", abs(last - before_last) / last, bound=0.05)

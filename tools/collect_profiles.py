@@ -11,7 +11,10 @@ OWN = ["k_project_scatter", "k_project_resolve", "k_normals", "k_nn_tiles", "k_n
 
 
 def last_json(path):
-    return json.loads(open(path).read().strip().splitlines()[-1])
+    for line in reversed(open(path).read().strip().splitlines()):      # (libraries may print after the line: RCCL's version banner did)
+        if line.startswith("{"):
+            return json.loads(line)
+    raise ValueError(path + ": no JSON line")
 
 
 NEW = os.path.exists(os.path.join(src, "step_breakdown_f32.txt"))          # bundle layout since round 3 (tools/prof_round.sh)

@@ -163,6 +163,8 @@ def main(argv=None):
     ap.add_argument("--scans", type=int, default=41, help="scans per sequence")
     ap.add_argument("--precisions", default="float32,bfloat16,float16")
     ap.add_argument("--seed", type=int, default=11)
+    ap.add_argument("--hip-graph", default="auto", help="auto | true | false (config key hip_graph)")
+    ap.add_argument("--anneal-fraction", type=float, default=1.0 / 3.0)
     ap.add_argument("--on-disk", action="store_true", help="store_dataset_in_RAM: false (the YAML's default) instead of the RAM-resident dataset")
     ap.add_argument("--workers", type=int, default=0)
     ap.add_argument("--out", default=os.path.join(ROOT, "gpurun_out", "convergence.json"))
@@ -180,7 +182,9 @@ def main(argv=None):
     try:
         for precision in args.precisions.split(","):
             report["runs"][precision] = train_and_test(device, tree, truth, precision, args.epochs, args.lr, args.batch, args.seed, out_dir,
-                                                       extra={"store_dataset_in_RAM": not args.on_disk, "num_dataloader_workers": args.workers})
+                                                       extra={"store_dataset_in_RAM": not args.on_disk, "num_dataloader_workers": args.workers,
+                                                              "hip_graph": {"true": True, "false": False}.get(args.hip_graph, "auto")},
+                                                       anneal_fraction=args.anneal_fraction)
             r = report["runs"][precision]
             print(precision, "steps", r["steps"], "loss", r.get("loss_first_epochs_mean"), "->", r.get("loss_plateau_last_epochs_mean"),
                   "held-out", r["held_out_sequence"]["translation_error_percent"], "%", r["held_out_sequence"]["rotation_error_deg_per_m"], "deg/m", flush=True)
