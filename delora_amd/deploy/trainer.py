@@ -222,7 +222,8 @@ class Trainer(deployer.Deployer):
         period = (starts[-1] - starts[0]) / (len(starts) - 1)
         res["replay_host_period_ms"] = round(1e3 * period, 3)
         eager = res.get("host_period_ms")
-        keep = eager is None or 1e3 * period < 0.97 * max(eager, res.get("host_enqueue_ms", 0.0)) or bool(self.config.get("hip_graph_keep_if_slower", False))
+        gain = float(self.config.get("hip_graph_min_gain", 0.03))
+        keep = eager is None or 1e3 * period < (1.0 - gain) * max(eager, res.get("host_enqueue_ms", 0.0)) or bool(self.config.get("hip_graph_keep_if_slower", False))
         res["decision"] = "graph" if keep else "eager (replay measured, not faster)"
         if not keep:
             self._graph_decision[phase] = "eager"

@@ -335,7 +335,7 @@ def test_training_from_the_on_disk_format_through_the_packed_feed(tmp_path, with
                       max(float((a - b).abs().max()) for a, b in zip(p0, p1)), bound=1e-7)
 
 
-@pytest.mark.parametrize("feed_kind", ["dataloader", "packed-in-process", "packed-2-workers"])
+@pytest.mark.parametrize("feed_kind", ["dataloader", "packed-in-process", "packed-2-workers", "packed-in-process-reverted"])
 def test_product_loop_switches_to_graph_replay_and_keeps_the_trajectory(tmp_path, feed_kind):
     """`hip_graph: auto` (the default) in the product loop, on the reference's default batch size 1 with the full-width network on the HIP
     path: `Trainer.train_epoch` times its first eager steps, decides (forced here by `hip_graph_auto_threshold: 0`), captures the step
@@ -344,6 +344,9 @@ def test_product_loop_switches_to_graph_replay_and_keeps_the_trajectory(tmp_path
     PackedBatch, one device copy into the static buffers).  Epoch metrics and final weights must equal those of the eager run
     (`hip_graph: false`) on the same samples."""
     workers = 2 if feed_kind == "packed-2-workers" else 0
+    # "reverted": the replays are judged not worth keeping (`hip_graph_min_gain` no replay can reach), so the loop goes eager -> capture ->
+    # a few replays -> eager again, all inside one run: every hand-over must leave weights, Adam state and the epoch sums intact
+    reverted = feed_kind.endswith("reverted")
     from delora_amd.data import feed, synthetic
     from delora_amd.data.dataset import PreprocessedPointCloudDataset
     from delora_amd.deploy.trainer import Trainer
@@ -359,8 +362,8 @@ def test_product_loop_switches_to_graph_replay_and_keeps_the_trajectory(tmp_path
     for mode in (False, "auto"):
         cfg = util.repo_config(16, 128, device="cuda:0", batch_size=1, unsupervised_at_start=True, inference_only=False,
                                checkpoint_dir=str(tmp_path), learning_rate=1e-5, num_dataloader_workers=workers, store_dataset_in_RAM=False,
-                               shuffle_training_data=False, hip_graph=mode, hip_graph_auto_threshold=0.0, hip_graph_keep_if_slower=True,
-                               packed_feed=feed_kind != "dataloader")
+                               shuffle_training_data=False, hip_graph=mode, hip_graph_auto_threshold=0.0, hip_graph_keep_if_slower=not reverted,
+                               hip_graph_min_gain=0.999 if reverted else 0.03, packed_feed=feed_kind != "dataloader")
         cfg["kitti"]["preprocessed_path"] = str(tmp_path / "data")
         cfg["kitti"]["data_identifiers"] = cfg["kitti"]["training_identifiers"] = [0]
         torch.manual_seed(7)
@@ -376,8 +379,12 @@ def test_product_loop_switches_to_graph_replay_and_keeps_the_trajectory(tmp_path
             loader.close()
     tr = runs["auto"][2]
     probe = tr.PROBE_SKIP + tr.PROBE_STEPS
-    assert tr.graph_probe_result[True]["decision"] == "graph" and tr._graphed.captured
-    assert tr.graph_steps == 3 * 12 - probe and tr._graphed.fallback_steps == 0, (tr.graph_steps, tr._graphed.fallback_steps)
+    if reverted:
+        assert tr.graph_probe_result[True]["decision"].startswith("eager (replay measured") and tr._graphed is None
+        assert tr.graph_steps == tr.PROBE_STEPS + 1, tr.graph_steps
+    else:
+        assert tr.graph_probe_result[True]["decision"] == "graph" and tr._graphed.captured
+        assert tr.graph_steps == 3 * 12 - probe and tr._graphed.fallback_steps == 0, (tr.graph_steps, tr._graphed.fallback_steps)
     assert runs[False][2].graph_steps == 0
     worst = 0.0
     for m_e, m_g in zip(runs[False][0], runs["auto"][0]):
