@@ -402,3 +402,24 @@ def test_fused_heads_against_the_torch_modules(act, B):
     util.measured(f"{tag}: gradient of the pooled feature (relative)", _rel(x2.grad, gx_ref), bound=TIGHT)
     worst = max(_rel(params[n].grad, ref[n]) for n in names)
     util.measured(f"{tag}: worst parameter gradient vs torch autograd (relative)", worst, bound=TIGHT)
+
+
+def test_batched_weight_transform_is_the_single_layer_transform_bit_for_bit():
+    """`dl_wino_weights_batch_f32` (one launch per autograd segment; LDS-staged so that its stores are contiguous runs) against
+    `dl_wino_weights_f32` (one thread per (k, c), scattered 4-byte stores): the same arithmetic per element, so the Winograd-domain
+    weights must be EQUAL -- for every channel pair of the trunk, with and without the backward set, and for a layer whose input
+    channels do not divide into the batched kernel's 32-channel blocks (plain launches)."""
+    from delora_amd.models import ring_conv as rc
+    dev = _dev()
+    g = torch.Generator(device="cpu").manual_seed(5)
+    shapes = [(64, 64), (128, 64), (128, 128), (256, 128), (256, 256), (512, 256), (512, 512)]
+    ws = [(torch.randn((k, c, 3, 3), generator=g) * 0.1).to(dev).contiguous(memory_format=torch.channels_last) for k, c in shapes]
+    for want_bwd in (True, False):
+        got = rc.wino_weights_batch(ws, want_bwd=want_bwd)
+        for w, (uf, ub) in zip(ws, got):
+            rf, rb = rc.wino_weights(w, want_bwd=want_bwd)
+            assert torch.equal(uf, rf) and (not want_bwd or torch.equal(ub, rb)), tuple(w.shape)
+    odd = [(torch.randn((64, 24, 3, 3), generator=g) * 0.1).to(dev).contiguous(memory_format=torch.channels_last), ws[0]]
+    for w, (uf, ub) in zip(odd, rc.wino_weights_batch(odd)):
+        rf, rb = rc.wino_weights(w)
+        assert torch.equal(uf, rf) and torch.equal(ub, rb), tuple(w.shape)
