@@ -19,6 +19,20 @@ def pytest_configure(config):
         pass
 
 
+@pytest.fixture(autouse=True)
+def _module_switches_do_not_leak():
+    """The kernels' module-level switches are process state: `Trainer._wrap_ddp` cuts the trunk into three autograd Functions for the rest
+    of the process (ring_conv.TRUNK_SEGMENTS = "layer": same kernels, other slab boundaries in the merged weight-gradient launches), and a
+    later test would silently run another summation order than it does on its own -- a long training run then follows another
+    trajectory (round 5: the convergence test gave other figures inside the full suite than alone).  Restored after every test."""
+    from delora_amd.models import ring_conv
+    names = ("TRUNK_SEGMENTS", "USE_WINOGRAD", "USE_WINOGRAD_WGRAD", "WGRAD_BATCHED", "BACKWARD_TRACE", "ALLOC_SKEW", "WGRAD_PENDING_MAX_BYTES")
+    saved = {n: getattr(ring_conv, n) for n in names if hasattr(ring_conv, n)}
+    yield
+    for n, v in saved.items():
+        setattr(ring_conv, n, v)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")

@@ -164,6 +164,8 @@ def main(argv=None):
     ap.add_argument("--precisions", default="float32,bfloat16,float16")
     ap.add_argument("--seed", type=int, default=11)
     ap.add_argument("--hip-graph", default="auto", help="auto | true | false (config key hip_graph)")
+    ap.add_argument("--trunk-segments", default="", help="mono | layer | block: how the trunk is cut into autograd Functions (ring_conv.TRUNK_SEGMENTS; "
+                    "layer is what a DDP rank uses -- same kernels, other slab boundaries in the merged weight-gradient launches)")
     ap.add_argument("--anneal-fraction", type=float, default=1.0 / 3.0)
     ap.add_argument("--on-disk", action="store_true", help="store_dataset_in_RAM: false (the YAML's default) instead of the RAM-resident dataset")
     ap.add_argument("--workers", type=int, default=0)
@@ -171,6 +173,9 @@ def main(argv=None):
     args = ap.parse_args(argv)
     device = torch.device("cuda", 0)
     torch.cuda.set_device(0)
+    if args.trunk_segments:
+        from delora_amd.models import ring_conv
+        ring_conv.TRUNK_SEGMENTS = args.trunk_segments
     t0 = time.perf_counter()
     tree, truth = build_dataset(device, args.sequences, args.scans)
     out_dir = tempfile.mkdtemp(prefix="delora_conv_out_")
@@ -178,7 +183,8 @@ def main(argv=None):
               "image": "64x720", "batch": args.batch, "learning_rate": args.lr, "reference_learning_rate": 1e-5,
               "dataset": f"{args.sequences} training sequences + 1 held out, {args.scans} scans each (synthetic scenes, ~0.45 m and <=1.5 deg yaw per scan), "
                          f"preprocessed offline at 64x2250; generation {time.perf_counter() - t0:.0f} s",
-              "segment_lengths_m": [2.0, 5.0, 10.0, 15.0], "runs": {}}
+              "segment_lengths_m": [2.0, 5.0, 10.0, 15.0], "hip_graph": args.hip_graph, "trunk_segments": args.trunk_segments or "mono",
+              "epochs": args.epochs, "anneal_fraction": args.anneal_fraction, "runs": {}}
     try:
         for precision in args.precisions.split(","):
             report["runs"][precision] = train_and_test(device, tree, truth, precision, args.epochs, args.lr, args.batch, args.seed, out_dir,
