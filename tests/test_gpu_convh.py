@@ -214,6 +214,39 @@ def test_half_precision_network_against_the_fp32_network_at_full_size(dtype, siz
     assert all(torch.isfinite(a).all() for a in gh)
 
 
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16], ids=["bf16", "fp16"])
+def test_half_trunk_cuts_give_the_gradients_of_the_uncut_trunk(dtype, monkeypatch):
+    """The half-precision trunk as ONE autograd Function (single GPU) against the three-Function cut of a DDP rank (`trunk_segments:
+    layer`) and the per-block cut: same kernels on the same operands, so outputs must be equal and every parameter gradient must agree to
+    the order of the fp32 partial sums in the merged weight-gradient launches (the cuts merge other sets of layers).  Round 5: a long
+    bf16 / fp16 training run follows ANOTHER trajectory under the layer cut than uncut -- this test establishes
+    that the cut is not a different computation."""
+    from delora_amd.models import ring_conv
+    dev = _dev()
+    B, H, W = 2, 64, 720
+    m = _model_pair(dev, H, W)
+    g = torch.Generator(device="cpu").manual_seed(9)
+    x = (torch.randn((B, 8, H, W), generator=g) * 5.0).to(dev)
+
+    def run(mode):
+        monkeypatch.setattr(ring_conv, "TRUNK_SEGMENTS", mode)
+        m.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=dtype):
+            t, q = m(x)
+        loss = (t.float().square().sum() + (q.float() * torch.tensor([0.3, -0.2, 0.5, 1.0], device=dev)).sum())
+        loss.backward()
+        return t.detach().float(), q.detach().float(), [p.grad.detach().clone() for p in m.parameters()]
+
+    t0, q0, g0 = run("mono")
+    name = str(dtype)[6:]
+    for mode in ("layer", "block"):
+        t1, q1, g1 = run(mode)
+        assert torch.equal(t0, t1) and torch.equal(q0, q1), mode
+        worst = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) for a, b in zip(g1, g0))
+        util.measured(f"half trunk {name}, cut '{mode}' vs uncut: worst parameter-gradient difference (relative to the gradient's largest element)",
+                      worst, bound=2e-5)
+
+
 def test_half_trunk_takes_no_library_convolution():
     """Inside autocast the trunk must run on the library's own kernels: the forward saves half-precision activations and the
     backward returns fp32 weight gradients in channels_last storage (the layout of the parameters)."""
