@@ -63,7 +63,7 @@ def test_every_precision_trains_to_the_same_plateau_and_trajectory_error(tmp_pat
     # three-Function cut of a DDP rank, whose merged weight-gradient launches sum in another order).  The half precisions are less robust
     # at this learning rate: on the trajectory of THIS configuration (trunk as one Function, eager steps; deterministic on every box) all
     # three end in the same state to 5e-4 -- on the three-Function trajectory bf16 / fp16 were still wandering at epoch 360 (plateau x1.21 /
-    # x1.15, per-step rotation error x2.1 / x1.9; profiles/r05_convergence_layer_cut.json).  The assertions below therefore hold the
+    # x1.15, per-step rotation error x2.1 / x1.9; profiles/r05_convergence_trajectories.json).  The assertions below therefore hold the
     # half precisions to "trains, same ballpark"; the figures themselves go to the report and to DESIGN.md section 8.
     util.measured("fp32 training: mean unsupervised loss of the last 20 epochs / of the first 8", last / first, bound=0.85)
     util.measured("fp32 training: the plateau -- |last 20 epochs - the 20 before| / last", abs(last - before_last) / last, bound=0.05)
