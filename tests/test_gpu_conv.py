@@ -200,7 +200,12 @@ def test_hip_trunk_matches_module_path(act, wino, size, monkeypatch):
             worst, name = e, k
         if e > 2e-5:
             print(f"  gradient of {k}: relative difference {e:.3e}")
-    util.measured(f"{tagn}: worst relative parameter-gradient difference hip vs modules ({name})", worst, bound=(5e-5 if act == "tanh" else 1e-5))   # measured 4-7e-6 (tanh), 8e-7 (relu: no mask flips on this seeded input; one flipped mask would show as ~1e-4)
+    # measured 4-7e-6 (tanh) and 7-9e-7 (relu) -- as long as no relu mask flips.  The module path's library convolutions differ from run
+    # to run in their last bits (the poses of this very test vary between 6e-7 and 9e-7 across runs), and ONE pre-activation near zero
+    # that the two paths round to different sides is a flipped mask: the gradient of every weight upstream of it then differs by 2-3e-4
+    # (1.3e-3 for conv1), everything downstream stays at 1e-6 -- seen once in round 5 (a flip in layer3.0).  The relu bound covers
+    # isolated flips; a wrong kernel shows up in the tanh cases (no discontinuity) at 5e-5 and in the operator tests.
+    util.measured(f"{tagn}: worst relative parameter-gradient difference hip vs modules ({name})", worst, bound=(5e-5 if act == "tanh" else 5e-3))
     assert m_hip.resnet.layer1[0].conv1.weight.grad.stride() == m_hip.resnet.layer1[0].conv1.weight.stride()
 
 
