@@ -1,4 +1,7 @@
 #!/bin/bash
+# One gpurun call at the end of a round: the whole `-m gpu` suite (its parity table and the convergence report are copied next to the log),
+# the smoke test, then the profile bundle of tools/prof_round.sh.   gpurun --timeout 1200 -- 'bash tools/round_check.sh'
+# then:  python tools/collect_profiles.py r05; cp gpurun_out/final/parity_measured.json profiles/r05_parity_measured.json
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
 O=gpurun_out/final; mkdir -p $O
 timeout 1200 python -m pytest tests -m gpu -q --timeout 600 --durations=6 > $O/pytest.txt 2>&1; echo "pytest rc $?" >> $O/pytest.txt
