@@ -83,10 +83,10 @@ class Trainer(deployer.Deployer):
     def graph_policy(self):
         """config ``hip_graph``: ``true`` -> every eligible step is replayed as one captured HIP graph, ``false`` -> eager, ``"auto"``
         (the default, also when the key is absent -- the reference's YAML does not have it) -> MEASURE: the first eager steps of a
-        training phase are timed, and the step is captured when the host needs as long to enqueue it as the GPU needs to run it.
-        That is the reference's own default operating point -- ``batch_size: 1`` on 64x720 images (config/hyperparameters.yaml:3,
-        config_datasets.yaml:21): ~100 launches for ~1 ms of GPU work -- and not BASELINE's 64x2048, batch 8 (GPU-bound: capture
-        buys nothing there and stays off)."""
+        training phase are timed, and the step is captured when the host needs as long per step as the GPU does.  That is the
+        reference's own default operating point -- ``batch_size: 1`` on 64x720 images (config/hyperparameters.yaml:3,
+        config_datasets.yaml:21): ~120 launches, 2.3 ms to enqueue for 2.3 ms of GPU work, plus the loader -- and not BASELINE's
+        64x2048, batch 8 (2.4 ms of enqueue for a 13.8 ms step: capture buys nothing there and stays off)."""
         from .graph_step import GraphedStep
         if getattr(self.device, "type", "cpu") != "cuda" or not GraphedStep.config_eligible(self):
             return "off"
@@ -157,6 +157,8 @@ class Trainer(deployer.Deployer):
         self.graph_steps = getattr(self, "graph_steps", 0)
         if getattr(self, "_graphed", None) is not None:
             self._graphed.take_epoch_sums()             # (steps replayed outside an epoch, e.g. by a caller's own loop)
+            if self._graphed_phase != bool(self.config["unsupervised_at_start"]):
+                self._graphed = None                    # the training phase changed: the old capture (and its memory pool) goes now
         for counter, preprocessed_dicts in enumerate(iterator):
             phase = bool(self.config["unsupervised_at_start"])
             mode = "eager" if policy == "off" else ("graph" if policy == "on" else self._graph_decision.get(phase, "probe"))
@@ -214,9 +216,10 @@ class Trainer(deployer.Deployer):
 
     def _judge_replay(self, phase, starts):
         """`auto` only: the host's period over the first replayed steps against the eager period the probe measured.  hipGraphLaunch
-        of this ROCm release enqueues a captured step node by node, at about the cost of the eager enqueue -- measured on the
-        reference's default batch-1 step: 2.22 ms to replay 130 kernel nodes against 2.33 ms to enqueue them eagerly -- so a replay
-        that does not shorten the host's period by at least 3 % is dropped again (config ``hip_graph_keep_if_slower`` keeps it)."""
+        of this ROCm release enqueues a captured step node by node -- measured on the reference's default batch-1 step: 0.9-1.6 ms to
+        replay its ~120 kernel nodes against 2.2-2.6 ms to enqueue them eagerly, 2.2 against 2.3 ms on a loaded host -- so a replay
+        that does not shorten the host's period by at least 3 % (``hip_graph_min_gain``) is dropped again; ``hip_graph_keep_if_slower``
+        keeps it regardless."""
         del self._graph_trial[phase]
         res = self.graph_probe_result.get(phase, {})
         period = (starts[-1] - starts[0]) / (len(starts) - 1)
