@@ -61,3 +61,28 @@ def test_cpu_tensors_are_rejected_not_emulated():
     sensor = geometry.Sensor(16, 128, (-0.4, 0.03), (-3.1, 3.1))
     with pytest.raises(_lib.DeloraHipError):
         geometry.normals(torch.zeros(1, 4, 16, 128))
+
+
+def test_split_k_plan_of_the_winograd_launcher():
+    """`dl_wino_conv3x3_workspace_bytes` = the launch plan of `dl_wino_conv3x3_nhwc_f32` seen from outside (pure host arithmetic; without
+    a GPU the CU count falls back to 256, an MI355X's): launches that fill the chip take no scratch -- every stride-1 layer of BASELINE's
+    64x2048, batch 8 and of the shipped 64x720 at batch 8 --, the reference's default batch 1 at 64x720 splits the input channels of its
+    128- / 256- / 512-channel layers over idle CUs (ranges of at least 32 channels, all workgroups in one round of the CUs), and
+    64-channel layers are never split."""
+    from delora_amd import _lib
+    lib = _lib.load()
+    ws = lib.dl_wino_conv3x3_workspace_bytes
+
+    def splits(N, H, W, C, K):
+        b = ws(N, H, W, C, K)
+        assert b % (N * H * W * K * 4) == 0
+        return b // (N * H * W * K * 4)
+
+    for (H, W, C) in ((64, 512, 64), (64, 256, 128), (64, 128, 256), (32, 64, 512)):                 # 64x2048, batch 8
+        assert splits(8, H, W, C, C) == 0
+    for (H, W, C) in ((64, 180, 64), (64, 90, 128), (64, 45, 256), (32, 23, 512)):                   # 64x720, batch 8
+        assert splits(8, H, W, C, C) == 0
+    assert splits(1, 64, 180, 64, 64) == 0                                                           # 8 chunks: left alone
+    assert splits(1, 64, 90, 128, 128) == 4 and splits(1, 64, 45, 256, 256) == 4 and splits(1, 32, 23, 512, 512) == 8
+    assert splits(1, 16, 256, 128, 128) == 4 and splits(2, 8, 32, 512, 512) == 16                    # (layer2 / layer4 of the smoke test's 16x1024 pair)
+    assert ws(0, 64, 64, 64, 64) == 0 and ws(1, 64, 64, 60, 64) == 0                                # (bad shapes: no plan, the launch rejects them)
