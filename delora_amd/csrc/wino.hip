@@ -127,6 +127,39 @@ __global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ 
 // sinking every piece to its first use.  (Fetching the raw pieces straight into registers -- 8 scattered 16-byte loads
 // per thread and chunk, each 32-byte pixel slice requested by ~4 threads -- measured 15 % slower: the vector-memory
 // path, not the matrix pipe, became the limit.)
+// Ablation switches of the tuning builds (tools/wino_lab.hip; results are WRONG with any of them set, only the time is of interest):
+// WN_ABL bit 0: no U DMA in the chunk loop, 1: no raw DMA, 2: no input transform, 3: no chunk barrier, 4: no fragment reads
+#ifndef WN_ABL
+#define WN_ABL 0
+#endif
+#ifndef WN_EXP
+#define WN_EXP 0
+#endif
+#if WN_ABL & 1
+#define WN_IF_U(...)
+#else
+#define WN_IF_U(...) __VA_ARGS__
+#endif
+#if WN_ABL & 2
+#define WN_IF_RAW(...)
+#else
+#define WN_IF_RAW(...) __VA_ARGS__
+#endif
+#if WN_ABL & 4
+#define WN_IF_T(...)
+#else
+#define WN_IF_T(...) __VA_ARGS__
+#endif
+#if WN_ABL & 8
+#define WN_IF_BAR(...)
+#else
+#define WN_IF_BAR(...) __VA_ARGS__
+#endif
+#if WN_ABL & 16
+#define WN_IF_FR(...)
+#else
+#define WN_IF_FR(...) __VA_ARGS__
+#endif
 #ifdef CV_TUNE
 __device__ unsigned long long g_wn_t[8 * 8192];       // phase time stamps per group (tools/conv_harness wino-phases)
 #define WN_T(I) { if (tid == 0 && grp < 8192) g_wn_t[grp * 8 + (I)] = clock64(); }
@@ -236,15 +269,41 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   // LDS wait into s_waitcnt lgkmcnt(0); hidden from it, the fragment / transform reads are waited for individually.  Every barrier that
   // hands DMA-written data over is preceded by an explicit s_waitcnt vmcnt(0) -- __syncthreads() alone does NOT wait for these loads.
   const unsigned lds_base = (unsigned)(__SIZE_TYPE__)((__attribute__((address_space(3))) char*)lds);
+#if WN_ABL & 256
+  float wn_dummy = 0.f;
+#endif
 #define WN_LDSADDR(LPTR) (lds_base + 4u * (unsigned)((LPTR) - lds))
+#if WN_ABL & 256          /* a plain 4-byte load into a dummy register instead of the DMA: the vector-memory issue without the LDS write */
+#define WN_GLDS(BASE, OFFB, LPTR)                                                                                         \
+  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_dword %0, %1, %2"                                           \
+               : "=v"(wn_dummy) : "v"(OFFB), "s"(BASE), "s"(__builtin_amdgcn_readfirstlane((int)WN_LDSADDR(LPTR))) : "memory");
+#elif WN_ABL & 512        /* the DMA without the M0 write (every piece lands wherever M0 points) */
+#define WN_GLDS(BASE, OFFB, LPTR)                                                                                         \
+  asm volatile("global_load_lds_dwordx4 %0, %1"                                           \
+               :: "v"(OFFB), "s"(BASE), "s"(__builtin_amdgcn_readfirstlane((int)WN_LDSADDR(LPTR))) : "memory");
+#elif WN_ABL & 1024       /* 4 bytes per lane instead of 16 */
+#define WN_GLDS(BASE, OFFB, LPTR)                                                                                         \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"                                           \
+               :: "v"(OFFB), "s"(BASE), "s"(__builtin_amdgcn_readfirstlane((int)WN_LDSADDR(LPTR))) : "memory");
+#elif WN_ABL & 128          /* the scalar part of a DMA piece only */
+#define WN_GLDS(BASE, OFFB, LPTR)                                                                                         \
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0"                                           \
+               :: "v"(OFFB), "s"(BASE), "s"(__builtin_amdgcn_readfirstlane((int)WN_LDSADDR(LPTR))) : "memory");
+#else
 #define WN_GLDS(BASE, OFFB, LPTR)                                                                                         \
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                           \
                :: "v"(OFFB), "s"(BASE), "s"(__builtin_amdgcn_readfirstlane((int)WN_LDSADDR(LPTR))) : "memory");
+#endif
+#if WN_ABL & 64           /* every piece re-reads chunk 0 (cache-resident): the issue cost of the DMA without its memory traffic */
+#define WN_CHSEL(CH) 0
+#else
+#define WN_CHSEL(CH) (CH)
+#endif
 #define WN_U_PIECE_X(UG, IT, CH, BUFP) \
-  WN_GLDS(a.u + ((size_t)((CH) + cb) * 16 * a.K * 8 + k0 * 8), (UG)[IT], (BUFP) + __builtin_amdgcn_readfirstlane(u_l[IT]))
+  WN_GLDS(a.u + ((size_t)(WN_CHSEL(CH) + cb) * 16 * a.K * 8 + k0 * 8), (UG)[IT], (BUFP) + __builtin_amdgcn_readfirstlane(u_l[IT]))
 #define WN_U_PIECE(IT, CH, BUFP) WN_U_PIECE_X(u_g, IT, CH, BUFP)
 #define WN_RAW_PIECE(IT, CH) \
-  WN_GLDS(xn + ((CH) + cb) * WN_CK, raw_g[IT], rawbase + ((CH) & 1) * RAWBUF + __builtin_amdgcn_readfirstlane(raw_l[IT]))
+  WN_GLDS(xn + (WN_CHSEL(CH) + cb) * WN_CK, raw_g[IT], rawbase + ((CH) & 1) * RAWBUF + __builtin_amdgcn_readfirstlane(raw_l[IT]))
 #define WN_RAW_ALL(CH) { _Pragma("unroll") for (int it = 0; it < NR_IT; ++it) WN_RAW_PIECE(it, CH) }
 #define WN_U_ALL(CH, BUFP) { _Pragma("unroll") for (int it = 0; it < NU_IT; ++it) WN_U_PIECE(it, CH, BUFP) }
   // row I of T = d B for this thread's column: two 16-byte reads of the raw patch (issued ahead of their use: a read and its use in
@@ -326,25 +385,51 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
       float* nxt = WN_BUFOF(ch + 1);
       const float* rb = rawbase + ((ch + 1) & 1) * RAWBUF;
       float* vb = nxt + t_wr;
-      WN_M(0, 0, WN_LOAD_FRAGS(1)) WN_M(0, 1, WN_U_PIECE(0, ch + 1, nxt) WN_U_PIECE(1, ch + 1, nxt))
-      WN_M(0, 2, WN_U_PIECE(2, ch + 1, nxt) WN_U_PIECE(3, ch + 1, nxt))
+#if WN_EXP == 2 || WN_EXP == 3   /* DMA pieces spread over the first half of the chunk (EXP 3: the xh = 1 waves one slice later) */
+#if WN_EXP == 3
+#define WN_DP(A, B) if (xh == 0) { A } else { B }
+#else
+#define WN_DP(A, B) A
+#endif
+#define WN_RAWP(IT) if (ch + 2 < nchunks) { if ((IT) < NR_IT) WN_RAW_PIECE(IT, ch + 2) }
+      WN_M(0, 0, WN_IF_FR(WN_LOAD_FRAGS(1))) WN_M(0, 1, WN_DP(WN_U_PIECE(0, ch + 1, nxt), )) WN_M(0, 2, WN_DP(, WN_U_PIECE(0, ch + 1, nxt))) WN_M(0, 3, )
+      WN_M(1, 0, WN_IF_FR(WN_LOAD_FRAGS(2)) WN_DP(WN_U_PIECE(1, ch + 1, nxt), )) WN_M(1, 1, WN_IF_T(WN_TROW_LD(0, rb) WN_TROW_LD(1, rb))) WN_M(1, 2, WN_DP(, WN_U_PIECE(1, ch + 1, nxt))) WN_M(1, 3, WN_IF_T(WN_TROW_FIN(0) WN_TROW_FIN(1)))
+      WN_M(2, 0, WN_IF_FR(WN_LOAD_FRAGS(3)) WN_DP(WN_U_PIECE(2, ch + 1, nxt), )) WN_M(2, 1, WN_IF_T(WN_TROW_LD(2, rb) WN_TROW_LD(3, rb))) WN_M(2, 2, WN_DP(, WN_U_PIECE(2, ch + 1, nxt))) WN_M(2, 3, WN_IF_T(WN_TROW_FIN(2) WN_TROW_FIN(3)))
+      WN_M(3, 0, WN_IF_FR(WN_LOAD_FRAGS(4)) WN_IF_T(*reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = tt[0] - tt[2];))
+      WN_M(3, 1, WN_IF_T(*reinterpret_cast<f32x4*>(vb + 1 * 4 * WN_PLANE) = tt[1] + tt[2];)) WN_M(3, 2, WN_DP(WN_U_PIECE(3, ch + 1, nxt), )) WN_M(3, 3, WN_DP(, WN_U_PIECE(3, ch + 1, nxt)))
+      WN_M(4, 0, WN_IF_FR(WN_LOAD_FRAGS(5)) WN_IF_T(*reinterpret_cast<f32x4*>(vb + 2 * 4 * WN_PLANE) = tt[2] - tt[1];))
+      WN_M(4, 1, WN_IF_T(*reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = tt[1] - tt[3];)) WN_M(4, 2, WN_DP(WN_RAWP(0), )) WN_M(4, 3, WN_DP(, WN_RAWP(0)))
+      WN_M(5, 0, WN_IF_FR(WN_LOAD_FRAGS(6))) WN_M(5, 1, WN_DP(WN_RAWP(1), )) WN_M(5, 2, WN_DP(, WN_RAWP(1))) WN_M(5, 3, )
+      WN_M(6, 0, WN_IF_FR(WN_LOAD_FRAGS(7))) WN_M(6, 1, ) WN_M(6, 2, ) WN_M(6, 3, )
+#elif WN_EXP == 1          /* all DMA pieces in front of the first fragment reads of the chunk: the wave's LDS queue is empty there */
+      WN_M(0, 0, WN_IF_U(WN_U_ALL(ch + 1, nxt)) WN_IF_RAW(if (ch + 2 < nchunks) WN_RAW_ALL(ch + 2)) WN_IF_FR(WN_LOAD_FRAGS(1))) WN_M(0, 1, ) WN_M(0, 2, ) WN_M(0, 3, )
+#else
+      WN_M(0, 0, WN_IF_FR(WN_LOAD_FRAGS(1))) WN_M(0, 1, WN_IF_U(WN_U_PIECE(0, ch + 1, nxt) WN_U_PIECE(1, ch + 1, nxt)))
+      WN_M(0, 2, WN_IF_U(WN_U_PIECE(2, ch + 1, nxt) WN_U_PIECE(3, ch + 1, nxt)))
       // raw(ch+2) overwrites raw(ch), which every wave finished reading before the last barrier
-      WN_M(0, 3, if (ch + 2 < nchunks) WN_RAW_ALL(ch + 2))
+      WN_M(0, 3, WN_IF_RAW(if (ch + 2 < nchunks) WN_RAW_ALL(ch + 2)))
+#endif
+#if !(WN_EXP == 2 || WN_EXP == 3)
       // LDS traffic only in the first two slices of a plane, arithmetic in the last two: whatever a plane's first MFMA waits for is then
       // two slices old.  (Laid out when the DMA was a builtin and every LDS wait a full drain, lgkmcnt(0); with the DMA in inline
       // assembly the waits are counted and the layout costs nothing -- measured equal, kept.)
-      WN_M(1, 0, WN_LOAD_FRAGS(2)) WN_M(1, 1, WN_TROW_LD(0, rb) WN_TROW_LD(1, rb)) WN_M(1, 2, ) WN_M(1, 3, WN_TROW_FIN(0) WN_TROW_FIN(1))
-      WN_M(2, 0, WN_LOAD_FRAGS(3)) WN_M(2, 1, WN_TROW_LD(2, rb) WN_TROW_LD(3, rb)) WN_M(2, 2, ) WN_M(2, 3, WN_TROW_FIN(2) WN_TROW_FIN(3))
-      WN_M(3, 0, WN_LOAD_FRAGS(4) *reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = tt[0] - tt[2];)
-      WN_M(3, 1, *reinterpret_cast<f32x4*>(vb + 1 * 4 * WN_PLANE) = tt[1] + tt[2];) WN_M(3, 2, ) WN_M(3, 3, )
-      WN_M(4, 0, WN_LOAD_FRAGS(5) *reinterpret_cast<f32x4*>(vb + 2 * 4 * WN_PLANE) = tt[2] - tt[1];)
-      WN_M(4, 1, *reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = tt[1] - tt[3];) WN_M(4, 2, ) WN_M(4, 3, )
-      WN_M(5, 0, WN_LOAD_FRAGS(6)) WN_M(5, 1, ) WN_M(5, 2, ) WN_M(5, 3, )
-      WN_M(6, 0, WN_LOAD_FRAGS(7)) WN_M(6, 1, ) WN_M(6, 2, ) WN_M(6, 3, )
+      WN_M(1, 0, WN_IF_FR(WN_LOAD_FRAGS(2))) WN_M(1, 1, WN_IF_T(WN_TROW_LD(0, rb) WN_TROW_LD(1, rb))) WN_M(1, 2, ) WN_M(1, 3, WN_IF_T(WN_TROW_FIN(0) WN_TROW_FIN(1)))
+      WN_M(2, 0, WN_IF_FR(WN_LOAD_FRAGS(3))) WN_M(2, 1, WN_IF_T(WN_TROW_LD(2, rb) WN_TROW_LD(3, rb))) WN_M(2, 2, ) WN_M(2, 3, WN_IF_T(WN_TROW_FIN(2) WN_TROW_FIN(3)))
+      WN_M(3, 0, WN_IF_FR(WN_LOAD_FRAGS(4)) WN_IF_T(*reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = tt[0] - tt[2];))
+      WN_M(3, 1, WN_IF_T(*reinterpret_cast<f32x4*>(vb + 1 * 4 * WN_PLANE) = tt[1] + tt[2];)) WN_M(3, 2, ) WN_M(3, 3, )
+      WN_M(4, 0, WN_IF_FR(WN_LOAD_FRAGS(5)) WN_IF_T(*reinterpret_cast<f32x4*>(vb + 2 * 4 * WN_PLANE) = tt[2] - tt[1];))
+      WN_M(4, 1, WN_IF_T(*reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = tt[1] - tt[3];)) WN_M(4, 2, ) WN_M(4, 3, )
+      WN_M(5, 0, WN_IF_FR(WN_LOAD_FRAGS(6))) WN_M(5, 1, ) WN_M(5, 2, ) WN_M(5, 3, )
+      WN_M(6, 0, WN_IF_FR(WN_LOAD_FRAGS(7))) WN_M(6, 1, ) WN_M(6, 2, ) WN_M(6, 3, )
+#endif
+#if WN_ABL & 32
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+#endif
+      WN_IF_BAR(__builtin_amdgcn_s_barrier();)
       __builtin_amdgcn_sched_barrier(0);
-      WN_M(7, 0, WN_LOAD_FRAGS_FROM(0, nxt)) WN_M(7, 1, ) WN_M(7, 2, ) WN_M(7, 3, )
+      WN_M(7, 0, WN_IF_FR(WN_LOAD_FRAGS_FROM(0, nxt))) WN_M(7, 1, ) WN_M(7, 2, ) WN_M(7, 3, )
     }
     {
       float* cur = WN_BUFOF(nchunks - 1);
@@ -610,6 +695,30 @@ extern "C" int dl_wino_weights_f32(const float* w, float* u_fwd, float* u_bwd, i
 // {j, 4 + j}.  Addressing validated by tools/exp/wino_wgrad_emulate.py; tools/exp/wino_wgrad.hip is the stand-alone check.
 // Measured (B=8, slab sum and G^T . G kernels included): layer2 259 us (direct kernel 335), layer3 463 (607), layer4 464 (608); 64-channel layers stay direct.
 #define WW_THREADS 512
+// ablation switches of the tuning builds (see WN_ABL): bit 0 no DMA in the chunk loop, 1 no transforms, 2 no barriers, 3 no fragment reads
+#ifndef WW_ABL
+#define WW_ABL 0
+#endif
+#if WW_ABL & 1
+#define WW_IF_DMA(...)
+#else
+#define WW_IF_DMA(...) __VA_ARGS__
+#endif
+#if WW_ABL & 2
+#define WW_IF_T(...)
+#else
+#define WW_IF_T(...) __VA_ARGS__
+#endif
+#if WW_ABL & 4
+#define WW_IF_BAR(...)
+#else
+#define WW_IF_BAR(...) __VA_ARGS__
+#endif
+#if WW_ABL & 8
+#define WW_IF_FR(...)
+#else
+#define WW_IF_FR(...) __VA_ARGS__
+#endif
 #define WW_PLANE 528                     // floats per plane: 64 rows x 8 tiles + 16 of padding
 #define WW_BUF (2 * 16 * WW_PLANE)       // one (Gh, Dh) pair
 #define WW_RAWPIX 72                     // raw input patch of a chunk: 4 rows x 18 columns (8 tiles), 64 channels each
@@ -820,20 +929,24 @@ __device__ __forceinline__ void wino_wgrad_body(const WWArgs& a, const int blk) 
     WW2_MASKS(c1)
     // LDS reads in the first two slices of a plane, arithmetic two slices later: the compiler guards the first use of an LDS result
     // with a wait for ALL outstanding LDS operations, and with this layout everything it waits for is at least two slices old
-    WW2_M(0, 0, WW2_FR(1) WW2_TDL(0) WW2_TDL(1)) WW2_M(0, 1, WW2_TGL(0) WW2_TGL(1)) WW2_M(0, 2, ) WW2_M(0, 3, WW2_TD(0) WW2_TG(0))
-    WW2_M(1, 0, WW2_FR(2) WW2_TDL(2) WW2_TDL(3)) WW2_M(1, 1, WW2_TGL(2) WW2_TGL(3)) WW2_M(1, 2, WW2_TD(1) WW2_TG(1)) WW2_M(1, 3, WW2_TD(2) WW2_TG(2))
-    WW2_M(2, 0, WW2_FR(3)) WW2_M(2, 1, ) WW2_M(2, 2, WW2_TD(3) WW2_TG(3)) WW2_M(2, 3, )
+    WW2_M(0, 0, WW_IF_FR(WW2_FR(1)) WW_IF_T(WW2_TDL(0) WW2_TDL(1))) WW2_M(0, 1, WW_IF_T(WW2_TGL(0) WW2_TGL(1))) WW2_M(0, 2, ) WW2_M(0, 3, WW_IF_T(WW2_TD(0) WW2_TG(0)))
+    WW2_M(1, 0, WW_IF_FR(WW2_FR(2)) WW_IF_T(WW2_TDL(2) WW2_TDL(3))) WW2_M(1, 1, WW_IF_T(WW2_TGL(2) WW2_TGL(3))) WW2_M(1, 2, WW_IF_T(WW2_TD(1) WW2_TG(1))) WW2_M(1, 3, WW_IF_T(WW2_TD(2) WW2_TG(2)))
+    WW2_M(2, 0, WW_IF_FR(WW2_FR(3))) WW2_M(2, 1, ) WW2_M(2, 2, WW_IF_T(WW2_TD(3) WW2_TG(3))) WW2_M(2, 3, )
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                                    // M: the raw patches have been read by everybody
+    WW_IF_BAR(__builtin_amdgcn_s_barrier();)                                         // M: the raw patches have been read by everybody
     __builtin_amdgcn_sched_barrier(0);
-    WW2_M(3, 0, WW2_FR(4) WW2_DMA(c2)) WW2_M(3, 1, WW2_WRITE(nxt + 16 * WW_PLANE + w_off, vv)) WW2_M(3, 2, WW2_WRITE(nxt + w_off, vg)) WW2_M(3, 3, )
-    WW2_M(4, 0, WW2_FR(5)) WW2_M(4, 1, ) WW2_M(4, 2, ) WW2_M(4, 3, )
-    WW2_M(5, 0, WW2_FR(6)) WW2_M(5, 1, ) WW2_M(5, 2, ) WW2_M(5, 3, )
-    WW2_M(6, 0, WW2_FR(7)) WW2_M(6, 1, ) WW2_M(6, 2, ) WW2_M(6, 3, )
+    WW2_M(3, 0, WW_IF_FR(WW2_FR(4)) WW_IF_DMA(WW2_DMA(c2))) WW2_M(3, 1, WW_IF_T(WW2_WRITE(nxt + 16 * WW_PLANE + w_off, vv))) WW2_M(3, 2, WW_IF_T(WW2_WRITE(nxt + w_off, vg))) WW2_M(3, 3, )
+    WW2_M(4, 0, WW_IF_FR(WW2_FR(5))) WW2_M(4, 1, ) WW2_M(4, 2, ) WW2_M(4, 3, )
+    WW2_M(5, 0, WW_IF_FR(WW2_FR(6))) WW2_M(5, 1, ) WW2_M(5, 2, ) WW2_M(5, 3, )
+    WW2_M(6, 0, WW_IF_FR(WW2_FR(7))) WW2_M(6, 1, ) WW2_M(6, 2, ) WW2_M(6, 3, )
+#if WW_ABL & 16
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                                    // E: operands of chunk ch+1 visible, raw patch landed
+#endif
+    WW_IF_BAR(__builtin_amdgcn_s_barrier();)                                         // E: operands of chunk ch+1 visible, raw patch landed
     __builtin_amdgcn_sched_barrier(0);
-    WW2_M(7, 0, WW2_FR_FROM(0, nxt)) WW2_M(7, 1, ) WW2_M(7, 2, ) WW2_M(7, 3, )
+    WW2_M(7, 0, WW_IF_FR(WW2_FR_FROM(0, nxt))) WW2_M(7, 1, ) WW2_M(7, 2, ) WW2_M(7, 3, )
   }
 #undef WW2_DMA
 #undef WW2_GLDS
