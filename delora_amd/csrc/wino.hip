@@ -973,8 +973,305 @@ __device__ __forceinline__ void wino_wgrad_body(const WWArgs& a, const int blk) 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 6: the chunk loop for images that divide into chunks (RAG = false: every BASELINE shape).  What changed and why
+// (tools/exp/mfma_overlap.hip, profiles/r06_mfma_shadow.txt): v_mfma_f32_32x32x2_f32 runs at the fp32 VECTOR rate because it shares the
+// SIMD's vector issue -- a VALU instruction next to it is not hidden in its shadow, it costs the SIMD 3.3 cycles of matrix time with two
+// waves per SIMD (packed fp32: 5.3, v_readfirstlane: 6, an LDS read: 1.1-1.4, a scalar instruction: ~0.5).  The round-3 body spent 171
+// VALU instructions per wave and chunk on the two transforms (22 % of the kernel by ablation): every thread formed ONE column of
+// B^T d B / A g A^T for four tiles from scalar LDS reads, with multiplications by +-1 / 0 to stay branch-free.  Here:
+//   * thread = (channel, tile pair) and forms ALL sixteen Winograd-domain values of its two tiles: waves 0-3 the input patches (24 LDS
+//     reads, 32 packed adds), waves 4-7 the output-gradient tiles (8 reads, 20 packed operations) -- a SIMD hosts one wave of each kind.
+//     Both row stages run on (row, row + 1) register pairs; the half selectors and sign modifiers of the packed instructions do what
+//     the multiplications did (inline assembly; tools/exp/pk_probe.hip checks the modifier semantics on the hardware);
+//   * operand layout [plane pair (a >> 1, b)][row][tile][a & 1]: a thread's results are 16-byte rows (two tiles x two planes), and one
+//     16-byte fragment read still feeds four MFMAs -- two for each plane of the pair, both owned by the reading wave;
+//   * rows above / below the image are zeroed under a chunk-uniform branch instead of masking every value of every chunk;
+//   * the chunk's position in the image advances incrementally in scalar registers (no division); every DMA piece is 4 pixels x 64
+//     channels of ONE image row with a chunk-invariant per-lane offset and a scalar base, and the pieces of a wave share one M0 write:
+//     the instruction's immediate offset moves the LDS address and the global address together (pk_probe.hip), the base compensates.
+#define W3_PLANE 1024                    // floats of one plane pair: 64 rows x (8 tiles x 2 planes)
+#define W3_OPER (8 * W3_PLANE)           // one operand: 8 plane pairs
+#define W3_BUF (2 * W3_OPER)             // (Gh, Dh)
+#define W3_RAWROW (20 * 64)              // floats of one input-patch row: 5 DMA pieces of 4 pixels x 64 channels (18 pixels used)
+#define W3_RAW (4 * W3_RAWROW)
+#define W3_GRAW (2 * 16 * 64)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// (x.lo - y.lo, x.hi + y.lo) and (y.lo - x.hi, x.hi - y.hi): the second row stage of B^T . on the row pairs x = (T0, T1), y = (T2, T3)
+__device__ __forceinline__ f32x2 w3_v01(f32x2 x, f32x2 y) {
+  f32x2 r;
+  asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0] neg_lo:[0,1] neg_hi:[0,0]" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+__device__ __forceinline__ f32x2 w3_v23(f32x2 x, f32x2 y) {
+  f32x2 r;
+  asm volatile("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(y));
+  return r;
+}
+// A . on the row pair h = (h0, h1): (h0, h0 + h1) and (h0 - h1, -h1); NEG: the same for -h.  c01 = (0, 1), c10 = (1, 0): a product
+// with 1 is exact and the sum is rounded once, so the results are those of the plain additions.
+template <bool NEG> __device__ __forceinline__ f32x2 w3_g01(f32x2 h, f32x2 c01) {
+  f32x2 r;
+  if (NEG) asm volatile("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[1,1,0] neg_lo:[1,0,1] neg_hi:[1,0,1]" : "=v"(r) : "v"(h), "v"(c01));
+  else asm volatile("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(h), "v"(c01));
+  return r;
+}
+template <bool NEG> __device__ __forceinline__ f32x2 w3_g23(f32x2 h, f32x2 c10) {
+  f32x2 r;
+  if (NEG) asm volatile("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,0,1] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(c10));
+  else asm volatile("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,0,1] op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(h), "v"(c10));
+  return r;
+}
+
+struct W3Pos { int n, ta, b8; };
+
+__device__ __forceinline__ void wino_wgrad_body3(const WWArgs& a, const int blk) {
+  static_assert((2 * W3_BUF + W3_RAW + W3_GRAW) * 4 <= 163840, "LDS budget");
+  __shared__ __attribute__((aligned(16))) float lds[2 * W3_BUF + W3_RAW + W3_GRAW];
+  float* raw = lds + 2 * W3_BUF;
+  float* graw = raw + W3_RAW;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, half = lane >> 5;
+  const int mb = wave & 1, nb = (wave >> 1) & 1, xh = wave >> 2;
+  const int CT = a.C / 64;
+  int t = blk;
+  const int slab = t % a.nslabs; t /= a.nslabs;
+  const int ct = t % CT;
+  const int kt = t / CT;
+  const int k0 = kt * 64, c0 = ct * 64;
+  const int th = a.H / 2, tw8 = (a.W / 2) / 8;
+  const int total_chunks = a.N * th * tw8;
+  const int ch_begin = slab * a.chunks_per_slab;
+  const int ch_end = min(ch_begin + a.chunks_per_slab, total_chunks);
+  if (ch_begin >= ch_end) return;                                                   // (never: every slab holds a chunk)
+
+  // ---- transform role: waves 0-3 form Dh = B^T d B (rows = input channels), waves 4-7 Gh = A g A^T (rows = output channels); lane = row
+  // of the block, tp = tile pair (tiles 2 tp, 2 tp + 1 of the chunk's eight)
+  const int tp = wave & 3;
+  const int w_off = lane * 16 + ((tp ^ ((lane >> 2) & 3)) * 4);        // 16-byte slot of (row, tile pair), XOR-swizzled against bank conflicts
+  const float* rsrc = (xh == 0 ? raw : graw) + (4 * tp) * 64 + lane;
+  // ---- DMA role: wave w brings pieces of patch row w >> 1 (even waves: pixels 0-11, odd waves: 12-19) and pixels 4 (w & 3) .. of row w >> 2
+  // of the output-gradient patch.  Per-lane byte offsets (pixel lane >> 4 of the piece, 16-byte channel quad lane & 15):
+  const unsigned voff_x = (unsigned)((lane >> 4) * a.C * 4 + (lane & 15) * 16);
+  const unsigned voff_g = (unsigned)((lane >> 4) * a.K * 4 + (lane & 15) * 16);
+  // first piece of the first chunk of an image row: pixel 0 is column W - 1 (wrap-around), pixels 1-3 columns 0-2, relative to the row's start;
+  // last piece of the last chunk: pixel 0 is column W - 1, pixel 1 column 0 (pixels 2, 3 are not used: column 0 again)
+  const unsigned voff_l = (unsigned)(((lane >> 4) == 0 ? a.W - 1 : (lane >> 4) - 1) * a.C * 4 + (lane & 15) * 16);
+  const unsigned voff_r = (unsigned)(((lane >> 4) == 0 ? a.W - 1 : 0) * a.C * 4 + (lane & 15) * 16);
+  const int d_row = wave >> 1, d_odd = wave & 1;
+  const unsigned lds_base = (unsigned)(__SIZE_TYPE__)((__attribute__((address_space(3))) char*)lds);
+  const int m0_raw = __builtin_amdgcn_readfirstlane((int)(lds_base + 4u * (unsigned)((int)(raw - lds) + d_row * W3_RAWROW + d_odd * 3 * 256)));
+  const int m0_g = __builtin_amdgcn_readfirstlane((int)(lds_base + 4u * (unsigned)((int)(graw - lds) + wave * 256)));
+  // (LDS DMA from inline assembly, as in k_wino_conv; one M0 write per group of pieces, the pieces 1 KiB apart in LDS by the immediate
+  // offset -- which moves the global address as well: piece s takes its base minus s KiB)
+  auto dma = [&](const W3Pos& p) {
+    int row = 2 * p.ta - 1 + d_row;
+    row = row < 0 ? 0 : (row >= a.H ? a.H - 1 : row);                                       // (rows outside the image: zeroed by the transform)
+    const float* xrow = a.x + ((size_t)(p.n * a.H + row) * a.W) * a.C + c0;                  // column 0 of the image row
+    const float* xcol = xrow + (ptrdiff_t)(16 * p.b8 - 1 + 12 * d_odd) * a.C;                // first pixel of this wave's first piece
+    const float* x1 = xcol + 4 * a.C - 256;
+    if (!d_odd) {
+      const float* x2 = xcol + 8 * a.C - 512;
+      if (p.b8 == 0)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %3, %4 offset:1024\n\tglobal_load_lds_dwordx4 %3, %5 offset:2048"
+                     :: "s"(m0_raw), "v"(voff_l), "s"(xrow), "v"(voff_x), "s"(x1), "s"(x2) : "memory");
+      else
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024\n\tglobal_load_lds_dwordx4 %1, %4 offset:2048"
+                     :: "s"(m0_raw), "v"(voff_x), "s"(xcol), "s"(x1), "s"(x2) : "memory");
+    } else {
+      if (p.b8 == tw8 - 1)
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %3, %4 offset:1024"
+                     :: "s"(m0_raw), "v"(voff_x), "s"(xcol), "v"(voff_r), "s"(xrow - 256) : "memory");
+      else
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %3 offset:1024"
+                     :: "s"(m0_raw), "v"(voff_x), "s"(xcol), "s"(x1) : "memory");
+    }
+    const float* gp = a.g + ((size_t)(p.n * a.H + 2 * p.ta + (wave >> 2)) * a.W + 16 * p.b8 + 4 * (wave & 3)) * a.K + k0;
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0_g), "v"(voff_g), "s"(gp) : "memory");
+  };
+  auto advance = [&](W3Pos& p) {                                                      // the next chunk in (n, tile row, block of 8 tiles) order
+    if (++p.b8 == tw8) { p.b8 = 0; if (++p.ta == th) { p.ta = 0; ++p.n; } }
+  };
+
+  f32x16 acc[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+  // fragment reads: lane (li, half) of a plane pair reads the 16-byte slots `half` and `2 + half` of its row (tiles {2 half, 2 half + 1} and
+  // {4 + 2 half, ..} x both planes): element e of a read is plane e & 1, tile (e >> 1) of the slot's two
+  const int arow = mb * 32 + li, brow = nb * 32 + li;
+  const int a_off0 = xh * 4 * W3_PLANE + arow * 16 + ((half ^ ((arow >> 2) & 3)) * 4);
+  const int a_off1 = xh * 4 * W3_PLANE + arow * 16 + (((2 + half) ^ ((arow >> 2) & 3)) * 4);
+  const int b_off0 = W3_OPER + xh * 4 * W3_PLANE + brow * 16 + ((half ^ ((brow >> 2) & 3)) * 4);
+  const int b_off1 = W3_OPER + xh * 4 * W3_PLANE + brow * 16 + (((2 + half) ^ ((brow >> 2) & 3)) * 4);
+
+  // ---- the two transforms, in pieces (placed behind individual MFMAs below)
+  f32x2 P[2][6];                       // Dh: input patch, rows (2 rp, 2 rp + 1) x columns 4 tp .. 4 tp + 5;  Gh: P[0][0..3] = (g[0][px], g[1][px])
+  f32x2 T[2][4], V01[2][4], V23[2][4];
+  const f32x2 c01 = {0.f, 1.f}, c10 = {1.f, 0.f};
+#define W3_DLD(RP, J0, J1)  { _Pragma("unroll") for (int j = (J0); j < (J1); ++j) { P[RP][j][0] = rsrc[((2 * (RP)) * 20 + j) * 64]; P[RP][j][1] = rsrc[((2 * (RP) + 1) * 20 + j) * 64]; } }
+#define W3_DMASK()          { if (top) { _Pragma("unroll") for (int j = 0; j < 6; ++j) P[0][j][0] = 0.f; }                        \
+                              if (bot) { _Pragma("unroll") for (int j = 0; j < 6; ++j) P[1][j][1] = 0.f; } }
+#define W3_DT(E, RP, B)     { constexpr int o_ = 2 * (E);                                                                           \
+                              T[RP][B] = (B) == 0 ? P[RP][o_] - P[RP][o_ + 2] : (B) == 1 ? P[RP][o_ + 1] + P[RP][o_ + 2]               \
+                                       : (B) == 2 ? P[RP][o_ + 2] - P[RP][o_ + 1] : P[RP][o_ + 1] - P[RP][o_ + 3]; }
+#define W3_DV(E, B)         { V01[E][B] = w3_v01(T[0][B], T[1][B]); V23[E][B] = w3_v23(T[0][B], T[1][B]); }
+#define W3_WR(OPER, B)      { f32x4 lo_ = {V01[0][B][0], V01[0][B][1], V01[1][B][0], V01[1][B][1]};                                  \
+                              f32x4 hi_ = {V23[0][B][0], V23[0][B][1], V23[1][B][0], V23[1][B][1]};                                  \
+                              *reinterpret_cast<f32x4*>(nxt + (OPER) + (B) * W3_PLANE + w_off) = lo_;                                \
+                              *reinterpret_cast<f32x4*>(nxt + (OPER) + (4 + (B)) * W3_PLANE + w_off) = hi_; }
+#define W3_GLD()            { _Pragma("unroll") for (int j = 0; j < 4; ++j) { P[0][j][0] = rsrc[j * 64]; P[0][j][1] = rsrc[(16 + j) * 64]; } }
+  // tile E of the pair: columns 2 E, 2 E + 1 of the thread's four.  h_b: b = 0: g0, 1: g0 + g1, 2: g0 - g1, 3: -g1 (as modifiers)
+#define W3_GH(E)            { T[E][1] = P[0][2 * (E)] + P[0][2 * (E) + 1]; T[E][2] = P[0][2 * (E)] - P[0][2 * (E) + 1]; }
+#define W3_GV(E, B)         { if ((B) == 0) { V01[E][0] = w3_g01<false>(P[0][2 * (E)], c01); V23[E][0] = w3_g23<false>(P[0][2 * (E)], c10); }              \
+                              else if ((B) == 3) { V01[E][3] = w3_g01<true>(P[0][2 * (E) + 1], c01); V23[E][3] = w3_g23<true>(P[0][2 * (E) + 1], c10); } \
+                              else { V01[E][B] = w3_g01<false>(T[E][B], c01); V23[E][B] = w3_g23<false>(T[E][B], c10); } }
+
+#define W3_FR_FROM(HP, BP)                                                                                                \
+  {                                                                                                                       \
+    av[(HP) & 1] = *reinterpret_cast<const f32x4*>((BP) + ((HP) >> 1) * W3_PLANE + (((HP) & 1) ? a_off1 : a_off0));       \
+    bv[(HP) & 1] = *reinterpret_cast<const f32x4*>((BP) + ((HP) >> 1) * W3_PLANE + (((HP) & 1) ? b_off1 : b_off0));       \
+  }
+#define W3_FR(HP) W3_FR_FROM(HP, cur)
+  // MFMA J of half plane HP = (plane pair HP >> 1, slots HP & 1): plane J & 1 of the pair, accumulator (J & 1) * 4 + (HP >> 1)
+#define W3_M(HP, J, ...)                                                                                                  \
+  {                                                                                                                       \
+    acc[((J) & 1) * 4 + ((HP) >> 1)] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(HP) & 1][J], bv[(HP) & 1][J], acc[((J) & 1) * 4 + ((HP) >> 1)], 0, 0, 0); \
+    asm volatile("" : "+v"(acc[((J) & 1) * 4 + ((HP) >> 1)]) :: "memory");                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    __VA_ARGS__                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+  }
+
+  // prologue: patches of the first chunk, its operands, patches of the second chunk
+  W3Pos p1;
+  {
+    int u = ch_begin;
+    p1.b8 = u % tw8; u /= tw8;
+    p1.ta = u % th;
+    p1.n = u / th;
+  }
+  dma(p1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  {
+    float* nxt = lds;
+    const bool top = p1.ta == 0, bot = p1.ta == th - 1;
+    if (xh == 0) {
+      W3_DLD(0, 0, 6) W3_DLD(1, 0, 6) W3_DMASK()
+      W3_DT(0, 0, 0) W3_DT(0, 0, 1) W3_DT(0, 0, 2) W3_DT(0, 0, 3) W3_DT(0, 1, 0) W3_DT(0, 1, 1) W3_DT(0, 1, 2) W3_DT(0, 1, 3)
+      W3_DV(0, 0) W3_DV(0, 1) W3_DV(0, 2) W3_DV(0, 3)
+      W3_DT(1, 0, 0) W3_DT(1, 0, 1) W3_DT(1, 0, 2) W3_DT(1, 0, 3) W3_DT(1, 1, 0) W3_DT(1, 1, 1) W3_DT(1, 1, 2) W3_DT(1, 1, 3)
+      W3_DV(1, 0) W3_DV(1, 1) W3_DV(1, 2) W3_DV(1, 3)
+      W3_WR(W3_OPER, 0) W3_WR(W3_OPER, 1) W3_WR(W3_OPER, 2) W3_WR(W3_OPER, 3)
+    } else {
+      W3_GLD() W3_GH(0) W3_GH(1)
+      W3_GV(0, 0) W3_GV(0, 1) W3_GV(0, 2) W3_GV(0, 3) W3_GV(1, 0) W3_GV(1, 1) W3_GV(1, 2) W3_GV(1, 3)
+      W3_WR(0, 0) W3_WR(0, 1) W3_WR(0, 2) W3_WR(0, 3)
+    }
+  }
+  __syncthreads();
+  if (ch_begin + 1 < ch_end) advance(p1);
+  dma(p1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  f32x4 av[2], bv[2];
+  {
+    const float* cur = lds;
+    W3_FR(0)
+  }
+  // Per iteration: half planes 0-1 multiply while every thread reads the patches of chunk ch + 1 (landed during the previous iteration);
+  // barrier M (patches read); the DMA of chunk ch + 2 goes out and the transforms run, two packed instructions per MFMA, results to the
+  // other buffer; barrier E in front of the LAST half plane, whose fragments every wave holds already.
+#define W3_TAIL()                                                                                                         \
+    W3_M(6, 0, W3_FR(7)) W3_M(6, 1, ) W3_M(6, 2, ) W3_M(6, 3, )                                                           \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                           \
+    __builtin_amdgcn_s_barrier();                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+    W3_M(7, 0, W3_FR_FROM(0, nxt)) W3_M(7, 1, ) W3_M(7, 2, ) W3_M(7, 3, )
+#define W3_BAR_M()                                                                                                        \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                                    \
+    __builtin_amdgcn_s_barrier();                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);
+  if (xh == 0) {
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+      const float* cur = lds + ((ch - ch_begin) & 1) * W3_BUF;
+      float* nxt = lds + ((ch - ch_begin + 1) & 1) * W3_BUF;
+      const bool top = p1.ta == 0, bot = p1.ta == th - 1;                           // of chunk ch + 1, whose patches are in LDS
+      W3Pos p2 = p1;
+      if (ch + 2 < ch_end) advance(p2);
+      W3_M(0, 0, W3_FR(1) W3_DLD(0, 0, 3)) W3_M(0, 1, W3_DLD(0, 3, 6)) W3_M(0, 2, W3_DLD(1, 0, 3)) W3_M(0, 3, W3_DLD(1, 3, 6))
+      W3_M(1, 0, W3_FR(2)) W3_M(1, 1, ) W3_M(1, 2, ) W3_M(1, 3, )
+      W3_BAR_M()
+      W3_M(2, 0, W3_FR(3) dma(p2);) W3_M(2, 1, W3_DMASK() W3_DT(0, 0, 0) W3_DT(0, 0, 1)) W3_M(2, 2, W3_DT(0, 0, 2) W3_DT(0, 0, 3)) W3_M(2, 3, W3_DT(0, 1, 0) W3_DT(0, 1, 1))
+      W3_M(3, 0, W3_FR(4) W3_DT(0, 1, 2) W3_DT(0, 1, 3)) W3_M(3, 1, W3_DV(0, 0)) W3_M(3, 2, W3_DV(0, 1)) W3_M(3, 3, W3_DV(0, 2))
+      W3_M(4, 0, W3_FR(5) W3_DV(0, 3)) W3_M(4, 1, W3_DT(1, 0, 0) W3_DT(1, 0, 1)) W3_M(4, 2, W3_DT(1, 0, 2) W3_DT(1, 0, 3)) W3_M(4, 3, W3_DT(1, 1, 0) W3_DT(1, 1, 1))
+      W3_M(5, 0, W3_FR(6) W3_DT(1, 1, 2) W3_DT(1, 1, 3)) W3_M(5, 1, W3_DV(1, 0) W3_WR(W3_OPER, 0)) W3_M(5, 2, W3_DV(1, 1) W3_WR(W3_OPER, 1)) W3_M(5, 3, W3_DV(1, 2) W3_WR(W3_OPER, 2))
+      W3_M(6, 0, W3_FR(7) W3_DV(1, 3) W3_WR(W3_OPER, 3)) W3_M(6, 1, ) W3_M(6, 2, ) W3_M(6, 3, )
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      W3_M(7, 0, W3_FR_FROM(0, nxt)) W3_M(7, 1, ) W3_M(7, 2, ) W3_M(7, 3, )
+      p1 = p2;
+    }
+  } else {
+    for (int ch = ch_begin; ch < ch_end; ++ch) {
+      const float* cur = lds + ((ch - ch_begin) & 1) * W3_BUF;
+      float* nxt = lds + ((ch - ch_begin + 1) & 1) * W3_BUF;
+      W3Pos p2 = p1;
+      if (ch + 2 < ch_end) advance(p2);
+      W3_M(0, 0, W3_FR(1) W3_GLD()) W3_M(0, 1, ) W3_M(0, 2, ) W3_M(0, 3, )
+      W3_M(1, 0, W3_FR(2)) W3_M(1, 1, ) W3_M(1, 2, ) W3_M(1, 3, )
+      W3_BAR_M()
+      W3_M(2, 0, W3_FR(3) dma(p2);) W3_M(2, 1, W3_GH(0)) W3_M(2, 2, W3_GV(0, 0)) W3_M(2, 3, W3_GV(0, 1))
+      W3_M(3, 0, W3_FR(4)) W3_M(3, 1, W3_GV(0, 2)) W3_M(3, 2, W3_GV(0, 3)) W3_M(3, 3, W3_GH(1))
+      W3_M(4, 0, W3_FR(5)) W3_M(4, 1, W3_GV(1, 0) W3_WR(0, 0)) W3_M(4, 2, W3_GV(1, 1) W3_WR(0, 1)) W3_M(4, 3, W3_GV(1, 2) W3_WR(0, 2))
+      W3_M(5, 0, W3_FR(6)) W3_M(5, 1, W3_GV(1, 3) W3_WR(0, 3)) W3_M(5, 2, ) W3_M(5, 3, )
+      W3_M(6, 0, W3_FR(7)) W3_M(6, 1, ) W3_M(6, 2, ) W3_M(6, 3, )
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      W3_M(7, 0, W3_FR_FROM(0, nxt)) W3_M(7, 1, ) W3_M(7, 2, ) W3_M(7, 3, )
+      p1 = p2;
+    }
+  }
+#undef W3_TAIL
+#undef W3_BAR_M
+#undef W3_DLD
+#undef W3_DMASK
+#undef W3_DT
+#undef W3_DV
+#undef W3_WR
+#undef W3_GLD
+#undef W3_GH
+#undef W3_GV
+#undef W3_FR
+#undef W3_FR_FROM
+#undef W3_M
+  // partial of this slab: ws[slab][xi][k0 + m][c0 + n]; accumulator register q of lane (li, half) is
+  // row m = mb*32 + 8*(q/4) + 4*half + q%4, column n = nb*32 + li; accumulator xl = (a & 1) * 4 + b is plane xi = xh * 8 + xl
+  float* wp = a.ws + ((size_t)slab * 16) * a.K * a.C;
+#pragma unroll
+  for (int xl = 0; xl < 8; ++xl) {
+    const int xi = xh * 8 + xl;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = mb * 32 + 8 * (q / 4) + 4 * half + (q % 4);
+      wp[((size_t)xi * a.K + k0 + m) * a.C + c0 + nb * 32 + li] = acc[xl][q];
+    }
+  }
+}
+
 template <bool RAG>
 __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad(WWArgs a) {
+#ifndef WW_OLD
+  if constexpr (!RAG) wino_wgrad_body3(a, blockIdx.x);
+  else
+#endif
   wino_wgrad_body<RAG>(a, blockIdx.x);
 }
 
@@ -992,6 +1289,10 @@ __global__ __launch_bounds__(WW_THREADS) void k_wino_wgrad_batch(WWBatchArgs b) 
   for (int i = 1; i < DL_WGRAD_BATCH; ++i)
     if (i < b.n && (int)blockIdx.x >= b.first_wg[i]) l = i;
   const WWArgs a = b.layer[l];
+#ifndef WW_OLD
+  if constexpr (!RAG) wino_wgrad_body3(a, (int)blockIdx.x - b.first_wg[l]);
+  else
+#endif
   wino_wgrad_body<RAG>(a, (int)blockIdx.x - b.first_wg[l]);
 }
 
