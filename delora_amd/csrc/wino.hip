@@ -1014,14 +1014,14 @@ __device__ __forceinline__ f32x2 w3_v23(f32x2 x, f32x2 y) {
 // with 1 is exact and the sum is rounded once, so the results are those of the plain additions.
 template <bool NEG> __device__ __forceinline__ f32x2 w3_g01(f32x2 h, f32x2 c01) {
   f32x2 r;
-  if (NEG) asm volatile("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[1,1,0] neg_lo:[1,0,1] neg_hi:[1,0,1]" : "=v"(r) : "v"(h), "v"(c01));
-  else asm volatile("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(h), "v"(c01));
+  if (NEG) asm volatile("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[1,1,0] neg_lo:[1,0,1] neg_hi:[1,0,1]" : "=v"(r) : "v"(h), "s"(c01));
+  else asm volatile("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[1,0,0] op_sel_hi:[1,1,0]" : "=v"(r) : "v"(h), "s"(c01));
   return r;
 }
 template <bool NEG> __device__ __forceinline__ f32x2 w3_g23(f32x2 h, f32x2 c10) {
   f32x2 r;
-  if (NEG) asm volatile("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,0,1] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(c10));
-  else asm volatile("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,0,1] op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(h), "v"(c10));
+  if (NEG) asm volatile("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,0,1] op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(r) : "v"(h), "s"(c10));
+  else asm volatile("v_pk_fma_f32 %0, %1, %2, %1 op_sel:[0,0,1] op_sel_hi:[0,1,1] neg_lo:[0,0,1] neg_hi:[0,0,1]" : "=v"(r) : "v"(h), "s"(c10));
   return r;
 }
 
@@ -1049,6 +1049,7 @@ __device__ __forceinline__ void wino_wgrad_body3(const WWArgs& a, const int blk)
 
   // ---- transform role: waves 0-3 form Dh = B^T d B (rows = input channels), waves 4-7 Gh = A g A^T (rows = output channels); lane = row
   // of the block, tp = tile pair (tiles 2 tp, 2 tp + 1 of the chunk's eight)
+  const unsigned lds_base = (unsigned)(__SIZE_TYPE__)((__attribute__((address_space(3))) char*)lds);
   const int tp = wave & 3;
   const int w_off = lane * 16 + ((tp ^ ((lane >> 2) & 3)) * 4);        // 16-byte slot of (row, tile pair), XOR-swizzled against bank conflicts
   const float* rsrc = (xh == 0 ? raw : graw) + (4 * tp) * 64 + lane;
@@ -1061,7 +1062,6 @@ __device__ __forceinline__ void wino_wgrad_body3(const WWArgs& a, const int blk)
   const unsigned voff_l = (unsigned)(((lane >> 4) == 0 ? a.W - 1 : (lane >> 4) - 1) * a.C * 4 + (lane & 15) * 16);
   const unsigned voff_r = (unsigned)(((lane >> 4) == 0 ? a.W - 1 : 0) * a.C * 4 + (lane & 15) * 16);
   const int d_row = wave >> 1, d_odd = wave & 1;
-  const unsigned lds_base = (unsigned)(__SIZE_TYPE__)((__attribute__((address_space(3))) char*)lds);
   const int m0_raw = __builtin_amdgcn_readfirstlane((int)(lds_base + 4u * (unsigned)((int)(raw - lds) + d_row * W3_RAWROW + d_odd * 3 * 256)));
   const int m0_g = __builtin_amdgcn_readfirstlane((int)(lds_base + 4u * (unsigned)((int)(graw - lds) + wave * 256)));
   // (LDS DMA from inline assembly, as in k_wino_conv; one M0 write per group of pieces, the pieces 1 KiB apart in LDS by the immediate
@@ -1112,7 +1112,16 @@ __device__ __forceinline__ void wino_wgrad_body3(const WWArgs& a, const int blk)
   f32x2 P[2][6];                       // Dh: input patch, rows (2 rp, 2 rp + 1) x columns 4 tp .. 4 tp + 5;  Gh: P[0][0..3] = (g[0][px], g[1][px])
   f32x2 T[2][4], V01[2][4], V23[2][4];
   const f32x2 c01 = {0.f, 1.f}, c10 = {1.f, 0.f};
-#define W3_DLD(RP, J0, J1)  { _Pragma("unroll") for (int j = (J0); j < (J1); ++j) { P[RP][j][0] = rsrc[((2 * (RP)) * 20 + j) * 64]; P[RP][j][1] = rsrc[((2 * (RP) + 1) * 20 + j) * 64]; } }
+  // (row, row + 1) pairs straight from LDS: ds_read2st64_b32 takes two offsets in units of 64 floats = one pixel.  Issued from inline assembly
+  // (the compiler merges plain scalar reads into NEIGHBOURING-pixel pairs and then needs a v_mov per value to re-pair them); it does not
+  // count these reads, so every use is behind an explicit s_waitcnt lgkmcnt(0) (barrier M / the prologue's) -- its own counted waits only
+  // become more conservative
+  const unsigned rsrc_a = lds_base + 4u * (unsigned)(rsrc - lds);
+#define W3_RD2(DST, O0, O1) asm volatile("ds_read2st64_b32 %0, %1 offset0:" #O0 " offset1:" #O1 : "=v"(DST) : "v"(rsrc_a) : "memory");
+#define W3_DLD_0A() W3_RD2(P[0][0], 0, 20) W3_RD2(P[0][1], 1, 21) W3_RD2(P[0][2], 2, 22)
+#define W3_DLD_0B() W3_RD2(P[0][3], 3, 23) W3_RD2(P[0][4], 4, 24) W3_RD2(P[0][5], 5, 25)
+#define W3_DLD_1A() W3_RD2(P[1][0], 40, 60) W3_RD2(P[1][1], 41, 61) W3_RD2(P[1][2], 42, 62)
+#define W3_DLD_1B() W3_RD2(P[1][3], 43, 63) W3_RD2(P[1][4], 44, 64) W3_RD2(P[1][5], 45, 65)
 #define W3_DMASK()          { if (top) { _Pragma("unroll") for (int j = 0; j < 6; ++j) P[0][j][0] = 0.f; }                        \
                               if (bot) { _Pragma("unroll") for (int j = 0; j < 6; ++j) P[1][j][1] = 0.f; } }
 #define W3_DT(E, RP, B)     { constexpr int o_ = 2 * (E);                                                                           \
@@ -1123,7 +1132,7 @@ __device__ __forceinline__ void wino_wgrad_body3(const WWArgs& a, const int blk)
                               f32x4 hi_ = {V23[0][B][0], V23[0][B][1], V23[1][B][0], V23[1][B][1]};                                  \
                               *reinterpret_cast<f32x4*>(nxt + (OPER) + (B) * W3_PLANE + w_off) = lo_;                                \
                               *reinterpret_cast<f32x4*>(nxt + (OPER) + (4 + (B)) * W3_PLANE + w_off) = hi_; }
-#define W3_GLD()            { _Pragma("unroll") for (int j = 0; j < 4; ++j) { P[0][j][0] = rsrc[j * 64]; P[0][j][1] = rsrc[(16 + j) * 64]; } }
+#define W3_GLD()            W3_RD2(P[0][0], 0, 16) W3_RD2(P[0][1], 1, 17) W3_RD2(P[0][2], 2, 18) W3_RD2(P[0][3], 3, 19)
   // tile E of the pair: columns 2 E, 2 E + 1 of the thread's four.  h_b: b = 0: g0, 1: g0 + g1, 2: g0 - g1, 3: -g1 (as modifiers)
 #define W3_GH(E)            { T[E][1] = P[0][2 * (E)] + P[0][2 * (E) + 1]; T[E][2] = P[0][2 * (E)] - P[0][2 * (E) + 1]; }
 #define W3_GV(E, B)         { if ((B) == 0) { V01[E][0] = w3_g01<false>(P[0][2 * (E)], c01); V23[E][0] = w3_g23<false>(P[0][2 * (E)], c10); }              \
@@ -1161,14 +1170,18 @@ __device__ __forceinline__ void wino_wgrad_body3(const WWArgs& a, const int blk)
     float* nxt = lds;
     const bool top = p1.ta == 0, bot = p1.ta == th - 1;
     if (xh == 0) {
-      W3_DLD(0, 0, 6) W3_DLD(1, 0, 6) W3_DMASK()
+      W3_DLD_0A() W3_DLD_0B() W3_DLD_1A() W3_DLD_1B()
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      W3_DMASK()
       W3_DT(0, 0, 0) W3_DT(0, 0, 1) W3_DT(0, 0, 2) W3_DT(0, 0, 3) W3_DT(0, 1, 0) W3_DT(0, 1, 1) W3_DT(0, 1, 2) W3_DT(0, 1, 3)
       W3_DV(0, 0) W3_DV(0, 1) W3_DV(0, 2) W3_DV(0, 3)
       W3_DT(1, 0, 0) W3_DT(1, 0, 1) W3_DT(1, 0, 2) W3_DT(1, 0, 3) W3_DT(1, 1, 0) W3_DT(1, 1, 1) W3_DT(1, 1, 2) W3_DT(1, 1, 3)
       W3_DV(1, 0) W3_DV(1, 1) W3_DV(1, 2) W3_DV(1, 3)
       W3_WR(W3_OPER, 0) W3_WR(W3_OPER, 1) W3_WR(W3_OPER, 2) W3_WR(W3_OPER, 3)
     } else {
-      W3_GLD() W3_GH(0) W3_GH(1)
+      W3_GLD()
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      W3_GH(0) W3_GH(1)
       W3_GV(0, 0) W3_GV(0, 1) W3_GV(0, 2) W3_GV(0, 3) W3_GV(1, 0) W3_GV(1, 1) W3_GV(1, 2) W3_GV(1, 3)
       W3_WR(0, 0) W3_WR(0, 1) W3_WR(0, 2) W3_WR(0, 3)
     }
@@ -1204,18 +1217,20 @@ __device__ __forceinline__ void wino_wgrad_body3(const WWArgs& a, const int blk)
       const bool top = p1.ta == 0, bot = p1.ta == th - 1;                           // of chunk ch + 1, whose patches are in LDS
       W3Pos p2 = p1;
       if (ch + 2 < ch_end) advance(p2);
-      W3_M(0, 0, W3_FR(1) W3_DLD(0, 0, 3)) W3_M(0, 1, W3_DLD(0, 3, 6)) W3_M(0, 2, W3_DLD(1, 0, 3)) W3_M(0, 3, W3_DLD(1, 3, 6))
-      W3_M(1, 0, W3_FR(2)) W3_M(1, 1, ) W3_M(1, 2, ) W3_M(1, 3, )
-      W3_BAR_M()
-      W3_M(2, 0, W3_FR(3) dma(p2);) W3_M(2, 1, W3_DMASK() W3_DT(0, 0, 0) W3_DT(0, 0, 1)) W3_M(2, 2, W3_DT(0, 0, 2) W3_DT(0, 0, 3)) W3_M(2, 3, W3_DT(0, 1, 0) W3_DT(0, 1, 1))
-      W3_M(3, 0, W3_FR(4) W3_DT(0, 1, 2) W3_DT(0, 1, 3)) W3_M(3, 1, W3_DV(0, 0)) W3_M(3, 2, W3_DV(0, 1)) W3_M(3, 3, W3_DV(0, 2))
-      W3_M(4, 0, W3_FR(5) W3_DV(0, 3)) W3_M(4, 1, W3_DT(1, 0, 0) W3_DT(1, 0, 1)) W3_M(4, 2, W3_DT(1, 0, 2) W3_DT(1, 0, 3)) W3_M(4, 3, W3_DT(1, 1, 0) W3_DT(1, 1, 1))
-      W3_M(5, 0, W3_FR(6) W3_DT(1, 1, 2) W3_DT(1, 1, 3)) W3_M(5, 1, W3_DV(1, 0) W3_WR(W3_OPER, 0)) W3_M(5, 2, W3_DV(1, 1) W3_WR(W3_OPER, 1)) W3_M(5, 3, W3_DV(1, 2) W3_WR(W3_OPER, 2))
-      W3_M(6, 0, W3_FR(7) W3_DV(1, 3) W3_WR(W3_OPER, 3)) W3_M(6, 1, ) W3_M(6, 2, ) W3_M(6, 3, )
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      W3_M(0, 0, WW_IF_FR(W3_FR(1)) WW_IF_T(W3_DLD_0A())) W3_M(0, 1, WW_IF_T(W3_DLD_0B())) W3_M(0, 2, WW_IF_T(W3_DLD_1A())) W3_M(0, 3, WW_IF_T(W3_DLD_1B()))
+      W3_M(1, 0, WW_IF_FR(W3_FR(2))) W3_M(1, 1, ) W3_M(1, 2, ) W3_M(1, 3, )
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      WW_IF_BAR(__builtin_amdgcn_s_barrier();)
       __builtin_amdgcn_sched_barrier(0);
-      W3_M(7, 0, W3_FR_FROM(0, nxt)) W3_M(7, 1, ) W3_M(7, 2, ) W3_M(7, 3, )
+      W3_M(2, 0, WW_IF_FR(W3_FR(3)) WW_IF_DMA(dma(p2);)) W3_M(2, 1, WW_IF_T(W3_DMASK()) WW_IF_T(W3_DT(0, 0, 0)) WW_IF_T(W3_DT(0, 0, 1))) W3_M(2, 2, WW_IF_T(W3_DT(0, 0, 2)) WW_IF_T(W3_DT(0, 0, 3))) W3_M(2, 3, WW_IF_T(W3_DT(0, 1, 0)) WW_IF_T(W3_DT(0, 1, 1)))
+      W3_M(3, 0, WW_IF_FR(W3_FR(4)) WW_IF_T(W3_DT(0, 1, 2)) WW_IF_T(W3_DT(0, 1, 3))) W3_M(3, 1, WW_IF_T(W3_DV(0, 0))) W3_M(3, 2, WW_IF_T(W3_DV(0, 1))) W3_M(3, 3, WW_IF_T(W3_DV(0, 2)))
+      W3_M(4, 0, WW_IF_FR(W3_FR(5)) WW_IF_T(W3_DV(0, 3))) W3_M(4, 1, WW_IF_T(W3_DT(1, 0, 0)) WW_IF_T(W3_DT(1, 0, 1))) W3_M(4, 2, WW_IF_T(W3_DT(1, 0, 2)) WW_IF_T(W3_DT(1, 0, 3))) W3_M(4, 3, WW_IF_T(W3_DT(1, 1, 0)) WW_IF_T(W3_DT(1, 1, 1)))
+      W3_M(5, 0, WW_IF_FR(W3_FR(6)) WW_IF_T(W3_DT(1, 1, 2)) WW_IF_T(W3_DT(1, 1, 3))) W3_M(5, 1, WW_IF_T(W3_DV(1, 0)) WW_IF_T(W3_WR(W3_OPER, 0))) W3_M(5, 2, WW_IF_T(W3_DV(1, 1)) WW_IF_T(W3_WR(W3_OPER, 1))) W3_M(5, 3, WW_IF_T(W3_DV(1, 2)) WW_IF_T(W3_WR(W3_OPER, 2)))
+      W3_M(6, 0, WW_IF_FR(W3_FR(7)) WW_IF_T(W3_DV(1, 3)) WW_IF_T(W3_WR(W3_OPER, 3))) W3_M(6, 1, ) W3_M(6, 2, ) W3_M(6, 3, )
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      WW_IF_BAR(__builtin_amdgcn_s_barrier();)
+      __builtin_amdgcn_sched_barrier(0);
+      W3_M(7, 0, WW_IF_FR(W3_FR_FROM(0, nxt))) W3_M(7, 1, ) W3_M(7, 2, ) W3_M(7, 3, )
       p1 = p2;
     }
   } else {
@@ -1224,24 +1239,30 @@ __device__ __forceinline__ void wino_wgrad_body3(const WWArgs& a, const int blk)
       float* nxt = lds + ((ch - ch_begin + 1) & 1) * W3_BUF;
       W3Pos p2 = p1;
       if (ch + 2 < ch_end) advance(p2);
-      W3_M(0, 0, W3_FR(1) W3_GLD()) W3_M(0, 1, ) W3_M(0, 2, ) W3_M(0, 3, )
-      W3_M(1, 0, W3_FR(2)) W3_M(1, 1, ) W3_M(1, 2, ) W3_M(1, 3, )
-      W3_BAR_M()
-      W3_M(2, 0, W3_FR(3) dma(p2);) W3_M(2, 1, W3_GH(0)) W3_M(2, 2, W3_GV(0, 0)) W3_M(2, 3, W3_GV(0, 1))
-      W3_M(3, 0, W3_FR(4)) W3_M(3, 1, W3_GV(0, 2)) W3_M(3, 2, W3_GV(0, 3)) W3_M(3, 3, W3_GH(1))
-      W3_M(4, 0, W3_FR(5)) W3_M(4, 1, W3_GV(1, 0) W3_WR(0, 0)) W3_M(4, 2, W3_GV(1, 1) W3_WR(0, 1)) W3_M(4, 3, W3_GV(1, 2) W3_WR(0, 2))
-      W3_M(5, 0, W3_FR(6)) W3_M(5, 1, W3_GV(1, 3) W3_WR(0, 3)) W3_M(5, 2, ) W3_M(5, 3, )
-      W3_M(6, 0, W3_FR(7)) W3_M(6, 1, ) W3_M(6, 2, ) W3_M(6, 3, )
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+      W3_M(0, 0, WW_IF_FR(W3_FR(1)) WW_IF_T(W3_GLD())) W3_M(0, 1, ) W3_M(0, 2, ) W3_M(0, 3, )
+      W3_M(1, 0, WW_IF_FR(W3_FR(2))) W3_M(1, 1, ) W3_M(1, 2, ) W3_M(1, 3, )
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      WW_IF_BAR(__builtin_amdgcn_s_barrier();)
       __builtin_amdgcn_sched_barrier(0);
-      W3_M(7, 0, W3_FR_FROM(0, nxt)) W3_M(7, 1, ) W3_M(7, 2, ) W3_M(7, 3, )
+      W3_M(2, 0, WW_IF_FR(W3_FR(3)) WW_IF_DMA(dma(p2);)) W3_M(2, 1, WW_IF_T(W3_GH(0))) W3_M(2, 2, WW_IF_T(W3_GV(0, 0))) W3_M(2, 3, WW_IF_T(W3_GV(0, 1)))
+      W3_M(3, 0, WW_IF_FR(W3_FR(4))) W3_M(3, 1, WW_IF_T(W3_GV(0, 2))) W3_M(3, 2, WW_IF_T(W3_GV(0, 3))) W3_M(3, 3, WW_IF_T(W3_GH(1)))
+      W3_M(4, 0, WW_IF_FR(W3_FR(5))) W3_M(4, 1, WW_IF_T(W3_GV(1, 0)) WW_IF_T(W3_WR(0, 0))) W3_M(4, 2, WW_IF_T(W3_GV(1, 1)) WW_IF_T(W3_WR(0, 1))) W3_M(4, 3, WW_IF_T(W3_GV(1, 2)) WW_IF_T(W3_WR(0, 2)))
+      W3_M(5, 0, WW_IF_FR(W3_FR(6))) W3_M(5, 1, WW_IF_T(W3_GV(1, 3)) WW_IF_T(W3_WR(0, 3))) W3_M(5, 2, ) W3_M(5, 3, )
+      W3_M(6, 0, WW_IF_FR(W3_FR(7))) W3_M(6, 1, ) W3_M(6, 2, ) W3_M(6, 3, )
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      WW_IF_BAR(__builtin_amdgcn_s_barrier();)
+      __builtin_amdgcn_sched_barrier(0);
+      W3_M(7, 0, WW_IF_FR(W3_FR_FROM(0, nxt))) W3_M(7, 1, ) W3_M(7, 2, ) W3_M(7, 3, )
       p1 = p2;
     }
   }
 #undef W3_TAIL
 #undef W3_BAR_M
-#undef W3_DLD
+#undef W3_RD2
+#undef W3_DLD_0A
+#undef W3_DLD_0B
+#undef W3_DLD_1A
+#undef W3_DLD_1B
 #undef W3_DMASK
 #undef W3_DT
 #undef W3_DV
