@@ -1051,7 +1051,10 @@ __device__ __forceinline__ void wino_wgrad_body3(const WWArgs& a, const int blk)
   // of the block, tp = tile pair (tiles 2 tp, 2 tp + 1 of the chunk's eight)
   const unsigned lds_base = (unsigned)(__SIZE_TYPE__)((__attribute__((address_space(3))) char*)lds);
   const int tp = wave & 3;
-  const int w_off = lane * 16 + ((tp ^ ((lane >> 2) & 3)) * 4);        // 16-byte slot of (row, tile pair), XOR-swizzled against bank conflicts
+  // 16-byte slot of (row, tile pair) inside the row's 64 bytes, XOR-swizzled: f(row) = (bit 2, bit 1 ^ bit 3) makes the 16-byte fragment reads
+  // (16-lane groups of rows {0-3, 12-15, 20-27}, 64 banks) AND these 16-byte stores (8 consecutive rows, 32 banks) conflict-free
+#define W3_SWZ(R) ((((R) >> 2) & 1) | (((((R) >> 1) ^ ((R) >> 3)) & 1) << 1))
+  const int w_off = lane * 16 + ((tp ^ W3_SWZ(lane)) * 4);
   const float* rsrc = (xh == 0 ? raw : graw) + (4 * tp) * 64 + lane;
   // ---- DMA role: wave w brings pieces of patch row w >> 1 (even waves: pixels 0-11, odd waves: 12-19) and pixels 4 (w & 3) .. of row w >> 2
   // of the output-gradient patch.  Per-lane byte offsets (pixel lane >> 4 of the piece, 16-byte channel quad lane & 15):
@@ -1103,10 +1106,10 @@ __device__ __forceinline__ void wino_wgrad_body3(const WWArgs& a, const int blk)
   // fragment reads: lane (li, half) of a plane pair reads the 16-byte slots `half` and `2 + half` of its row (tiles {2 half, 2 half + 1} and
   // {4 + 2 half, ..} x both planes): element e of a read is plane e & 1, tile (e >> 1) of the slot's two
   const int arow = mb * 32 + li, brow = nb * 32 + li;
-  const int a_off0 = xh * 4 * W3_PLANE + arow * 16 + ((half ^ ((arow >> 2) & 3)) * 4);
-  const int a_off1 = xh * 4 * W3_PLANE + arow * 16 + (((2 + half) ^ ((arow >> 2) & 3)) * 4);
-  const int b_off0 = W3_OPER + xh * 4 * W3_PLANE + brow * 16 + ((half ^ ((brow >> 2) & 3)) * 4);
-  const int b_off1 = W3_OPER + xh * 4 * W3_PLANE + brow * 16 + (((2 + half) ^ ((brow >> 2) & 3)) * 4);
+  const int a_off0 = xh * 4 * W3_PLANE + arow * 16 + ((half ^ W3_SWZ(arow)) * 4);
+  const int a_off1 = xh * 4 * W3_PLANE + arow * 16 + (((2 + half) ^ W3_SWZ(arow)) * 4);
+  const int b_off0 = W3_OPER + xh * 4 * W3_PLANE + brow * 16 + ((half ^ W3_SWZ(brow)) * 4);
+  const int b_off1 = W3_OPER + xh * 4 * W3_PLANE + brow * 16 + (((2 + half) ^ W3_SWZ(brow)) * 4);
 
   // ---- the two transforms, in pieces (placed behind individual MFMAs below)
   f32x2 P[2][6];                       // Dh: input patch, rows (2 rp, 2 rp + 1) x columns 4 tp .. 4 tp + 5;  Gh: P[0][0..3] = (g[0][px], g[1][px])
@@ -1256,6 +1259,7 @@ __device__ __forceinline__ void wino_wgrad_body3(const WWArgs& a, const int blk)
       p1 = p2;
     }
   }
+#undef W3_SWZ
 #undef W3_TAIL
 #undef W3_BAR_M
 #undef W3_RD2
