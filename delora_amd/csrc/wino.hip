@@ -27,6 +27,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 #define WN_THREADS 512
@@ -86,8 +87,20 @@ __device__ __forceinline__ void wn_weight_transform(const float (&g)[3][3], floa
   }
 }
 
-// w [K][3][3][C] -> u_fwd [C/8][16][K][8] (reduction over c) and u_bwd [K/8][16][C][8] (the transposed convolution of the
-// input gradient: taps flipped, channel roles swapped, reduction over k).  One thread per (k, c).
+// Layout of the Winograd-domain weights (round 6): the reduction channels in chunks of 8, the output rows (k of u_fwd, c of u_bwd) in
+// blocks of 64, and inside a (chunk, block) the 16 planes as the bytes k_wino_conv wants to find in LDS: [16][64 rows][8] with the
+// 16-byte halves of a row swapped where bit 3 of the row index is set (the XOR swizzle of the fragment reads).  The DMA of a chunk is
+// then a LINEAR copy of 32 KiB -- one per-lane offset (16 lane) for every piece, pieces addressed by immediate offsets from one M0 --
+// instead of a gather with the swizzle in per-lane source offsets and an M0 write per piece.  Row counts that do not divide into blocks
+// of 64 (never consumed by k_wino_conv) keep the plain [chunk][16][rows][8] order.
+__device__ __host__ __forceinline__ size_t wn_u_index(int rows, int chunk, int xi, int r, int e) {
+  if (rows % 64) return (((size_t)chunk * 16 + xi) * rows + r) * 8 + e;
+  const int rb = r >> 6, rr = r & 63;
+  return ((((size_t)chunk * (rows / 64) + rb) * 16 + xi) * 64 + rr) * 8 + ((((e >> 2) ^ ((rr >> 3) & 1)) << 2) | (e & 3));
+}
+
+// w [K][3][3][C] -> u_fwd (reduction over c, rows k) and u_bwd (the transposed convolution of the input gradient: taps flipped, channel
+// roles swapped, reduction over k, rows c).  One thread per (k, c).
 __global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ w, float* __restrict__ u_fwd,
                                                       float* __restrict__ u_bwd, int K, int C) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -104,12 +117,12 @@ __global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ 
   if (u_fwd) {
     wn_weight_transform(g, u);
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi) u_fwd[(((size_t)(c / 8) * 16 + xi) * K + k) * 8 + (c % 8)] = u[xi / 4][xi % 4];
+    for (int xi = 0; xi < 16; ++xi) u_fwd[wn_u_index(K, c / 8, xi, k, c % 8)] = u[xi / 4][xi % 4];
   }
   if (u_bwd) {
     wn_weight_transform(gf, u);
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi) u_bwd[(((size_t)(k / 8) * 16 + xi) * C + c) * 8 + (k % 8)] = u[xi / 4][xi % 4];
+    for (int xi = 0; xi < 16; ++xi) u_bwd[wn_u_index(C, k / 8, xi, c, k % 8)] = u[xi / 4][xi % 4];
   }
 }
 
@@ -132,9 +145,7 @@ __global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ 
 #ifndef WN_ABL
 #define WN_ABL 0
 #endif
-#ifndef WN_EXP
-#define WN_EXP 0
-#endif
+
 #if WN_ABL & 1
 #define WN_IF_U(...)
 #else
@@ -183,7 +194,6 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   constexpr int RAWBUF = NRI * 256;                             // floats
   constexpr int NR_IT = (NRI + 7) / 8;                          // DMA pieces per wave
   constexpr int BUF = 2 * 16 * WN_PLANE;                        // floats of one (V, U) buffer pair
-  constexpr int NU_IT = 16 * WN_KB * 2 / WN_THREADS;             // 4
   static_assert((2 * BUF + 2 * RAWBUF) * 4 <= 163840, "LDS budget");
   __shared__ __attribute__((aligned(16))) float lds[2 * BUF + 2 * RAWBUF];
   float* rawbase = lds + 2 * BUF;
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   // the current group uses the lower 74 KB as its exchange / transposition space
 #define WN_BUFOF(CH) (lds + (((CH) + 1) & 1) * BUF)
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, half = lane >> 5;
   const int mb = wave & 1, nb = (wave >> 1) & 1, xh = wave >> 2;
   const int KT = a.K / WN_KB;
@@ -202,29 +212,27 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   const int nchunks = a.C / WN_CK / nsplit;                           // chunks per workgroup (the launcher makes the split exact)
 
   // transform role of this thread: tile, channel quad, column b of the 4x4 domain
-  const int tb = tid & 3, tc4 = (tid >> 2) & 1, ttile = tid >> 3;
+  // Round 6: column b is WAVE-UNIFORM (it was the lane's low bits): which raw columns combine is then an address, the sign a scalar
+  // register, and row i of T = d B is two packed fused multiply-adds d[i][jA] + sgn d[i][jB] (a product with +-1 is exact, the sum is
+  // rounded once: the values of round 3's sg0 d[j0] + sg1 d[j1]).  Next to v_mfma_f32_32x32x2_f32 a VALU instruction is NOT free (it costs
+  // the SIMD ~3.3 cycles of matrix time, a packed one 5.3: tools/exp/mfma_overlap.hip); the masks of the rows outside the image and the
+  // sign multiplications were 60 of the transform's 94 instructions per wave and chunk.
+  const int tb = wave & 3, tc4 = lane & 1, ttile = (wave >> 2) * 32 + (lane >> 1);
   const int ttr = ttile / TC, ttc = ttile % TC;
-  const int j0 = tb == 0 ? 0 : 1, j1 = tb == 3 ? 3 : 2;             // the two raw columns column b combines
-  const float sg0 = tb == 2 ? -1.f : 1.f, sg1 = (tb == 0 || tb == 3) ? -1.f : 1.f;   // T[.][b] = sg0*d[.][j0] + sg1*d[.][j1]
+  const int j0 = tb == 0 ? 0 : (tb == 2 ? 2 : 1), j1 = tb == 2 ? 1 : (tb == 3 ? 3 : 2);      // b = 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
+  const float sgn_s = tb == 1 ? 1.f : -1.f;
+  const f32x2 sgn = {sgn_s, sgn_s};
   const int t_wr = tb * WN_PLANE + ttile * 8 + ((tc4 ^ ((ttile >> 3) & 1)) * 4);
   const int t_rd = ((2 * ttr) * RW + 2 * ttc) * 8 + tc4 * 4;        // raw(row 0, col 0) of this tile's window
-  // DMA pieces of this wave: raw pixels r*32 + lane/2, channel quad lane & 1 (ids beyond the patch re-read its last
-  // pixel; rows outside the image read row 0 / H-1 and are masked by the transform)
-  int raw_l[NR_IT];
-#pragma unroll
-  for (int it = 0; it < NR_IT; ++it) raw_l[it] = min(wave + it * 8, NRI - 1) * 256;
-  // U: wave w copies the half-planes 4w .. 4w+3 (plane = id >> 1, rows 32 * (id & 1) ..); a lane's LDS slot is linear in
-  // the lane id as the instruction requires, so the 16-byte XOR swizzle is applied to the SOURCE address instead
-  // (32-bit UNSIGNED per-lane offsets next to wave-uniform 64-bit bases: the DMA then takes its address as scalar base + vector
-  // offset and no per-lane 64-bit address has to live in registers across the chunk loop)
-  unsigned u_g[NU_IT];
-  int u_l[NU_IT];
-#pragma unroll
-  for (int it = 0; it < NU_IT; ++it) {
-    const int id = wave * NU_IT + it, xi = id >> 1, kk = (id & 1) * 32 + (lane >> 1), slot = lane & 1;
-    u_g[it] = 4u * (unsigned)((xi * a.K + kk) * 8 + ((slot ^ ((kk >> 3) & 1)) * 4));     // bytes; + k0 * 8 + chunk * 16 * K * 8 floats
-    u_l[it] = 16 * WN_PLANE + xi * WN_PLANE + (id & 1) * 256;                // wave-uniform base (floats)
-  }
+  // DMA pieces of this wave (round 6: the pieces of a wave are neighbours in LDS and share ONE M0 write -- the immediate offset of
+  // global_load_lds moves the LDS address and the global address together (tools/exp/pk_probe.hip); an M0 write per piece, with the
+  // v_readfirstlane in front of it, was half of the DMA's cost):
+  //   raw: pieces 2 wave, 2 wave + 1 of the patch (pixels 32 piece + lane / 2, channel quad lane & 1; rows outside the image read row
+  //        0 / H-1 and are zeroed by the transform), the second one 1 KiB behind the first -- its scalar base is 1 KiB lower;
+  //   U:   planes 2 wave, 2 wave + 1 of the chunk's 32 KiB block (wn_u_index), a linear copy: every piece has the per-lane offset 16 lane;
+  //        the planes lie 2112 bytes apart in LDS and 2048 in memory, so the second plane's base is 64 bytes lower.
+  constexpr int NRAW_W = (NRI + 1) / 2;                          // waves that have raw pieces
+  const unsigned lane16 = 16u * (unsigned)lane;
   const int arow = mb * 32 + li, brow = nb * 32 + li;
   const int a_off = arow * 8 + ((half ^ ((arow >> 3) & 1)) * 4);
   const int b_off = 16 * WN_PLANE + brow * 8 + ((half ^ ((brow >> 3) & 1)) * 4);
@@ -236,7 +244,8 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   int cb = 0;                                                           // first chunk of this workgroup's channel range (SPLIT)
   float* ysp = a.y;                                                     // where this group's result goes (SPLIT: its range's partial plane)
   const float* xn;
-  int rowmask[4];                                                     // zero rows above / below the image
+  int rowmask[4];                                                     // zero rows above / below the image ...
+  bool edge;                                                          // ... which only the first / last row of tile groups has (uniform)
   unsigned raw_g[NR_IT];
 #define WN_SETUP(G, LN)                                                                                                   \
   {                                                                                                                       \
@@ -253,8 +262,9 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
       const int h_ = h_base_ + 2 * ttr + i;                                                                               \
       rowmask[i] = (h_ >= 0 && h_ < a.H) ? -1 : 0;                                                                        \
     }                                                                                                                     \
+    edge = __builtin_amdgcn_readfirstlane((int)(h_base_ < 0 || h_base_ + RH > a.H)) != 0;                                                                           \
     _Pragma("unroll") for (int it = 0; it < NR_IT; ++it) {                                                                \
-      const int p_ = min(min(wave + it * 8, NRI - 1) * 32 + ((LN) >> 1), NPIX - 1);        /* recomputed: registers are scarce */ \
+      const int p_ = min(min(2 * wave + it, NRI - 1) * 32 + ((LN) >> 1), NPIX - 1);        /* recomputed: registers are scarce */ \
       int h_ = h_base_ + p_ / RW;                                                                                         \
       h_ = h_ < 0 ? 0 : (h_ >= a.H ? a.H - 1 : h_);                                                                       \
       int w_ = w_base_ + p_ % RW;                                                                                         \
@@ -264,48 +274,31 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
     }                                                                                                                     \
   }
 
-  // One LDS DMA piece: 64 lanes x 16 bytes from (wave-uniform base BASE) + (per-lane byte offset OFFB) to the LDS address LPTR + 16 lane.
+  // LDS DMA: 64 lanes x 16 bytes per piece from (wave-uniform base) + (per-lane byte offset) to the LDS address M0 + immediate + 16 lane.
   // Issued from inline assembly (see CH_GLDS in convh_common.h): while a global_load_lds BUILTIN is outstanding the compiler turns every
   // LDS wait into s_waitcnt lgkmcnt(0); hidden from it, the fragment / transform reads are waited for individually.  Every barrier that
   // hands DMA-written data over is preceded by an explicit s_waitcnt vmcnt(0) -- __syncthreads() alone does NOT wait for these loads.
   const unsigned lds_base = (unsigned)(__SIZE_TYPE__)((__attribute__((address_space(3))) char*)lds);
-#if WN_ABL & 256
-  float wn_dummy = 0.f;
-#endif
-#define WN_LDSADDR(LPTR) (lds_base + 4u * (unsigned)((LPTR) - lds))
-#if WN_ABL & 256          /* a plain 4-byte load into a dummy register instead of the DMA: the vector-memory issue without the LDS write */
-#define WN_GLDS(BASE, OFFB, LPTR)                                                                                         \
-  asm volatile("s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_dword %0, %1, %2"                                           \
-               : "=v"(wn_dummy) : "v"(OFFB), "s"(BASE), "s"(__builtin_amdgcn_readfirstlane((int)WN_LDSADDR(LPTR))) : "memory");
-#elif WN_ABL & 512        /* the DMA without the M0 write (every piece lands wherever M0 points) */
-#define WN_GLDS(BASE, OFFB, LPTR)                                                                                         \
-  asm volatile("global_load_lds_dwordx4 %0, %1"                                           \
-               :: "v"(OFFB), "s"(BASE), "s"(__builtin_amdgcn_readfirstlane((int)WN_LDSADDR(LPTR))) : "memory");
-#elif WN_ABL & 1024       /* 4 bytes per lane instead of 16 */
-#define WN_GLDS(BASE, OFFB, LPTR)                                                                                         \
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %0, %1"                                           \
-               :: "v"(OFFB), "s"(BASE), "s"(__builtin_amdgcn_readfirstlane((int)WN_LDSADDR(LPTR))) : "memory");
-#elif WN_ABL & 128          /* the scalar part of a DMA piece only */
-#define WN_GLDS(BASE, OFFB, LPTR)                                                                                         \
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0"                                           \
-               :: "v"(OFFB), "s"(BASE), "s"(__builtin_amdgcn_readfirstlane((int)WN_LDSADDR(LPTR))) : "memory");
-#else
-#define WN_GLDS(BASE, OFFB, LPTR)                                                                                         \
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"                                           \
-               :: "v"(OFFB), "s"(BASE), "s"(__builtin_amdgcn_readfirstlane((int)WN_LDSADDR(LPTR))) : "memory");
-#endif
-#if WN_ABL & 64           /* every piece re-reads chunk 0 (cache-resident): the issue cost of the DMA without its memory traffic */
-#define WN_CHSEL(CH) 0
-#else
-#define WN_CHSEL(CH) (CH)
-#endif
-#define WN_U_PIECE_X(UG, IT, CH, BUFP) \
-  WN_GLDS(a.u + ((size_t)(WN_CHSEL(CH) + cb) * 16 * a.K * 8 + k0 * 8), (UG)[IT], (BUFP) + __builtin_amdgcn_readfirstlane(u_l[IT]))
-#define WN_U_PIECE(IT, CH, BUFP) WN_U_PIECE_X(u_g, IT, CH, BUFP)
-#define WN_RAW_PIECE(IT, CH) \
-  WN_GLDS(xn + (WN_CHSEL(CH) + cb) * WN_CK, raw_g[IT], rawbase + ((CH) & 1) * RAWBUF + __builtin_amdgcn_readfirstlane(raw_l[IT]))
-#define WN_RAW_ALL(CH) { _Pragma("unroll") for (int it = 0; it < NR_IT; ++it) WN_RAW_PIECE(it, CH) }
-#define WN_U_ALL(CH, BUFP) { _Pragma("unroll") for (int it = 0; it < NU_IT; ++it) WN_U_PIECE(it, CH, BUFP) }
+  const int m0_raw = __builtin_amdgcn_readfirstlane((int)(lds_base + 4u * (unsigned)(2 * BUF + min(2 * wave, NRI - 1) * 256)));      // raw buffer 0
+  const int m0_u = __builtin_amdgcn_readfirstlane((int)(lds_base + 4u * (unsigned)(16 * WN_PLANE + 2 * wave * WN_PLANE)));            // (V, U) buffer 0
+#define WN_RAW_ALL(CH)                                                                                                    \
+  {                                                                                                                       \
+    const float* rp_ = xn + ((CH) + cb) * WN_CK;                                                                          \
+    const int m_ = m0_raw + ((CH) & 1) * (RAWBUF * 4);                                                                    \
+    if (2 * wave + 1 < NRI)                                                                                               \
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\tglobal_load_lds_dwordx4 %2, %4 offset:1024"     \
+                   :: "s"(m_), "v"(raw_g[0]), "v"(raw_g[NR_IT - 1]), "s"(rp_), "s"(rp_ - 256) : "memory");                  \
+    else if (2 * wave < NRI)                                                                                              \
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m_), "v"(raw_g[0]), "s"(rp_) : "memory");  \
+  }
+#define WN_U_ALL(CH, BUFP)                                                                                                \
+  {                                                                                                                       \
+    const float* up_ = a.u + (((size_t)((CH) + cb) * KT + (k0 >> 6)) * 16 + 2 * wave) * 512;                               \
+    const int m_ = m0_u + (int)((BUFP) - lds) * 4;                                                                        \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\tglobal_load_lds_dwordx4 %1, %2 offset:1024\n\t" \
+                 "global_load_lds_dwordx4 %1, %3 offset:2112\n\tglobal_load_lds_dwordx4 %1, %3 offset:3136"                \
+                 :: "s"(m_), "v"(lane16), "s"(up_), "s"(up_ - 16) : "memory");                                            \
+  }
   // row I of T = d B for this thread's column: two 16-byte reads of the raw patch (issued ahead of their use: a read and its use in
   // the same slice stalls the wave for an LDS round trip while its partner on the SIMD is in the same phase), masked for rows
   // outside the image
@@ -316,21 +309,33 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   }
 #define WN_TROW_FIN(I)                                                                                                    \
   {                                                                                                                       \
-    tt[I] = sg0 * __builtin_bit_cast(f32x4, dd[(I) & 1][0] & rowmask[I]) + sg1 * __builtin_bit_cast(f32x4, dd[(I) & 1][1] & rowmask[I]); \
+    if (edge) { asm volatile("" ::: "memory"); dd[(I) & 1][0] &= rowmask[I]; dd[(I) & 1][1] &= rowmask[I]; }     /* (a real branch) */ \
+    const f32x4 da_ = __builtin_bit_cast(f32x4, dd[(I) & 1][0]), db_ = __builtin_bit_cast(f32x4, dd[(I) & 1][1]);         \
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(tt[I][0]) : "v"(__builtin_shufflevector(db_, db_, 0, 1)), "s"(sgn), "v"(__builtin_shufflevector(da_, da_, 0, 1))); \
+    asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(tt[I][1]) : "v"(__builtin_shufflevector(db_, db_, 2, 3)), "s"(sgn), "v"(__builtin_shufflevector(da_, da_, 2, 3))); \
   }
 #define WN_TROW(I, RB) WN_TROW_LD(I, RB) WN_TROW_FIN(I)
+  // x + y / x - y of four channels as two packed instructions (inline assembly: the compiler scalarises the plain vector expressions)
+#define WN_PK_ADD(X, Y) ({ f32x2 l_, h_;                                                                                    \
+    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(l_) : "v"((X)[0]), "v"((Y)[0]));                                        \
+    asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(h_) : "v"((X)[1]), "v"((Y)[1]));                                        \
+    __builtin_shufflevector(l_, h_, 0, 1, 2, 3); })
+#define WN_PK_SUB(X, Y) ({ f32x2 l_, h_;                                                                                    \
+    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(l_) : "v"((X)[0]), "v"((Y)[0]));              \
+    asm volatile("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(h_) : "v"((X)[1]), "v"((Y)[1]));              \
+    __builtin_shufflevector(l_, h_, 0, 1, 2, 3); })
   // V(0) of the group in hand from its raw(0): the one transform that is not hidden behind MFMAs
 #define WN_V0()                                                                                                           \
   {                                                                                                                       \
-    f32x4 tt[4];                                                                                                          \
+    f32x2 tt[4][2];                                                                                                       \
     i32x4 dd[2][2];                                                                                                       \
     const float* rb_ = rawbase;                                                                                           \
     float* vb_ = WN_BUFOF(0) + t_wr;                                                                                      \
     WN_TROW(0, rb_) WN_TROW(1, rb_) WN_TROW(2, rb_) WN_TROW(3, rb_)                                                       \
-    *reinterpret_cast<f32x4*>(vb_ + 0 * 4 * WN_PLANE) = tt[0] - tt[2];                                                    \
-    *reinterpret_cast<f32x4*>(vb_ + 1 * 4 * WN_PLANE) = tt[1] + tt[2];                                                    \
-    *reinterpret_cast<f32x4*>(vb_ + 2 * 4 * WN_PLANE) = tt[2] - tt[1];                                                    \
-    *reinterpret_cast<f32x4*>(vb_ + 3 * 4 * WN_PLANE) = tt[1] - tt[3];                                                    \
+    *reinterpret_cast<f32x4*>(vb_ + 0 * 4 * WN_PLANE) = WN_PK_SUB(tt[0], tt[2]);                                                    \
+    *reinterpret_cast<f32x4*>(vb_ + 1 * 4 * WN_PLANE) = WN_PK_ADD(tt[1], tt[2]);                                                    \
+    *reinterpret_cast<f32x4*>(vb_ + 2 * 4 * WN_PLANE) = WN_PK_SUB(tt[2], tt[1]);                                                    \
+    *reinterpret_cast<f32x4*>(vb_ + 3 * 4 * WN_PLANE) = WN_PK_SUB(tt[1], tt[3]);                                                    \
   }
 #define WN_LOAD_FRAGS_FROM(XL, BP)                                                                                        \
   {                                                                                                                       \
@@ -357,7 +362,8 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   for (;;) {
     __syncthreads();
     WN_T(0)
-    f32x4 av[2], bv[2], tt[4];                       // (declared per group: nothing of them is carried from one group to the next)
+    f32x4 av[2], bv[2];                              // (declared per group: nothing of them is carried from one group to the next)
+    f32x2 tt[4][2];
     i32x4 dd[2][2];
     f32x16 acc[8];
 #pragma unroll
@@ -385,43 +391,21 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
       float* nxt = WN_BUFOF(ch + 1);
       const float* rb = rawbase + ((ch + 1) & 1) * RAWBUF;
       float* vb = nxt + t_wr;
-#if WN_EXP == 2 || WN_EXP == 3   /* DMA pieces spread over the first half of the chunk (EXP 3: the xh = 1 waves one slice later) */
-#if WN_EXP == 3
-#define WN_DP(A, B) if (xh == 0) { A } else { B }
-#else
-#define WN_DP(A, B) A
-#endif
-#define WN_RAWP(IT) if (ch + 2 < nchunks) { if ((IT) < NR_IT) WN_RAW_PIECE(IT, ch + 2) }
-      WN_M(0, 0, WN_IF_FR(WN_LOAD_FRAGS(1))) WN_M(0, 1, WN_DP(WN_U_PIECE(0, ch + 1, nxt), )) WN_M(0, 2, WN_DP(, WN_U_PIECE(0, ch + 1, nxt))) WN_M(0, 3, )
-      WN_M(1, 0, WN_IF_FR(WN_LOAD_FRAGS(2)) WN_DP(WN_U_PIECE(1, ch + 1, nxt), )) WN_M(1, 1, WN_IF_T(WN_TROW_LD(0, rb) WN_TROW_LD(1, rb))) WN_M(1, 2, WN_DP(, WN_U_PIECE(1, ch + 1, nxt))) WN_M(1, 3, WN_IF_T(WN_TROW_FIN(0) WN_TROW_FIN(1)))
-      WN_M(2, 0, WN_IF_FR(WN_LOAD_FRAGS(3)) WN_DP(WN_U_PIECE(2, ch + 1, nxt), )) WN_M(2, 1, WN_IF_T(WN_TROW_LD(2, rb) WN_TROW_LD(3, rb))) WN_M(2, 2, WN_DP(, WN_U_PIECE(2, ch + 1, nxt))) WN_M(2, 3, WN_IF_T(WN_TROW_FIN(2) WN_TROW_FIN(3)))
-      WN_M(3, 0, WN_IF_FR(WN_LOAD_FRAGS(4)) WN_IF_T(*reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = tt[0] - tt[2];))
-      WN_M(3, 1, WN_IF_T(*reinterpret_cast<f32x4*>(vb + 1 * 4 * WN_PLANE) = tt[1] + tt[2];)) WN_M(3, 2, WN_DP(WN_U_PIECE(3, ch + 1, nxt), )) WN_M(3, 3, WN_DP(, WN_U_PIECE(3, ch + 1, nxt)))
-      WN_M(4, 0, WN_IF_FR(WN_LOAD_FRAGS(5)) WN_IF_T(*reinterpret_cast<f32x4*>(vb + 2 * 4 * WN_PLANE) = tt[2] - tt[1];))
-      WN_M(4, 1, WN_IF_T(*reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = tt[1] - tt[3];)) WN_M(4, 2, WN_DP(WN_RAWP(0), )) WN_M(4, 3, WN_DP(, WN_RAWP(0)))
-      WN_M(5, 0, WN_IF_FR(WN_LOAD_FRAGS(6))) WN_M(5, 1, WN_DP(WN_RAWP(1), )) WN_M(5, 2, WN_DP(, WN_RAWP(1))) WN_M(5, 3, )
-      WN_M(6, 0, WN_IF_FR(WN_LOAD_FRAGS(7))) WN_M(6, 1, ) WN_M(6, 2, ) WN_M(6, 3, )
-#elif WN_EXP == 1          /* all DMA pieces in front of the first fragment reads of the chunk: the wave's LDS queue is empty there */
-      WN_M(0, 0, WN_IF_U(WN_U_ALL(ch + 1, nxt)) WN_IF_RAW(if (ch + 2 < nchunks) WN_RAW_ALL(ch + 2)) WN_IF_FR(WN_LOAD_FRAGS(1))) WN_M(0, 1, ) WN_M(0, 2, ) WN_M(0, 3, )
-#else
-      WN_M(0, 0, WN_IF_FR(WN_LOAD_FRAGS(1))) WN_M(0, 1, WN_IF_U(WN_U_PIECE(0, ch + 1, nxt) WN_U_PIECE(1, ch + 1, nxt)))
-      WN_M(0, 2, WN_IF_U(WN_U_PIECE(2, ch + 1, nxt) WN_U_PIECE(3, ch + 1, nxt)))
+      WN_M(0, 0, WN_IF_FR(WN_LOAD_FRAGS(1))) WN_M(0, 1, WN_IF_U(WN_U_ALL(ch + 1, nxt)))
+      WN_M(0, 2, )
       // raw(ch+2) overwrites raw(ch), which every wave finished reading before the last barrier
       WN_M(0, 3, WN_IF_RAW(if (ch + 2 < nchunks) WN_RAW_ALL(ch + 2)))
-#endif
-#if !(WN_EXP == 2 || WN_EXP == 3)
       // LDS traffic only in the first two slices of a plane, arithmetic in the last two: whatever a plane's first MFMA waits for is then
       // two slices old.  (Laid out when the DMA was a builtin and every LDS wait a full drain, lgkmcnt(0); with the DMA in inline
       // assembly the waits are counted and the layout costs nothing -- measured equal, kept.)
       WN_M(1, 0, WN_IF_FR(WN_LOAD_FRAGS(2))) WN_M(1, 1, WN_IF_T(WN_TROW_LD(0, rb) WN_TROW_LD(1, rb))) WN_M(1, 2, ) WN_M(1, 3, WN_IF_T(WN_TROW_FIN(0) WN_TROW_FIN(1)))
       WN_M(2, 0, WN_IF_FR(WN_LOAD_FRAGS(3))) WN_M(2, 1, WN_IF_T(WN_TROW_LD(2, rb) WN_TROW_LD(3, rb))) WN_M(2, 2, ) WN_M(2, 3, WN_IF_T(WN_TROW_FIN(2) WN_TROW_FIN(3)))
-      WN_M(3, 0, WN_IF_FR(WN_LOAD_FRAGS(4)) WN_IF_T(*reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = tt[0] - tt[2];))
-      WN_M(3, 1, WN_IF_T(*reinterpret_cast<f32x4*>(vb + 1 * 4 * WN_PLANE) = tt[1] + tt[2];)) WN_M(3, 2, ) WN_M(3, 3, )
-      WN_M(4, 0, WN_IF_FR(WN_LOAD_FRAGS(5)) WN_IF_T(*reinterpret_cast<f32x4*>(vb + 2 * 4 * WN_PLANE) = tt[2] - tt[1];))
-      WN_M(4, 1, WN_IF_T(*reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = tt[1] - tt[3];)) WN_M(4, 2, ) WN_M(4, 3, )
+      WN_M(3, 0, WN_IF_FR(WN_LOAD_FRAGS(4)) WN_IF_T(*reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = WN_PK_SUB(tt[0], tt[2]);))
+      WN_M(3, 1, WN_IF_T(*reinterpret_cast<f32x4*>(vb + 1 * 4 * WN_PLANE) = WN_PK_ADD(tt[1], tt[2]);)) WN_M(3, 2, ) WN_M(3, 3, )
+      WN_M(4, 0, WN_IF_FR(WN_LOAD_FRAGS(5)) WN_IF_T(*reinterpret_cast<f32x4*>(vb + 2 * 4 * WN_PLANE) = WN_PK_SUB(tt[2], tt[1]);))
+      WN_M(4, 1, WN_IF_T(*reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = WN_PK_SUB(tt[1], tt[3]);)) WN_M(4, 2, ) WN_M(4, 3, )
       WN_M(5, 0, WN_IF_FR(WN_LOAD_FRAGS(6))) WN_M(5, 1, ) WN_M(5, 2, ) WN_M(5, 3, )
       WN_M(6, 0, WN_IF_FR(WN_LOAD_FRAGS(7))) WN_M(6, 1, ) WN_M(6, 2, ) WN_M(6, 3, )
-#endif
 #if WN_ABL & 32
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else
@@ -471,14 +455,7 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
       WN_SETUP(nextg, lane_e)
       WN_RAW_ALL(0)
       WN_RAW_ALL(min(1, nchunks - 1))
-      unsigned u_gn[NU_IT];
-#pragma unroll
-      for (int it = 0; it < NU_IT; ++it) {
-        const int id = wave * NU_IT + it, xi = id >> 1, kk = (id & 1) * 32 + (lane_e >> 1), slot = lane_e & 1;
-        u_gn[it] = 4u * (unsigned)((xi * a.K + kk) * 8 + ((slot ^ ((kk >> 3) & 1)) * 4));
-      }
-#pragma unroll
-      for (int it = 0; it < NU_IT; ++it) WN_U_PIECE_X(u_gn, it, 0, WN_BUFOF(0))
+      WN_U_ALL(0, WN_BUFOF(0))
     }
 
     // The contribution to the partner's row goes to LDS as soon as it exists (exchange region per (block, direction): 2 x 16 x 64
@@ -569,14 +546,11 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
   }
 #undef WN_BUFOF
 #undef WN_SETUP
-#undef WN_GLDS
-#undef WN_LDSADDR
-#undef WN_U_PIECE
-#undef WN_U_PIECE_X
-#undef WN_RAW_PIECE
 #undef WN_RAW_ALL
 #undef WN_U_ALL
 #undef WN_TROW
+#undef WN_PK_ADD
+#undef WN_PK_SUB
 #undef WN_TROW_LD
 #undef WN_TROW_FIN
 #undef WN_V0
@@ -626,25 +600,28 @@ __global__ __launch_bounds__(256) void k_wino_weights_batch(WinoBatchArgs a) {
     }
   if (u_fwd) {
     wn_weight_transform(g, u);
-    // stage[xi][c / 8][k][c % 8] = the block's share of plane xi in u_fwd's own order: 4 runs (c / 8) of 64 floats
+    // stage[xi][c / 8][k][c % 8] = the block's share of plane xi in u_fwd's own order: 4 runs (c / 8) of 64 floats -- 8 consecutive rows
+    // of one block of 64 (k0 is a multiple of 8: the rows share bit 3, i.e. the swap of their 16-byte halves)
+    const int ef = (((cc >> 2) & 1) ^ ((k0 >> 3) & 1)) * 4 + (cc & 3);
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi) stage[xi * 256 + ((cc >> 3) * 8 + kk) * 8 + (cc & 7)] = u[xi / 4][xi % 4];
+    for (int xi = 0; xi < 16; ++xi) stage[xi * 256 + ((cc >> 3) * 8 + kk) * 8 + ef] = u[xi / 4][xi % 4];
     __syncthreads();
     const int cg = t >> 6, rest = t & 63;
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi)
-      u_fwd[(((size_t)(c0 / 8 + cg) * 16 + xi) * K + k0) * 8 + rest] = stage[xi * 256 + t];
+      u_fwd[wn_u_index(K, c0 / 8 + cg, xi, k0, 0) + rest] = stage[xi * 256 + t];
     __syncthreads();
   }
   if (u_bwd) {
     wn_weight_transform(gf, u);
-    // stage[xi][c][k % 8]: one run of 256 floats per plane
+    // stage[xi][c][k % 8]: one run of 256 floats per plane (32 consecutive rows of one block of 64)
+    const int eb = (((kk >> 2) & 1) ^ (((c0 + cc) >> 3) & 1)) * 4 + (kk & 3);
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi) stage[xi * 256 + cc * 8 + kk] = u[xi / 4][xi % 4];
+    for (int xi = 0; xi < 16; ++xi) stage[xi * 256 + cc * 8 + eb] = u[xi / 4][xi % 4];
     __syncthreads();
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi)
-      u_bwd[(((size_t)(k0 / 8) * 16 + xi) * C + c0) * 8 + t] = stage[xi * 256 + t];
+      u_bwd[wn_u_index(C, k0 / 8, xi, c0, 0) + t] = stage[xi * 256 + t];
   }
 }
 
@@ -662,11 +639,11 @@ extern "C" int dl_wino_weights_batch_f32(const dl_wino_layer* layers, int32_t n,
     a.w[i] = L.w; a.u_fwd[i] = L.u_fwd; a.u_bwd[i] = L.u_bwd; a.K[i] = L.K; a.C[i] = L.C;
     a.first_block[i] = blocks;
     blocks += (L.K / 8) * ((L.C + 31) / 32);
-    tiles = tiles && L.C % 32 == 0;
+    tiles = tiles && L.C % 64 == 0 && L.K % 64 == 0;
   }
   a.first_block[n] = blocks;
   if (tiles) hipLaunchKernelGGL(k_wino_weights_batch, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
-  else                                                 // (no layer of the trunk: 8 <= C < 32 or C % 32 != 0 -- one plain launch per layer)
+  else                                                 // (no layer of the trunk: channel counts that are not multiples of 64 -- one plain launch per layer)
     for (int i = 0; i < n; ++i)
       hipLaunchKernelGGL(k_wino_weights, dim3((layers[i].K * layers[i].C + 255) / 256), dim3(256), 0, (hipStream_t)stream, layers[i].w,
                          layers[i].u_fwd, layers[i].u_bwd, layers[i].K, layers[i].C);
@@ -996,8 +973,6 @@ __device__ __forceinline__ void wino_wgrad_body(const WWArgs& a, const int blk) 
 #define W3_RAWROW (20 * 64)              // floats of one input-patch row: 5 DMA pieces of 4 pixels x 64 channels (18 pixels used)
 #define W3_RAW (4 * W3_RAWROW)
 #define W3_GRAW (2 * 16 * 64)
-
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // (x.lo - y.lo, x.hi + y.lo) and (y.lo - x.hi, x.hi - y.hi): the second row stage of B^T . on the row pairs x = (T0, T1), y = (T2, T3)
 __device__ __forceinline__ f32x2 w3_v01(f32x2 x, f32x2 y) {

@@ -15,7 +15,11 @@
 
 #define CV_TUNE 1
 #include "../delora_amd/csrc/abi.hip"
+#ifdef WINO_SRC                      // A/B against another revision of the kernels: -DWINO_SRC='"/path/to/wino.hip"'
+#include WINO_SRC
+#else
 #include "../delora_amd/csrc/wino.hip"
+#endif
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s:%d %s\n", __FILE__, __LINE__, hipGetErrorString(e_)); exit(2); } } while (0)
 
@@ -152,6 +156,7 @@ static void time_layer(const Shape& s, int reps, std::mt19937& gen, double* sums
   int idx = 0;
   auto run = [&](const char* what, auto fn) {
     if (fn()) { printf("%-22s %-8s unsupported: %s\n", s.name, what, dl_last_error()); return; }
+    for (int i = 0; i < reps; ++i) fn();             // (clocks settle: the first launches after an idle phase run slower)
     CK(hipDeviceSynchronize());
     CK(hipEventRecord(a));
     for (int i = 0; i < reps; ++i) fn();
