@@ -93,10 +93,12 @@ __device__ __forceinline__ void wn_weight_transform(const float (&g)[3][3], floa
 // then a LINEAR copy of 32 KiB -- one per-lane offset (16 lane) for every piece, pieces addressed by immediate offsets from one M0 --
 // instead of a gather with the swizzle in per-lane source offsets and an M0 write per piece.  Row counts that do not divide into blocks
 // of 64 (never consumed by k_wino_conv) keep the plain [chunk][16][rows][8] order.
+__device__ __host__ __forceinline__ size_t wn_u_row(int rows, int chunk, int xi, int r) {           // first float of row r's eight
+  if (rows % 64) return (((size_t)chunk * 16 + xi) * rows + r) * 8;
+  return ((((size_t)chunk * (rows / 64) + (r >> 6)) * 16 + xi) * 64 + (r & 63)) * 8;
+}
 __device__ __host__ __forceinline__ size_t wn_u_index(int rows, int chunk, int xi, int r, int e) {
-  if (rows % 64) return (((size_t)chunk * 16 + xi) * rows + r) * 8 + e;
-  const int rb = r >> 6, rr = r & 63;
-  return ((((size_t)chunk * (rows / 64) + rb) * 16 + xi) * 64 + rr) * 8 + ((((e >> 2) ^ ((rr >> 3) & 1)) << 2) | (e & 3));
+  return wn_u_row(rows, chunk, xi, r) + ((rows % 64) ? e : ((((e >> 2) ^ ((r >> 3) & 1)) << 2) | (e & 3)));
 }
 
 // w [K][3][3][C] -> u_fwd (reduction over c, rows k) and u_bwd (the transposed convolution of the input gradient: taps flipped, channel
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(256) void k_wino_weights_batch(WinoBatchArgs a) {
     const int cg = t >> 6, rest = t & 63;
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi)
-      u_fwd[wn_u_index(K, c0 / 8 + cg, xi, k0, 0) + rest] = stage[xi * 256 + t];
+      u_fwd[wn_u_row(K, c0 / 8 + cg, xi, k0) + rest] = stage[xi * 256 + t];
     __syncthreads();
   }
   if (u_bwd) {
@@ -621,7 +623,7 @@ __global__ __launch_bounds__(256) void k_wino_weights_batch(WinoBatchArgs a) {
     __syncthreads();
 #pragma unroll
     for (int xi = 0; xi < 16; ++xi)
-      u_bwd[wn_u_index(C, k0 / 8, xi, c0, 0) + t] = stage[xi * 256 + t];
+      u_bwd[wn_u_row(C, k0 / 8, xi, c0) + t] = stage[xi * 256 + t];
   }
 }
 

@@ -184,7 +184,10 @@ int main(int argc, char** argv) {
   if (!strcmp(mode, "check")) {
     const Shape small[] = {{"2x8x128 64->64", 2, 8, 128, 64, 64}, {"1x4x64 128->128", 1, 4, 64, 128, 128}, {"2x8x32 64->128", 2, 8, 32, 64, 128},
                            {"1x8x256 128->64", 1, 8, 256, 128, 64}, {"2x6x36 64->64 (ragged)", 2, 6, 36, 64, 64}, {"1x5x46 128->64 (odd)", 1, 5, 46, 128, 64},
-                           {"2x16x64 256->256", 2, 16, 64, 256, 256}};
+                           {"2x16x64 256->256", 2, 16, 64, 256, 256},
+                           // the trunk of a 16x1024 pair at batch 2 (tests/test_gpu_conv.py): split launches, 4-row images
+                           {"2x16x256 64->64", 2, 16, 256, 64, 64}, {"2x16x128 128->128", 2, 16, 128, 128, 128}, {"2x8x64 256->256", 2, 8, 64, 256, 256},
+                           {"2x4x32 512->512", 2, 4, 32, 512, 512}};
     int bad = 0;
     for (const auto& s : small) bad += check(s, gen);
     printf(bad ? "WINO LAB CHECK FAILED (%d)\n" : "WINO LAB CHECK OK\n", bad);
