@@ -128,6 +128,57 @@ __global__ __launch_bounds__(256) void k_wino_weights(const float* __restrict__ 
   }
 }
 
+// x - y and -x - y of sixteen accumulator registers as eight packed instructions each (the compiler emits scalar v_sub_f32 for vector
+// subtractions; outside the chunk loop the vector ALU is what the workgroup waits for)
+#define WN_PK16(MODS)                                                                                                     \
+  f32x2 r0, r1, r2, r3, r4, r5, r6, r7;                                                                                   \
+  asm volatile("v_pk_add_f32 %0, %1, %2 " MODS : "=v"(r0) : "v"(__builtin_shufflevector(x, x, 0, 1)), "v"(__builtin_shufflevector(y, y, 0, 1)));     \
+  asm volatile("v_pk_add_f32 %0, %1, %2 " MODS : "=v"(r1) : "v"(__builtin_shufflevector(x, x, 2, 3)), "v"(__builtin_shufflevector(y, y, 2, 3)));     \
+  asm volatile("v_pk_add_f32 %0, %1, %2 " MODS : "=v"(r2) : "v"(__builtin_shufflevector(x, x, 4, 5)), "v"(__builtin_shufflevector(y, y, 4, 5)));     \
+  asm volatile("v_pk_add_f32 %0, %1, %2 " MODS : "=v"(r3) : "v"(__builtin_shufflevector(x, x, 6, 7)), "v"(__builtin_shufflevector(y, y, 6, 7)));     \
+  asm volatile("v_pk_add_f32 %0, %1, %2 " MODS : "=v"(r4) : "v"(__builtin_shufflevector(x, x, 8, 9)), "v"(__builtin_shufflevector(y, y, 8, 9)));     \
+  asm volatile("v_pk_add_f32 %0, %1, %2 " MODS : "=v"(r5) : "v"(__builtin_shufflevector(x, x, 10, 11)), "v"(__builtin_shufflevector(y, y, 10, 11))); \
+  asm volatile("v_pk_add_f32 %0, %1, %2 " MODS : "=v"(r6) : "v"(__builtin_shufflevector(x, x, 12, 13)), "v"(__builtin_shufflevector(y, y, 12, 13))); \
+  asm volatile("v_pk_add_f32 %0, %1, %2 " MODS : "=v"(r7) : "v"(__builtin_shufflevector(x, x, 14, 15)), "v"(__builtin_shufflevector(y, y, 14, 15))); \
+  const f32x4 a0 = __builtin_shufflevector(r0, r1, 0, 1, 2, 3), a1 = __builtin_shufflevector(r2, r3, 0, 1, 2, 3);         \
+  const f32x4 a2 = __builtin_shufflevector(r4, r5, 0, 1, 2, 3), a3 = __builtin_shufflevector(r6, r7, 0, 1, 2, 3);         \
+  typedef float f32x8_ __attribute__((ext_vector_type(8)));                                                               \
+  const f32x8_ b0 = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7), b1 = __builtin_shufflevector(a2, a3, 0, 1, 2, 3, 4, 5, 6, 7); \
+  return __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+__device__ __forceinline__ f32x16 wn_sub16(f32x16 x, f32x16 y) { WN_PK16("neg_lo:[0,1] neg_hi:[0,1]") }
+__device__ __forceinline__ f32x16 wn_nsub16(f32x16 x, f32x16 y) { WN_PK16("neg_lo:[1,1] neg_hi:[1,1]") }
+#undef WN_PK16
+
+// The stores of a tile group for the flag combinations the network uses (tanh or no activation): compile-time flags, so the eight items of
+// a lane are read, computed and stored in three straight batches instead of eight branchy read -> compute -> store chains.
+template <bool ADD, bool ACT, bool DACT, bool RAG>
+__device__ __forceinline__ void wn_store_items(const float* ep_lane, const f32x4 (&opv)[8], const unsigned (&ooff)[8], float* ysp, const float* add) {
+  f32x4 v[8];
+#pragma unroll
+  for (int it = 0; it < 8; ++it) v[it] = *reinterpret_cast<const f32x4*>(ep_lane + it * 8 * 32);
+  if (ADD && DACT) {
+    f32x4 sc[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) sc[it] = *reinterpret_cast<const f32x4*>(add + ((!RAG || ooff[it] != 0xffffffffu) ? ooff[it] : 0u));
+#pragma unroll
+    for (int it = 0; it < 8; ++it) v[it] += sc[it];
+  } else if (ADD) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) v[it] += opv[it];
+  }
+  if (ACT) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) { v[it][0] = dl_tanh(v[it][0]); v[it][1] = dl_tanh(v[it][1]); v[it][2] = dl_tanh(v[it][2]); v[it][3] = dl_tanh(v[it][3]); }
+  }
+  if (DACT) {
+#pragma unroll
+    for (int it = 0; it < 8; ++it) v[it] *= 1.f - opv[it] * opv[it];
+  }
+#pragma unroll
+  for (int it = 0; it < 8; ++it)
+    if (!RAG || ooff[it] != 0xffffffffu) *reinterpret_cast<f32x4*>(ysp + ooff[it]) = v[it];
+}
+
 // TC tile columns x TR tile rows = 64 tiles per workgroup.
 //
 // Pipeline (one barrier per chunk).  LDS holds two (V, U) buffers and two raw-patch buffers.  While the waves multiply
@@ -351,7 +402,15 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
     __VA_ARGS__                                                                                                           \
     __builtin_amdgcn_sched_barrier(0);                                                                                    \
   }
+  // the first MFMA of a plane in the first chunk of a group: C = 0 (an inline constant: the 128 accumulator registers are never zeroed)
+#define WN_MZ(XL, J, ...)                                                                                                 \
+  {                                                                                                                       \
+    acc[XL] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[(XL) & 1][J], bv[(XL) & 1][J], wn_zero16, 0, 0, 0);                 \
+    __VA_ARGS__                                                                                                           \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+  }
 
+  const f32x16 wn_zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   int grp = blockIdx.x;                              // the launcher guarantees gridDim.x <= ngroups
   WN_SETUP(grp, lane)
   // prologue of the first group: raw(0), raw(1), U(0) -> LDS; V(0) from raw(0)
@@ -367,11 +426,7 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
     f32x4 av[2], bv[2];                              // (declared per group: nothing of them is carried from one group to the next)
     f32x2 tt[4][2];
     i32x4 dd[2][2];
-    f32x16 acc[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    f32x16 acc[8];                                   // (never zeroed: the first MFMA of a plane in the group's first chunk takes C = 0)
     {
       float* cur = WN_BUFOF(0);
       WN_LOAD_FRAGS(0)
@@ -388,46 +443,49 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
     // registers by then, so its four MFMAs run behind the barrier and cover the fetch of the next chunk's first fragments.
     // (Fetching the raw pieces straight into registers -- 8 scattered 16-byte loads per thread and chunk, each 32-byte pixel slice
     // requested by ~4 threads -- measured 15 % slower: the vector-memory path, not the matrix pipe, became the limit.)
-    for (int ch = 0; ch + 1 < nchunks; ++ch) {
-      float* cur = WN_BUFOF(ch);
-      float* nxt = WN_BUFOF(ch + 1);
-      const float* rb = rawbase + ((ch + 1) & 1) * RAWBUF;
-      float* vb = nxt + t_wr;
-      WN_M(0, 0, WN_IF_FR(WN_LOAD_FRAGS(1))) WN_M(0, 1, WN_IF_U(WN_U_ALL(ch + 1, nxt)))
-      WN_M(0, 2, )
-      // raw(ch+2) overwrites raw(ch), which every wave finished reading before the last barrier
-      WN_M(0, 3, WN_IF_RAW(if (ch + 2 < nchunks) WN_RAW_ALL(ch + 2)))
-      // LDS traffic only in the first two slices of a plane, arithmetic in the last two: whatever a plane's first MFMA waits for is then
-      // two slices old.  (Laid out when the DMA was a builtin and every LDS wait a full drain, lgkmcnt(0); with the DMA in inline
-      // assembly the waits are counted and the layout costs nothing -- measured equal, kept.)
-      WN_M(1, 0, WN_IF_FR(WN_LOAD_FRAGS(2))) WN_M(1, 1, WN_IF_T(WN_TROW_LD(0, rb) WN_TROW_LD(1, rb))) WN_M(1, 2, ) WN_M(1, 3, WN_IF_T(WN_TROW_FIN(0) WN_TROW_FIN(1)))
-      WN_M(2, 0, WN_IF_FR(WN_LOAD_FRAGS(3))) WN_M(2, 1, WN_IF_T(WN_TROW_LD(2, rb) WN_TROW_LD(3, rb))) WN_M(2, 2, ) WN_M(2, 3, WN_IF_T(WN_TROW_FIN(2) WN_TROW_FIN(3)))
-      WN_M(3, 0, WN_IF_FR(WN_LOAD_FRAGS(4)) WN_IF_T(*reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = WN_PK_SUB(tt[0], tt[2]);))
-      WN_M(3, 1, WN_IF_T(*reinterpret_cast<f32x4*>(vb + 1 * 4 * WN_PLANE) = WN_PK_ADD(tt[1], tt[2]);)) WN_M(3, 2, ) WN_M(3, 3, )
-      WN_M(4, 0, WN_IF_FR(WN_LOAD_FRAGS(5)) WN_IF_T(*reinterpret_cast<f32x4*>(vb + 2 * 4 * WN_PLANE) = WN_PK_SUB(tt[2], tt[1]);))
-      WN_M(4, 1, WN_IF_T(*reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = WN_PK_SUB(tt[1], tt[3]);)) WN_M(4, 2, ) WN_M(4, 3, )
-      WN_M(5, 0, WN_IF_FR(WN_LOAD_FRAGS(6))) WN_M(5, 1, ) WN_M(5, 2, ) WN_M(5, 3, )
-      WN_M(6, 0, WN_IF_FR(WN_LOAD_FRAGS(7))) WN_M(6, 1, ) WN_M(6, 2, ) WN_M(6, 3, )
-#if WN_ABL & 32
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#endif
-      WN_IF_BAR(__builtin_amdgcn_s_barrier();)
-      __builtin_amdgcn_sched_barrier(0);
-      WN_M(7, 0, WN_IF_FR(WN_LOAD_FRAGS_FROM(0, nxt))) WN_M(7, 1, ) WN_M(7, 2, ) WN_M(7, 3, )
+#define WN_CHUNK_BODY(MF)                                                                                                 \
+    {                                                                                                                     \
+      float* cur = WN_BUFOF(ch);                                                                                          \
+      float* nxt = WN_BUFOF(ch + 1);                                                                                      \
+      const float* rb = rawbase + ((ch + 1) & 1) * RAWBUF;                                                                \
+      float* vb = nxt + t_wr;                                                                                             \
+      MF(0, 0, WN_IF_FR(WN_LOAD_FRAGS(1))) WN_M(0, 1, WN_IF_U(WN_U_ALL(ch + 1, nxt)))                                     \
+      WN_M(0, 2, )                                                                                                        \
+      /* raw(ch+2) overwrites raw(ch), which every wave finished reading before the last barrier */                      \
+      WN_M(0, 3, WN_IF_RAW(if (ch + 2 < nchunks) WN_RAW_ALL(ch + 2)))                                                     \
+      /* LDS reads in the first two slices of a plane, arithmetic in the last two: whatever a plane's first MFMA waits for is two slices old */ \
+      MF(1, 0, WN_IF_FR(WN_LOAD_FRAGS(2))) WN_M(1, 1, WN_IF_T(WN_TROW_LD(0, rb) WN_TROW_LD(1, rb))) WN_M(1, 2, ) WN_M(1, 3, WN_IF_T(WN_TROW_FIN(0) WN_TROW_FIN(1))) \
+      MF(2, 0, WN_IF_FR(WN_LOAD_FRAGS(3))) WN_M(2, 1, WN_IF_T(WN_TROW_LD(2, rb) WN_TROW_LD(3, rb))) WN_M(2, 2, ) WN_M(2, 3, WN_IF_T(WN_TROW_FIN(2) WN_TROW_FIN(3))) \
+      MF(3, 0, WN_IF_FR(WN_LOAD_FRAGS(4)) WN_IF_T(*reinterpret_cast<f32x4*>(vb + 0 * 4 * WN_PLANE) = WN_PK_SUB(tt[0], tt[2]);))   \
+      WN_M(3, 1, WN_IF_T(*reinterpret_cast<f32x4*>(vb + 1 * 4 * WN_PLANE) = WN_PK_ADD(tt[1], tt[2]);)) WN_M(3, 2, ) WN_M(3, 3, ) \
+      MF(4, 0, WN_IF_FR(WN_LOAD_FRAGS(5)) WN_IF_T(*reinterpret_cast<f32x4*>(vb + 2 * 4 * WN_PLANE) = WN_PK_SUB(tt[2], tt[1]);))   \
+      WN_M(4, 1, WN_IF_T(*reinterpret_cast<f32x4*>(vb + 3 * 4 * WN_PLANE) = WN_PK_SUB(tt[1], tt[3]);)) WN_M(4, 2, ) WN_M(4, 3, ) \
+      MF(5, 0, WN_IF_FR(WN_LOAD_FRAGS(6))) WN_M(5, 1, ) WN_M(5, 2, ) WN_M(5, 3, )                                         \
+      MF(6, 0, WN_IF_FR(WN_LOAD_FRAGS(7))) WN_M(6, 1, ) WN_M(6, 2, ) WN_M(6, 3, )                                         \
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                                         \
+      WN_IF_BAR(__builtin_amdgcn_s_barrier();)                                                                            \
+      __builtin_amdgcn_sched_barrier(0);                                                                                  \
+      MF(7, 0, WN_IF_FR(WN_LOAD_FRAGS_FROM(0, nxt))) WN_M(7, 1, ) WN_M(7, 2, ) WN_M(7, 3, )                               \
     }
-    {
-      float* cur = WN_BUFOF(nchunks - 1);
-      WN_M(0, 0, WN_LOAD_FRAGS(1)) WN_M(0, 1, ) WN_M(0, 2, ) WN_M(0, 3, )
-      WN_M(1, 0, WN_LOAD_FRAGS(2)) WN_M(1, 1, ) WN_M(1, 2, ) WN_M(1, 3, )
-      WN_M(2, 0, WN_LOAD_FRAGS(3)) WN_M(2, 1, ) WN_M(2, 2, ) WN_M(2, 3, )
-      WN_M(3, 0, WN_LOAD_FRAGS(4)) WN_M(3, 1, ) WN_M(3, 2, ) WN_M(3, 3, )
-      WN_M(4, 0, WN_LOAD_FRAGS(5)) WN_M(4, 1, ) WN_M(4, 2, ) WN_M(4, 3, )
-      WN_M(5, 0, WN_LOAD_FRAGS(6)) WN_M(5, 1, ) WN_M(5, 2, ) WN_M(5, 3, )
-      WN_M(6, 0, WN_LOAD_FRAGS(7)) WN_M(6, 1, ) WN_M(6, 2, ) WN_M(6, 3, )
-      WN_M(7, 0, ) WN_M(7, 1, ) WN_M(7, 2, ) WN_M(7, 3, )
+#define WN_TAIL_BODY(MF)                                                                                                  \
+    {                                                                                                                     \
+      float* cur = WN_BUFOF(nchunks - 1);                                                                                 \
+      MF(0, 0, WN_LOAD_FRAGS(1)) WN_M(0, 1, ) WN_M(0, 2, ) WN_M(0, 3, )                                                   \
+      MF(1, 0, WN_LOAD_FRAGS(2)) WN_M(1, 1, ) WN_M(1, 2, ) WN_M(1, 3, )                                                   \
+      MF(2, 0, WN_LOAD_FRAGS(3)) WN_M(2, 1, ) WN_M(2, 2, ) WN_M(2, 3, )                                                   \
+      MF(3, 0, WN_LOAD_FRAGS(4)) WN_M(3, 1, ) WN_M(3, 2, ) WN_M(3, 3, )                                                   \
+      MF(4, 0, WN_LOAD_FRAGS(5)) WN_M(4, 1, ) WN_M(4, 2, ) WN_M(4, 3, )                                                   \
+      MF(5, 0, WN_LOAD_FRAGS(6)) WN_M(5, 1, ) WN_M(5, 2, ) WN_M(5, 3, )                                                   \
+      MF(6, 0, WN_LOAD_FRAGS(7)) WN_M(6, 1, ) WN_M(6, 2, ) WN_M(6, 3, )                                                   \
+      MF(7, 0, ) WN_M(7, 1, ) WN_M(7, 2, ) WN_M(7, 3, )                                                                   \
     }
+    if (nchunks > 1) {
+      { const int ch = 0; WN_CHUNK_BODY(WN_MZ) }
+      for (int ch = 1; ch + 1 < nchunks; ++ch) WN_CHUNK_BODY(WN_M)
+      WN_TAIL_BODY(WN_M)
+    } else WN_TAIL_BODY(WN_MZ)
+#undef WN_CHUNK_BODY
+#undef WN_TAIL_BODY
     __syncthreads();                                 // every wave is done with the staging buffers
     WN_T(1)
 
@@ -438,15 +496,20 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
     const int li_e = lane_e & 31, half_e = lane_e >> 5;
     // Output offsets of this lane's eight epilogue items (item i = lane + 64 it: row = i >> 3 = tile_in_block * 2 + q, channel
     // quad i & 7), taken before the group variables move on
+    // (round 6: item it = tile 4 (8 mb + it) + (lane >> 4) of the block, pixel column q = (lane >> 3) & 1: the tile's row / column of the group
+    // and the image row are wave-uniform -- scalar arithmetic -- and the lane contributes one offset that is the same for all eight items;
+    // the generic per-item div / mod cost ~140 vector instructions per group, and outside the chunk loop the vector ALU is the bottleneck)
     unsigned ooff[8];                                // (element offsets fit 31 bits: checked by the entry point)
+    {
+      const int lcol = (lane_e >> 4) * 2 + ((lane_e >> 3) & 1);          // pixel column of the lane relative to its item's first tile
+      const unsigned lane_off = (unsigned)(lcol * a.K + (lane_e & 7) * 4);
 #pragma unroll
-    for (int it = 0; it < 8; ++it) {
-      const int i = lane_e + it * 64, row = i >> 3, c4 = i & 7;
-      const int tile = mb * 32 + (row >> 1), q = row & 1;
-      const int tr = tile / TC, tc = tile % TC;
-      const int oh = (gh * TR + tr) * 2 + xh, ow = (gw * TC + tc) * 2 + q;
-      ooff[it] = (unsigned)(((n * a.H + oh) * a.W + ow) * a.K + k0 + nb * 32 + c4 * 4);
-      if (RAG && (oh >= a.H || ow >= a.W)) ooff[it] = 0xffffffffu;       // a surplus pixel (offsets are below 2^31)
+      for (int it = 0; it < 8; ++it) {
+        const int ut = 4 * (mb * 8 + it), tr = ut / TC, tc = ut % TC;   // (uniform)
+        const int oh = (gh * TR + tr) * 2 + xh, ow0 = (gw * TC + tc) * 2;
+        ooff[it] = (unsigned)(((n * a.H + oh) * a.W + ow0) * a.K + k0 + nb * 32) + lane_off;
+        if (RAG && (oh >= a.H || ow0 + lcol >= a.W)) ooff[it] = 0xffffffffu;       // a surplus pixel (offsets are below 2^31)
+      }
     }
     if (SPLIT) ysp = a.y + (size_t)(cb / nchunks) * ((size_t)a.N * a.H * a.W * a.K);
     // The first operands of the NEXT group are requested now: raw(0), raw(1) into the raw buffers, U(0) into the upper (V, U) buffer --
@@ -472,10 +535,10 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
       for (int q = 0; q < 2; ++q) {
         f32x16 p0, p1;                                  // P[2xh][q], P[2xh+1][q]
         if (q == 0) { p0 = acc[0] + acc[1] + acc[2]; p1 = acc[4] + acc[5] + acc[6]; }
-        else        { p0 = acc[1] - acc[2] - acc[3]; p1 = acc[5] - acc[6] - acc[7]; }
+        else        { p0 = wn_sub16(wn_sub16(acc[1], acc[2]), acc[3]); p1 = wn_sub16(wn_sub16(acc[5], acc[6]), acc[7]); }
         f32x16 snd;
         if (xh == 0) { keep[q] = p0 + p1; snd = p1; }              // rows 0,1: Y0 += P0 + P1, Y1 += P1
-        else         { keep[q] = -p0 - p1; snd = p0; }             // rows 2,3: Y0 += P2,      Y1 += -P2 - P3
+        else         { keep[q] = wn_nsub16(p0, p1); snd = p0; }    // rows 2,3: Y0 += P2,      Y1 += -P2 - P3
 #pragma unroll
         for (int r = 0; r < 16; ++r) dst[(q * 16 + r) * 64] = snd[r];
         __builtin_amdgcn_sched_barrier(0);
@@ -525,6 +588,12 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
     }
     WN_T(3)
     const bool tanh_act = a.act == 1;
+    if (tanh_act || !(f_act || f_dact)) {
+      const float* epl = ep + (lane_e >> 3) * ES + (lane_e & 7) * 4;
+      if (f_dact) { if (f_add) wn_store_items<true, false, true, RAG>(epl, opv, ooff, ysp, a.add); else wn_store_items<false, false, true, RAG>(epl, opv, ooff, ysp, a.add); }
+      else if (f_act) { if (f_add) wn_store_items<true, true, false, RAG>(epl, opv, ooff, ysp, a.add); else wn_store_items<false, true, false, RAG>(epl, opv, ooff, ysp, a.add); }
+      else { if (f_add) wn_store_items<true, false, false, RAG>(epl, opv, ooff, ysp, a.add); else wn_store_items<false, false, false, RAG>(epl, opv, ooff, ysp, a.add); }
+    } else
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int i = lane_e + it * 64, row = i >> 3, c4 = i & 7;
@@ -559,6 +628,7 @@ __global__ __launch_bounds__(WN_THREADS) void k_wino_conv(WinoArgs a) {
 #undef WN_LOAD_FRAGS
 #undef WN_LOAD_FRAGS_FROM
 #undef WN_M
+#undef WN_MZ
 }
 
 // The same transform for up to DL_WINO_BATCH layers in ONE launch (the 13 stride-1 layers of the trunk took 13 launches of
