@@ -69,6 +69,7 @@ class GraphedStep:
         for p_, st in trainer.optimizer.state.items():           # steps taken so far were counted on the host
             if torch.is_tensor(st.get("step")) and not st["step"].is_cuda:
                 st["step"] = st["step"].to(p_.device)
+        snapshot = None
         try:
             self.pack(example_batch)
             snapshot = self._snapshot() if restore_after_warmup else None
@@ -86,7 +87,7 @@ class GraphedStep:
             torch.cuda.current_stream().wait_stream(side)
             if snapshot is not None:
                 self._restore(snapshot)
-                del snapshot
+                snapshot = None
             torch.cuda.synchronize()
             if os.environ.get("DL_GRAPH_DEBUG"):
                 print("[graph_step] warm-up on the side stream finished; capturing", flush=True)
@@ -104,6 +105,22 @@ class GraphedStep:
             print(f"[delora_amd] HIP graph capture of the step failed ({type(e).__name__}: {e}); running eagerly")
             self.graph = None
             torch.cuda.synchronize()
+            # (advisor, round 5) a failure in the warm-up or the capture set-up must not leave the warm-up's real steps behind: weights
+            # and Adam moments go back to where the caller had them, and the optimiser back to its eager form
+            if snapshot is not None:
+                self._restore(snapshot)
+                torch.cuda.synchronize()
+            self.release_optimizer()
+
+    def release_optimizer(self):
+        """Undo what a capture asked of the optimiser (`capturable`, step counters on the device): the eager step and the checkpoints
+        it writes are then those of a trainer that never built a graph.  Called when a capture fails or is dropped again."""
+        opt = self.trainer.optimizer
+        for group in opt.param_groups:
+            group["capturable"] = False
+        for st in opt.state.values():
+            if torch.is_tensor(st.get("step")) and st["step"].is_cuda:
+                st["step"] = st["step"].detach().to("cpu")
 
     @staticmethod
     def _metric_vector(ep):

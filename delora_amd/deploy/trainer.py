@@ -81,16 +81,17 @@ class Trainer(deployer.Deployer):
 
     # ------------------------------------------------------------------------------------------ eager step or replayed graph
     def graph_policy(self):
-        """config ``hip_graph``: ``true`` -> every eligible step is replayed as one captured HIP graph, ``false`` -> eager, ``"auto"``
-        (the default, also when the key is absent -- the reference's YAML does not have it) -> MEASURE: the first eager steps of a
-        training phase are timed, and the step is captured when the host needs as long per step as the GPU does.  That is the
-        reference's own default operating point -- ``batch_size: 1`` on 64x720 images (config/hyperparameters.yaml:3,
-        config_datasets.yaml:21): ~120 launches, 2.3 ms to enqueue for 2.3 ms of GPU work, plus the loader -- and not BASELINE's
-        64x2048, batch 8 (2.4 ms of enqueue for a 13.8 ms step: capture buys nothing there and stays off)."""
+        """config ``hip_graph``: ``true`` -> every eligible step is replayed as one captured HIP graph; ``false`` (the default, also when
+        the key is absent -- the reference's YAML does not have it) -> eager; ``"auto"`` -> MEASURE: the first eager steps of a training
+        phase are timed and the step is captured when the host needs as long per step as the GPU does (the reference's default operating
+        point, ``batch_size: 1`` on 64x720: ~120 launches, 2.3 ms to enqueue for 2.3 ms of GPU work), then timed again and kept only if
+        the replay is faster.  Round 6 (advisor): `auto` is opt-in -- its decision depends on wall-clock measurements, a captured Adam step
+        differs from the eager one by an ulp, and a training run's trajectory must not depend on how busy the host was; what the default
+        gives up is the 2 % the replay bought at batch 1 (2.31 -> 2.26 ms)."""
         from .graph_step import GraphedStep
         if getattr(self.device, "type", "cpu") != "cuda" or not GraphedStep.config_eligible(self):
             return "off"
-        v = self.config.get("hip_graph", "auto")
+        v = self.config.get("hip_graph", False)
         if isinstance(v, str):
             v = v.strip().lower()
         if v in (True, 1, "true", "on", "yes"):
@@ -154,6 +155,9 @@ class Trainer(deployer.Deployer):
         policy = self.graph_policy()
         if not hasattr(self, "_graph_decision"):
             self._graph_decision, self._graph_probe, self.graph_probe_result = {}, {}, {}
+        self._graph_probe.clear()            # a measurement never spans an epoch boundary (checkpoint / logging time is not the step's period)
+        if hasattr(self, "_graph_trial"):
+            self._graph_trial = {k: [] for k in self._graph_trial}
         self.graph_steps = getattr(self, "graph_steps", 0)
         if getattr(self, "_graphed", None) is not None:
             self._graphed.take_epoch_sums()             # (steps replayed outside an epoch, e.g. by a caller's own loop)
@@ -194,6 +198,12 @@ class Trainer(deployer.Deployer):
             self._graphed_phase = phase
             if self.graph_policy() == "auto" and g.captured:
                 self.__dict__.setdefault("_graph_trial", {})[phase] = []      # start times of the first replayed steps (_judge_replay)
+            if self.graph_policy() == "auto" and not g.captured:
+                # a failed capture ends the experiment for this phase: plain eager steps from the caller's own batches, not eager steps
+                # through the capture's full-capacity static buffers
+                self._graph_decision[phase] = "eager"
+                self.graph_probe_result.setdefault(phase, {})["decision"] = "eager (capture failed)"
+                self._graphed = None
             if self.rank == 0:
                 print(f"[delora_amd] training step captured as a HIP graph: {g.captured} ({'unsupervised' if phase else 'identity'} phase, "
                       f"{g.capacity} points per scan)")
@@ -202,6 +212,9 @@ class Trainer(deployer.Deployer):
         if trial is not None:
             import time
             trial.append(time.perf_counter())
+        if not g.captured and getattr(self, "_graphed", None) is None:       # (auto: the capture just failed, see above)
+            self.optimizer.zero_grad(set_to_none=True)
+            return self.step(preprocessed_dicts=preprocessed_dicts, epoch_losses=epoch_losses, log_images_bool=False)[0]
         ep, _ = g(preprocessed_dicts)
         replayed = g.replayed_steps - before
         self.graph_steps += replayed
@@ -231,6 +244,7 @@ class Trainer(deployer.Deployer):
         if not keep:
             self._graph_decision[phase] = "eager"
             self._fold_pending = self._graphed.take_epoch_sums()      # metrics of the replayed steps: folded into the running epoch
+            self._graphed.release_optimizer()                         # eager steps and checkpoints in the non-graph form again
             del self._graphed
             self._graphed = None
         if self.rank == 0:

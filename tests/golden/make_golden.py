@@ -507,7 +507,7 @@ def _run_reference_step(cfg, state, picks):
 
 def fx_step_full(out):
     """The reference's Trainer.step (src/deploy/deployer.py:237-375) at FULL size with the FULL 11.9 M-parameter network: 64x2048 B=1 and
-    B=2, 128x2048 B=1.  Inputs and weights come from the portable generators of delora_amd/data/synthetic.py (bit-identical on every
+    B=2, B=8 (BASELINE configs[1]), 128x2048 B=1.  Inputs and weights come from the portable generators of delora_amd/data/synthetic.py (bit-identical on every
     machine; their sha256 is part of the fixture), so the fixture holds only results: poses, loss scalars, per-parameter gradient
     norms, the Adam update, pair counts."""
     import models.model as rmodel
@@ -515,7 +515,11 @@ def fx_step_full(out):
     for name, (H, W, vfov_deg, n_pts, seeds) in {
             "step_full_64_b1": (64, 2048, None, 150000, [7101]),
             "step_full_64_b2": (64, 2048, None, 150000, [7102, 7103]),
-            "step_full_128_b1": (128, 2048, (-22.5, 22.5), 260000, [7104])}.items():
+            "step_full_128_b1": (128, 2048, (-22.5, 22.5), 260000, [7104]),
+            # BASELINE configs[1] itself: the (B-j)/B accumulation over EIGHT samples through the full network (deployer.py:290-332)
+            "step_full_64_b8": (64, 2048, None, 150000, [7110 + j for j in range(8)])}.items():
+        if os.environ.get("DELORA_GOLDEN_ONLY") and name not in os.environ["DELORA_GOLDEN_ONLY"].split(","):
+            continue
         B = len(seeds)
         with tempfile.TemporaryDirectory() as tmp:
             cfg = reference_config(H, W, unsupervised_at_start=True, inference_only=False, batch_size=B, store_dataset_in_RAM=False)

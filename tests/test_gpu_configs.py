@@ -580,10 +580,10 @@ def test_ddp_all_reduce_overlaps_the_trunk_backward():
 
 
 # ------------------------------------------------------- the reference's own Trainer.step at full size (full-size digests)
-@pytest.mark.parametrize("name", ["step_full_64_b1", "step_full_64_b2", "step_full_128_b1", "step_b8_small"])
+@pytest.mark.parametrize("name", ["step_full_64_b1", "step_full_64_b2", "step_full_64_b8", "step_full_128_b1", "step_b8_small"])
 def test_step_matches_the_references_own_trainer_step(name):
     """tests/golden/step_full_*.npz hold what the REFERENCE's `Trainer.step` (src/deploy/deployer.py:237-375) produced at 64x2048
-    (B=1, B=2) and 128x2048 (B=1) with the FULL 11.9 M-parameter network, and at B=8 on the small network: poses, the five loss
+    (B=1, B=2 and B=8 = BASELINE configs[1], the bench's own batch) and 128x2048 (B=1) with the FULL 11.9 M-parameter network, and at B=8 on the small network: poses, the five loss
     scalars, the 30 per-parameter gradient norms, the Adam update, pair counts.  Inputs and weights are regenerated here from seeds
     by the portable generators and sha-checked against the fixture, so the HIP path (stored normal lists through the projection,
     HIP stem + trunk, search, loss, backward, Adam) is tied to the reference DIRECTLY at full width, not through the narrow module."""
@@ -662,9 +662,12 @@ def test_run_training_cli_with_the_unmodified_yaml_takes_the_hip_path_and_the_gr
     from delora_amd.data import synthetic
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     shutil.copytree(os.path.join(root, "config"), tmp_path / "config")
+    opt = tmp_path / "config" / "deployment_options.yaml"
     if workers:
-        opt = tmp_path / "config" / "deployment_options.yaml"
-        opt.write_text(opt.read_text().replace("num_dataloader_workers: 0", f"num_dataloader_workers: {workers}"))
+        opt.write_text(opt.read_text().replace("num_dataloader_workers: 0", f"num_dataloader_workers: {workers}")
+                       + "\nhip_graph: auto\n")             # the opt-in measuring policy (round 6: eager is the default) ...
+    else:
+        assert "hip_graph" not in opt.read_text()              # ... and the YAML exactly as shipped: eager steps
     rng = np.random.default_rng(0)
     for seq in range(9):                                               # training_identifiers 0..8 of the kitti block
         scans, _ = synthetic.make_sequence(100 + seq, 3, rings=64, azimuth_steps=200)
@@ -680,21 +683,24 @@ def test_run_training_cli_with_the_unmodified_yaml_takes_the_hip_path_and_the_gr
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "MODULE path" not in r.stdout, "the unmodified YAML (64x720) must run on the HIP stem + trunk"
     assert r.stdout.count("Epoch Summary") == 2 and "nan" not in r.stdout.lower()
-    # `hip_graph: auto` (the key is absent from the YAML) must have MEASURED the default operating point -- batch 1: ~100 launches whose
-    # enqueue time is of the order of their GPU time -- and said what it decided; when it found the step host-bound, the rest of the
-    # two epochs must have been replayed as a captured graph, from the in-process packed feed (workers 0) and from worker processes (2)
+    # With `hip_graph: auto` added (the 2-worker run) the loop must have MEASURED the default operating point -- batch 1: ~100 launches whose
+    # enqueue time is of the order of their GPU time -- and said what it decided; when it found the step host-bound, the rest of the two
+    # epochs must have been replayed as a captured graph, fed from worker processes.  The YAML as shipped (0 workers) takes eager steps.
     import re
-    m = re.search(r"hip_graph auto \(identity phase\): the host needs ([0-9.]+) ms per step .* the stream ([0-9.]+) ms -> the step is (host|GPU)-bound", r.stdout)
-    assert m, r.stdout[-3000:]
-    util.measured(f"unmodified YAML through the CLI ({workers} workers): host period / stream time of the batch-1 step (>= 0.8: replayed as a graph)",
-                  float(m.group(1)) / float(m.group(2)), bound=50.0)
     replayed = [int(x) for x in re.findall(r"steps replayed as a HIP graph so far: (\d+)", r.stdout)]
     assert len(replayed) == 2
-    if m.group(3) == "host":
-        assert "training step captured as a HIP graph: True" in r.stdout, r.stdout[-3000:]
-        assert replayed[-1] >= 4, replayed             # 36 steps - 16 probe steps (twice, should the phase change after epoch 0)
+    if not workers:
+        assert "hip_graph auto" not in r.stdout and replayed[-1] == 0, r.stdout[-3000:]
     else:
-        assert replayed[-1] == 0, replayed
+        m = re.search(r"hip_graph auto \(identity phase\): the host needs ([0-9.]+) ms per step .* the stream ([0-9.]+) ms -> the step is (host|GPU)-bound", r.stdout)
+        assert m, r.stdout[-3000:]
+        util.measured(f"YAML + `hip_graph: auto` through the CLI ({workers} workers): host period / stream time of the batch-1 step (>= 0.8: replayed as a graph)",
+                      float(m.group(1)) / float(m.group(2)), bound=50.0)
+        if m.group(3) == "host" and "capture of the step failed" not in r.stdout:
+            assert "training step captured as a HIP graph: True" in r.stdout, r.stdout[-3000:]
+            assert replayed[-1] >= 4 or "back to the eager step" in r.stdout, replayed
+        elif m.group(3) == "GPU":
+            assert replayed[-1] == 0, replayed
     ck = torch.load("/tmp/dropin_latest_checkpoint.pth", map_location="cpu", weights_only=False)
     assert ck["epoch"] == 1 and ck["parameters"]["kitti"]["horizontal_cells"] == 720 and len(ck["model_state_dict"]) == 30
     for name in ("dropin_latest_checkpoint.pth", "dropin_checkpoint_epoch_0.pth"):

@@ -337,7 +337,7 @@ def test_training_from_the_on_disk_format_through_the_packed_feed(tmp_path, with
 
 @pytest.mark.parametrize("feed_kind", ["dataloader", "packed-in-process", "packed-2-workers", "packed-in-process-reverted"])
 def test_product_loop_switches_to_graph_replay_and_keeps_the_trajectory(tmp_path, feed_kind):
-    """`hip_graph: auto` (the default) in the product loop, on the reference's default batch size 1 with the full-width network on the HIP
+    """`hip_graph: auto` (opt-in since round 6) in the product loop, on the reference's default batch size 1 with the full-width network on the HIP
     path: `Trainer.train_epoch` times its first eager steps, decides (forced here by `hip_graph_auto_threshold: 0`), captures the step
     in the MIDDLE of an epoch -- the capture's warm-up steps are rolled back -- and replays every later batch, from the DataLoader
     (`packed_feed: false`: lists of dicts packed scan by scan) and from the packed feed (in-process and with two workers: a

@@ -888,8 +888,8 @@ def test_relative_pose_errors_known_answers():
 
 
 def test_graph_policy_reads_the_config_key():
-    """Trainer.graph_policy: `hip_graph` absent = "auto" (measure and decide), true / false force it, and a configuration a capture
-    cannot serve (augmentation, range normalisation, several ranks, fp16 loss scaling) or a CPU run is always eager."""
+    """Trainer.graph_policy: `hip_graph` absent = eager (round 6: a training trajectory must not depend on wall-clock measurements;
+    "auto" = measure and decide is opt-in), true / false force it, and a configuration a capture cannot serve (augmentation, range normalisation, several ranks, fp16 loss scaling) or a CPU run is always eager."""
     from delora_amd.deploy.trainer import Trainer
 
     class T(Trainer):
@@ -897,7 +897,7 @@ def test_graph_policy_reads_the_config_key():
             self.config, self.device, self.world_size, self.grad_scaler = config, torch.device(device), world, scaler
 
     base = {"normalization_scaling": False, "random_point_cloud_rotations": False, "use_jit": False}
-    assert T(dict(base)).graph_policy() == "auto"
+    assert T(dict(base)).graph_policy() == "off"
     for v, want in ((True, "on"), ("true", "on"), (False, "off"), ("off", "off"), ("auto", "auto"), ("Auto", "auto")):
         assert T(dict(base, hip_graph=v)).graph_policy() == want, v
     assert T(dict(base, hip_graph=True), device="cpu").graph_policy() == "off"

@@ -139,7 +139,7 @@ def test_losses_po2po_alone():
         orc.icp_losses(src, src_n, tgt, tgt_n, po2po_alone=True)
 
 
-@pytest.mark.parametrize("name", ["step_b8_small", "step_full_64_b1"])
+@pytest.mark.parametrize("name", ["step_b8_small", "step_full_64_b1", "step_full_64_b8"])
 def test_step_losses_from_portable_inputs(name):
     """Fixtures whose inputs are regenerated from seeds (sha-checked): the reference's Trainer.step at B=8 (weights (B-j)/B over a long
     batch) and at the FULL image size 64x2048 with the full network -- the oracle, given the reference's poses, reproduces the
