@@ -43,7 +43,7 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X_MICROARCH.md: dense bf16 / fp16 matrix
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="scan pairs per GPU per step")
     ap.add_argument("--height", type=int, default=64)
@@ -1011,6 +1011,15 @@ def main():
     identity_pretrained_state(trainer.raw_model)
     trace("trainer built")
     counter = {"i": 0}
+    # N > 1: the gradient all-reduce is the path's only exchange; its timeline (per bucket: handed over / completed; the part that is not
+    # hidden behind the backward pass) is recorded in a pass of its own AFTER the timed steps (deploy/ddp_trace.py).  The hook is
+    # registered now -- DistributedDataParallel takes one hook per model -- and does what the default one does (divide, all-reduce).
+    timeline = None
+    if world > 1:
+        from delora_amd.deploy.ddp_trace import DdpTimeline
+        timeline = DdpTimeline()
+        timeline.enabled = False
+        timeline.attach(trainer.model, last_grad_param=trainer.raw_model.resnet.conv1.weight)
 
     def run_step(batch=None):
         if batch is None:
@@ -1019,7 +1028,11 @@ def main():
         trainer.optimizer.zero_grad(set_to_none=True)
         ep = trainer.new_epoch_losses()
         from delora_amd.deploy.step_geometry import PackedBatch
+        if timeline is not None:
+            timeline.begin_step()
         ep, T = trainer.step(preprocessed_dicts=batch if isinstance(batch, PackedBatch) else [dict(s) for s in batch], epoch_losses=ep)
+        if timeline is not None:
+            timeline.end_step()
         return ep
 
     # Priming (set-up, not warm-up): one step on each of the distinct ragged batches, so that torch's caching allocator has seen every
@@ -1099,8 +1112,10 @@ def main():
     # (492 pairs/s against 545 with --no-profile, same box, back to back).  The timed region therefore carries events in every
     # EVENT_EVERY-th step only (dl_profile_pause in between): 5 of the default 20 steps, 130 Winograd launches.  The 5 ms autocast
     # step and a DDP rank have no slack at all: there the K timed steps carry no events and the rooflines come from a second pass.
+    # Round 6: the K timed steps of the headline carry NO events in any mode (review: event-carrying launches perturbed exactly the number
+    # being reported); the rooflines are read from a second pass over the same steps.
     EVENT_EVERY = 4
-    in_timed = not args.amp and world == 1
+    in_timed = False
     evented = {"steps": 0}
 
     def run_step_sampled():
@@ -1128,6 +1143,24 @@ def main():
     if can_profile:
         conv_prof, untimed = _lib.profile_end()
         assert untimed == 0, f"{untimed} launches were not timed: raise the profile capacity"
+    ddp_timeline = None
+    if timeline is not None:
+        timeline.enabled = True
+        n_tl = max(4, min(16, args.steps))
+        timed_region(n_tl, run_step)
+        timeline.enabled = False
+        mine = timeline.summary(last=n_tl)
+        mine["rank"] = rank
+        mine["feed_wait_ms_per_step"] = 0.0          # the timed steps read HBM-resident batches; the disk-fed legs (N = 1) measure the feed
+        every = [None] * world
+        torch.distributed.all_gather_object(every, mine)
+        ex = [r.get("exposed_allreduce_ms") for r in every if r.get("exposed_allreduce_ms") is not None]
+        ddp_timeline = {"steps": n_tl, "exposed_allreduce_ms": ({"min": min(ex), "max": max(ex), "mean": round(sum(ex) / len(ex), 3)} if ex else None),
+                        "per_rank": every,
+                        "note": "a pass of its own after the timed steps: per bucket of the gradient all-reduce the time it was handed over and the "
+                                "time it completed (ms from the start of the step, HIP events), the end of the backward computation (the stem's first "
+                                "convolution receives its gradient last), and exposed = completion of the last bucket - end of the backward computation"}
+        trace("DDP timeline recorded")
     final_loss = float(ep["loss_epoch"])
     pairs = world * args.batch * args.steps
     ranks_seen = torch.distributed.get_world_size() if world > 1 else 1
@@ -1148,6 +1181,7 @@ def main():
         "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if world > 1 and backend == "nccl" else None),
         "visible_gpus": torch.cuda.device_count(),
         "rank_ms_per_step": ({"min": min(rank_ms), "max": max(rank_ms), "per_rank": rank_ms} if rank_ms else None),
+        "ddp_timeline": ddp_timeline,
     }
     if rank == 0:
         rows, counts = kernel_table(trainer, batches[0], args.kernel_reps)

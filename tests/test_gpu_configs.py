@@ -428,6 +428,44 @@ def test_bench_eight_ranks_dry_run_on_one_gpu():
     assert len(rk["per_rank"]) == 8 and 0 < rk["min"] <= rk["max"] <= j["ms_per_step"] * 1.001 + 1e-3
     assert j["scaling"] == "weak" and j["steps"] == 3 and np.isfinite(j["final_loss"]) and j["value"] > 0
     assert "cpu_baseline" not in j and "shipped_config" not in j and "hip trunk" in j["config"]["cnn_impl"]
+    # round 6: what the first real scaling run needs to explain itself -- per rank, the timeline of the gradient all-reduce
+    tl = j["ddp_timeline"]
+    assert tl and len(tl["per_rank"]) == 8 and sorted(r["rank"] for r in tl["per_rank"]) == list(range(8))
+    for r in tl["per_rank"]:
+        assert r["steps"] >= 3 and r["exposed_allreduce_ms"] is not None and r["exposed_allreduce_ms"] >= 0.0 and r["feed_wait_ms_per_step"] == 0.0
+        assert 4.6e7 < r["bytes_per_step"] < 4.9e7 and len(r["buckets"]) >= 2            # the 47.5 MB of fp32 gradients in 5 MB buckets
+        assert all(b["ready_ms"] is not None and b["done_ms"] is not None and b["done_ms"] >= b["ready_ms"] - 1e-3 for b in r["buckets"])
+        assert r["backward_end_ms"] > 0
+
+
+def test_rccl_two_gpus_bench_and_timeline():
+    """BASELINE configs[2] on real links, as far as a test can go: `bench.py --gpus 2` over RCCL with one rank per GPU.  Skipped unless the
+    box shows at least two GPUs (the development boxes have one; the driver's 8-GPU node runs it): n_gpus = rccl_ranks = 2, a finite loss,
+    both ranks' step times, and the all-reduce timeline with its exposed part."""
+    _dev()
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs (RCCL over xGMI); a 1-GPU box covers the launch path over gloo in the tests next to this one")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "DELORA_BENCH_SHARE_GPU", "DELORA_BENCH_BACKEND"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "3", "--kernel-reps", "2", "--no-live-pmc", "--no-profile"]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=root, start_new_session=True)
+    try:
+        out, err = proc.communicate(timeout=900)
+    except subprocess.TimeoutExpired:
+        os.killpg(proc.pid, 9)
+        out, err = proc.communicate()
+        pytest.fail("bench.py --gpus 2 over RCCL did not finish in 900 s:\n" + err[-3000:])
+    assert proc.returncode == 0, (out[-1500:], err[-3000:])
+    lines = [x for x in out.splitlines() if x.startswith("{")]
+    assert len(lines) == 1
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["rccl_ranks"] == 2 and j["collective_backend"] == "nccl" and np.isfinite(j["final_loss"])
+    tl = j["ddp_timeline"]
+    assert len(tl["per_rank"]) == 2 and all(r["exposed_allreduce_ms"] is not None for r in tl["per_rank"])
+    util.measured("bench.py --gpus 2 over RCCL: scan-pairs/s (two ranks)", float(j["value"]))
+    util.measured("bench.py --gpus 2 over RCCL: exposed all-reduce per step (ms, worst rank)", float(tl["exposed_allreduce_ms"]["max"]))
 
 
 @pytest.mark.parametrize("launcher", ["torchrun", "plain"])

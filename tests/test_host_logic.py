@@ -117,6 +117,47 @@ def _ddp_worker(rank, world, port, return_dict):
         torch.distributed.destroy_process_group()
 
 
+def _timeline_worker(rank, world, port, return_dict):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from delora_amd.deploy.ddp_trace import DdpTimeline
+        torch.manual_seed(3)
+        net = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.Tanh(), torch.nn.Linear(256, 256), torch.nn.Tanh(), torch.nn.Linear(256, 8))
+        ref = torch.nn.Sequential(torch.nn.Linear(64, 256), torch.nn.Tanh(), torch.nn.Linear(256, 256), torch.nn.Tanh(), torch.nn.Linear(256, 8))
+        ref.load_state_dict(net.state_dict())
+        ddp = torch.nn.parallel.DistributedDataParallel(net, bucket_cap_mb=0.1)
+        tl = DdpTimeline().attach(ddp, last_grad_param=net[0].weight)
+        x = torch.randn((4, 64), generator=torch.Generator().manual_seed(10 + rank))
+        for _ in range(3):
+            ddp.zero_grad(set_to_none=True)
+            tl.begin_step()
+            ddp(x).square().sum().backward()
+            tl.end_step()
+        # the hook must do what DDP's default does: the averaged gradient of the two ranks' losses
+        xs = [torch.randn((4, 64), generator=torch.Generator().manual_seed(10 + r)) for r in range(world)]
+        sum(ref(v).square().sum() for v in xs).backward()
+        worst = max(float((p.grad - q.grad / world).abs().max()) for p, q in zip(net.parameters(), ref.parameters()))
+        return_dict[rank] = {"summary": tl.summary(), "worst": worst}
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+def test_ddp_timeline_records_buckets_and_keeps_the_default_reduction():
+    """deploy/ddp_trace.py on a 2-rank gloo group: the communication hook averages the gradients exactly as DDP's default does, every
+    bucket of a step has a hand-over and a completion time, the bytes add up to the model's gradients, and the exposed part of the
+    all-reduce is a non-negative number of milliseconds (bench.py --gpus N reports this per rank)."""
+    ret = mp.Manager().dict()
+    mp.spawn(_timeline_worker, args=(2, 36500 + (os.getpid() % 2000), ret), nprocs=2, join=True)
+    nbytes = 4 * (64 * 256 + 256 + 256 * 256 + 256 + 256 * 8 + 8)
+    for r in (0, 1):
+        assert ret[r]["worst"] < 1e-6
+        s = ret[r]["summary"]
+        assert s["steps"] == 3 and s["bytes_per_step"] == nbytes and len(s["buckets"]) >= 2
+        assert s["exposed_allreduce_ms"] is not None and s["exposed_allreduce_ms"] >= 0.0 and s["backward_end_ms"] > 0
+        assert all(b["done_ms"] >= b["ready_ms"] for b in s["buckets"])
+
+
 def test_two_ranks_reproduce_the_single_process_batch():
     """2 ranks x B=1 (gloo) == 1 process x B=2: same poses, same averaged gradients, same Adam update, same loss --
     i.e. the loss weights follow the sample's index in the GLOBAL batch."""
