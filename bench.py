@@ -830,7 +830,7 @@ def kernel_table(trainer, batch, reps):
     #          256 MiB infinity cache ends up full of clean unrelated lines -- the kernel's reads are the only HBM traffic while it runs
     #   dirty  the 1 GiB of writes alone (rounds 2-3 measured this): the cache is full of somebody else's DIRTY lines, every line the
     #          kernel brings in forces a write-back, and the kernel is charged for 54 MB of writes it did not ask for
-    # (tools/exp/loss_cold.py -> profiles/r04_loss_cold.txt: a read-only flush gives the same time as write-then-read, i.e. reads do
+    # (tools/loss_cold.py -> profiles/r04_loss_cold.txt: a read-only flush gives the same time as write-then-read, i.e. reads do
     # allocate in the infinity cache and the clean flush is a real one)
     flush = torch.empty((256 * 1024 * 1024,), dtype=torch.float32, device=trainer.device)
     flush2 = torch.zeros((256 * 1024 * 1024,), dtype=torch.float32, device=trainer.device)

@@ -29,7 +29,7 @@ int dl_check_launch(const char* what) {
 }
 
 // Buffer initialisation as an ordinary kernel.  hipMemsetAsync is avoided on purpose: captured into a HIP graph its memset
-// node did not survive a second replay of the full-size step on this stack (memory access fault; tools/exp/graph_bisect.py),
+// node did not survive a second replay of the full-size step on this stack (memory access fault; found by bisecting the captured step in round 4),
 // a kernel node does.  n_words 4-byte words; 16-byte stores when the buffer is 16-byte aligned.
 __global__ __launch_bounds__(DL_BLOCK) void k_fill_words(uint32_t* __restrict__ p, uint32_t v, size_t n_words, size_t n_vec) {
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));

@@ -246,7 +246,7 @@ __global__ __launch_bounds__(DL_BLOCK) void k_stem_wgrad_reduce(const float* __r
 // avgpool + flatten before fc).  One workgroup per (image, 64 channels): 16 channel quads x 16 pixel lanes, every lane sums
 // its pixels in order, the 16 partial sums of a quad are added in a fixed tree through LDS -- deterministic, and a plain
 // kernel node when the step is captured into a HIP graph (torch's multi-block reduction zeroes its semaphores with a
-// memset node, which did not survive replays on this stack: tools/exp/graph_unit.py).
+// memset node, which did not survive replays on this stack; found by bisecting the captured step in round 4).
 __global__ __launch_bounds__(DL_BLOCK) void k_mean_hw_nhwc(const float* __restrict__ x, int P, int C, float* __restrict__ y) {
   __shared__ f32x4s part[16][17];
   const int n = blockIdx.y, c4 = blockIdx.x * 16 + (threadIdx.x & 15), pl = threadIdx.x >> 4;

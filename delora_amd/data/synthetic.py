@@ -23,10 +23,24 @@ def _rot_zyx(yaw, pitch, roll):
 class Scene:
     """Axis-aligned room [-ax,ax]x[-ay,ay], ground z=-h, ceiling z=+c, plus solid boxes."""
 
-    def __init__(self, rng, half_x=22.0, half_y=9.0, sensor_height=1.73, ceiling=6.0, n_boxes=6):
+    def __init__(self, rng, half_x=22.0, half_y=9.0, sensor_height=1.73, ceiling=6.0, n_boxes=6, cross_walls=0, pillars=0):
+        """cross_walls / pillars (round 6, default 0 = the scenes every committed fixture was generated with): thin walls ACROSS the
+        direction of travel, reaching from a side wall to 2.5 m short of the centre line, on alternating sides, and full-height square
+        pillars -- surfaces whose normals have a component along x, so that a point-to-plane loss can observe the forward translation
+        (in a bare corridor walls, ground and ceiling are all parallel to the motion)."""
         self.half_x, self.half_y = half_x, half_y
         self.ground, self.ceiling = -sensor_height, ceiling
         boxes = []
+        for k in range(int(cross_walls)):
+            cx = -0.9 * half_x + (k + rng.uniform(0.2, 0.8)) * (1.8 * half_x / max(1, int(cross_walls)))
+            side = 1.0 if k % 2 == 0 else -1.0
+            y_in, y_out = side * rng.uniform(2.5, 4.0), side * half_y
+            boxes.append((cx - 0.15, cx + 0.15, min(y_in, y_out), max(y_in, y_out), self.ground, self.ground + rng.uniform(2.0, 3.5)))
+        for _ in range(int(pillars)):
+            cx = rng.uniform(-0.9 * half_x, 0.9 * half_x)
+            cy = rng.uniform(2.0, 0.9 * half_y) * (1.0 if rng.uniform() < 0.5 else -1.0)
+            r = rng.uniform(0.25, 0.5)
+            boxes.append((cx - r, cx + r, cy - r, cy + r, self.ground, ceiling))
         for _ in range(n_boxes):
             cx = rng.uniform(-0.8 * half_x, 0.8 * half_x)
             cy = rng.uniform(-0.8 * half_y, 0.8 * half_y)
@@ -214,12 +228,12 @@ def digest(arrays):
     return h.hexdigest()
 
 
-def make_sequence(seed, n_scans, rings=64, azimuth_steps=2250, vfov_deg=(-24.5, 2.0), step=(0.45, 0.02, 0.005), max_yaw_deg=1.5, **kw):
+def make_sequence(seed, n_scans, rings=64, azimuth_steps=2250, vfov_deg=(-24.5, 2.0), step=(0.45, 0.02, 0.005), max_yaw_deg=1.5, scene=None, **kw):
     """``n_scans`` consecutive scans of ONE scene along a smooth trajectory (sensor poses R_k, t_k in the scene frame; every step
     moves ~``step`` metres and turns by up to ``max_yaw_deg``): a synthetic sequence in the sense of the reference's dataset
     (src/data/dataset.py:124-154: sample k = the pair (scan k, scan k+1)).  Returns (list of ``[3,N_k]`` fp32 scans, list of 4x4 poses)."""
     rng = np.random.default_rng(seed)
-    scene = Scene(rng, half_x=40.0)
+    scene = Scene(rng, half_x=40.0, **(scene or {}))
     R, t = np.eye(3), np.array([-0.5 * step[0] * n_scans, 0.0, 0.0])
     scans, poses = [], []
     for _ in range(n_scans):

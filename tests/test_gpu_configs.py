@@ -664,11 +664,31 @@ def test_step_matches_the_references_own_trainer_step(name):
     terms = trainer.last_step["loss_terms"].detach().cpu().numpy().astype(np.float64)
     util.measured(f"{name}: per-sample loss terms vs the reference-pinned oracle (relative)",
                   float((np.abs(terms - g["terms"]) / np.maximum(np.abs(g["terms"]), 1e-12)).max()), bound=REL)
-    worst = 0.0
+    errs = []
     for k, p in trainer.raw_model.named_parameters():
         ref = float(g["gradnorm::" + k])
-        worst = max(worst, abs(float(p.grad.double().norm()) - ref) / max(ref, 1e-12))
-    util.measured(f"{name}: worst relative error of the 30 per-parameter gradient norms vs the reference", worst, bound=REL)
+        errs.append((abs(float(p.grad.double().norm()) - ref) / max(ref, 1e-12), k, ref))
+    errs.sort(reverse=True)
+    print(f"  {name}: largest gradient-norm deviations: " + ", ".join(f"{k} {e:.2e} (|g| {r:.3g})" for e, k, r in errs[:4]))
+    worst = errs[0][0]
+    slack = 0.0
+    if "T64" in g:
+        # The fixture also holds the reference's step with the NETWORK evaluated in float64 (make_golden.py: referee64).  At batch 8 the
+        # reference's own float32 run is further from that referee than this library is (oneDNN convolves a batch of eight with other
+        # algorithms than a batch of one or two: its poses move by 5e-6, its conv1 gradient by 3e-4) -- so the bar applies to the referee,
+        # and the comparison with the float32 run is allowed the reference's own rounding on top.
+        ref_own = max(abs(float(g["gradnorm::" + k]) - float(g["gradnorm64::" + k])) / max(float(g["gradnorm64::" + k]), 1e-12)
+                      for k, _ in trainer.raw_model.named_parameters())
+        ours64 = max(abs(float(p.grad.double().norm()) - float(g["gradnorm64::" + k])) / max(float(g["gradnorm64::" + k]), 1e-12)
+                     for k, p in trainer.raw_model.named_parameters())
+        util.measured(f"{name}: the REFERENCE's float32 gradient norms vs its own float64 evaluation (worst, relative)", ref_own)
+        util.measured(f"{name}: worst relative error of the 30 gradient norms vs the reference evaluated in float64", ours64, bound=REL)
+        util.measured(f"{name}: the REFERENCE's float32 poses vs its own float64 evaluation (relative to the largest element)",
+                      float(np.abs(g["T"] - g["T64"]).max() / np.abs(g["T64"]).max()))
+        util.measured(f"{name}: poses vs the reference evaluated in float64 (relative to the largest element)",
+                      float(np.abs(T.detach().cpu().numpy() - g["T64"]).max() / np.abs(g["T64"]).max()), bound=REL)
+        slack = ref_own
+    util.measured(f"{name}: worst relative error of the 30 per-parameter gradient norms vs the reference ({errs[0][1]})", worst, bound=REL + slack)
     after = trainer.raw_model.state_dict()
     for k in before:                                        # Adam's first step moves every weight by ~lr*sign(grad)
         got = float((after[k].double() - before[k].double()).sum())

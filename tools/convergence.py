@@ -32,7 +32,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def build_dataset(device, train_sequences, scans_per_sequence, seed=7000, rings=64, azimuth_steps=2250, workdir=None):
+def build_dataset(device, train_sequences, scans_per_sequence, seed=7000, rings=64, azimuth_steps=2250, workdir=None, scene=None):
     """Sequences 0..S-1 = training, sequence S = held out.  Returns (tree path, {sequence: ground-truth relative transforms [K,4,4]})."""
     from delora_amd import config as cfgmod
     from delora_amd.data import synthetic
@@ -48,7 +48,7 @@ def build_dataset(device, train_sequences, scans_per_sequence, seed=7000, rings=
     truth = {}
     pre = Preprocesser(cfg)
     for s in range(train_sequences + 1):
-        scans, poses = synthetic.make_sequence(seed + 17 * s, scans_per_sequence, rings=rings, azimuth_steps=azimuth_steps)
+        scans, poses = synthetic.make_sequence(seed + 17 * s, scans_per_sequence, rings=rings, azimuth_steps=azimuth_steps, scene=scene)
         pre.preprocess_scans(scans, "kitti", s)
         truth[s] = np.stack([np.linalg.inv(a) @ b for a, b in zip(poses[:-1], poses[1:])])
     return tmp, truth

@@ -93,12 +93,13 @@ template <int TYPE, int N, bool ONECHAIN> static void run(const char* name, int 
 #define ALLN(T, NAME, TH) run<T, 4, false>(NAME, TH); run<T, 8, false>(NAME, TH); run<T, 16, false>(NAME, TH); run<T, 8, true>(NAME, TH);
 int main(int argc, char** argv) {
   setvbuf(stdout, nullptr, _IOLBF, 0);
-  const int th = argc > 1 ? atoi(argv[1]) : 512;
-  run<0, 0, false>("none", th);
-  run<4, 4, false>("s_add_u32", th); run<4, 8, false>("s_add_u32", th); run<4, 16, false>("s_add_u32", th); run<13, 4, false>("v_readfirstlane", th); run<13, 8, false>("v_readfirstlane", th);
-  run<5, 1, false>("ds_read_b128", th); run<5, 2, false>("ds_read_b128", th); run<5, 4, false>("ds_read_b128", th);
-  run<10, 1, false>("ds_write_b128", th); run<10, 2, false>("ds_write_b128", th);
-  run<15, 1, false>("ds_write_b64", th); run<15, 2, false>("ds_write_b64", th); run<15, 4, false>("ds_write_b64", th); run<16, 4, false>("ds_write_b32", th);
-  run<14, 2, false>("ds_read_b64", th); run<14, 4, false>("ds_read_b64", th);
+  const int th = argc > 1 ? atoi(argv[1]) : 512;            // 256: one wave per SIMD, 512: two
+  run<0, 0, false>("none", th); run<0, 0, true>("none", th);
+  run<1, 4, false>("v_add_f32", th); run<1, 8, false>("v_add_f32", th); run<1, 16, false>("v_add_f32", th); run<1, 8, true>("v_add_f32", th);
+  run<2, 8, false>("v_and_b32", th); run<3, 4, false>("v_pk_add_f32", th); run<3, 8, false>("v_pk_add_f32", th); run<9, 8, false>("v_pk_fma_f32", th);
+  run<4, 4, false>("s_add_u32", th); run<4, 16, false>("s_add_u32", th); run<13, 4, false>("v_readfirstlane", th);
+  run<5, 1, false>("ds_read_b128", th); run<5, 2, false>("ds_read_b128", th); run<5, 4, false>("ds_read_b128", th); run<14, 4, false>("ds_read_b64", th);
+  run<10, 1, false>("ds_write_b128", th); run<10, 2, false>("ds_write_b128", th); run<15, 2, false>("ds_write_b64", th); run<16, 4, false>("ds_write_b32", th);
+  run<12, 1, false>("glds_x4", th); run<12, 2, false>("glds_x4", th);
   return 0;
 }

@@ -4,7 +4,7 @@ full of dirty lines whose write-back competes with the kernel's reads) against 1
 (the ramp of a 54 MB launch).  usage: python tools/exp/loss_cold.py"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import bench
 from delora_amd import geometry as G
 from delora_amd.deploy.step_geometry import HipStepGeometry

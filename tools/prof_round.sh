@@ -4,7 +4,7 @@
 # launch table + FETCH_SIZE / WRITE_SIZE per layer (tools/conv_layers.py), matrix-core counters of the Winograd and the
 # half-precision kernels.  Counters are collected in their own runs, with --kernel-trace only.
 cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
-R=${ROUND:-r05}
+R=${ROUND:-r06}
 out=gpurun_out/profiles_$R; rm -rf $out; mkdir -p $out
 T=/tmp/prof_$R; rm -rf $T; mkdir -p $T
 python bench.py > $out/bench.json 2> $out/bench.err; tail -1 $out/bench.json | cut -c1-300
@@ -39,7 +39,7 @@ rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $T/geo_write_s 
 cp $(find $T/geo_fetch_s -name "*counter_collection.csv" | head -1) $out/geo_fetch_shuffled/geo_counter_collection.csv
 cp $(find $T/geo_write_s -name "*counter_collection.csv" | head -1) $out/geo_write_shuffled/geo_counter_collection.csv
 python tools/loss_warm.py 50 > $out/loss_warm.txt 2>/dev/null
-python tools/exp/loss_cold.py 2>/dev/null | grep '^B=' > $out/loss_cold.txt
+python tools/loss_cold.py 2>/dev/null | grep '^B=' > $out/loss_cold.txt
 # convolution kernels: stand-alone harnesses (host-checked correctness + per-layer times)
 (tools/bin/conv_harness all 10; tools/bin/conv_harness wino 10; tools/bin/wino_wgrad check; tools/bin/wino_wgrad time 10) > $out/conv_harness.txt 2>&1
 (tools/bin/convh_harness check; tools/bin/convh_harness time 10; tools/bin/convh_harness check f16 | tail -3; tools/bin/hw_probe | tail -3) > $out/convh_harness.txt 2>&1
@@ -55,7 +55,11 @@ PMC="SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA
 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $T/conv_pmc -o conv -- tools/bin/conv_harness wino 2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $T/ww_pmc -o conv -- tools/bin/wino_wgrad time 2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc $PMC --output-format csv -d $T/convh_pmc -o conv -- tools/bin/convh_harness time 2 > /dev/null 2>&1
-(python tools/exp/conv_pmc.py $(find $T/conv_pmc -name "*counter_collection.csv" | head -1); python tools/exp/conv_pmc.py $(find $T/ww_pmc -name "*counter_collection.csv" | head -1) k_wino_wgrad) > $out/conv_pmc.txt 2>&1
-python tools/exp/convh_pmc.py $(find $T/convh_pmc -name "*counter_collection.csv" | head -1) > $out/convh_pmc.txt 2>&1
+(python tools/conv_pmc.py $(find $T/conv_pmc -name "*counter_collection.csv" | head -1); python tools/conv_pmc.py $(find $T/ww_pmc -name "*counter_collection.csv" | head -1) k_wino_wgrad) > $out/conv_pmc.txt 2>&1
+python tools/convh_pmc.py $(find $T/convh_pmc -name "*counter_collection.csv" | head -1) > $out/convh_pmc.txt 2>&1
 (tools/bin/scatter_probe 20; echo "-- points in raster order"; tools/bin/scatter_probe 20 1) > $out/scatter_probe.txt 2>&1
+# round 6: the Winograd kernels alone (check, per-layer times, phase stamps, counters) and what issues in the shadow of an fp32 MFMA
+(tools/bin/wino_lab check; tools/bin/wino_lab time 30; tools/bin/wino_lab phases) > $out/wino_lab.txt 2>&1
+tools/lab_pmc.sh > /dev/null 2>&1; cp gpurun_out/lab_pmc.txt $out/wino_lab_pmc.txt
+(timeout 120 tools/bin/mfma_overlap 512; timeout 60 tools/bin/mfma_dma; timeout 60 tools/bin/pk_probe) > $out/mfma_shadow.txt 2>&1
 du -sh $out; ls $out
