@@ -116,8 +116,11 @@ class GraphedStep:
         """Undo what a capture asked of the optimiser (`capturable`, step counters on the device): the eager step and the checkpoints
         it writes are then those of a trainer that never built a graph.  Called when a capture fails or is dropped again."""
         opt = self.trainer.optimizer
+        fused = any(bool(group.get("fused")) for group in opt.param_groups)
         for group in opt.param_groups:
             group["capturable"] = False
+        if fused:
+            return                                   # torch's single-kernel Adam keeps its step counters on the device in every mode
         for st in opt.state.values():
             if torch.is_tensor(st.get("step")) and st["step"].is_cuda:
                 st["step"] = st["step"].detach().to("cpu")

@@ -110,15 +110,16 @@ class Trainer(deployer.Deployer):
         the next one arrives (period >= stream time); when the GPU is, the queue fills up, the events measure pure GPU time and the
         host's period is shorter."""
         import time
-        st = self._graph_probe.setdefault(phase, {"n": 0, "host": 0.0, "events": [], "t_first": None, "t_last": None})
+        st = self._graph_probe.setdefault(phase, {"n": 0, "host": 0.0, "events": [], "prev": None, "period_sum": 0.0, "periods": 0})
         timed = st["n"] >= self.PROBE_SKIP
         if timed:
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             t0 = time.perf_counter()
-            if st["t_first"] is None:
-                st["t_first"] = t0
-            st["t_last"] = t0
+            if st["prev"] is not None:                  # (None at the first timed step and at the first step of an epoch: the gap between
+                st["period_sum"] += t0 - st["prev"]     #  two epochs -- checkpoint, logging -- is not a step's period)
+                st["periods"] += 1
+            st["prev"] = t0
         out = run_eager()
         if timed:
             st["host"] += time.perf_counter() - t0
@@ -130,7 +131,7 @@ class Trainer(deployer.Deployer):
             k = len(st["events"])
             gpu = sum(x.elapsed_time(y) for x, y in st["events"]) * 1e-3 / k
             enqueue = st["host"] / k
-            period = (st["t_last"] - st["t_first"]) / max(1, k - 1)       # start of the first timed step to the start of the last
+            period = st["period_sum"] / max(1, st["periods"])               # step start to step start, inside epochs only
             ratio = max(period, enqueue) / max(gpu, 1e-9)
             decision = "graph" if ratio >= float(self.config.get("hip_graph_auto_threshold", self.PROBE_HOST_BOUND)) else "eager"
             self._graph_decision[phase] = decision
@@ -155,9 +156,10 @@ class Trainer(deployer.Deployer):
         policy = self.graph_policy()
         if not hasattr(self, "_graph_decision"):
             self._graph_decision, self._graph_probe, self.graph_probe_result = {}, {}, {}
-        self._graph_probe.clear()            # a measurement never spans an epoch boundary (checkpoint / logging time is not the step's period)
-        if hasattr(self, "_graph_trial"):
-            self._graph_trial = {k: [] for k in self._graph_trial}
+        for st in self._graph_probe.values():       # a measured period never spans an epoch boundary (checkpoint / logging time is not the step's)
+            st["prev"] = None
+        for tr_ in getattr(self, "_graph_trial", {}).values():
+            tr_["prev"] = None
         self.graph_steps = getattr(self, "graph_steps", 0)
         if getattr(self, "_graphed", None) is not None:
             self._graphed.take_epoch_sums()             # (steps replayed outside an epoch, e.g. by a caller's own loop)
@@ -197,7 +199,7 @@ class Trainer(deployer.Deployer):
             g = self._graphed = GraphedStep(self, preprocessed_dicts, max_points=cap)
             self._graphed_phase = phase
             if self.graph_policy() == "auto" and g.captured:
-                self.__dict__.setdefault("_graph_trial", {})[phase] = []      # start times of the first replayed steps (_judge_replay)
+                self.__dict__.setdefault("_graph_trial", {})[phase] = {"prev": None, "sum": 0.0, "n": 0}   # periods of the first replays (_judge_replay)
             if self.graph_policy() == "auto" and not g.captured:
                 # a failed capture ends the experiment for this phase: plain eager steps from the caller's own batches, not eager steps
                 # through the capture's full-capacity static buffers
@@ -211,15 +213,19 @@ class Trainer(deployer.Deployer):
         trial = self._graph_trial.get(phase) if hasattr(self, "_graph_trial") else None
         if trial is not None:
             import time
-            trial.append(time.perf_counter())
+            now = time.perf_counter()
+            if trial["prev"] is not None:
+                trial["sum"] += now - trial["prev"]
+                trial["n"] += 1
+            trial["prev"] = now
         if not g.captured and getattr(self, "_graphed", None) is None:       # (auto: the capture just failed, see above)
             self.optimizer.zero_grad(set_to_none=True)
             return self.step(preprocessed_dicts=preprocessed_dicts, epoch_losses=epoch_losses, log_images_bool=False)[0]
         ep, _ = g(preprocessed_dicts)
         replayed = g.replayed_steps - before
         self.graph_steps += replayed
-        if trial is not None and len(trial) > self.PROBE_STEPS:
-            self._judge_replay(phase, trial)
+        if trial is not None and trial["n"] >= self.PROBE_STEPS:
+            self._judge_replay(phase, trial["sum"] / trial["n"])
         if replayed and g.acc is not None:
             return epoch_losses                      # the replay added its metrics to the graph's own accumulator (folded in per epoch)
         for k, v in ep.items():                      # eager fallback / no accumulator: the outputs are (static) tensors, add their VALUES
@@ -227,7 +233,7 @@ class Trainer(deployer.Deployer):
                 epoch_losses[k] = epoch_losses[k] + v
         return epoch_losses
 
-    def _judge_replay(self, phase, starts):
+    def _judge_replay(self, phase, period):
         """`auto` only: the host's period over the first replayed steps against the eager period the probe measured.  hipGraphLaunch
         of this ROCm release enqueues a captured step node by node -- measured on the reference's default batch-1 step: 0.9-1.6 ms to
         replay its ~120 kernel nodes against 2.2-2.6 ms to enqueue them eagerly, 2.2 against 2.3 ms on a loaded host -- so a replay
@@ -235,7 +241,6 @@ class Trainer(deployer.Deployer):
         keeps it regardless."""
         del self._graph_trial[phase]
         res = self.graph_probe_result.get(phase, {})
-        period = (starts[-1] - starts[0]) / (len(starts) - 1)
         res["replay_host_period_ms"] = round(1e3 * period, 3)
         eager = res.get("host_period_ms")
         gain = float(self.config.get("hip_graph_min_gain", 0.03))

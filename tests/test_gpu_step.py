@@ -381,7 +381,9 @@ def test_product_loop_switches_to_graph_replay_and_keeps_the_trajectory(tmp_path
     probe = tr.PROBE_SKIP + tr.PROBE_STEPS
     if reverted:
         assert tr.graph_probe_result[True]["decision"].startswith("eager (replay measured") and tr._graphed is None
-        assert tr.graph_steps == tr.PROBE_STEPS + 1, tr.graph_steps
+        # PROBE_STEPS step-to-step periods are measured before the verdict; the gap between two epochs is not one (round 6), so a trial
+        # that crosses an epoch boundary (12 steps per epoch here) takes one replay more
+        assert tr.graph_steps in (tr.PROBE_STEPS + 1, tr.PROBE_STEPS + 2), tr.graph_steps
     else:
         assert tr.graph_probe_result[True]["decision"] == "graph" and tr._graphed.captured
         assert tr.graph_steps == 3 * 12 - probe and tr._graphed.fallback_steps == 0, (tr.graph_steps, tr._graphed.fallback_steps)
