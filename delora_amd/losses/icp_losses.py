@@ -17,9 +17,20 @@ class ICPLosses(torch.nn.Module):
         if config["normal_loss"] not in ("squared", "linear"):
             raise Exception("The normal loss which is defined here is not admissible.")
 
+    _warned_quadratic = False
+
     @staticmethod
     def find_target_correspondences(target_point_cloud, source_point_cloud):
-        """Index of the exact nearest target point for every source point (both ``[1,3,M]``)."""
+        """Index of the exact nearest target point for every source point (both ``[1,3,M]``).  The list interface has no image lattice to
+        search on, so this is the exhaustive O(M^2) kernel: 17 G distance evaluations per call for two 64x2048 scans.  Said once, loudly,
+        above 32 k points -- the training step (``Deployer.step``) uses the lattice search of ``geometry.nn_correspond`` instead."""
+        n_src, n_tgt = int(source_point_cloud.shape[-1]), int(target_point_cloud.shape[-1])
+        if max(n_src, n_tgt) > 32768 and not ICPLosses._warned_quadratic:
+            ICPLosses._warned_quadratic = True
+            import warnings
+            warnings.warn(f"ICPLosses (list interface): exhaustive nearest-neighbour search over {n_src} x {n_tgt} points "
+                          f"({n_src * n_tgt / 1e9:.1f} G distance evaluations per call); the image-based step path "
+                          "(Deployer.step / geometry.nn_correspond) is exact as well and ~100x faster", RuntimeWarning, stacklevel=3)
         return geometry.nn_bruteforce(source_point_cloud[0], target_point_cloud[0]).long()
 
     def forward(self, source_point_cloud_transformed, source_normal_list_transformed, target_point_cloud,

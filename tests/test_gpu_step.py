@@ -433,6 +433,9 @@ def _ddp_gpu_worker(rank, world, port, ret):
         torch.distributed.destroy_process_group()
 
 
+DDP_GRAD_BOUND = 2e-5          # measured 1.2e-6 (round 6)
+
+
 def test_data_parallel_step_on_gpu_matches_reference_batch():
     """Two DDP ranks (one GPU, gloo transport; RCCL itself needs >1 GPU) x B=1 through the HIP path reproduce the
     reference's single-process B=2 step: poses, loss, averaged gradient norms."""
@@ -441,10 +444,18 @@ def test_data_parallel_step_on_gpu_matches_reference_batch():
     g = util.load_golden("step_b2")
     ret = mp.Manager().dict()
     mp.spawn(_ddp_gpu_worker, args=(2, 29650 + (os.getpid() % 300), ret), nprocs=2, join=True)
+    worst, name = 0.0, ""
     for r in (0, 1):
         assert np.allclose(ret[r]["T"][0].numpy(), g["T"][r], rtol=REL, atol=REL * np.abs(g["T"]).max())
         for k, v in ret[r]["gn"].items():
-            assert np.isclose(v, float(g["gradnorm::" + k]), rtol=3e-3, atol=1e-9), k
+            e = abs(v - float(g["gradnorm::" + k])) / max(float(g["gradnorm::" + k]), 1e-12)
+            if e > worst:
+                worst, name = e, k
+    # (review, round 5: this bound was 3e-3; it is now ten times the largest deviation ever measured, like every other gradient bound.  The
+    # narrow network of this fixture runs its convolutions on the library (MIOpen picks an algorithm per BATCH SIZE: one sample per rank here,
+    # two in the reference's step), which is where the deviation comes from -- the full-width HIP trunk is held to 1e-4 in
+    # test_step_matches_the_references_own_trainer_step.)
+    util.measured(f"two DDP ranks x B=1 on the GPU vs the reference's B=2 step: worst relative gradient-norm deviation ({name})", worst, bound=DDP_GRAD_BOUND)
     assert np.isclose(ret[0]["loss"] + ret[1]["loss"], g["ep::loss_epoch"], rtol=REL)
 
 
@@ -516,6 +527,43 @@ def test_graphed_step_equals_eager_step():
     assert np.allclose(got, eager, rtol=1e-3), (got, eager)
     for (k, a), (_, b) in zip(tr_g.raw_model.state_dict().items(), tr_e.raw_model.state_dict().items()):
         assert torch.allclose(a, b, rtol=1e-2, atol=2e-4), k
+
+
+def test_graphed_step_equals_eager_step_on_the_hip_trunk():
+    """The same comparison where it can be tight (review, round 5): the FULL-width network on a 16x512 pair runs on this library's own
+    kernels -- fixed-order partial sums, no atomics -- so four replayed steps must reproduce four eager steps to fp32 rounding of the
+    capturable Adam update (its bias corrections are computed on the device: an ulp per step), not to 1e-3."""
+    from delora_amd.data.dataset import SyntheticPairDataset
+    from delora_amd.deploy.graph_step import GraphedStep
+    from delora_amd.deploy.trainer import Trainer
+    _dev()
+
+    def make():
+        cfg = util.repo_config(16, 512, device="cuda:0", unsupervised_at_start=True, inference_only=False, batch_size=2, learning_rate=1e-5)
+        ds = SyntheticPairDataset(cfg, "kitti", 2, rings=16, azimuth_steps=600)
+        torch.manual_seed(7)
+        tr = Trainer(cfg, dataset=ds)
+        assert tr.raw_model.resnet.hip_path_takes(16, 512, batch=2)
+        return tr, tr.to_device([ds[0], ds[1]])
+
+    tr_e, batch = make()
+    eager = []
+    for _ in range(4):
+        tr_e.optimizer.zero_grad(set_to_none=True)
+        ep, _ = tr_e.step(preprocessed_dicts=[dict(b) for b in batch], epoch_losses=tr_e.new_epoch_losses())
+        eager.append(float(ep["loss_epoch"]))
+    tr_g, batch_g = make()
+    gs = GraphedStep(tr_g, batch_g, warmup=3)
+    assert gs.captured
+    got = []
+    for _ in range(4):
+        ep, _ = gs()
+        got.append(float(ep["loss_epoch"]))
+    util.measured("graph replay vs eager on the HIP trunk (16x512, full width): worst relative loss difference over four steps",
+                  float(np.max(np.abs(np.array(got) - np.array(eager)) / np.abs(np.array(eager)))), bound=2e-6)
+    worst = max(float((a - b).abs().max()) for a, b in zip(tr_g.raw_model.state_dict().values(), tr_e.raw_model.state_dict().values()))
+    util.measured("graph replay vs eager on the HIP trunk: largest weight difference after four steps (lr 1e-5: a step moves a weight by <= 1e-5)",
+                  worst, bound=2e-7)
 
 
 def test_mixed_sensor_batch_on_gpu():
