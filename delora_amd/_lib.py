@@ -8,7 +8,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libdelora_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class DeloraHipError(RuntimeError):

@@ -24,6 +24,9 @@
 
 #define NTH 4
 #define NTW 64
+#ifndef NRM_FP32_GAP
+#define NRM_FP32_GAP 1e-3f      // relative gap of the two smallest eigenvalues above which the fp32 eigenvector is taken (1e30: never)
+#endif
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -57,6 +60,48 @@ __device__ __forceinline__ void smallest_eigenvector(double a00, double a01, dou
     float r = 0.5f * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
     r = fminf(fmaxf(r, -1.0f), 1.0f);
     lam = third + 2.0f * (p2 * (1.0f / 6.0f) * ip) * __cosf(acosf(r) * third + 2.0943951f);
+  }
+  // Round 6: where the two smallest eigenvalues are well separated -- a plane with structure in both directions, an edge: everything
+  // but thin lines of points -- the eigenvector comes from the SAME construction in fp32 (adjugate column of A - lam I, one
+  // Rayleigh-quotient step): its error is ~eps32 / gap <= 1e-4 at the threshold, inside the 2e-4 + 50 eps32 / gap the parity tests
+  // allow, and the fp64 solve below (40 % of the kernel's instructions, at half rate) runs only in waves that hold a degenerate pixel.
+  // gap = lam_mid - lam_min = 2 sqrt(p2 / 6) sqrt(3) sin(acos(r) / 3) in units of the trace.
+  float gap_rel = 0.f;
+  {
+    if (p2 > 1e-13f) {
+      const float ip = __frsqrt_rn(p2 * (1.0f / 6.0f));
+      const float c00 = b00 * ip, c11 = b11 * ip, c22 = b22 * ip, c01 = f01 * ip, c02 = f02 * ip, c12 = f12 * ip;
+      float r = 0.5f * (c00 * (c11 * c22 - c12 * c12) - c01 * (c01 * c22 - c12 * c02) + c02 * (c01 * c12 - c11 * c02));
+      r = fminf(fmaxf(r, -1.0f), 1.0f);
+      gap_rel = 2.0f * (p2 * (1.0f / 6.0f) * ip) * 1.7320508f * __sinf(acosf(r) * third);
+    }
+  }
+  if (gap_rel >= NRM_FP32_GAP) {
+    const float g00 = (float)a00, g11 = (float)a11, g22 = (float)a22;
+    const float m00 = g00 - lam, m11 = g11 - lam, m22 = g22 - lam;
+    const float k00 = m11 * m22 - f12 * f12, k01 = f02 * f12 - f01 * m22, k02 = f01 * f12 - f02 * m11,
+                k11 = m00 * m22 - f02 * f02, k12 = f01 * f02 - m00 * f12, k22 = m00 * m11 - f01 * f01;
+    const float d0 = fabsf(k00), d1 = fabsf(k11), d2 = fabsf(k22);
+    float y0, y1, y2;
+    if (d0 >= d1 && d0 >= d2) { y0 = k00; y1 = k01; y2 = k02; }
+    else if (d1 >= d2)        { y0 = k01; y1 = k11; y2 = k12; }
+    else                      { y0 = k02; y1 = k12; y2 = k22; }
+    float sc = __frsqrt_rn(fmaxf(y0 * y0 + y1 * y1 + y2 * y2, 1e-37f));
+    y0 *= sc; y1 *= sc; y2 *= sc;
+    // one Rayleigh-quotient step: y <- adj(A - rho I) y, rho = y.A y (|y| = 1)
+    const float v0 = g00 * y0 + f01 * y1 + f02 * y2, v1 = f01 * y0 + g11 * y1 + f12 * y2, v2 = f02 * y0 + f12 * y1 + g22 * y2;
+    const float rho = y0 * v0 + y1 * v1 + y2 * v2;
+    const float n00 = g00 - rho, n11 = g11 - rho, n22 = g22 - rho;
+    const float j00 = n11 * n22 - f12 * f12, j01 = f02 * f12 - f01 * n22, j02 = f01 * f12 - f02 * n11,
+                j11 = n00 * n22 - f02 * f02, j12 = f01 * f02 - n00 * f12, j22 = n00 * n11 - f01 * f01;
+    float z0 = j00 * y0 + j01 * y1 + j02 * y2, z1 = j01 * y0 + j11 * y1 + j12 * y2, z2 = j02 * y0 + j12 * y1 + j22 * y2;
+    const float zz = z0 * z0 + z1 * z1 + z2 * z2;
+    if (zz > 1e-30f) { sc = __frsqrt_rn(zz); y0 = z0 * sc; y1 = z1 * sc; y2 = z2 * sc; }
+    // one Newton step on the norm (rsq is an approximation), in fp32
+    const float nn_ = y0 * y0 + y1 * y1 + y2 * y2;
+    const float fix = 1.5f - 0.5f * nn_;
+    nx = (double)(y0 * fix); ny = (double)(y1 * fix); nz = (double)(y2 * fix);
+    return;
   }
   const double mu = (double)lam;
   double x0, x1, x2;

@@ -184,7 +184,7 @@ def wino_ok(H, W, C, K):
 
 
 def wino_weights(w_param, want_fwd=True, want_bwd=True):
-    """Winograd-domain weights of a 3x3 layer: (u_fwd [C/8,16,K,8], u_bwd [K/8,16,C,8]) from the parameter ``[K,C,3,3]``."""
+    """Winograd-domain weights of a 3x3 layer: (u_fwd, u_bwd: 16 K C floats each in the blocked layout of csrc/wino.hip: wn_u_index) from the parameter ``[K,C,3,3]``."""
     lib = _lib.load()
     w = weight_storage(w_param)
     K, C = w.shape[0], w.shape[3]

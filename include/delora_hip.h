@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define DL_ABI_VERSION 6   /* 6: dl_project takes n_cols and ONE workspace (key plane + staging records of the vote), dl_wino_conv3x3_nhwc_f32 an optional split-K workspace; 5: batched weight gradients (dl_conv2d_wgrad_batch_*); 4: free image sizes in the convolution family (the strided input gradients take the INPUT image size and a seam workspace); 3: half-precision convolutions, launch profiler */
+#define DL_ABI_VERSION 7   /* 7: the Winograd-domain weights are an opaque operand (blocked LDS-image layout); 6: dl_project takes n_cols and ONE workspace (key plane + staging records of the vote), dl_wino_conv3x3_nhwc_f32 an optional split-K workspace; 5: batched weight gradients (dl_conv2d_wgrad_batch_*); 4: free image sizes in the convolution family (the strided input gradients take the INPUT image size and a seam workspace); 3: half-precision convolutions, launch profiler */
 
 typedef void* dl_stream;
 
@@ -298,8 +298,12 @@ int dl_conv2d_wgrad_nhwc_f32(const float* x, const float* g, float* dw, void* wo
  * The same stride-1 3x3 convolution (forward and, with the backward weight set, input gradient) as fused Winograd
  * F(2x2,3x3) on the fp32 matrix cores: 2.25x fewer multiplications; input transform, 16 batched GEMMs, output transform and
  * the epilogue of dl_conv2d_nhwc_f32 in one launch (the transformed tensors never reach HBM).
- *   dl_wino_weights_f32: w [K][3][3][C] -> u_fwd [C/8][16][K][8] and/or u_bwd [K/8][16][C][8] (each 16*K*C floats =
- *                        dl_wino_weights_floats; either may be NULL).  Run once per optimiser step.
+ *   dl_wino_weights_f32: w [K][3][3][C] -> u_fwd and/or u_bwd (each 16*K*C floats = dl_wino_weights_floats; either may be NULL).
+ *                        Run once per optimiser step.  Layout (an OPAQUE operand of dl_wino_conv3x3_nhwc_f32 since ABI 7): reduction
+ *                        channels in chunks of 8, output rows (k of u_fwd, c of u_bwd) in blocks of 64, and per (chunk, block) the
+ *                        16 planes as [16][64 rows][8] with the 16-byte halves of a row swapped where bit 3 of the row is set --
+ *                        the bytes the kernel's LDS DMA copies linearly.  Row counts that are not multiples of 64 (no convolution
+ *                        entry point consumes them) keep [chunk][16][rows][8].
  *   dl_wino_conv3x3_nhwc_f32: x [N][H][W][C], u = u_fwd of the layer -> y [N][H][W][K]; for the input gradient pass the
  *                        output gradient as x, u = u_bwd and swap C and K.  epilogue / act / add / dsrc as above.
  *   Shapes: any image size (a workgroup takes 64 tiles as 2x32, 4x16, 8x8 or 16x4, whichever wastes the fewest; tile groups hang over
@@ -312,8 +316,8 @@ int dl_wino_weights_f32(const float* w, float* u_fwd, float* u_bwd, int32_t K, i
 #define DL_WINO_BATCH 16
 typedef struct {
   const float* w;      /* [K][3][3][C] */
-  float* u_fwd;        /* [C/8][16][K][8] or null */
-  float* u_bwd;        /* [K/8][16][C][8] or null */
+  float* u_fwd;        /* 16*K*C floats (layout above) or null */
+  float* u_bwd;        /* 16*K*C floats or null */
   int32_t K, C;
 } dl_wino_layer;
 int dl_wino_weights_batch_f32(const dl_wino_layer* layers, int32_t n, dl_stream stream);
