@@ -55,7 +55,7 @@ static inline int project_garg(int S, int G) { return (S >= 8 && project_plain_g
 
 __global__ __launch_bounds__(DL_BLOCK) void k_project_scatter(
     const float* __restrict__ pts, int64_t cs, const int32_t* __restrict__ offs, int S, int C, int G, SensorK sen,
-    unsigned long long* __restrict__ keys, float4* __restrict__ stage0, float4* __restrict__ stage1, float* __restrict__ uvr) {
+    unsigned long long* __restrict__ keys, float4* __restrict__ stage0, float4* __restrict__ stage1, float* __restrict__ uvr, int64_t n_cols) {
   int s, chunk;
   if (!project_block(S, G, s, chunk)) return;
   const int n0 = offs[s];
@@ -77,6 +77,7 @@ __global__ __launch_bounds__(DL_BLOCK) void k_project_scatter(
       v = coord_v(x, y, z, sen);
     }
     if (uvr) { uvr[g] = u; uvr[cs + g] = v; uvr[2 * cs + g] = r; }
+    if (g >= n_cols) continue;                  // offsets that disagree with the sized workspace: no store, no vote
     stage0[g] = make_float4(x, y, z, r);
     if (stage1)
       stage1[g] = make_float4(pts[3 * cs + g], C > 4 ? pts[4 * cs + g] : 0.f, C > 5 ? pts[5 * cs + g] : 0.f, 0.f);
@@ -135,7 +136,9 @@ __global__ __launch_bounds__(DL_BLOCK) void k_project_resolve(
   }
 }
 
-static inline size_t project_keys_bytes(int32_t S, int32_t H, int32_t W) { return (size_t)S * H * W * sizeof(uint64_t); }
+// (advisor, round 5) the staging records behind the key plane are read and written as float4: the plane's size is rounded up to 16 bytes
+// (S*H*W odd would leave them 8-byte aligned); the vote's staging stores are guarded by the record count the workspace was sized for
+static inline size_t project_keys_bytes(int32_t S, int32_t H, int32_t W) { return (((size_t)S * H * W * sizeof(uint64_t)) + 15) & ~(size_t)15; }
 
 extern "C" size_t dl_project_workspace_bytes(int32_t S, int32_t H, int32_t W, int64_t n_cols, int32_t C) {
   if (S <= 0 || H <= 0 || W <= 0 || n_cols < 0 || C < 3) return 0;
@@ -161,13 +164,13 @@ extern "C" int dl_project(const float* pts, int64_t pts_cs, int64_t n_cols, cons
   float4* stage1 = C > 3 ? stage0 + n_cols : nullptr;
   // the key plane and the counters are initialised by a kernel on the same stream (dl_fill_words: a kernel node, not a
   // memset node, when the step is captured into a HIP graph); a launch failure is reported by dl_check_launch below
-  dl_fill_words(keys, 0xffffffffu, project_keys_bytes(S, sen.H, sen.W) / 4, st);
+  dl_fill_words(keys, 0xffffffffu, (size_t)S * sen.HW * 2, st);
   if (kept) dl_fill_words(kept, 0u, (size_t)S, st);
   if (max_n > 0) {
     int G = (max_n + DL_BLOCK - 1) / DL_BLOCK;
     if (G > 1024) G = 1024;
     hipLaunchKernelGGL(k_project_scatter, dim3(project_grid(S, G)), dim3(DL_BLOCK), 0, st, pts, pts_cs, offs, S, C, project_garg(S, G),
-                       sen, keys, stage0, stage1, uvr);
+                       sen, keys, stage0, stage1, uvr, n_cols);
   }
   const int G = (sen.HW + DL_BLOCK - 1) / DL_BLOCK;
   hipLaunchKernelGGL(k_project_resolve, dim3(project_grid(S, G)), dim3(DL_BLOCK), 0, st, pts, pts_cs, offs, S, C, project_garg(S, G), sen,

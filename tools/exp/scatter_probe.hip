@@ -95,8 +95,8 @@ int main(int argc, char** argv) {
       CK(hipEventRecord(e0, 0));
       switch (mode) {
         case 0: dl_project(pts, total, total, d_offs, S, 3, N, &sen, image4, nullptr, packed, nullptr, pix2pt, ws, nullptr, nullptr, nullptr); break;
-        case 1: hipLaunchKernelGGL(k_project_scatter, dim3(8 * G * ((S + 7) / 8)), dim3(256), 0, 0, pts, total, d_offs, S, 3, G, k, keys, stage0, (float4*)nullptr, (float*)nullptr); break;
-        case 2: hipLaunchKernelGGL(k_project_scatter, dim3(S * G), dim3(256), 0, 0, pts, total, d_offs, S, 3, -G, k, keys, stage0, (float4*)nullptr, (float*)nullptr); break;
+        case 1: hipLaunchKernelGGL(k_project_scatter, dim3(8 * G * ((S + 7) / 8)), dim3(256), 0, 0, pts, total, d_offs, S, 3, G, k, keys, stage0, (float4*)nullptr, (float*)nullptr, (int64_t)total); break;
+        case 2: hipLaunchKernelGGL(k_project_scatter, dim3(S * G), dim3(256), 0, 0, pts, total, d_offs, S, 3, -G, k, keys, stage0, (float4*)nullptr, (float*)nullptr, (int64_t)total); break;
         case 3: hipLaunchKernelGGL(k_project_resolve, dim3(8 * GP * ((S + 7) / 8)), dim3(256), 0, 0, pts, total, d_offs, S, 3, GP, k, (const unsigned long long*)keys, (const float4*)stage0, (const float4*)nullptr, image4, (float*)nullptr, (float4*)packed, (float4*)nullptr, pix2pt, (int32_t*)nullptr); break;
         case 4: hipLaunchKernelGGL(k_project_resolve, dim3(S * GP), dim3(256), 0, 0, pts, total, d_offs, S, 3, -GP, k, (const unsigned long long*)keys, (const float4*)stage0, (const float4*)nullptr, image4, (float*)nullptr, (float4*)packed, (float4*)nullptr, pix2pt, (int32_t*)nullptr); break;
         case 5: hipLaunchKernelGGL(k_noatomic, dim3(G, S), dim3(256), 0, 0, pts, total, d_offs, k, keys); break;
