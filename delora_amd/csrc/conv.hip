@@ -350,7 +350,7 @@ struct WgArgs {
   int N, H, W, C, K, Ho, Wo, chunks_per_slab, nslabs;
 };
 // (the body of the kernel for workgroup `blk` of one layer: k_wgrad_f32 runs one layer per launch, k_wgrad_f32_batch several)
-template <int BMK, int BNC, int PK, int SH, int SW, int KS>
+template <int BMK, int BNC, int PK, int SH, int SW, int KS, bool FAST>
 __device__ __forceinline__ void wgrad_f32_body(const float* __restrict__ x, const float* __restrict__ g, float* __restrict__ part, int N, int H,
                                                int W, int C, int K, int Ho, int Wo, int chunks_per_slab, int nslabs, const int blk) {
   // pixel chunk: PK consecutive output columns of one output row; a slab is a run of consecutive chunks
@@ -399,10 +399,45 @@ __device__ __forceinline__ void wgrad_f32_body(const float* __restrict__ x, cons
   const int ch_end = min(ch_begin + chunks_per_slab, total_chunks);
 
   f32x4 x_r[NX_IT], g_r[NG_IT];
+  // Round 6: a vector instruction next to an fp32 MFMA costs matrix time (wino.hip), and this loader spent 277 of them per
+  // chunk of 72 MFMAs -- a modulo by the run-time width and 64-bit address arithmetic for every staged item.  Per item two registers now
+  // hold what does not change from chunk to chunk (its element offset inside the chunk's window and its (row, column) there); a chunk
+  // adds a scalar base, wraps the column with two compares (the window is at most one image width wide: checked once, else the generic
+  // path below) and zeroes rows outside the image: ~12 instructions per item, 32-bit offsets next to a scalar 64-bit base.
+  // (FAST: the launcher checked RW <= W and 32-bit element offsets per sample)
+  constexpr bool fast = FAST;
+  int x_rel[FAST ? NX_IT : 1], x_rc[FAST ? NX_IT : 1];
+  if (FAST) {
+    _Pragma("unroll") for (int it = 0; it < NX_IT; ++it) {
+      WG_XITEM(it)
+      (void)x_l_;
+      x_rel[it] = (x_row_ * W + x_col_) * C + x_c4_;
+      x_rc[it] = (x_row_ << 16) | x_col_;
+    }
+  }
 #define WG_FETCH(CH)                                                                                                      \
   {                                                                                                                       \
     const int row_ = (CH) / chunks_per_row, wo0_ = ((CH) % chunks_per_row) * PK;                                          \
     const int n_ = row_ / Ho, ho_ = row_ % Ho;                                                                            \
+    if (fast) {                                                                                                           \
+      const int h0_ = ho_ * SH - PAD, w0_ = wo0_ * SW - PAD, wc_ = W * C;                                                 \
+      const float* xs_ = x + (size_t)n_ * H * W * C + c0;                      /* scalar */                               \
+      const int base_ = (h0_ * W + w0_) * C;                                   /* scalar, may be negative */              \
+      _Pragma("unroll") for (int it = 0; it < NX_IT; ++it) {                                                              \
+        const int h = h0_ + (x_rc[FAST ? it : 0] >> 16), w = w0_ + (x_rc[FAST ? it : 0] & 0xffff);                        \
+        const bool in = (unsigned)h < (unsigned)H;                                                                        \
+        const int off = base_ + x_rel[FAST ? it : 0] + (w < 0 ? wc_ : 0) - (w >= W ? wc_ : 0);                            \
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xs_ + (unsigned)(in ? off : 0));                                  \
+        x_r[it] = in ? v : (f32x4){0.f, 0.f, 0.f, 0.f};                                                                   \
+      }                                                                                                                   \
+      const float* gs_ = g + ((size_t)(n_ * Ho + ho_) * Wo + wo0_) * K + k0;   /* scalar */                               \
+      _Pragma("unroll") for (int it = 0; it < NG_IT; ++it) {                                                              \
+        WG_GITEM(it)                                                                                                      \
+        const bool gin = wo0_ + g_p_ < Wo;                                                                                \
+        const f32x4 gv = *reinterpret_cast<const f32x4*>(gs_ + (unsigned)(gin ? g_p_ * K + g_k4_ : 0));                   \
+        g_r[it] = gin ? gv : (f32x4){0.f, 0.f, 0.f, 0.f};                                                                 \
+      }                                                                                                                   \
+    } else {                                                                                                              \
     _Pragma("unroll") for (int it = 0; it < NX_IT; ++it) {                                                                \
       WG_XITEM(it)                                                                                                        \
       (void)x_l_;                                                                                                         \
@@ -418,6 +453,7 @@ __device__ __forceinline__ void wgrad_f32_body(const float* __restrict__ x, cons
       const bool gin = wo0_ + g_p_ < Wo;           /* pixels beyond the row's end contribute nothing */                    \
       const f32x4 gv = *reinterpret_cast<const f32x4*>(g + (((size_t)n_ * Ho + ho_) * Wo + (gin ? wo0_ + g_p_ : 0)) * K + k0 + g_k4_); \
       g_r[it] = gin ? gv : (f32x4){0.f, 0.f, 0.f, 0.f};                                                                    \
+    }                                                                                                                     \
     }                                                                                                                     \
   }
 #define WG_STAGE()                                                                                                        \
@@ -494,11 +530,16 @@ __device__ __forceinline__ void wgrad_f32_body(const float* __restrict__ x, cons
   }
 }
 
-template <int BMK, int BNC, int PK, int SH, int SW, int KS>
+template <int BMK, int BNC, int PK, int SH, int SW, int KS, bool FAST = false>
 __global__ __launch_bounds__(CV_THREADS, 2) void k_wgrad_f32(const float* __restrict__ x, const float* __restrict__ g,
                                                              float* __restrict__ part, int N, int H, int W, int C, int K,
                                                              int Ho, int Wo, int chunks_per_slab, int nslabs) {
-  wgrad_f32_body<BMK, BNC, PK, SH, SW, KS>(x, g, part, N, H, W, C, K, Ho, Wo, chunks_per_slab, nslabs, blockIdx.x);
+  wgrad_f32_body<BMK, BNC, PK, SH, SW, KS, FAST>(x, g, part, N, H, W, C, K, Ho, Wo, chunks_per_slab, nslabs, blockIdx.x);
+}
+// FAST (the staged window is at most one image width wide, element offsets of a sample fit 31 bits): every layer of the network
+template <int PK, int SW, int KS>
+static inline bool wgrad_fast(int H, int W, int C, int K, int Ho, int Wo) {
+  return (PK - 1) * SW + KS <= W && (size_t)H * W * C < ((size_t)1 << 30) && (size_t)Ho * Wo * K < ((size_t)1 << 30);
 }
 
 // Several layers in one launch (dl_conv2d_wgrad_batch_nhwc_f32, see include/delora_hip.h): layer table in the kernel arguments,
@@ -508,14 +549,14 @@ struct WgBatchArgs {
   int first_wg[DL_WGRAD_BATCH + 1];
   int n;
 };
-template <int BMK, int BNC, int PK, int SH, int SW, int KS>
+template <int BMK, int BNC, int PK, int SH, int SW, int KS, bool FAST = false>
 __global__ __launch_bounds__(CV_THREADS, 2) void k_wgrad_f32_batch(WgBatchArgs b) {
   int l = 0;
 #pragma unroll
   for (int i = 1; i < DL_WGRAD_BATCH; ++i)
     if (i < b.n && (int)blockIdx.x >= b.first_wg[i]) l = i;
   const WgArgs a = b.layer[l];
-  wgrad_f32_body<BMK, BNC, PK, SH, SW, KS>(a.x, a.g, a.part, a.N, a.H, a.W, a.C, a.K, a.Ho, a.Wo, a.chunks_per_slab, a.nslabs, (int)blockIdx.x - b.first_wg[l]);
+  wgrad_f32_body<BMK, BNC, PK, SH, SW, KS, FAST>(a.x, a.g, a.part, a.N, a.H, a.W, a.C, a.K, a.Ho, a.Wo, a.chunks_per_slab, a.nslabs, (int)blockIdx.x - b.first_wg[l]);
 }
 
 // Sum of the slab partials in a fixed order (slab 0, 1, 2, ... per element: deterministic).  Eight slabs are loaded per
@@ -860,8 +901,12 @@ static int launch_wgrad(const float* x, const float* g, float* dw, float* ws, in
   const int chunks_per_slab = (total_chunks + nslabs - 1) / nslabs;
   const DlProfTag tag{"k_wgrad_f32", "wgrad", N, H, W, C, K, KS, SH, SW, 2.0 * N * Ho * Wo * (double)K * C * KS * KS,
                       4.0 * ((double)N * H * W * C + (double)N * Ho * Wo * K + (double)K * KS * KS * C)};
-  DL_LAUNCH(tag, (k_wgrad_f32<BMK, BNC, PK, SH, SW, KS>), dim3(tiles * nslabs), dim3(CV_THREADS), st, x, g, ws, N,
-            H, W, C, K, Ho, Wo, chunks_per_slab, nslabs);
+  if (wgrad_fast<PK, SW, KS>(H, W, C, K, Ho, Wo))
+    DL_LAUNCH(tag, (k_wgrad_f32<BMK, BNC, PK, SH, SW, KS, true>), dim3(tiles * nslabs), dim3(CV_THREADS), st, x, g, ws, N,
+              H, W, C, K, Ho, Wo, chunks_per_slab, nslabs);
+  else
+    DL_LAUNCH(tag, (k_wgrad_f32<BMK, BNC, PK, SH, SW, KS>), dim3(tiles * nslabs), dim3(CV_THREADS), st, x, g, ws, N,
+              H, W, C, K, Ho, Wo, chunks_per_slab, nslabs);
   const size_t count = (size_t)K * KS * KS * C;
   hipLaunchKernelGGL(k_wgrad_reduce, dim3((unsigned)((count / 4 + CV_THREADS - 1) / CV_THREADS)), dim3(CV_THREADS), 0, st,
                      (const float*)ws, nslabs, count, dw);
@@ -939,7 +984,13 @@ int wg_batch_plan(const dl_wgrad_layer* L, int n, std::vector<WgItem>& items) {
 }
 template <int SH, int SW, int KS>
 void launch_wgrad_batch(const WgBatchArgs& b, int wgs, const DlProfTag& tag, hipStream_t st) {
-  DL_LAUNCH(tag, (k_wgrad_f32_batch<64, 64, wg_pk(SW, KS), SH, SW, KS>), dim3(wgs), dim3(CV_THREADS), st, b);
+  bool fast = true;
+  for (int i = 0; i < b.n; ++i) {
+    const WgArgs& a = b.layer[i];
+    fast = fast && wgrad_fast<wg_pk(SW, KS), SW, KS>(a.H, a.W, a.C, a.K, a.Ho, a.Wo);
+  }
+  if (fast) DL_LAUNCH(tag, (k_wgrad_f32_batch<64, 64, wg_pk(SW, KS), SH, SW, KS, true>), dim3(wgs), dim3(CV_THREADS), st, b);
+  else DL_LAUNCH(tag, (k_wgrad_f32_batch<64, 64, wg_pk(SW, KS), SH, SW, KS>), dim3(wgs), dim3(CV_THREADS), st, b);
 }
 }  // namespace
 
