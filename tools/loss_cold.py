@@ -5,6 +5,8 @@ full of dirty lines whose write-back competes with the kernel's reads) against 1
 import os, sys
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+import delora_amd._lib as _L
+if len(sys.argv) > 1: _L.LIB_PATH = sys.argv[1]
 import bench
 from delora_amd import geometry as G
 from delora_amd.deploy.step_geometry import HipStepGeometry
@@ -13,7 +15,7 @@ dev = torch.device("cuda:0")
 flush = torch.zeros((256 * 1024 * 1024,), dtype=torch.float32, device=dev)
 sink = torch.zeros((1,), device=dev)
 flush2 = torch.zeros((256 * 1024 * 1024,), dtype=torch.float32, device=dev)
-for B in (8, 16):
+for B in ((8,) if len(sys.argv) > 2 else (8, 16)):
     A = type("A", (), dict(batch=B, height=64, width=2048))
     cfg = bench.build_config(type("X", (), dict(height=64, width=2048, batch=B, amp="", channels_last=False))(), dev)
     batch = bench.make_batch(A(), 0, dev)
