@@ -46,6 +46,15 @@ __device__ int* g_nn_prof = nullptr;
 extern "C" int dl_nn_debug_set(int* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_nn_prof), &p, sizeof(p)); }
 #endif
 
+#ifdef NN_STATS                 // tools/nn_lab: how many nodes the walks touch (wave-level counts; lane 0 adds)
+__device__ unsigned long long g_nn_stats[8];   // 0 queries (wave walk) 1 super visits 2 tile tests 3 tile scans | 4 queries (16-lane walk) 5 tile tests 6 tile scans | 7 scan16 pixels
+#define NN_STAT(I, N) do { if ((threadIdx.x & (DL_WAVE - 1)) == 0) atomicAdd(&g_nn_stats[I], (unsigned long long)(N)); } while (0)
+#define NN_STAT16(I, N) do { if ((threadIdx.x & 15) == 0) atomicAdd(&g_nn_stats[I], (unsigned long long)(N)); } while (0)
+#else
+#define NN_STAT(I, N) do { } while (0)
+#define NN_STAT16(I, N) do { } while (0)
+#endif
+
 #define NN_SEED_MIN 8192        // bound windows beyond this many pixels are re-derived after a seed scan around q's pixel
 #ifndef NN_SCAN_MAX
 #define NN_SCAN_MAX 256        // bound windows up to this many pixels are scanned directly, 16 lanes per query
@@ -420,6 +429,8 @@ __device__ __forceinline__ void scan_tiles(const Window& w, const float4* __rest
                 box_lower(tbox_b[2 * (tr * ntc_all + tc)], tbox_b[2 * (tr * ntc_all + tc) + 1], qx, qy, qz) <= dcur;
     }
     unsigned long long mask = __ballot(survive);
+    NN_STAT(2, min(ntiles - t0, DL_WAVE));
+    NN_STAT(3, __popcll(mask));
     while (mask) {
       // up to four surviving tiles per trip: their four wave-wide loads are issued before any is consumed (one L2 round trip
       // instead of four dependent ones)
@@ -604,7 +615,10 @@ __device__ __forceinline__ void pyramid_walk(const float4* __restrict__ super_b,
     dcur = fminf(dcur, wave_min_f(ub));
     survive = survive && lb1 <= dcur;
     unsigned long long mask = __ballot(survive);
+    NN_STAT(1, 1 + (sB >= 0));
+    NN_STAT(2, __popcll(__ballot(lb1 < 3.0e38f)));
     while (mask) {
+      NN_STAT(3, min(__popcll(mask), 4));
       float4 c4[4];
       int pp[4];
 #pragma unroll
@@ -690,6 +704,7 @@ __device__ __forceinline__ void nn_scan16(const int vblock, const int vgrid, con
     float thr = lbest < 1e30 ? (float)lbest * (1.0f + 1e-5f) : 3.0e38f;
     const int nchunk = (nc + 15) >> 4;
     const int steps = (r1 - r0 + 1) * nchunk;
+    NN_STAT16(7, (r1 - r0 + 1) * nc);
     for (int st = 0; st < steps; st += 4) {               // four independent 16-pixel pieces in flight
       float4 c4[4];
       int pp[4];
@@ -768,6 +783,7 @@ __device__ __forceinline__ void nn_hard16(const int vblock, const int vgrid, con
     int tc0 = c0 / NN_TC, ntc = (c0 % NN_TC + nc + NN_TC - 1) / NN_TC;
     if (nc >= W || ntc >= ntc_all || ((W % NN_TC) != 0 && c0 + nc > W)) { tc0 = 0; ntc = ntc_all; }
     const int ntiles = live ? (tr1 - tr0 + 1) * ntc : 0;
+    NN_STAT16(4, live ? 1 : 0);
     double lbest = rec.d2;
     int lidx = -1;
     float thr = lbest < 1e30 ? (float)lbest * (1.0f + 1e-5f) : 3.0e38f;
@@ -792,6 +808,8 @@ __device__ __forceinline__ void nn_hard16(const int vblock, const int vgrid, con
       }
       // this row's 16 survivor bits
       unsigned gmask = (unsigned)((__ballot(survive) >> rowbase) & 0xffffull);
+      NN_STAT16(5, max(0, min(ntiles - t0, 16)));
+      NN_STAT16(6, __builtin_popcount(gmask));
       while (__any(gmask != 0)) {
         // one surviving tile per row and trip: its four 16-pixel rows are loaded together
         const bool has = gmask != 0;
@@ -874,6 +892,7 @@ __device__ __forceinline__ void nn_hard(const int vblock, const int vgrid, const
 #endif
     const NNHard rec = ws.hard[h];
     const int b = rec.b;
+    NN_STAT(0, 1);
     Window w;
     w.r0 = (int)(rec.rows & 0xffffu); w.r1 = (int)(rec.rows >> 16);
     w.c0 = (int)(rec.cols & 0xffffu); w.nc = (int)(rec.cols >> 16) + 1;
