@@ -176,6 +176,33 @@ __device__ __forceinline__ Window bound_window(const QueryF& q, float d, const S
   return w;
 }
 
+// Pass A's fixed window: (2 NN_RV + 1) rows of (2 NN_RU + 1) candidates around (v0, cbase + NN_RU), fp64 distances, ties to the lower
+// pixel index.  SEAM: the columns wrap (c >= W -> c - W).
+template <bool SEAM>
+__device__ __forceinline__ void window_rows(const float4* __restrict__ tp, int v0, int cbase, int H, int W, float fx, float fy, float fz,
+                                            double& best, int& bidx) {
+#pragma unroll
+  for (int dv = -NN_RV; dv <= NN_RV; ++dv) {
+    const int v = v0 + dv;
+    if (v < 0 || v >= H) continue;
+    float4 cc[2 * NN_RU + 1];
+    const int p0 = v * W + cbase;
+    const float4* rp = tp + p0;
+#pragma unroll
+    for (int i = 0; i <= 2 * NN_RU; ++i) {       // one row of candidates: all (16-byte) loads first
+      if (SEAM) cc[i] = cbase + i >= W ? rp[i - W] : rp[i];
+      else cc[i] = rp[i];
+    }
+#pragma unroll
+    for (int i = 0; i <= 2 * NN_RU; ++i) {
+      const int cp = (SEAM && cbase + i >= W) ? p0 + i - W : p0 + i;
+      const bool empty = (cc[i].x == 0.f && cc[i].y == 0.f && cc[i].z == 0.f);
+      const double d2 = empty ? 1e300 : dist2(fx, fy, fz, cc[i].x, cc[i].y, cc[i].z);
+      if (d2 < best || (d2 == best && d2 < 1e299 && cp < bidx)) { best = d2; bidx = cp; }
+    }
+  }
+}
+
 __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
     const float* __restrict__ src, int64_t src_ss, const float* __restrict__ srcn, int64_t srcn_ss,
     const float4* __restrict__ tgt, int64_t tgt_ss4, const float4* __restrict__ tgtn, int64_t tgtn_ss4,
@@ -210,87 +237,89 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
       }
     }
   }
-  if (visible) {
-    // one atomic per workgroup, spread over 32 sub-counters per sample (2048 same-address atomics per sample
-    // serialise for ~80 us at the end of the kernel); nn_hard (k_nn_pass_b) folds the sub-counters into visible[b]
-    __shared__ int s_vis;
-    if (threadIdx.x == 0) s_vis = 0;
-    __syncthreads();
-    const unsigned long long vm = __ballot(vis);
-    if ((threadIdx.x & (DL_WAVE - 1)) == 0 && vm) atomicAdd(&s_vis, (int)__popcll(vm));
-    __syncthreads();
-    if (threadIdx.x == 0 && s_vis) atomicAdd(&ws.counter[NN_VIS0 + b * 32 + (blockIdx.x & 31)], s_vis);
-  }
-  if (px >= HW) return;
-  float* mp = match ? match + (size_t)b * 6 * HW + px : nullptr;
-  if (!active) {
+  // No early exits: the whole workgroup meets again at the append below.
+  float* mp = (match && px < HW) ? match + (size_t)b * 6 * HW + px : nullptr;
+  if (px < HW && !active) {
     nn_pix[(size_t)b * HW + px] = -1;
     if (mp) { mp[0] = 0.f; mp[HW] = 0.f; mp[2 * HW] = 0.f; mp[3 * HW] = 0.f; mp[4 * HW] = 0.f; mp[5 * HW] = 0.f; }
-    return;
   }
-
-  const float4* tp = tgt + (size_t)b * tgt_ss4;
-  const int u0 = (int)rintf(q.uq);
-  int v0 = (int)rintf(q.vq);
-  v0 = v0 < 0 ? 0 : (v0 > H - 1 ? H - 1 : v0);
-  double best = 1e300;
-  int bidx = -1;
-  const int cbase = wrap_col(u0 - NN_RU, W);
-#pragma unroll
-  for (int dv = -NN_RV; dv <= NN_RV; ++dv) {
-    const int v = v0 + dv;
-    if (v < 0 || v >= H) continue;
-    float4 cc[2 * NN_RU + 1];
-    int cp[2 * NN_RU + 1];
-#pragma unroll
-    for (int i = 0; i <= 2 * NN_RU; ++i) {       // one row of candidates: all (16-byte) loads first
-      int c = cbase + i;
-      c = c >= W ? c - W : c;
-      cp[i] = v * W + c;
-      cc[i] = tp[cp[i]];
+  int cls = -1;                  // list of an uncertified query: 0 tile walk with one wave, 1 window scan, 2 tile walk with 16 lanes
+  NNHard h;
+  if (px < HW && active) {
+    const float4* tp = tgt + (size_t)b * tgt_ss4;
+    const int u0 = (int)rintf(q.uq);
+    int v0 = (int)rintf(q.vq);
+    v0 = v0 < 0 ? 0 : (v0 > H - 1 ? H - 1 : v0);
+    double best = 1e300;
+    int bidx = -1;
+    const int cbase = wrap_col(u0 - NN_RU, W);
+    // A window that does not run through the azimuth seam (all but the waves at the two ends of an image row) is read through one
+    // pointer per row with immediate offsets; the wrapped form costs ~7 VALU instructions of address arithmetic per candidate.
+    if (__ballot(cbase + 2 * NN_RU >= W) == 0ull) window_rows<false>(tp, v0, cbase, H, W, fx, fy, fz, best, bidx);
+    else window_rows<true>(tp, v0, cbase, H, W, fx, fy, fz, best, bidx);
+    if (best >= 1e299) bidx = -1;
+    // certificate: every pixel that can hold a closer target lies inside the scanned window (and the needed columns do
+    // not run through the azimuth seam, where the scanned columns were wrapped)
+    bool exact = false;
+    Window w;
+    w.r0 = 0; w.r1 = H - 1; w.c0 = 0; w.nc = W;              // nothing found: the whole image
+    if (bidx >= 0) {
+      const float d = (float)sqrt(best) * NN_UP;
+      w = bound_window(q, d, sen);
+      const bool rows_ok = (w.r0 >= v0 - NN_RV) && (w.r1 <= v0 + NN_RV);
+      const bool cols_ok = (w.nc <= 2 * NN_RU + 1) && (w.c0 >= u0 - NN_RU) && (w.c0 + w.nc - 1 <= u0 + NN_RU) &&
+                           (w.c0 + w.nc - 1 <= W - 1);
+      exact = rows_ok && cols_ok;
     }
-#pragma unroll
-    for (int i = 0; i <= 2 * NN_RU; ++i) {
-      const bool empty = (cc[i].x == 0.f && cc[i].y == 0.f && cc[i].z == 0.f);
-      const double d2 = empty ? 1e300 : dist2(fx, fy, fz, cc[i].x, cc[i].y, cc[i].z);
-      if (d2 < best || (d2 == best && d2 < 1e299 && cp[i] < bidx)) { best = d2; bidx = cp[i]; }
+    if (exact) {
+      nn_pix[(size_t)b * HW + px] = bidx;
+      if (mp) {      // matched target point and normal in source pixel order: the loss pass streams them
+        const float4 p4 = tp[bidx];
+        const float4 n4 = tgtn ? (tgtn + (size_t)b * tgtn_ss4)[bidx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        mp[0] = p4.x; mp[HW] = p4.y; mp[2 * HW] = p4.z; mp[3 * HW] = n4.x; mp[4 * HW] = n4.y; mp[5 * HW] = n4.z;
+      }
+    } else {
+      // three lists, all served by k_nn_pass_b: windows of at most NN_SCAN_MAX pixels (most of them: a few hundred) are scanned
+      // exhaustively by 16-lane groups (nn_scan16); larger ones walk tiles with 16 lanes (nn_hard16) or a whole wave (nn_hard)
+      const int wpx = (w.r1 - w.r0 + 1) * w.nc;
+      cls = wpx <= NN_SCAN_MAX ? 1 : (wpx <= NN_SEED_MIN ? 2 : 0);
+      h.d2 = best; h.slot = b * HW + px; h.idx = bidx; h.qx = fx; h.qy = fy; h.qz = fz; h.b = b;
+      h.rows = (uint32_t)w.r0 | ((uint32_t)w.r1 << 16);
+      h.cols = (uint32_t)w.c0 | ((uint32_t)(w.nc - 1) << 16);
     }
   }
-  if (best >= 1e299) bidx = -1;
-  // certificate: every pixel that can hold a closer target lies inside the scanned window (and the needed columns do
-  // not run through the azimuth seam, where the scanned columns were wrapped)
-  bool exact = false;
-  Window w;
-  w.r0 = 0; w.r1 = H - 1; w.c0 = 0; w.nc = W;              // nothing found: the whole image
-  if (bidx >= 0) {
-    const float d = (float)sqrt(best) * NN_UP;
-    w = bound_window(q, d, sen);
-    const bool rows_ok = (w.r0 >= v0 - NN_RV) && (w.r1 <= v0 + NN_RV);
-    const bool cols_ok = (w.nc <= 2 * NN_RU + 1) && (w.c0 >= u0 - NN_RU) && (w.c0 + w.nc - 1 <= u0 + NN_RU) &&
-                         (w.c0 + w.nc - 1 <= W - 1);
-    exact = rows_ok && cols_ok;
+  // Append, aggregated by hand over the workgroup: every wave adds its three list counts (and its visible-pixel count) to LDS
+  // counters with one LDS atomic instruction (lanes 0..3), the workgroup takes its ranges with ONE 64-bit atomic for the two lists
+  // that share hard[] plus one for mid[], every lane ranks itself inside its list from the ballots.  (As one atomicAdd per lane -- the
+  // compiler does not merge them -- the appends were 72 us of this kernel's 148 at the bench's residual and 198 of 262 us for random
+  // poses: same-address atomics retire one every ~3 ns.)  hard[] holds tile-walk queries from the front, scanned queries from the end.
+  __shared__ int s_cnt[4], s_base[3];
+  if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & (DL_WAVE - 1);
+  const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), mv = __ballot(vis);
+  int woff = 0;
+  {
+    const unsigned long long mm = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : mv));
+    if (lane < 4 && mm) woff = atomicAdd(&s_cnt[lane], (int)__popcll(mm));
   }
-  if (exact) {
-    nn_pix[(size_t)b * HW + px] = bidx;
-    if (mp) {      // matched target point and normal in source pixel order: the loss pass streams them
-      const float4 p4 = tp[bidx];
-      const float4 n4 = tgtn ? (tgtn + (size_t)b * tgtn_ss4)[bidx] : make_float4(0.f, 0.f, 0.f, 0.f);
-      mp[0] = p4.x; mp[HW] = p4.y; mp[2 * HW] = p4.z; mp[3 * HW] = n4.x; mp[4 * HW] = n4.y; mp[5 * HW] = n4.z;
-    }
-  } else {
-    // two lists in one array: windows of at most NN_SCAN_MAX pixels (most of them: a few hundred) grow from the end
-    // and are scanned exhaustively by 16-lane groups (nn_scan16); larger ones grow from the front (nn_hard: tile walk) -- all three lists are served by k_nn_pass_b
-    const int wpx = (w.r1 - w.r0 + 1) * w.nc;
-    NNHard* list = ws.hard;
-    int pos;
-    if (wpx <= NN_SCAN_MAX) pos = ws.capacity - 1 - atomicAdd(ws.counter + 1, 1);
-    else if (wpx <= NN_SEED_MIN) { list = ws.mid; pos = atomicAdd(ws.counter + 2, 1); }   // tile walk, 16 lanes (nn_hard16)
-    else pos = atomicAdd(ws.counter, 1);                                                   // tile walk, one wave (nn_hard)
-    NNHard h;
-    h.d2 = best; h.slot = b * HW + px; h.idx = bidx; h.qx = fx; h.qy = fy; h.qz = fz; h.b = b;
-    h.rows = (uint32_t)w.r0 | ((uint32_t)w.r1 << 16);
-    h.cols = (uint32_t)w.c0 | ((uint32_t)(w.nc - 1) << 16);
-    list[pos] = h;
+  __syncthreads();
+  if (threadIdx.x == 0 && (s_cnt[0] | s_cnt[1])) {
+    const unsigned long long r = atomicAdd(reinterpret_cast<unsigned long long*>(ws.counter),
+                                           (unsigned long long)(unsigned)s_cnt[0] | ((unsigned long long)(unsigned)s_cnt[1] << 32));
+    s_base[0] = (int)(unsigned)r;
+    s_base[1] = (int)(unsigned)(r >> 32);
+  }
+  if (threadIdx.x == 1 && s_cnt[2]) s_base[2] = atomicAdd(ws.counter + 2, s_cnt[2]);
+  // visible pixels: spread over 32 sub-counters per sample; nn_hard (k_nn_pass_b) folds them into visible[b]
+  if (threadIdx.x == 2 && visible && s_cnt[3]) atomicAdd(&ws.counter[NN_VIS0 + b * 32 + (blockIdx.x & 31)], s_cnt[3]);
+  __syncthreads();
+  if (cls >= 0) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int w0 = __builtin_amdgcn_readlane(woff, 0), w1 = __builtin_amdgcn_readlane(woff, 1), w2 = __builtin_amdgcn_readlane(woff, 2);
+    if (cls == 0) ws.hard[s_base[0] + w0 + (int)__popcll(m0 & below)] = h;
+    else if (cls == 1) ws.hard[ws.capacity - 1 - (s_base[1] + w1 + (int)__popcll(m1 & below))] = h;
+    else ws.mid[s_base[2] + w2 + (int)__popcll(m2 & below)] = h;
   }
 }
 
@@ -393,6 +422,26 @@ __device__ __forceinline__ float box_lower(const float4 lo, const float4 hi, flo
   return sqrtf(fmaf(ez, ez, fmaf(ey, ey, ex * ex))) * (1.0f - 8e-6f) - 1e-6f;
 }
 
+// One candidate of a scanning loop: fp32 screen against the lane's best (thr bounds it from above), fp64 only for what passes.  The
+// validity tests (a lane without a pixel carries zeros, an empty pixel is zeros) sit BEHIND the screen and behind a wave-uniform
+// branch: after the first candidates no lane of the wave passes it, and the common path is seven VALU instructions per candidate
+// (the kernels of this file are VALU-bound: profiles/r06_nn_lab.txt).
+__device__ __forceinline__ void nn_consider(const float4 c, const int p, const float qx, const float qy, const float qz, float& thr,
+                                            double& lbest, int& lidx) {
+  const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
+  const float d2f = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+  const bool near = d2f <= thr;
+  if (__ballot(near)) {
+    if (near && p >= 0 && !(c.x == 0.f && c.y == 0.f && c.z == 0.f)) {
+      const double d2 = dist2(qx, qy, qz, c.x, c.y, c.z);
+      if (d2 < lbest || (d2 == lbest && lidx >= 0 && p < lidx)) {
+        lbest = d2; lidx = p;
+        thr = (float)lbest * (1.0f + 1e-5f);
+      }
+    }
+  }
+}
+
 // Final, exact stage of pass B for one query (wave-uniform arguments): the bound window is walked tile by tile; 64
 // tiles are tested per trip (one per lane: sphere distance against the best distance so far) and surviving tiles are
 // scanned one pixel per lane; the cull distance is refreshed once per trip.
@@ -452,18 +501,7 @@ __device__ __forceinline__ void scan_tiles(const Window& w, const float4* __rest
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int p = pp[u];
-        const float dx = qx - c4[u].x, dy = qy - c4[u].y, dz = qz - c4[u].z;
-        const float d2f = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-        if (p >= 0 && !(c4[u].x == 0.f && c4[u].y == 0.f && c4[u].z == 0.f) && d2f <= thr) {
-          const double d2 = dist2(qx, qy, qz, c4[u].x, c4[u].y, c4[u].z);
-          if (d2 < lbest || (d2 == lbest && lidx >= 0 && p < lidx)) {
-            lbest = d2; lidx = p;
-            thr = (float)lbest * (1.0f + 1e-5f);
-          }
-        }
-      }
+      for (int u = 0; u < 4; ++u) nn_consider(c4[u], pp[u], qx, qy, qz, thr, lbest, lidx);
     }
     // refresh the cull distance from the lanes' bests (each lane's thr bounds its own best from above).  (Scanning the
     // survivors best-first with a refresh after every tile was measured slower: two wave reductions per tile cost more
@@ -637,18 +675,7 @@ __device__ __forceinline__ void pyramid_walk(const float4* __restrict__ super_b,
         }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int p = pp[u];
-        const float dx = qx - c4[u].x, dy = qy - c4[u].y, dz = qz - c4[u].z;
-        const float d2f = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-        if (p >= 0 && !(c4[u].x == 0.f && c4[u].y == 0.f && c4[u].z == 0.f) && d2f <= thr) {
-          const double d2 = dist2(qx, qy, qz, c4[u].x, c4[u].y, c4[u].z);
-          if (d2 < lbest || (d2 == lbest && lidx >= 0 && p < lidx)) {
-            lbest = d2; lidx = p;
-            thr = (float)lbest * (1.0f + 1e-5f);
-          }
-        }
-      }
+      for (int u = 0; u < 4; ++u) nn_consider(c4[u], pp[u], qx, qy, qz, thr, lbest, lidx);
       // tiles not yet read of this super tile may now be out of reach
       const float tmin = wave_min_f(thr);
       thr = fminf(thr, tmin * (1.0f + 1e-5f));
@@ -705,32 +732,22 @@ __device__ __forceinline__ void nn_scan16(const int vblock, const int vgrid, con
     const int nchunk = (nc + 15) >> 4;
     const int steps = (r1 - r0 + 1) * nchunk;
     NN_STAT16(7, (r1 - r0 + 1) * nc);
+    int rowp = r0 * W, cc = l16;                          // the piece's image row (as a pixel offset) and this lane's column in the window
     for (int st = 0; st < steps; st += 4) {               // four independent 16-pixel pieces in flight
       float4 c4[4];
       int pp[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int s = st + u;
-        const int r = s / nchunk, j = s - r * nchunk;
-        const int cc = j * 16 + l16;
+      for (int u = 0; u < 4; ++u) {                        // (pieces are counted along, not divided out: s / nchunk was 35 instructions each)
         int c = c0 + cc;
         c = c >= W ? c - W : c;
-        const bool ok = s < steps && cc < nc;
-        pp[u] = ok ? (r0 + r) * W + c : -1;
+        const bool ok = st + u < steps && cc < nc;
+        pp[u] = ok ? rowp + c : -1;
         c4[u] = ok ? tp[pp[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
+        cc += 16;
+        if (cc - l16 >= nchunk * 16) { cc = l16; rowp += W; }
       }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float dx = qx - c4[u].x, dy = qy - c4[u].y, dz = qz - c4[u].z;
-        const float d2f = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-        if (pp[u] >= 0 && !(c4[u].x == 0.f && c4[u].y == 0.f && c4[u].z == 0.f) && d2f <= thr) {
-          const double d2 = dist2(qx, qy, qz, c4[u].x, c4[u].y, c4[u].z);
-          if (d2 < lbest || (d2 == lbest && lidx >= 0 && pp[u] < lidx)) {
-            lbest = d2; lidx = pp[u];
-            thr = (float)lbest * (1.0f + 1e-5f);
-          }
-        }
-      }
+      for (int u = 0; u < 4; ++u) nn_consider(c4[u], pp[u], qx, qy, qz, thr, lbest, lidx);
     }
     if (lidx < 0) lbest = 1e300;
     row_argmin(lbest, lidx);
@@ -827,17 +844,7 @@ __device__ __forceinline__ void nn_hard16(const int vblock, const int vgrid, con
           c4[u] = ok ? tp[pp[u]] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
 #pragma unroll
-        for (int u = 0; u < NN_TR; ++u) {
-          const float dx = qx - c4[u].x, dy = qy - c4[u].y, dz = qz - c4[u].z;
-          const float d2f = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-          if (pp[u] >= 0 && !(c4[u].x == 0.f && c4[u].y == 0.f && c4[u].z == 0.f) && d2f <= thr) {
-            const double d2 = dist2(qx, qy, qz, c4[u].x, c4[u].y, c4[u].z);
-            if (d2 < lbest || (d2 == lbest && lidx >= 0 && pp[u] < lidx)) {
-              lbest = d2; lidx = pp[u];
-              thr = (float)lbest * (1.0f + 1e-5f);
-            }
-          }
-        }
+        for (int u = 0; u < NN_TR; ++u) nn_consider(c4[u], pp[u], qx, qy, qz, thr, lbest, lidx);
       }
       // refresh the row's cull distance from its lanes' bests
       const float tmin = __uint_as_float(row_min_u(__float_as_uint(thr)));
@@ -938,9 +945,12 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_pass_b(const float4* __restrict
                                                         int32_t* __restrict__ nn_pix, float* __restrict__ match,
                                                         int32_t* __restrict__ visible, int nb, NNWorkspace ws, int part) {
   const int blk = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
-  if (blk < part) nn_hard16(blk, part, tgt, tgt_ss4, tgtn, tgtn_ss4, sen, nn_pix, match, ws);
-  else if (blk < 2 * part) nn_hard(blk - part, part, tgt, tgt_ss4, tgtn, tgtn_ss4, sen, nn_pix, match, visible, nb, ws);
-  else nn_scan16(blk - 2 * part, part, tgt, tgt_ss4, tgtn, tgtn_ss4, sen, nn_pix, match, ws);
+#ifndef NN_SKIP
+#define NN_SKIP 0              // tools/nn_lab: time of one list = the kernel without it (results are wrong by construction)
+#endif
+  if (blk < part) { if (!(NN_SKIP & 1)) nn_hard16(blk, part, tgt, tgt_ss4, tgtn, tgtn_ss4, sen, nn_pix, match, ws); }
+  else if (blk < 2 * part) { if (!(NN_SKIP & 2)) nn_hard(blk - part, part, tgt, tgt_ss4, tgtn, tgtn_ss4, sen, nn_pix, match, visible, nb, ws); }
+  else if (!(NN_SKIP & 4)) nn_scan16(blk - 2 * part, part, tgt, tgt_ss4, tgtn, tgtn_ss4, sen, nn_pix, match, ws);
 }
 
 extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const float* src_normals,
