@@ -22,6 +22,8 @@
 // HBM-bound residual kernel.
 #include "common.h"
 
+#include <mutex>
+
 #define NN_RV 2
 #define NN_RU 5
 #define NN_MARGIN 0.01f        // pixels: slack on the rounding of the stored points' (and our own) image coordinates
@@ -47,7 +49,7 @@ extern "C" int dl_nn_debug_set(int* p) { return (int)hipMemcpyToSymbol(HIP_SYMBO
 #endif
 
 #ifdef NN_STATS                 // tools/nn_lab: how many nodes the walks touch (wave-level counts; lane 0 adds)
-__device__ unsigned long long g_nn_stats[8];   // 0 queries (wave walk) 1 super visits 2 tile tests 3 tile scans | 4 queries (16-lane walk) 5 tile tests 6 tile scans | 7 scan16 pixels
+__device__ unsigned long long g_nn_stats[32];  // 8 packets 9 their queries 10 super visits 11 tiles offered 12 tiles scanned   // 0 queries (wave walk) 1 super visits 2 tile tests 3 tile scans | 4 queries (16-lane walk) 5 tile tests 6 tile scans | 7 scan16 pixels
 #define NN_STAT(I, N) do { if ((threadIdx.x & (DL_WAVE - 1)) == 0) atomicAdd(&g_nn_stats[I], (unsigned long long)(N)); } while (0)
 #define NN_STAT16(I, N) do { if ((threadIdx.x & 15) == 0) atomicAdd(&g_nn_stats[I], (unsigned long long)(N)); } while (0)
 #else
@@ -60,15 +62,32 @@ __device__ unsigned long long g_nn_stats[8];   // 0 queries (wave walk) 1 super 
 #define NN_SCAN_MAX 256        // bound windows up to this many pixels are scanned directly, 16 lanes per query
 #endif
 
+struct NNPacket {               // one wave of pass A whose queries go through the packet walk together (16 bytes)
+  int32_t b;                   // sample
+  int32_t tile;                // the wave's 4 x 16 tile of source pixels (row-major tile index)
+  unsigned long long mask;     // lanes (= pixels of the tile) that still need their neighbour
+};
+
+#ifndef NN_PACKET_MIN
+#define NN_PACKET_MIN 16       // a wave of pass A with at least this many queries without a usable bound becomes a packet
+#endif
+#ifndef NN_PABL
+#define NN_PABL 0              // tools/nn_lab ablations of the packet walk (1: four pixels per tile, 2: no per-lane tile tests); wrong results
+#endif
+#ifndef NN_PACKET_FEW
+#define NN_PACKET_FEW 1024     // fewer packets than this (one per SIMD) are walked query by query
+#endif
+
 struct NNWorkspace {
   int capacity;                // records in hard[] (B*H*W)
-  int32_t* counter;            // counter[0] = number of hard queries (tile walk), counter[1] = of scanned queries
+  int32_t* counter;            // [0] hard queries (tile walk), [1] scanned queries, [2] 16-lane tile walks, [3] packets
   NNHard* hard;                // [B*HW]: tile-walk queries with one wave each from the front, scanned queries from the end
   NNHard* mid;                 // [B*HW]: tile-walk queries with one 16-lane group each (counter[2])
   float4* tiles;               // [B][ceil(H/4)][ceil(W/16)] bounding sphere (cx,cy,cz,radius) of every target tile; radius < 0: empty
   float4* super;               // [B][ceil(ntr/4)][ceil(ntc/8)] bounding sphere of every 4 x 8 block of tiles (16 x 128 pixels)
   float4* tbox;                // [B][tiles][2] tight axis-aligned bounding box (lo, hi) of every target tile's points; empty: lo > hi
   float4* sbox;                // [B][supers][2] the same for every super tile (the union of its children's boxes)
+  NNPacket* packets;           // [B][tiles]: packets of pass A (counter[3])
 };
 
 #define NN_SR 4                 // super tile: 4 x 8 tiles = 32 child spheres (half a wave)
@@ -94,11 +113,13 @@ static inline NNWorkspace carve_nn(void* ws, int B, int H, int W) {
   w.super = w.tiles + (size_t)B * nn_tiles(H, W);
   w.tbox = w.super + (size_t)B * nn_supers(H, W);
   w.sbox = w.tbox + 2 * (size_t)B * nn_tiles(H, W);
+  w.packets = (NNPacket*)(w.sbox + 2 * (size_t)B * nn_supers(H, W));
   return w;
 }
 
 extern "C" size_t dl_nn_workspace_bytes(int32_t B, int32_t H, int32_t W) {
-  return nn_header_bytes(B) + 2 * (size_t)B * H * W * sizeof(NNHard) + 3 * (size_t)B * (nn_tiles(H, W) + nn_supers(H, W)) * sizeof(float4);
+  return nn_header_bytes(B) + 2 * (size_t)B * H * W * sizeof(NNHard) + 3 * (size_t)B * (nn_tiles(H, W) + nn_supers(H, W)) * sizeof(float4) +
+         (size_t)B * nn_tiles(H, W) * sizeof(NNPacket);
 }
 
 // Angular description of a query in fp32.  The image is only a spatial index here: these values pick WHICH pixels
@@ -207,16 +228,24 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
     const float* __restrict__ src, int64_t src_ss, const float* __restrict__ srcn, int64_t srcn_ss,
     const float4* __restrict__ tgt, int64_t tgt_ss4, const float4* __restrict__ tgtn, int64_t tgtn_ss4,
     const float* __restrict__ T, SensorK sen, int need_wo, int32_t* __restrict__ nn_pix, float* __restrict__ match,
-    int32_t* __restrict__ visible, NNWorkspace ws) {
+    int32_t* __restrict__ visible, NNWorkspace ws, int use_packets) {
   const int b = blockIdx.y;
-  const int px = blockIdx.x * DL_BLOCK + threadIdx.x;
   const int HW = sen.HW, H = sen.H, W = sen.W;
+  // one wave = one 4 x 16 tile of source pixels (not 64 pixels of a row): its queries are a compact patch in space, which is what
+  // the packet walk of pass B needs, and neighbouring lanes' windows overlap in both directions
+  const int lane = threadIdx.x & (DL_WAVE - 1);
+  const int wtiles_c = (W + NN_TC - 1) / NN_TC;
+  const int wt = __builtin_amdgcn_readfirstlane((int)(blockIdx.x * (DL_BLOCK / DL_WAVE) + (threadIdx.x >> 6)));
+  const int wtr = wt / wtiles_c, wtc = wt - wtr * wtiles_c;
+  const int prow = wtr * NN_TR + (lane >> 4), pcol = wtc * NN_TC + (lane & 15);
+  const bool inside = prow < H && pcol < W;
+  const int px = inside ? prow * W + pcol : 0;
   float m[12];
   load_T(T, b, m);
   bool occupied = false, active = false, vis = false;
   float fx = 0, fy = 0, fz = 0;
   QueryF q;
-  if (px < HW) {
+  if (inside) {
     const float* sp = src + (size_t)b * src_ss + px;
     const float x = sp[0], y = sp[HW], z = sp[2 * HW];
     occupied = !(x == 0.f && y == 0.f && z == 0.f);
@@ -238,14 +267,14 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
     }
   }
   // No early exits: the whole workgroup meets again at the append below.
-  float* mp = (match && px < HW) ? match + (size_t)b * 6 * HW + px : nullptr;
-  if (px < HW && !active) {
+  float* mp = (match && inside) ? match + (size_t)b * 6 * HW + px : nullptr;
+  if (inside && !active) {
     nn_pix[(size_t)b * HW + px] = -1;
     if (mp) { mp[0] = 0.f; mp[HW] = 0.f; mp[2 * HW] = 0.f; mp[3 * HW] = 0.f; mp[4 * HW] = 0.f; mp[5 * HW] = 0.f; }
   }
   int cls = -1;                  // list of an uncertified query: 0 tile walk with one wave, 1 window scan, 2 tile walk with 16 lanes
   NNHard h;
-  if (px < HW && active) {
+  if (inside && active) {
     const float4* tp = tgt + (size_t)b * tgt_ss4;
     const int u0 = (int)rintf(q.uq);
     int v0 = (int)rintf(q.vq);
@@ -293,15 +322,25 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
   // that share hard[] plus one for mid[], every lane ranks itself inside its list from the ballots.  (As one atomicAdd per lane -- the
   // compiler does not merge them -- the appends were 72 us of this kernel's 148 at the bench's residual and 198 of 262 us for random
   // poses: same-address atomics retire one every ~3 ns.)  hard[] holds tile-walk queries from the front, scanned queries from the end.
-  __shared__ int s_cnt[4], s_base[3];
-  if (threadIdx.x < 4) s_cnt[threadIdx.x] = 0;
+  __shared__ int s_cnt[5], s_base[4];
+  if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
   __syncthreads();
-  const int lane = threadIdx.x & (DL_WAVE - 1);
-  const unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2), mv = __ballot(vis);
+  unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
+  const unsigned long long mv = __ballot(vis);
+  // A wave with many queries WITHOUT a usable bound (an untrained network's pose: all of them) hands the whole tile to the packet
+  // walk of pass B -- every uncertified lane of it, the ones with a window included: one 16-byte descriptor instead of up to 64
+  // records; pass B re-derives q and takes this pass's best from nn_pix.
+  const bool dense = use_packets && (int)__popcll(m0) >= NN_PACKET_MIN;
+  const unsigned long long pmask = m0 | m1 | m2;
+  if (dense) {
+    if (cls >= 0) nn_pix[(size_t)b * HW + px] = h.idx;
+    cls = -1;
+    m0 = m1 = m2 = 0ull;
+  }
   int woff = 0;
   {
-    const unsigned long long mm = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : mv));
-    if (lane < 4 && mm) woff = atomicAdd(&s_cnt[lane], (int)__popcll(mm));
+    const unsigned long long mm = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : (lane == 3 ? mv : (dense ? 1ull : 0ull))));
+    if (lane < 5 && mm) woff = atomicAdd(&s_cnt[lane], (int)__popcll(mm));
   }
   __syncthreads();
   if (threadIdx.x == 0 && (s_cnt[0] | s_cnt[1])) {
@@ -313,6 +352,7 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
   if (threadIdx.x == 1 && s_cnt[2]) s_base[2] = atomicAdd(ws.counter + 2, s_cnt[2]);
   // visible pixels: spread over 32 sub-counters per sample; nn_hard (k_nn_pass_b) folds them into visible[b]
   if (threadIdx.x == 2 && visible && s_cnt[3]) atomicAdd(&ws.counter[NN_VIS0 + b * 32 + (blockIdx.x & 31)], s_cnt[3]);
+  if (threadIdx.x == 3 && s_cnt[4]) s_base[3] = atomicAdd(ws.counter + 3, s_cnt[4]);
   __syncthreads();
   if (cls >= 0) {
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -320,6 +360,11 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
     if (cls == 0) ws.hard[s_base[0] + w0 + (int)__popcll(m0 & below)] = h;
     else if (cls == 1) ws.hard[ws.capacity - 1 - (s_base[1] + w1 + (int)__popcll(m1 & below))] = h;
     else ws.mid[s_base[2] + w2 + (int)__popcll(m2 & below)] = h;
+  }
+  if (dense && lane == 4) {
+    NNPacket d;
+    d.b = b; d.tile = wt; d.mask = pmask;
+    ws.packets[s_base[3] + woff] = d;
   }
 }
 
@@ -341,6 +386,19 @@ __device__ __forceinline__ unsigned wave_min_u(unsigned v) {
 }
 // non-negative floats order like their bit patterns
 __device__ __forceinline__ float wave_min_f(float v) { return __uint_as_float(wave_min_u(__float_as_uint(v))); }
+__device__ __forceinline__ unsigned wave_max_u(unsigned v) {
+  v = max(v, dpp_u<0xB1>(v));
+  v = max(v, dpp_u<0x4E>(v));
+  v = max(v, dpp_u<0x124>(v));
+  v = max(v, dpp_u<0x128>(v));
+  const unsigned a = __builtin_amdgcn_readlane(v, 0), b = __builtin_amdgcn_readlane(v, 16),
+                 c = __builtin_amdgcn_readlane(v, 32), d = __builtin_amdgcn_readlane(v, 48);
+  return max(max(a, b), max(c, d));
+}
+__device__ __forceinline__ float wave_max_pf(float v) { return __uint_as_float(wave_max_u(__float_as_uint(v))); }   // non-negative floats
+// any finite float through a key that orders like the value
+__device__ __forceinline__ unsigned nn_f2key(float f) { const unsigned u = __float_as_uint(f); return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u); }
+__device__ __forceinline__ float nn_key2f(unsigned k) { return __uint_as_float(k ^ ((k >> 31) ? 0x80000000u : 0xffffffffu)); }
 
 // lexicographic minimum of (d2 >= 0, idx) over the wave; idx < 0 = no candidate (d2 = 1e300)
 __device__ __forceinline__ void wave_argmin(double& d2, int& idx) {
@@ -423,16 +481,16 @@ __device__ __forceinline__ float box_lower(const float4 lo, const float4 hi, flo
 }
 
 // One candidate of a scanning loop: fp32 screen against the lane's best (thr bounds it from above), fp64 only for what passes.  The
-// validity tests (a lane without a pixel carries zeros, an empty pixel is zeros) sit BEHIND the screen and behind a wave-uniform
-// branch: after the first candidates no lane of the wave passes it, and the common path is seven VALU instructions per candidate
-// (the kernels of this file are VALU-bound: profiles/r06_nn_lab.txt).
+// validity tests (a lane without a pixel carries zeros, an empty pixel is zeros) sit BEHIND the screen: an empty pixel is the point
+// (0,0,0), which fails the screen unless the origin is nearer than the lane's best.  The common path is seven vector and two scalar
+// instructions (compare, s_and_saveexec, s_cbranch_execz) -- a SIMD issues scalar instructions at the rate of vector ones, and a
+// wave-uniform "does any lane pass?" test in front of the branch cost six more of them (profiles/r06_nn_lab.txt).
 __device__ __forceinline__ void nn_consider(const float4 c, const int p, const float qx, const float qy, const float qz, float& thr,
                                             double& lbest, int& lidx) {
   const float dx = qx - c.x, dy = qy - c.y, dz = qz - c.z;
-  const float d2f = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-  const bool near = d2f <= thr;
-  if (__ballot(near)) {
-    if (near && p >= 0 && !(c.x == 0.f && c.y == 0.f && c.z == 0.f)) {
+  if (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) <= thr) {
+    NN_STAT(13, 1);
+    if (p >= 0 && ((__float_as_uint(c.x) | __float_as_uint(c.y) | __float_as_uint(c.z)) << 1) != 0u) {
       const double d2 = dist2(qx, qy, qz, c.x, c.y, c.z);
       if (d2 < lbest || (d2 == lbest && lidx >= 0 && p < lidx)) {
         lbest = d2; lidx = p;
@@ -871,6 +929,331 @@ __device__ __forceinline__ void nn_hard16(const int vblock, const int vgrid, con
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Packet walk: the 64 queries of one source tile (a compact patch of the source surface, rigidly moved: still compact) walk the
+// pyramid TOGETHER, one query per lane.  The per-query walk above spends ~1200 vector instructions per query -- sphere tests for one
+// query on 64 lanes, wave-wide reductions after every step -- and k_nn_pass_b is bound by exactly that for an untrained network's
+// random poses (profiles/r06_nn_lab.txt).  Here the nodes are culled once per packet against the packet's bounding sphere
+// (lanes = nodes), a surviving tile's pixels are read through the scalar path (wave-uniform addresses) and every lane tests them
+// against its own query with seven instructions per pixel and no reduction; the cull distance G = the largest of the lanes' upper
+// bounds is refreshed once per scanned tile.  Exact for the same reason as the per-query walk: a tile is skipped only if, for every
+// lane, its lower bound exceeds that lane's upper bound (the packet-level bound is below every lane's by the triangle inequality).
+__device__ __forceinline__ float readlane_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ unsigned wave_or_u(unsigned v) {
+  v |= dpp_u<0xB1>(v);
+  v |= dpp_u<0x4E>(v);
+  v |= dpp_u<0x124>(v);
+  v |= dpp_u<0x128>(v);
+  return __builtin_amdgcn_readlane(v, 0) | __builtin_amdgcn_readlane(v, 16) | __builtin_amdgcn_readlane(v, 32) | __builtin_amdgcn_readlane(v, 48);
+}
+// can the sphere s4 (wave-uniform) hold a point closer to this lane's query than ub?  Squared form: no square root per lane.
+__device__ __forceinline__ bool sphere_reaches(const float4 s4, float qx, float qy, float qz, float ub) {
+  const float dx = qx - s4.x, dy = qy - s4.y, dz = qz - s4.z;
+  const float t = ub + s4.w;
+  return fmaf(dz, dz, fmaf(dy, dy, dx * dx)) <= fmaf(t * t, 2e-5f, t * t) + 1e-6f;      // (ub = 3e38: inf, true)
+}
+
+__device__ __forceinline__ void packet_walk(const float4* __restrict__ super_b, const float4* __restrict__ tiles_b,
+                                            const float4* __restrict__ sbox_b, const float4* __restrict__ tbox_b,
+                                            const float4* __restrict__ tp, int H, int W, float qx, float qy, float qz, const bool act,
+                                            const int lane, float4* lds_tile, double& best, int& bidx) {
+  const int ntr = (H + NN_TR - 1) / NN_TR, ntc = (W + NN_TC - 1) / NN_TC;
+  const int nsr = (ntr + NN_SR - 1) / NN_SR, nsc = (ntc + NN_SC - 1) / NN_SC, nsuper = nsr * nsc;
+#ifdef NN_STATS
+  int scans_here = 0;
+  const long long t_begin = clock64();
+#endif
+  double lbest = best;
+  int lidx = bidx;
+  float thr = lbest < 1e30 ? (float)lbest * (1.0f + 1e-5f) : 3.0e38f;     // fp32 screen of this lane's squared distances
+  float ub = thr < 3.0e38f ? sqrtf(thr) * (1.0f + 1e-6f) : 3.0e38f;       // upper bound of this lane's answer
+  {  // lanes without a query ride along as copies of the first one that has one (the packet's box stays tight) and never pass a screen
+    const int fl = __builtin_ctzll(__ballot(act));
+    const float rx = readlane_f(qx, fl), ry = readlane_f(qy, fl), rz = readlane_f(qz, fl);
+    if (!act) { qx = rx; qy = ry; qz = rz; thr = -1.0f; ub = 0.f; }
+  }
+  // the packet's sphere: middle of the queries' box, radius rounded up.  It ORDERS the nodes and ends the walk; whether a node is
+  // opened is decided by the lanes' own bounds.
+  const float cx = 0.5f * (nn_key2f(wave_min_u(nn_f2key(qx))) + nn_key2f(wave_max_u(nn_f2key(qx))));
+  const float cy = 0.5f * (nn_key2f(wave_min_u(nn_f2key(qy))) + nn_key2f(wave_max_u(nn_f2key(qy))));
+  const float cz = 0.5f * (nn_key2f(wave_min_u(nn_f2key(qz))) + nn_key2f(wave_max_u(nn_f2key(qz))));
+  float rq;
+  {
+    const float dx = qx - cx, dy = qy - cy, dz = qz - cz;
+    rq = wave_max_pf(sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)))) * (1.0f + 4e-6f) + 1e-6f;
+  }
+  float G = wave_max_pf(ub);                                             // no lane's answer is farther than this
+  // level 2: every super tile against the packet's sphere (lanes = nodes)
+  float slb[NN_SUPER_TRIPS];
+  const int strips = (nsuper + DL_WAVE - 1) / DL_WAVE;
+#pragma unroll
+  for (int k = 0; k < NN_SUPER_TRIPS; ++k) {
+    slb[k] = 3.0e38f;
+    if (k < strips) {
+      const int sidx = k * DL_WAVE + lane;
+      float gub = 3.0e38f;
+      if (sidx < nsuper) {
+        const float4 s4 = super_b[sidx];
+        if (s4.w >= 0.f) {
+          const float dx = cx - s4.x, dy = cy - s4.y, dz = cz - s4.z;
+          const float dist = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+          float lb = (dist - s4.w) - 4e-6f * (dist + s4.w) - 1e-7f, un = (dist + s4.w) * (1.0f + 4e-6f) + 1e-7f, bl, bu;
+          box_bounds(sbox_b[2 * sidx], sbox_b[2 * sidx + 1], cx, cy, cz, bl, bu);
+          lb = fmaxf(lb, bl);
+          un = fminf(un, bu);
+          slb[k] = lb - rq * (1.0f + 1e-6f);
+          gub = (un + rq) * (1.0f + 1e-6f);
+        }
+      }
+      G = fminf(G, wave_min_f(gub));
+    }
+  }
+  if (act) { ub = fminf(ub, G); thr = fminf(thr, G * G * (1.0f + 1e-5f)); }
+  for (;;) {
+    // the unvisited super tile with the smallest lower bound, while the packet's bound allows it
+    float mine = slb[0];
+    int mk = 0;
+#pragma unroll
+    for (int k = 1; k < NN_SUPER_TRIPS; ++k)
+      if (slb[k] < mine) { mine = slb[k]; mk = k; }
+    const unsigned key = nn_f2key(mine);
+    const unsigned kmin = wave_min_u(key);
+    const float lbmin = nn_key2f(kmin);
+    if (!(lbmin <= G) || lbmin >= 3.0e38f) break;
+    const int wl = __builtin_ctzll(__ballot(key == kmin));
+    const int sA = __builtin_amdgcn_readlane(mk, wl) * DL_WAVE + wl;
+#pragma unroll
+    for (int k = 0; k < NN_SUPER_TRIPS; ++k)
+      if (k * DL_WAVE + lane == sA) slb[k] = 3.0e38f;
+    // ... opened only if its sphere reaches inside some lane's own bound
+    if (!__ballot(act && sphere_reaches(super_b[sA], qx, qy, qz, ub) && box_lower(sbox_b[2 * sA], sbox_b[2 * sA + 1], qx, qy, qz) <= ub)) continue;
+    NN_STAT(10, 1);
+    const int sr = sA / nsc, sc = sA - sr * nsc;
+    // level 1: its 32 tiles, one per lane (lanes 0..31), against the packet's sphere -- for the ORDER of the tiles and the packet's
+    // bound; the lanes keep their tile's sphere and box: the per-query tests below fetch them with v_readlane, not from memory (a
+    // scalar load is ~0.7 us when it misses the 16 KB scalar cache, and the first version of this walk was a chain of 250 of them)
+    const int ctr = sr * NN_SR + ((lane & 31) >> 3), ctc = sc * NN_SC + (lane & 7);
+    float clb = 3.0e38f, cub = 3.0e38f;
+    float4 cs4 = make_float4(0.f, 0.f, 0.f, -1.f), clo = make_float4(0.f, 0.f, 0.f, 0.f), chi = clo;
+    if (lane < NN_SR * NN_SC && ctr < ntr && ctc < ntc) {
+      cs4 = tiles_b[ctr * ntc + ctc];
+      if (cs4.w >= 0.f) {
+        clo = tbox_b[2 * (ctr * ntc + ctc)];
+        chi = tbox_b[2 * (ctr * ntc + ctc) + 1];
+        const float dx = cx - cs4.x, dy = cy - cs4.y, dz = cz - cs4.z;
+        const float dist = sqrtf(fmaf(dz, dz, fmaf(dy, dy, dx * dx)));
+        float lb = (dist - cs4.w) - 4e-6f * (dist + cs4.w) - 1e-7f, un = (dist + cs4.w) * (1.0f + 4e-6f) + 1e-7f, bl, bu;
+        box_bounds(clo, chi, cx, cy, cz, bl, bu);
+        lb = fmaxf(lb, bl);
+        un = fminf(un, bu);
+        clb = lb - rq * (1.0f + 1e-6f);
+        cub = (un + rq) * (1.0f + 1e-6f);
+      }
+    }
+    {
+      const float g2 = wave_min_f(cub);
+      if (g2 < G) { G = g2; if (act) { ub = fminf(ub, G); thr = fminf(thr, G * G * (1.0f + 1e-5f)); } }
+    }
+    // which of them does some lane need?  Every lane tests the spheres the packet's own bound leaves against its own bound: nine
+    // instructions per pair, no reduction until the end
+    const unsigned gm = (unsigned)__ballot(clb <= G && clb < 3.0e38f);
+    unsigned need = 0u;
+    for (unsigned g = (NN_PABL & 2) ? 0u : gm; g; g &= g - 1u) {
+      const int bit = __builtin_ctz(g);
+      const float4 s4 = make_float4(readlane_f(cs4.x, bit), readlane_f(cs4.y, bit),
+                                    readlane_f(cs4.z, bit), readlane_f(cs4.w, bit));
+      if (sphere_reaches(s4, qx, qy, qz, ub)) need |= 1u << bit;
+    }
+    unsigned long long cmask = (NN_PABL & 2) ? (unsigned long long)gm : (unsigned long long)(wave_or_u(act ? need : 0u) & gm);
+    while (cmask) {
+      // the nearest remaining tile first: the lanes' bounds tighten early
+      const unsigned ck = ((cmask >> lane) & 1ull) ? nn_f2key(clb) : 0xffffffffu;
+      const unsigned ckmin = wave_min_u(ck);
+      const int i = __builtin_ctzll(__ballot(ck == ckmin) & cmask);
+      cmask &= ~(1ull << i);
+      const int ttr = sr * NN_SR + (i >> 3), ttc = sc * NN_SC + (i & 7);
+      NN_STAT(11, 1);
+      const int row0 = ttr * NN_TR, col0 = ttc * NN_TC;
+      // its 64 pixels, one per lane (one coalesced load, issued before the test below needs anything from memory)
+      const int trow = row0 + (lane >> 4), tcol = col0 + (lane & 15);
+      float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (trow < H && tcol < W) mine = tp[trow * W + tcol];
+      {  // still needed, now that the lanes' bounds may have moved?  (sphere and box)
+        const float4 s4 = make_float4(readlane_f(cs4.x, i), readlane_f(cs4.y, i),
+                                      readlane_f(cs4.z, i), readlane_f(cs4.w, i));
+        const float4 lo = make_float4(readlane_f(clo.x, i), readlane_f(clo.y, i), readlane_f(clo.z, i), 0.f);
+        const float4 hi = make_float4(readlane_f(chi.x, i), readlane_f(chi.y, i), readlane_f(chi.z, i), 0.f);
+        if (!__ballot(act && sphere_reaches(s4, qx, qy, qz, ub) && box_lower(lo, hi, qx, qy, qz) <= ub)) continue;
+      }
+      NN_STAT(12, 1);
+#ifdef NN_STATS
+      ++scans_here;
+#endif
+      // every occupied pixel of the tile against every lane's query.  The tile goes through the wave's 1 KB of LDS: one ds_read_b128
+      // with a wave-uniform address hands a pixel to all 64 lanes without a vector instruction (three v_readlane per pixel measured
+      // slower than the seven instructions of the test itself; scalar loads are a chain of ~0.7 us round trips)
+      // The loop is written for the SCALAR port: a SIMD issues one scalar instruction per four cycles, the same rate as vector ones,
+      // and the first version spent 17 of them per pixel (occupancy bit, wave-uniform "any lane near?" test, pixel index) against seven
+      // vector instructions -- 150 cycles per pixel.  Now: no per-pixel occupancy test (an empty pixel is the point (0,0,0): it fails
+      // the screen unless the origin is nearer than the lane's best, and is then rejected inside), a plain divergent branch (compare,
+      // s_and_saveexec, s_cbranch_execz), the pixel index only inside it.
+      const unsigned long long occ = __ballot(((__float_as_uint(mine.x) | __float_as_uint(mine.y) | __float_as_uint(mine.z)) << 1) != 0u);
+      lds_tile[lane] = mine;
+      for (int r = 0; r < ((NN_PABL & 1) ? 1 : NN_TR); ++r) {
+        if (!((occ >> (r * NN_TC)) & 0xffffull)) continue;
+        const int pbase = (row0 + r) * W + col0;
+#pragma unroll
+        for (int c0 = 0; c0 < NN_TC; c0 += 4) {
+          float4 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) v[u] = lds_tile[r * NN_TC + c0 + u];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float dx = qx - v[u].x, dy = qy - v[u].y, dz = qz - v[u].z;
+            if (fmaf(dz, dz, fmaf(dy, dy, dx * dx)) <= thr) {
+              if (((__float_as_uint(v[u].x) | __float_as_uint(v[u].y) | __float_as_uint(v[u].z)) << 1) != 0u) {
+                const double d2 = dist2(qx, qy, qz, v[u].x, v[u].y, v[u].z);
+                const int pi = pbase + c0 + u;
+                if (d2 < lbest || (d2 == lbest && lidx >= 0 && pi < lidx)) {
+                  lbest = d2; lidx = pi;
+                  thr = (float)lbest * (1.0f + 1e-5f);
+                }
+              }
+            }
+          }
+        }
+      }
+      if (act && thr < 3.0e38f) ub = fminf(ub, sqrtf(thr) * (1.0f + 1e-6f));
+      G = fminf(G, wave_max_pf(ub));
+      cmask &= __ballot(clb <= G);
+    }
+  }
+#ifdef NN_STATS
+  {
+    int bin = 0;
+    for (int v = scans_here; v > 4 && bin < 7; v >>= 1) ++bin;          // <=4, <=9, <=19, <=39, <=79, <=159, <=319, more
+    NN_STAT(16 + bin, 1);
+    if ((threadIdx.x & 63) == 0) { atomicMax(&g_nn_stats[24], (unsigned long long)scans_here); atomicMax(&g_nn_stats[25], (unsigned long long)(clock64() - t_begin)); atomicAdd(&g_nn_stats[26], (unsigned long long)(clock64() - t_begin)); }
+  }
+#endif
+  best = lbest;
+  bidx = lidx;
+}
+
+// The packets of pass A when there are too few of them to fill the machine (a trained network: the odd tile that looks into the void):
+// a packet is ~15k instructions on ONE wave, ~100 us of latency.  Their queries are walked one per wave instead, as those of the hard
+// list; q is re-derived from the source image (the same expression as in pass A), pass A's best comes back through nn_pix.
+__device__ __forceinline__ void nn_packets_few(const int vblock, const int vgrid, const float* __restrict__ src, int64_t src_ss,
+                                           const float* __restrict__ T, const float4* __restrict__ tgt, int64_t tgt_ss4,
+                                           const float4* __restrict__ tgtn, int64_t tgtn_ss4, const SensorK& sen,
+                                           int32_t* __restrict__ nn_pix, float* __restrict__ match, const NNWorkspace& ws) {
+  const int lane = threadIdx.x & (DL_WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((vblock * DL_BLOCK + threadIdx.x) / DL_WAVE);
+  const int nwaves = vgrid * DL_BLOCK / DL_WAVE;
+  const int npk = ws.counter[3];
+  const int HW = sen.HW, H = sen.H, W = sen.W;
+  const int wtiles_c = (W + NN_TC - 1) / NN_TC;
+  const int ntiles_img = nn_tiles_dev(H, W);
+  const int nsuper_img = ((((H + NN_TR - 1) / NN_TR) + NN_SR - 1) / NN_SR) * ((((W + NN_TC - 1) / NN_TC) + NN_SC - 1) / NN_SC);
+  if (npk >= NN_PACKET_FEW) return;
+  {
+    for (int item = wave; item < npk * DL_WAVE; item += nwaves) {
+      const NNPacket d = ws.packets[item >> 6];
+      const int l = item & (DL_WAVE - 1);
+      if (!((d.mask >> l) & 1ull)) continue;
+      const int b = d.b;
+      const int wtr = d.tile / wtiles_c, wtc = d.tile - wtr * wtiles_c;
+      const int px = (wtr * NN_TR + (l >> 4)) * W + wtc * NN_TC + (l & 15);
+      const float4* tp = tgt + (size_t)b * tgt_ss4;
+      float m[12];
+      load_T(T, b, m);
+      const float* sp = src + (size_t)b * src_ss + px;
+      float qx, qy, qz;
+      transform_point(m, sp[0], sp[HW], sp[2 * HW], qx, qy, qz);
+      int bidx = nn_pix[(size_t)b * HW + px];
+      double best = 1e300;
+      if (bidx >= 0) {
+        const float4 c = tp[bidx];
+        best = dist2(qx, qy, qz, c.x, c.y, c.z);
+      }
+      pyramid_walk(ws.super + (size_t)b * nsuper_img, ws.tiles + (size_t)b * ntiles_img, ws.sbox + 2 * (size_t)b * nsuper_img,
+                   ws.tbox + 2 * (size_t)b * ntiles_img, tp, H, W, qx, qy, qz, lane, best, bidx);
+      if (lane == 0) nn_pix[(size_t)b * HW + px] = bidx;
+      if (match && lane < 6) {
+        float v = 0.f;
+        if (bidx >= 0) {
+          if (lane < 3) v = reinterpret_cast<const float*>(tp)[(size_t)bidx * 4 + lane];
+          else if (tgtn) v = reinterpret_cast<const float*>(tgtn + (size_t)b * tgtn_ss4)[(size_t)bidx * 4 + (lane - 3)];
+        }
+        match[(size_t)b * 6 * HW + (size_t)lane * HW + px] = v;
+      }
+    }
+  }
+}
+
+// Pass B for the packets of pass A, a kernel of its own (inside k_nn_pass_b its registers cost the other lists two waves per SIMD): one
+// wave per packet.  q is re-derived from the source image (the same expression as in pass A),
+// pass A's best candidate comes back through nn_pix.
+__global__ __launch_bounds__(DL_BLOCK) void k_nn_packets(const float* __restrict__ src, int64_t src_ss, const float* __restrict__ T,
+                                                         const float4* __restrict__ tgt, int64_t tgt_ss4, const float4* __restrict__ tgtn,
+                                                         int64_t tgtn_ss4, SensorK sen, int32_t* __restrict__ nn_pix, float* __restrict__ match,
+                                                         NNWorkspace ws) {
+  const int vblock = __builtin_amdgcn_readfirstlane((int)blockIdx.x), vgrid = (int)gridDim.x;
+  const int lane = threadIdx.x & (DL_WAVE - 1);
+  const int wave = __builtin_amdgcn_readfirstlane((vblock * DL_BLOCK + threadIdx.x) / DL_WAVE);
+  const int nwaves = vgrid * DL_BLOCK / DL_WAVE;
+  const int npk = ws.counter[3];
+  const int HW = sen.HW, H = sen.H, W = sen.W;
+  const int wtiles_c = (W + NN_TC - 1) / NN_TC;
+  const int ntiles_img = nn_tiles_dev(H, W);
+  const int nsuper_img = ((((H + NN_TR - 1) / NN_TR) + NN_SR - 1) / NN_SR) * ((((W + NN_TC - 1) / NN_TC) + NN_SC - 1) / NN_SC);
+  if (npk < NN_PACKET_FEW) return;                     // k_nn_pass_b walks them query by query (nn_packets_few)
+  __shared__ float4 s_tile[DL_BLOCK / DL_WAVE][DL_WAVE];
+  int static_round = 0;
+  for (;;) {
+    // a static share (one atomic work queue instead measured 55 us slower: 20k same-address atomics next to the counters every wave reads)
+    const int pk = wave + nwaves * static_round++;
+    if (pk >= npk) break;
+    const NNPacket d = ws.packets[pk];
+    const int b = d.b;
+    NN_STAT(8, 1);
+    NN_STAT(9, __popcll(d.mask));
+    const int wtr = d.tile / wtiles_c, wtc = d.tile - wtr * wtiles_c;
+    const int prow = wtr * NN_TR + (lane >> 4), pcol = wtc * NN_TC + (lane & 15);
+    const int px = prow * W + pcol;
+    const bool act = (d.mask >> lane) & 1ull;
+    const float4* tp = tgt + (size_t)b * tgt_ss4;
+    float m[12];
+    load_T(T, b, m);
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    double best = 1e300;
+    int bidx = -1;
+    if (act) {
+      const float* sp = src + (size_t)b * src_ss + px;
+      transform_point(m, sp[0], sp[HW], sp[2 * HW], qx, qy, qz);
+      bidx = nn_pix[(size_t)b * HW + px];
+      if (bidx >= 0) {
+        const float4 c = tp[bidx];
+        best = dist2(qx, qy, qz, c.x, c.y, c.z);
+      }
+    }
+    packet_walk(ws.super + (size_t)b * nsuper_img, ws.tiles + (size_t)b * ntiles_img, ws.sbox + 2 * (size_t)b * nsuper_img,
+                ws.tbox + 2 * (size_t)b * ntiles_img, tp, H, W, qx, qy, qz, act, lane, s_tile[threadIdx.x >> 6], best, bidx);
+    if (act) {
+      nn_pix[(size_t)b * HW + px] = bidx;
+      if (match) {
+        float4 p4 = make_float4(0.f, 0.f, 0.f, 0.f), n4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bidx >= 0) {
+          p4 = tp[bidx];
+          if (tgtn) n4 = (tgtn + (size_t)b * tgtn_ss4)[bidx];
+        }
+        float* mp = match + (size_t)b * 6 * HW + px;
+        mp[0] = p4.x; mp[HW] = p4.y; mp[2 * HW] = p4.z; mp[3 * HW] = n4.x; mp[4 * HW] = n4.y; mp[5 * HW] = n4.z;
+      }
+    }
+  }
+}
+
 // Pass B: one wave per query that pass A could not certify.  Everything per-query is wave-uniform (the record is read
 // through the scalar path): pass A already evaluated the projection of q and the bound window of its best distance at
 // full lane efficiency and stored the window with the query, so this kernel is the tile walk plus the final gather.
@@ -943,14 +1326,35 @@ __device__ __forceinline__ void nn_hard(const int vblock, const int vgrid, const
 __global__ __launch_bounds__(DL_BLOCK) void k_nn_pass_b(const float4* __restrict__ tgt, int64_t tgt_ss4,
                                                         const float4* __restrict__ tgtn, int64_t tgtn_ss4, SensorK sen,
                                                         int32_t* __restrict__ nn_pix, float* __restrict__ match,
-                                                        int32_t* __restrict__ visible, int nb, NNWorkspace ws, int part) {
+                                                        int32_t* __restrict__ visible, int nb, NNWorkspace ws, int part,
+                                                        const float* __restrict__ src, int64_t src_ss, const float* __restrict__ T) {
   const int blk = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
 #ifndef NN_SKIP
 #define NN_SKIP 0              // tools/nn_lab: time of one list = the kernel without it (results are wrong by construction)
 #endif
+  if (!(NN_SKIP & 8)) nn_packets_few(blk, 3 * part, src, src_ss, T, tgt, tgt_ss4, tgtn, tgtn_ss4, sen, nn_pix, match, ws);
   if (blk < part) { if (!(NN_SKIP & 1)) nn_hard16(blk, part, tgt, tgt_ss4, tgtn, tgtn_ss4, sen, nn_pix, match, ws); }
   else if (blk < 2 * part) { if (!(NN_SKIP & 2)) nn_hard(blk - part, part, tgt, tgt_ss4, tgtn, tgtn_ss4, sen, nn_pix, match, visible, nb, ws); }
   else if (!(NN_SKIP & 4)) nn_scan16(blk - 2 * part, part, tgt, tgt_ss4, tgtn, tgtn_ss4, sen, nn_pix, match, ws);
+}
+
+// One side stream per device for the packet kernel (created on first use, never destroyed: the library lives as long as the process).
+struct NNSide { hipStream_t s; hipEvent_t fork, join; };
+static NNSide* nn_side() {
+  static std::mutex mu;
+  static NNSide sides[64];
+  static int state[64];                 // 0 untried, 1 ready, -1 failed (the packet kernel then runs on the caller's stream)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (state[dev] == 0) {
+    NNSide& n = sides[dev];
+    state[dev] = (hipStreamCreateWithFlags(&n.s, hipStreamNonBlocking) == hipSuccess &&
+                  hipEventCreateWithFlags(&n.fork, hipEventDisableTiming) == hipSuccess &&
+                  hipEventCreateWithFlags(&n.join, hipEventDisableTiming) == hipSuccess) ? 1 : -1;
+    if (state[dev] < 0) (void)hipGetLastError();
+  }
+  return state[dev] == 1 ? &sides[dev] : nullptr;
 }
 
 extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const float* src_normals,
@@ -970,6 +1374,7 @@ extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const f
   if (sensor->H > 65535 || sensor->W > 65535)
     return dl_fail(DL_ERR_UNSUPPORTED, "dl_nn_correspond: images beyond 65535 rows or columns are not supported");
   NNWorkspace ws = carve_nn(workspace, B, sen.H, sen.W);
+  const bool use_packets = nn_supers(sen.H, sen.W) <= (size_t)NN_SUPER_TRIPS * DL_WAVE;   // the packet walk keeps the super tiles' bounds in registers
   // the hard-query counter indexes ws.hard[]: never launch the search on an uninitialised header
   dl_fill_words(ws.counter, 0u, nn_header_bytes(B) / 4, st);
   {
@@ -982,12 +1387,24 @@ extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const f
     hipLaunchKernelGGL(k_nn_supers, dim3((waves * DL_WAVE + DL_BLOCK - 1) / DL_BLOCK), dim3(DL_BLOCK), 0, st, (const float4*)ws.tiles, (const float4*)ws.tbox, sen.H, sen.W,
                        B, ws.super, ws.sbox);
   }
-  hipLaunchKernelGGL(k_nn_window, dim3((sen.HW + DL_BLOCK - 1) / DL_BLOCK, B), dim3(DL_BLOCK), 0, st,
+  hipLaunchKernelGGL(k_nn_window, dim3((unsigned)((nn_tiles(sen.H, sen.W) + DL_BLOCK / DL_WAVE - 1) / (DL_BLOCK / DL_WAVE)), B), dim3(DL_BLOCK), 0, st,
                      src_image4, src_ss, src_normals, srcn_ss, (const float4*)tgt_packed, tgt_ss / 4,
                      (const float4*)tgt_normals_packed, tgtn_ss / 4, T, sen, need_without_normals, nn_pix, match, visible,
-                     ws);
+                     ws, (int)use_packets);
+  // The packet kernel runs BESIDE pass B on a side stream of the library (fork / join through events: also what a stream capture
+  // records): with a trained network it returns at once, for an untrained one it is the long pole and pass B's lists hide behind it.
+#ifndef NN_SIDE_STREAM
+#define NN_SIDE_STREAM 0
+#endif
+  NNSide* side = (use_packets && NN_SIDE_STREAM) ? nn_side() : nullptr;
+  const bool forked = side && hipEventRecord(side->fork, st) == hipSuccess && hipStreamWaitEvent(side->s, side->fork, 0) == hipSuccess;
+  if (use_packets)
+    hipLaunchKernelGGL(k_nn_packets, dim3(4096), dim3(DL_BLOCK), 0, forked ? side->s : st, src_image4, src_ss, T, (const float4*)tgt_packed, tgt_ss / 4,
+                       (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, ws);
   hipLaunchKernelGGL(k_nn_pass_b, dim3(3 * 2048), dim3(DL_BLOCK), 0, st, (const float4*)tgt_packed, tgt_ss / 4,
-                     (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, visible, B, ws, 2048);
+                     (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, visible, B, ws, 2048, src_image4, src_ss, T);
+  if (forked && (hipEventRecord(side->join, side->s) != hipSuccess || hipStreamWaitEvent(st, side->join, 0) != hipSuccess))
+    return dl_fail(DL_ERR_LAUNCH, "dl_nn_correspond: joining the side stream failed");
   return dl_check_launch("dl_nn_correspond");
 }
 

@@ -257,14 +257,17 @@ int main(int argc, char** argv) {
       if (rc) { fprintf(stderr, "dl_nn_correspond: %s\n", dl_last_error()); exit(2); }
     };
 #ifdef NN_STATS
-    { unsigned long long z[8] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stats), z, sizeof(z))); }
+    { unsigned long long z[32] = {0}; CK(hipMemcpyToSymbol(HIP_SYMBOL(g_nn_stats), z, sizeof(z))); }
 #endif
     run();
     CK(hipStreamSynchronize(st));
 #ifdef NN_STATS
     {
-      unsigned long long z[8];
+      unsigned long long z[32];
       CK(hipMemcpyFromSymbol(z, HIP_SYMBOL(g_nn_stats), sizeof(z)));
+      printf("stats %-8s packets by tiles scanned (<=4 9 19 39 79 159 319 more): %llu %llu %llu %llu %llu %llu %llu %llu; most %llu; clock64 ticks per packet: mean %.0f, longest %llu\n", kRegimes[regime], z[16], z[17], z[18], z[19], z[20], z[21], z[22], z[23], z[24], z[26] / (double)std::max(z[8], 1ull), z[25]);
+      printf("stats %-8s packets: %llu with %.1f queries each; per packet %.1f super visits, %.1f tiles offered, %.1f tiles scanned; fp64 branch entries (all paths) %llu\n", kRegimes[regime], z[8],
+             z[9] / (double)std::max(z[8], 1ull), z[10] / (double)std::max(z[8], 1ull), z[11] / (double)std::max(z[8], 1ull), z[12] / (double)std::max(z[8], 1ull), z[13]);
       printf("stats %-8s wave walk: %llu queries, per query %.1f super visits, %.1f tile tests, %.1f tile scans | 16-lane walk: %llu queries, %.1f tile tests, %.1f tile scans | "
              "window scans: %.0f pixels per query\n", kRegimes[regime], z[0], z[1] / (double)std::max(z[0], 1ull), z[2] / (double)std::max(z[0], 1ull), z[3] / (double)std::max(z[0], 1ull),
              z[4], z[5] / (double)std::max(z[4], 1ull), z[6] / (double)std::max(z[4], 1ull), 0.0);
