@@ -415,22 +415,19 @@ __device__ __forceinline__ void wave_argmin(double& d2, int& idx) {
 
 __device__ __forceinline__ int nn_tiles_dev(int H, int W) { return ((H + NN_TR - 1) / NN_TR) * ((W + NN_TC - 1) / NN_TC); }
 
-__device__ __forceinline__ float wave_max_f(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, DL_WAVE));
-  return v;
-}
-__device__ __forceinline__ float wave_min_sf(float v) {       // signed values (k_nn_tiles: coordinates)
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o, DL_WAVE));
-  return v;
-}
+// any finite floats, through the DPP reductions (the ds_bpermute butterflies these replace were most of k_nn_tiles' 10 us)
+__device__ __forceinline__ float wave_max_f(float v) { return nn_key2f(wave_max_u(nn_f2key(v))); }
+__device__ __forceinline__ float wave_min_sf(float v) { return nn_key2f(wave_min_u(nn_f2key(v))); }
 
 // One wave per 4x16 target tile: bounding sphere of its occupied pixels (centre = middle of the bounding box, radius
 // rounded up).  A second level of the image-as-index: a tile whose sphere is farther from q than the best distance
 // cannot hold the neighbour, which turns the large windows of pass B from pixel scans into tile tests.
 __global__ __launch_bounds__(DL_BLOCK) void k_nn_tiles(const float4* __restrict__ tgt, int64_t tgt_ss4, int H, int W,
-                                                       int nb, float4* __restrict__ tiles, float4* __restrict__ tbox) {
+                                                       int nb, float4* __restrict__ tiles, float4* __restrict__ tbox,
+                                                       int32_t* __restrict__ header, int header_words) {
+  // the counters of the lists and the visible-pixel sub-counters start at zero (pass A runs after this kernel)
+  if (blockIdx.x == 0)
+    for (int i = threadIdx.x; i < header_words; i += DL_BLOCK) header[i] = 0;
   const int lane = threadIdx.x & (DL_WAVE - 1);
   const int ntr = (H + NN_TR - 1) / NN_TR, ntc = (W + NN_TC - 1) / NN_TC;
   const int t = (blockIdx.x * DL_BLOCK + threadIdx.x) / DL_WAVE;
@@ -1375,12 +1372,11 @@ extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const f
     return dl_fail(DL_ERR_UNSUPPORTED, "dl_nn_correspond: images beyond 65535 rows or columns are not supported");
   NNWorkspace ws = carve_nn(workspace, B, sen.H, sen.W);
   const bool use_packets = nn_supers(sen.H, sen.W) <= (size_t)NN_SUPER_TRIPS * DL_WAVE;   // the packet walk keeps the super tiles' bounds in registers
-  // the hard-query counter indexes ws.hard[]: never launch the search on an uninitialised header
-  dl_fill_words(ws.counter, 0u, nn_header_bytes(B) / 4, st);
+  // (the hard-query counters index ws.hard[]: k_nn_tiles zeroes the header before pass A can run)
   {
     const int waves = (int)(B * nn_tiles(sen.H, sen.W));
     hipLaunchKernelGGL(k_nn_tiles, dim3((waves * DL_WAVE + DL_BLOCK - 1) / DL_BLOCK), dim3(DL_BLOCK), 0, st,
-                       (const float4*)tgt_packed, tgt_ss / 4, sen.H, sen.W, B, ws.tiles, ws.tbox);
+                       (const float4*)tgt_packed, tgt_ss / 4, sen.H, sen.W, B, ws.tiles, ws.tbox, ws.counter, (int)(nn_header_bytes(B) / 4));
   }
   {
     const int waves = (int)(B * nn_supers(sen.H, sen.W));
