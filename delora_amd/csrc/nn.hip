@@ -22,6 +22,7 @@
 // HBM-bound residual kernel.
 #include "common.h"
 
+#include <algorithm>
 #include <mutex>
 
 #define NN_RV 2
@@ -1394,8 +1395,8 @@ extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const f
 #endif
   NNSide* side = (use_packets && NN_SIDE_STREAM) ? nn_side() : nullptr;
   const bool forked = side && hipEventRecord(side->fork, st) == hipSuccess && hipStreamWaitEvent(side->s, side->fork, 0) == hipSuccess;
-  if (use_packets)
-    hipLaunchKernelGGL(k_nn_packets, dim3(4096), dim3(DL_BLOCK), 0, forked ? side->s : st, src_image4, src_ss, T, (const float4*)tgt_packed, tgt_ss / 4,
+  if (use_packets && (size_t)B * nn_tiles(sen.H, sen.W) >= (size_t)NN_PACKET_FEW)      // (fewer source tiles than that: never enough packets)
+    hipLaunchKernelGGL(k_nn_packets, dim3((unsigned)std::min<size_t>(4096, ((size_t)B * nn_tiles(sen.H, sen.W) + 3) / 4)), dim3(DL_BLOCK), 0, forked ? side->s : st, src_image4, src_ss, T, (const float4*)tgt_packed, tgt_ss / 4,
                        (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, ws);
   hipLaunchKernelGGL(k_nn_pass_b, dim3(3 * 2048), dim3(DL_BLOCK), 0, st, (const float4*)tgt_packed, tgt_ss / 4,
                      (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, visible, B, ws, 2048, src_image4, src_ss, T);

@@ -377,6 +377,49 @@ def test_nn_full_size_against_bruteforce_kernel():
             assert (tpix[kd] != got).sum() <= 2          # exact ties only
 
 
+def test_nn_packet_walk_batched_random_poses():
+    """64x2048, batch 4, poses without a usable bound (random rotations, a 30 m translation, a tilted pose): most source tiles go through
+    the PACKET walk of pass B (k_nn_packets: the 64 queries of a tile walk the pyramid together); indices against the exhaustive
+    kernel, the matched points / normals planes against a gather of the target images."""
+    sensor, img, nrm, T_true = _pair_images(4242, 64, 2048, 64, 2250)
+    dev = img.device
+    rng = np.random.default_rng(11)
+    tilt = torch.from_numpy(T_true).view(1, 4, 4).clone().float()
+    tilt[0, :3, :3] = orc.transformation_matrix(torch.zeros(1, 3), torch.tensor([[0.03, -0.04, 0.01, 1.0]]))[0, :3, :3] @ tilt[0, :3, :3]
+    T = torch.cat([_random_T(rng), _random_T(rng, scale_t=30.0), _random_T(rng, scale_t=3.0), tilt]).float().to(dev)
+    B = T.shape[0]
+    imgs_t = img[0:1].expand(B, -1, -1, -1).contiguous()
+    imgs_s = img[1:2].expand(B, -1, -1, -1).contiguous()
+    nrm_s = nrm[1:2].expand(B, -1, -1, -1).contiguous()
+    tpk, tnpk = _geo().pack_image(imgs_t), _geo().pack_image(nrm[0:1].expand(B, -1, -1, -1).contiguous())
+    nn, _, match = _geo().nn_correspond(imgs_s, nrm_s, tpk, tnpk, T, sensor, need_without_normals=False)
+    torch.cuda.synchronize()
+    tflat = imgs_t[0, :3].reshape(3, -1)
+    nflat = nrm[0].reshape(3, -1)
+    for b in range(B):
+        tp, _, tpix = util.lists_from_images(imgs_t[b].cpu(), torch.zeros(3, 64, 2048))
+        sp, sn, spix = util.lists_from_images(imgs_s[b].cpu(), nrm_s[b].cpu())
+        has = (sn[0] != 0).any(dim=0)
+        q = orc.transform_points(T[b:b + 1].cpu(), sp[:, :, has])
+        bf = _geo().nn_bruteforce(q[0].to(dev), tp[0].to(dev)).cpu().long()
+        got = nn[b].reshape(-1).cpu().long()
+        exp = -torch.ones_like(got)
+        exp[spix[has]] = tpix[bf]
+        if not torch.equal(got, exp):
+            bad = torch.nonzero(got != exp).reshape(-1)
+            assert ((got[bad] >= 0) & (exp[bad] >= 0)).all()
+            qq = orc.transform_points(T[b:b + 1].cpu(), imgs_s[b, :3].reshape(3, -1).cpu()[:, bad].view(1, 3, -1))[0].double()
+            d_got = (qq - tflat.cpu().double()[:, got[bad]]).norm(dim=0)
+            d_exp = (qq - tflat.cpu().double()[:, exp[bad]]).norm(dim=0)
+            assert torch.all(d_got <= d_exp + _q_slack(qq)), f"sample {b}: {len(bad)} non-tie mismatches"
+            assert len(bad) <= 1e-4 * len(got) + 1
+        idx = nn[b].reshape(-1).long()
+        ok = idx >= 0
+        m = match[b].reshape(6, -1)
+        assert torch.equal(m[:3, ok], tflat[:, idx[ok]]) and torch.equal(m[3:, ok], nflat[:, idx[ok]])
+        assert (m[:, ~ok] == 0).all()
+
+
 def test_nn_empty_target_and_empty_source():
     vf, hf = util.kitti_fov()
     sensor = gpu_sensor(16, 128, vf, hf)
