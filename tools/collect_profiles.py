@@ -26,7 +26,7 @@ if NEW:
                  "geometry_kernel_stats.csv", "loss_calibration.txt", "loss_warm.txt", "loss_cold.txt", "conv_harness.txt", "convh_harness.txt",
                  "conv_layers_float32.txt", "conv_layers_bfloat16.txt", "conv_pmc.txt", "convh_pmc.txt", "scatter_probe.txt",
                  "step_breakdown_64x720_b1_f32.txt", "step_breakdown_64x720_b1_bf16.txt", "step_breakdown_64x720_b8_f32.txt",
-                 "shipped_step_b1_ab.txt", "feed_ranks.json", "wino_lab.txt", "wino_lab_pmc.txt"):
+                 "shipped_step_b1_ab.txt", "feed_ranks.json", "wino_lab.txt", "wino_lab_pmc.txt", "nn_lab_final.txt", "nn_counts.txt"):
         if os.path.exists(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(dst, f"{R}_{name}"))
     merged = {"launches": {}}

@@ -62,4 +62,7 @@ python tools/convh_pmc.py $(find $T/convh_pmc -name "*counter_collection.csv" | 
 (tools/bin/wino_lab check; tools/bin/wino_lab time 30; tools/bin/wino_lab phases) > $out/wino_lab.txt 2>&1
 tools/lab_pmc.sh > /dev/null 2>&1; cp gpurun_out/lab_pmc.txt $out/wino_lab_pmc.txt
 (timeout 120 tools/bin/mfma_overlap 512; timeout 60 tools/bin/mfma_dma; timeout 60 tools/bin/pk_probe) > $out/mfma_shadow.txt 2>&1
+# round 6: the exact search alone (check against the exhaustive kernel, times per regime, per-kernel times and counters), list sizes on the bench batch
+bash tools/nn_lab_run.sh tools/bin/nn_lab nn_lab_bundle > /dev/null 2>&1; cp gpurun_out/nn_lab_bundle.txt $out/nn_lab_final.txt
+python tools/nn_counts.py 2>/dev/null | grep '^shift' > $out/nn_counts.txt
 du -sh $out; ls $out
