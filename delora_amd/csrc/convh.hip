@@ -461,31 +461,32 @@ __global__ __launch_bounds__(256) void k_cast_f2h(const float* __restrict__ src,
 //                     PRE-activation, in half precision, which is what the trunk's backward starts from
 template <bool F16>
 __global__ __launch_bounds__(256) void k_mean_hw_h(const u16* __restrict__ x, int P, int C, float* __restrict__ y) {
-  __shared__ float part[16][16][9];                       // [pixel lane][channel octet][8 + pad]
-  const int n = blockIdx.y, c8 = blockIdx.x * 16 + (threadIdx.x & 15), pl = threadIdx.x >> 4;
+  // two channel octets x 128 pixel lanes per workgroup (round 6: 16 octets x 16 lanes left the batch with 32 workgroups)
+  __shared__ float part[128][2][9];                       // [pixel lane][channel octet][8 + pad]
+  const int n = blockIdx.y, o = threadIdx.x & 1, c8 = blockIdx.x * 2 + o, pl = threadIdx.x >> 1;
   float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (8 * c8 < C) {
     const u16* px = x + ((size_t)n * P) * C + 8 * c8;
-    for (int p = pl; p < P; p += 16) {
+    for (int p = pl; p < P; p += 128) {
       const u16x8 v = *reinterpret_cast<const u16x8*>(px + (size_t)p * C);
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += ch_h2f<F16>(v[e]);
     }
   }
 #pragma unroll
-  for (int e = 0; e < 8; ++e) part[pl][threadIdx.x & 15][e] = acc[e];
+  for (int e = 0; e < 8; ++e) part[pl][o][e] = acc[e];
   __syncthreads();
 #pragma unroll
-  for (int s = 8; s > 0; s >>= 1) {
+  for (int s = 64; s > 0; s >>= 1) {
     if (pl < s)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) part[pl][threadIdx.x & 15][e] += part[pl + s][threadIdx.x & 15][e];
+      for (int e = 0; e < 8; ++e) part[pl][o][e] += part[pl + s][o][e];
     __syncthreads();
   }
   if (pl == 0 && 8 * c8 < C) {
     const float inv = 1.0f / (float)P;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) y[(size_t)n * C + 8 * c8 + e] = part[0][threadIdx.x & 15][e] * inv;
+    for (int e = 0; e < 8; ++e) y[(size_t)n * C + 8 * c8 + e] = part[0][o][e] * inv;
   }
 }
 
@@ -817,7 +818,7 @@ extern "C" int dl_cast_f32_to_h(const float* src, void* dst, int64_t n, int32_t 
 extern "C" int dl_mean_hw_nhwc_h(const void* x, int32_t N, int32_t P, int32_t C, int32_t dtype, float* y, dl_stream stream) {
   if (!x || !y || N <= 0 || P <= 0 || C <= 0 || C % 8 || (dtype != DL_DTYPE_F16 && dtype != DL_DTYPE_BF16))
     return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_mean_hw_nhwc_h: bad argument (C %% 8, dtype F16 / BF16)");
-  const dim3 grid((C / 8 + 15) / 16, N);
+  const dim3 grid((C / 8 + 1) / 2, N);
   if (dtype == DL_DTYPE_F16) hipLaunchKernelGGL(k_mean_hw_h<true>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)x, P, C, y);
   else hipLaunchKernelGGL(k_mean_hw_h<false>, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)x, P, C, y);
   return dl_check_launch("dl_mean_hw_nhwc_h");

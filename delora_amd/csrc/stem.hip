@@ -243,28 +243,30 @@ __global__ __launch_bounds__(DL_BLOCK) void k_stem_wgrad_reduce(const float* __r
 }
 
 // Global average pooling of the last feature map, channels-last: x [N][P][C] -> y [N][C] (reference resnet_modified.py:
-// avgpool + flatten before fc).  One workgroup per (image, 64 channels): 16 channel quads x 16 pixel lanes, every lane sums
-// its pixels in order, the 16 partial sums of a quad are added in a fixed tree through LDS -- deterministic, and a plain
+// avgpool + flatten before fc).  One workgroup per (image, 16 channels): 4 channel quads x 64 pixel lanes, every lane sums
+// its pixels in order, the 64 partial sums of a quad are added in a fixed tree through LDS -- deterministic, and a plain
 // kernel node when the step is captured into a HIP graph (torch's multi-block reduction zeroes its semaphores with a
 // memset node, which did not survive replays on this stack; found by bisecting the captured step in round 4).
+#define MEAN_QUADS 4              // channel quads per workgroup: 16 channels x 64 pixel lanes (round 6: 64 channels x 16 lanes was 64 workgroups
+#define MEAN_LANES 64             // for the whole batch -- a quarter of the chip -- and 41 us for 134 MB)
 __global__ __launch_bounds__(DL_BLOCK) void k_mean_hw_nhwc(const float* __restrict__ x, int P, int C, float* __restrict__ y) {
-  __shared__ f32x4s part[16][17];
-  const int n = blockIdx.y, c4 = blockIdx.x * 16 + (threadIdx.x & 15), pl = threadIdx.x >> 4;
+  __shared__ f32x4s part[MEAN_LANES][MEAN_QUADS + 1];
+  const int n = blockIdx.y, q = threadIdx.x & (MEAN_QUADS - 1), c4 = blockIdx.x * MEAN_QUADS + q, pl = threadIdx.x / MEAN_QUADS;
   f32x4s acc = {0.f, 0.f, 0.f, 0.f};
   if (4 * c4 < C) {
     const float* px = x + ((size_t)n * P) * C + 4 * c4;
-    for (int p = pl; p < P; p += 16) acc += *reinterpret_cast<const f32x4s*>(px + (size_t)p * C);
+    for (int p = pl; p < P; p += MEAN_LANES) acc += *reinterpret_cast<const f32x4s*>(px + (size_t)p * C);
   }
-  part[pl][threadIdx.x & 15] = acc;
+  part[pl][q] = acc;
   __syncthreads();
 #pragma unroll
-  for (int s = 8; s > 0; s >>= 1) {
-    if (pl < s) part[pl][threadIdx.x & 15] += part[pl + s][threadIdx.x & 15];
+  for (int s = MEAN_LANES / 2; s > 0; s >>= 1) {
+    if (pl < s) part[pl][q] += part[pl + s][q];
     __syncthreads();
   }
   if (pl == 0 && 4 * c4 < C) {
     const float inv = 1.0f / (float)P;
-    const f32x4s v = part[0][threadIdx.x & 15];
+    const f32x4s v = part[0][q];
     *reinterpret_cast<f32x4s*>(y + (size_t)n * C + 4 * c4) = (f32x4s){v.x * inv, v.y * inv, v.z * inv, v.w * inv};
   }
 }
@@ -272,7 +274,7 @@ __global__ __launch_bounds__(DL_BLOCK) void k_mean_hw_nhwc(const float* __restri
 extern "C" int dl_mean_hw_nhwc_f32(const float* x, int32_t N, int32_t P, int32_t C, float* y, dl_stream stream) {
   if (!x || !y || N <= 0 || P <= 0 || C <= 0) return dl_fail(DL_ERR_INVALID_ARGUMENT, "dl_mean_hw_nhwc_f32: bad argument");
   if (C & 3) return dl_fail(DL_ERR_UNSUPPORTED, "dl_mean_hw_nhwc_f32: C=%d must be a multiple of 4", C);
-  hipLaunchKernelGGL(k_mean_hw_nhwc, dim3((C / 4 + 15) / 16, N), dim3(DL_BLOCK), 0, (hipStream_t)stream, x, P, C, y);
+  hipLaunchKernelGGL(k_mean_hw_nhwc, dim3((C / 4 + MEAN_QUADS - 1) / MEAN_QUADS, N), dim3(DL_BLOCK), 0, (hipStream_t)stream, x, P, C, y);
   return dl_check_launch("dl_mean_hw_nhwc_f32");
 }
 
