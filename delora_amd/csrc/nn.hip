@@ -7,23 +7,24 @@
 // spatial index: a target closer than d to the transformed source point q subtends an angle of at most
 // asin(d/|q|) with q, which bounds the pixel rows and columns that can hold it.
 //
-//   pass A (one lane per source pixel): transform, project q into the target image, scan a fixed
-//     (2*RV+1)x(2*RU+1) window, then CERTIFY the result: if the angular bound of the best distance found,
-//     widened by the half-pixel rounding of the projection plus a safety margin, lies inside the scanned
-//     window, the neighbour is exact.  Otherwise the query goes to a compact "hard" list.
-//   pass B (one wave per hard query): the window that the spherical-cap bound of pass A's best distance allows (pass A
-//     stores it with the query; columns wrap through the azimuth seam) is walked tile by tile through a pyramid of
-//     bounding spheres of 4x16-pixel target tiles: 64 tiles are tested per trip and only tiles whose sphere can hold a
-//     closer point are scanned, one pixel per lane.  With no usable bound (d >= |q|, or nothing found in pass A) the
-//     window is the whole image, so the result is exact in every regime.
+//   pass A (k_nn_window; one lane per source pixel, one wave per 4 x 16 source tile): transform, project q into the target
+//     image, scan a fixed (2*RV+1)x(2*RU+1) window, then CERTIFY the result: if the angular bound of the best distance
+//     found, widened by the half-pixel rounding of the projection plus a safety margin, lies inside the scanned window,
+//     the neighbour is exact.  Otherwise the query goes to one of three compact lists by the size of its bound window, or --
+//     a wave with many queries WITHOUT a usable bound -- the whole tile becomes one packet.
+//   pass B (k_nn_pass_b): windows of a few hundred pixels are scanned by 16 lanes per query; larger ones are walked tile
+//     by tile (bounding sphere and tight box per 4x16-pixel target tile, 16 lanes or a wave per query); a query without a
+//     bound walks a two-level pyramid over the whole image best first, so the result is exact in every regime.
+//   packets (k_nn_packets): the 64 queries of a source tile walk that pyramid together, one query per lane (an untrained
+//     network's random poses: every query is of this kind).
 //
 // The target image is read in its packed form (one 16-byte load per candidate pixel).  Distances are accumulated
-// in fp64 from the fp32 coordinates, as the KD-tree does; ties resolve to the lower pixel index.  Bound: L2/LDS + VALU (candidates are re-read from cache), reported separately from the
-// HBM-bound residual kernel.
+// in fp64 from the fp32 coordinates, as the KD-tree does; ties resolve to the lower pixel index.  Bound: vector and scalar
+// instruction issue (tools/nn_lab, profiles/r06_nn_lab.txt), reported separately from the HBM-bound
+// residual kernel.  nn_pix doubles as the hand-over of pass A's best candidate to the packet kernel.
 #include "common.h"
 
 #include <algorithm>
-#include <mutex>
 
 #define NN_RV 2
 #define NN_RU 5
@@ -1336,25 +1337,6 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_pass_b(const float4* __restrict
   else if (!(NN_SKIP & 4)) nn_scan16(blk - 2 * part, part, tgt, tgt_ss4, tgtn, tgtn_ss4, sen, nn_pix, match, ws);
 }
 
-// One side stream per device for the packet kernel (created on first use, never destroyed: the library lives as long as the process).
-struct NNSide { hipStream_t s; hipEvent_t fork, join; };
-static NNSide* nn_side() {
-  static std::mutex mu;
-  static NNSide sides[64];
-  static int state[64];                 // 0 untried, 1 ready, -1 failed (the packet kernel then runs on the caller's stream)
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-  std::lock_guard<std::mutex> lock(mu);
-  if (state[dev] == 0) {
-    NNSide& n = sides[dev];
-    state[dev] = (hipStreamCreateWithFlags(&n.s, hipStreamNonBlocking) == hipSuccess &&
-                  hipEventCreateWithFlags(&n.fork, hipEventDisableTiming) == hipSuccess &&
-                  hipEventCreateWithFlags(&n.join, hipEventDisableTiming) == hipSuccess) ? 1 : -1;
-    if (state[dev] < 0) (void)hipGetLastError();
-  }
-  return state[dev] == 1 ? &sides[dev] : nullptr;
-}
-
 extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const float* src_normals,
                                 int64_t srcn_ss, const float* tgt_packed, int64_t tgt_ss,
                                 const float* tgt_normals_packed, int64_t tgtn_ss, const float* T, int32_t B,
@@ -1388,20 +1370,14 @@ extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const f
                      src_image4, src_ss, src_normals, srcn_ss, (const float4*)tgt_packed, tgt_ss / 4,
                      (const float4*)tgt_normals_packed, tgtn_ss / 4, T, sen, need_without_normals, nn_pix, match, visible,
                      ws, (int)use_packets);
-  // The packet kernel runs BESIDE pass B on a side stream of the library (fork / join through events: also what a stream capture
-  // records): with a trained network it returns at once, for an untrained one it is the long pole and pass B's lists hide behind it.
-#ifndef NN_SIDE_STREAM
-#define NN_SIDE_STREAM 0
-#endif
-  NNSide* side = (use_packets && NN_SIDE_STREAM) ? nn_side() : nullptr;
-  const bool forked = side && hipEventRecord(side->fork, st) == hipSuccess && hipStreamWaitEvent(side->s, side->fork, 0) == hipSuccess;
+  // The packet kernel (an untrained network's poses) runs before pass B on the caller's stream: with a trained network it returns at
+  // once (~3 us).  Inside k_nn_pass_b its registers cost the other lists two waves per SIMD (+15 us per search), beside it on a second
+  // stream the fork / join events cost 12 us -- both measured in round 6.
   if (use_packets && (size_t)B * nn_tiles(sen.H, sen.W) >= (size_t)NN_PACKET_FEW)      // (fewer source tiles than that: never enough packets)
-    hipLaunchKernelGGL(k_nn_packets, dim3((unsigned)std::min<size_t>(4096, ((size_t)B * nn_tiles(sen.H, sen.W) + 3) / 4)), dim3(DL_BLOCK), 0, forked ? side->s : st, src_image4, src_ss, T, (const float4*)tgt_packed, tgt_ss / 4,
-                       (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, ws);
+    hipLaunchKernelGGL(k_nn_packets, dim3((unsigned)std::min<size_t>(4096, ((size_t)B * nn_tiles(sen.H, sen.W) + 3) / 4)), dim3(DL_BLOCK), 0, st,
+                       src_image4, src_ss, T, (const float4*)tgt_packed, tgt_ss / 4, (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, ws);
   hipLaunchKernelGGL(k_nn_pass_b, dim3(3 * 2048), dim3(DL_BLOCK), 0, st, (const float4*)tgt_packed, tgt_ss / 4,
                      (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, visible, B, ws, 2048, src_image4, src_ss, T);
-  if (forked && (hipEventRecord(side->join, side->s) != hipSuccess || hipStreamWaitEvent(st, side->join, 0) != hipSuccess))
-    return dl_fail(DL_ERR_LAUNCH, "dl_nn_correspond: joining the side stream failed");
   return dl_check_launch("dl_nn_correspond");
 }
 
