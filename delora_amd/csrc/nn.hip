@@ -332,7 +332,10 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
   // A wave with many queries WITHOUT a usable bound (an untrained network's pose: all of them) hands the whole tile to the packet
   // walk of pass B -- every uncertified lane of it, the ones with a window included: one 16-byte descriptor instead of up to 64
   // records; pass B re-derives q and takes this pass's best from nn_pix.
-  const bool dense = use_packets && (int)__popcll(m0) >= NN_PACKET_MIN;
+#ifndef NN_DENSE_MASK
+#define NN_DENSE_MASK m0
+#endif
+  const bool dense = use_packets && (int)__popcll(NN_DENSE_MASK) >= NN_PACKET_MIN;
   const unsigned long long pmask = m0 | m1 | m2;
   if (dense) {
     if (cls >= 0) nn_pix[(size_t)b * HW + px] = h.idx;
