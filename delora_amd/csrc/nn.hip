@@ -76,6 +76,10 @@ struct NNPacket {               // one wave of pass A whose queries go through t
 #ifndef NN_PABL
 #define NN_PABL 0              // tools/nn_lab ablations of the packet walk (1: four pixels per tile, 2: no per-lane tile tests); wrong results
 #endif
+#ifndef NN_PACKET_WINDOWED
+#define NN_PACKET_WINDOWED 4096 // windowed packets are used from this many on (fewer: their queries stay with the lists)
+#endif
+#define NN_REC_WPACKET 0x40000000   // NNHard.b: the query also belongs to a windowed packet
 #ifndef NN_PACKET_FEW
 #define NN_PACKET_FEW 1024     // fewer packets than this (one per SIMD) are walked query by query
 #endif
@@ -90,6 +94,7 @@ struct NNWorkspace {
   float4* tbox;                // [B][tiles][2] tight axis-aligned bounding box (lo, hi) of every target tile's points; empty: lo > hi
   float4* sbox;                // [B][supers][2] the same for every super tile (the union of its children's boxes)
   NNPacket* packets;           // [B][tiles]: packets of pass A (counter[3])
+  NNPacket* wpackets;          // [B][tiles]: windowed packets of pass A (counter[5]): used by pass B only when there are many
 };
 
 #define NN_SR 4                 // super tile: 4 x 8 tiles = 32 child spheres (half a wave)
@@ -116,12 +121,13 @@ static inline NNWorkspace carve_nn(void* ws, int B, int H, int W) {
   w.tbox = w.super + (size_t)B * nn_supers(H, W);
   w.sbox = w.tbox + 2 * (size_t)B * nn_tiles(H, W);
   w.packets = (NNPacket*)(w.sbox + 2 * (size_t)B * nn_supers(H, W));
+  w.wpackets = w.packets + (size_t)B * nn_tiles(H, W);
   return w;
 }
 
 extern "C" size_t dl_nn_workspace_bytes(int32_t B, int32_t H, int32_t W) {
   return nn_header_bytes(B) + 2 * (size_t)B * H * W * sizeof(NNHard) + 3 * (size_t)B * (nn_tiles(H, W) + nn_supers(H, W)) * sizeof(float4) +
-         (size_t)B * nn_tiles(H, W) * sizeof(NNPacket);
+         2 * (size_t)B * nn_tiles(H, W) * sizeof(NNPacket);
 }
 
 // Angular description of a query in fp32.  The image is only a spatial index here: these values pick WHICH pixels
@@ -324,8 +330,8 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
   // that share hard[] plus one for mid[], every lane ranks itself inside its list from the ballots.  (As one atomicAdd per lane -- the
   // compiler does not merge them -- the appends were 72 us of this kernel's 148 at the bench's residual and 198 of 262 us for random
   // poses: same-address atomics retire one every ~3 ns.)  hard[] holds tile-walk queries from the front, scanned queries from the end.
-  __shared__ int s_cnt[5], s_base[4];
-  if (threadIdx.x < 5) s_cnt[threadIdx.x] = 0;
+  __shared__ int s_cnt[6], s_base[5];
+  if (threadIdx.x < 6) s_cnt[threadIdx.x] = 0;
   __syncthreads();
   unsigned long long m0 = __ballot(cls == 0), m1 = __ballot(cls == 1), m2 = __ballot(cls == 2);
   const unsigned long long mv = __ballot(vis);
@@ -335,17 +341,25 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
 #ifndef NN_DENSE_MASK
 #define NN_DENSE_MASK m0
 #endif
-  const bool dense = use_packets && (int)__popcll(NN_DENSE_MASK) >= NN_PACKET_MIN;
+  const bool dense = use_packets && (int)__popcll(m0) >= NN_PACKET_MIN;
   const unsigned long long pmask = m0 | m1 | m2;
+  // ... and a wave with many queries whose bound windows are LARGE (tile walks: a network in mid-training, tilted by a few degrees)
+  // offers its tile as a WINDOWED packet on top of the records it appends: pass B takes the packets if there are thousands of them
+  // (they cost a third of the per-query walks then) and the records otherwise (a few hundred packets are only latency)
+  const bool wdense = use_packets && !dense && (int)__popcll(m0 | m2) >= NN_PACKET_MIN;
+  const unsigned long long wmask = m0 | m2;
   if (dense) {
     if (cls >= 0) nn_pix[(size_t)b * HW + px] = h.idx;
     cls = -1;
     m0 = m1 = m2 = 0ull;
+  } else if (wdense && (cls == 0 || cls == 2)) {
+    nn_pix[(size_t)b * HW + px] = h.idx;
+    h.b |= NN_REC_WPACKET;
   }
   int woff = 0;
   {
-    const unsigned long long mm = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : (lane == 3 ? mv : (dense ? 1ull : 0ull))));
-    if (lane < 5 && mm) woff = atomicAdd(&s_cnt[lane], (int)__popcll(mm));
+    const unsigned long long mm = lane == 0 ? m0 : (lane == 1 ? m1 : (lane == 2 ? m2 : (lane == 3 ? mv : (lane == 4 ? (dense ? 1ull : 0ull) : (wdense ? 1ull : 0ull)))));
+    if (lane < 6 && mm) woff = atomicAdd(&s_cnt[lane], (int)__popcll(mm));
   }
   __syncthreads();
   if (threadIdx.x == 0 && (s_cnt[0] | s_cnt[1])) {
@@ -358,6 +372,7 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
   // visible pixels: spread over 32 sub-counters per sample; nn_hard (k_nn_pass_b) folds them into visible[b]
   if (threadIdx.x == 2 && visible && s_cnt[3]) atomicAdd(&ws.counter[NN_VIS0 + b * 32 + (blockIdx.x & 31)], s_cnt[3]);
   if (threadIdx.x == 3 && s_cnt[4]) s_base[3] = atomicAdd(ws.counter + 3, s_cnt[4]);
+  if (threadIdx.x == 4 && s_cnt[5]) s_base[4] = atomicAdd(ws.counter + 5, s_cnt[5]);
   __syncthreads();
   if (cls >= 0) {
     const unsigned long long below = (1ull << lane) - 1ull;
@@ -370,6 +385,11 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_window(
     NNPacket d;
     d.b = b; d.tile = wt; d.mask = pmask;
     ws.packets[s_base[3] + woff] = d;
+  }
+  if (wdense && lane == 5) {
+    NNPacket d;
+    d.b = b; d.tile = wt; d.mask = wmask;
+    ws.wpackets[s_base[4] + woff] = d;
   }
 }
 
@@ -781,7 +801,7 @@ __device__ __forceinline__ void nn_scan16(const int vblock, const int vgrid, con
   const int HW = sen.HW, W = sen.W;
   for (int h = group; h < count; h += ngroups) {
     const NNHard rec = ws.hard[ws.capacity - 1 - h];
-    const int b = rec.b;
+    const int b = rec.b & 0xffff;
     const int r0 = (int)(rec.rows & 0xffffu), r1 = (int)(rec.rows >> 16);
     const int c0 = (int)(rec.cols & 0xffffu), nc = (int)(rec.cols >> 16) + 1;
     const float qx = rec.qx, qy = rec.qy, qz = rec.qz;
@@ -841,15 +861,17 @@ __device__ __forceinline__ void nn_hard16(const int vblock, const int vgrid, con
   const int group = (vblock * DL_BLOCK + threadIdx.x) >> 4;
   const int ngroups = vgrid * DL_BLOCK / 16;
   const int count = ws.counter[2];
+  const bool windowed = ws.counter[5] >= NN_PACKET_WINDOWED;     // pass B runs the windowed packets: their queries are skipped here
   const int HW = sen.HW, H = sen.H, W = sen.W;
   const int ntc_all = (W + NN_TC - 1) / NN_TC;
   const int ntiles_img = nn_tiles_dev(H, W);
   const int rounds = (count + ngroups - 1) / ngroups;
   for (int it = 0; it < rounds; ++it) {
     const int h = group + it * ngroups;
-    const bool live = h < count;
-    const NNHard rec = ws.mid[live ? h : 0];
-    const int b = rec.b;
+    const bool live0 = h < count;
+    const NNHard rec = ws.mid[live0 ? h : 0];
+    const bool live = live0 && !(windowed && (rec.b & NN_REC_WPACKET));       // (a windowed packet of pass B has this query)
+    const int b = rec.b & 0xffff;
     const float qx = rec.qx, qy = rec.qy, qz = rec.qz;
     const float4* tp = tgt + (size_t)b * tgt_ss4;
     const float4* tiles_b = ws.tiles + (size_t)b * ntiles_img;
@@ -1076,10 +1098,6 @@ __device__ __forceinline__ void packet_walk(const float4* __restrict__ super_b, 
       const int ttr = sr * NN_SR + (i >> 3), ttc = sc * NN_SC + (i & 7);
       NN_STAT(11, 1);
       const int row0 = ttr * NN_TR, col0 = ttc * NN_TC;
-      // its 64 pixels, one per lane (one coalesced load, issued before the test below needs anything from memory)
-      const int trow = row0 + (lane >> 4), tcol = col0 + (lane & 15);
-      float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (trow < H && tcol < W) mine = tp[trow * W + tcol];
       {  // still needed, now that the lanes' bounds may have moved?  (sphere and box)
         const float4 s4 = make_float4(readlane_f(cs4.x, i), readlane_f(cs4.y, i),
                                       readlane_f(cs4.z, i), readlane_f(cs4.w, i));
@@ -1091,6 +1109,11 @@ __device__ __forceinline__ void packet_walk(const float4* __restrict__ super_b, 
 #ifdef NN_STATS
       ++scans_here;
 #endif
+      // its 64 pixels, one per lane: one coalesced load (only for tiles that are scanned: a load per OFFERED tile was waited for when
+      // the next one reused its registers -- ~2 us each on the packet's critical path)
+      const int trow = row0 + (lane >> 4), tcol = col0 + (lane & 15);
+      float4 mine = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (trow < H && tcol < W) mine = tp[trow * W + tcol];
       // every occupied pixel of the tile against every lane's query.  The tile goes through the wave's 1 KB of LDS: one ds_read_b128
       // with a wave-uniform address hands a pixel to all 64 lanes without a vector instruction (three v_readlane per pixel measured
       // slower than the seven instructions of the test itself; scalar loads are a chain of ~0.7 us round trips)
@@ -1196,11 +1219,11 @@ __device__ __forceinline__ void nn_packets_few(const int vblock, const int vgrid
 // Pass B for the packets of pass A, a kernel of its own (inside k_nn_pass_b its registers cost the other lists two waves per SIMD): one
 // wave per packet.  q is re-derived from the source image (the same expression as in pass A),
 // pass A's best candidate comes back through nn_pix.
-__global__ __launch_bounds__(DL_BLOCK) void k_nn_packets(const float* __restrict__ src, int64_t src_ss, const float* __restrict__ T,
-                                                         const float4* __restrict__ tgt, int64_t tgt_ss4, const float4* __restrict__ tgtn,
-                                                         int64_t tgtn_ss4, SensorK sen, int32_t* __restrict__ nn_pix, float* __restrict__ match,
-                                                         NNWorkspace ws) {
-  const int vblock = __builtin_amdgcn_readfirstlane((int)blockIdx.x), vgrid = (int)gridDim.x;
+__device__ __forceinline__ void nn_packets_run(const int vblock, const int vgrid, const float* __restrict__ src, int64_t src_ss,
+                                               const float* __restrict__ T, const float4* __restrict__ tgt, int64_t tgt_ss4,
+                                               const float4* __restrict__ tgtn, int64_t tgtn_ss4, const SensorK& sen,
+                                               int32_t* __restrict__ nn_pix, float* __restrict__ match, const NNWorkspace& ws,
+                                               float4* lds_tile) {
   const int lane = threadIdx.x & (DL_WAVE - 1);
   const int wave = __builtin_amdgcn_readfirstlane((vblock * DL_BLOCK + threadIdx.x) / DL_WAVE);
   const int nwaves = vgrid * DL_BLOCK / DL_WAVE;
@@ -1209,14 +1232,15 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_packets(const float* __restrict
   const int wtiles_c = (W + NN_TC - 1) / NN_TC;
   const int ntiles_img = nn_tiles_dev(H, W);
   const int nsuper_img = ((((H + NN_TR - 1) / NN_TR) + NN_SR - 1) / NN_SR) * ((((W + NN_TC - 1) / NN_TC) + NN_SC - 1) / NN_SC);
-  if (npk < NN_PACKET_FEW) return;                     // k_nn_pass_b walks them query by query (nn_packets_few)
-  __shared__ float4 s_tile[DL_BLOCK / DL_WAVE][DL_WAVE];
+  const int e0 = npk >= NN_PACKET_FEW ? npk : 0;                           // (fewer: walked query by query, nn_packets_few)
+  const int nw = ws.counter[5];
+  const int e2 = nw >= NN_PACKET_WINDOWED ? nw : 0;                        // (fewer: their queries stay with the lists)
   int static_round = 0;
   for (;;) {
     // a static share (one atomic work queue instead measured 55 us slower: 20k same-address atomics next to the counters every wave reads)
     const int pk = wave + nwaves * static_round++;
-    if (pk >= npk) break;
-    const NNPacket d = ws.packets[pk];
+    if (pk >= e0 + e2) break;
+    const NNPacket d = pk < e0 ? ws.packets[pk] : ws.wpackets[pk - e0];
     const int b = d.b;
     NN_STAT(8, 1);
     NN_STAT(9, __popcll(d.mask));
@@ -1240,7 +1264,7 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_packets(const float* __restrict
       }
     }
     packet_walk(ws.super + (size_t)b * nsuper_img, ws.tiles + (size_t)b * ntiles_img, ws.sbox + 2 * (size_t)b * nsuper_img,
-                ws.tbox + 2 * (size_t)b * ntiles_img, tp, H, W, qx, qy, qz, act, lane, s_tile[threadIdx.x >> 6], best, bidx);
+                ws.tbox + 2 * (size_t)b * ntiles_img, tp, H, W, qx, qy, qz, act, lane, lds_tile, best, bidx);
     if (act) {
       nn_pix[(size_t)b * HW + px] = bidx;
       if (match) {
@@ -1254,6 +1278,18 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_packets(const float* __restrict
       }
     }
   }
+}
+
+#ifndef NN_MERGED
+#define NN_MERGED 1            // 1: the packets are the first range of k_nn_pass_b's workgroups; 0: a kernel of their own in front of it
+#endif
+__global__ __launch_bounds__(DL_BLOCK) void k_nn_packets(const float* __restrict__ src, int64_t src_ss, const float* __restrict__ T,
+                                                         const float4* __restrict__ tgt, int64_t tgt_ss4, const float4* __restrict__ tgtn,
+                                                         int64_t tgtn_ss4, SensorK sen, int32_t* __restrict__ nn_pix, float* __restrict__ match,
+                                                         NNWorkspace ws) {
+  __shared__ float4 s_tile[DL_BLOCK / DL_WAVE][DL_WAVE];
+  nn_packets_run(__builtin_amdgcn_readfirstlane((int)blockIdx.x), (int)gridDim.x, src, src_ss, T, tgt, tgt_ss4, tgtn, tgtn_ss4, sen, nn_pix, match, ws,
+                 s_tile[threadIdx.x >> 6]);
 }
 
 // Pass B: one wave per query that pass A could not certify.  Everything per-query is wave-uniform (the record is read
@@ -1270,6 +1306,7 @@ __device__ __forceinline__ void nn_hard(const int vblock, const int vgrid, const
   const int wave = __builtin_amdgcn_readfirstlane((vblock * DL_BLOCK + threadIdx.x) / DL_WAVE);
   const int nwaves = vgrid * DL_BLOCK / DL_WAVE;
   const int count = ws.counter[0];
+  const bool windowed = ws.counter[5] >= NN_PACKET_WINDOWED;
   const int HW = sen.HW, H = sen.H, W = sen.W;
   if (visible && vblock == 0 && (int)threadIdx.x < nb) {      // fold the visible-pixel sub-counters of pass A
     int sum = 0;
@@ -1283,7 +1320,8 @@ __device__ __forceinline__ void nn_hard(const int vblock, const int vgrid, const
     const long long t0_ = clock64();
 #endif
     const NNHard rec = ws.hard[h];
-    const int b = rec.b;
+    if (windowed && (rec.b & NN_REC_WPACKET)) continue;            // (a windowed packet of pass B has this query)
+    const int b = rec.b & 0xffff;
     NN_STAT(0, 1);
     Window w;
     w.r0 = (int)(rec.rows & 0xffffu); w.r1 = (int)(rec.rows >> 16);
@@ -1329,10 +1367,19 @@ __global__ __launch_bounds__(DL_BLOCK) void k_nn_pass_b(const float4* __restrict
                                                         const float4* __restrict__ tgtn, int64_t tgtn_ss4, SensorK sen,
                                                         int32_t* __restrict__ nn_pix, float* __restrict__ match,
                                                         int32_t* __restrict__ visible, int nb, NNWorkspace ws, int part,
-                                                        const float* __restrict__ src, int64_t src_ss, const float* __restrict__ T) {
-  const int blk = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
+                                                        const float* __restrict__ src, int64_t src_ss, const float* __restrict__ T, int pkb) {
+  int blk = __builtin_amdgcn_readfirstlane((int)blockIdx.x);
 #ifndef NN_SKIP
 #define NN_SKIP 0              // tools/nn_lab: time of one list = the kernel without it (results are wrong by construction)
+#endif
+#if NN_MERGED
+  // the packets first (the longest items of the grid: ~60 us on one wave each), the lists fill the machine beside them
+  __shared__ float4 s_tile[DL_BLOCK / DL_WAVE][DL_WAVE];
+  if (blk < pkb) {
+    if (!(NN_SKIP & 16)) nn_packets_run(blk, pkb, src, src_ss, T, tgt, tgt_ss4, tgtn, tgtn_ss4, sen, nn_pix, match, ws, s_tile[threadIdx.x >> 6]);
+    return;
+  }
+  blk -= pkb;
 #endif
   if (!(NN_SKIP & 8)) nn_packets_few(blk, 3 * part, src, src_ss, T, tgt, tgt_ss4, tgtn, tgtn_ss4, sen, nn_pix, match, ws);
   if (blk < part) { if (!(NN_SKIP & 1)) nn_hard16(blk, part, tgt, tgt_ss4, tgtn, tgtn_ss4, sen, nn_pix, match, ws); }
@@ -1373,14 +1420,18 @@ extern "C" int dl_nn_correspond(const float* src_image4, int64_t src_ss, const f
                      src_image4, src_ss, src_normals, srcn_ss, (const float4*)tgt_packed, tgt_ss / 4,
                      (const float4*)tgt_normals_packed, tgtn_ss / 4, T, sen, need_without_normals, nn_pix, match, visible,
                      ws, (int)use_packets);
-  // The packet kernel (an untrained network's poses) runs before pass B on the caller's stream: with a trained network it returns at
-  // once (~3 us).  Inside k_nn_pass_b its registers cost the other lists two waves per SIMD (+15 us per search), beside it on a second
-  // stream the fork / join events cost 12 us -- both measured in round 6.
-  if (use_packets && (size_t)B * nn_tiles(sen.H, sen.W) >= (size_t)NN_PACKET_FEW)      // (fewer source tiles than that: never enough packets)
-    hipLaunchKernelGGL(k_nn_packets, dim3((unsigned)std::min<size_t>(4096, ((size_t)B * nn_tiles(sen.H, sen.W) + 3) / 4)), dim3(DL_BLOCK), 0, st,
-                       src_image4, src_ss, T, (const float4*)tgt_packed, tgt_ss / 4, (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, ws);
-  hipLaunchKernelGGL(k_nn_pass_b, dim3(3 * 2048), dim3(DL_BLOCK), 0, st, (const float4*)tgt_packed, tgt_ss / 4,
-                     (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, visible, B, ws, 2048, src_image4, src_ss, T);
+  // Packets: one workgroup range in front of pass B's three (inside one grid they overlap the lists; as a kernel of their own in front
+  // of it their latency -- ~60 us on one wave -- is exposed whenever there are few of them).  One wave per possible packet, at most 4096
+  // workgroups; none where the batch has fewer source tiles than the packet threshold.
+  const bool packets_possible = use_packets && (size_t)B * nn_tiles(sen.H, sen.W) >= (size_t)NN_PACKET_FEW;
+  const int pkb = packets_possible ? (int)std::min<size_t>(4096, ((size_t)B * nn_tiles(sen.H, sen.W) + 3) / 4) : 0;
+#if !NN_MERGED
+  if (pkb)
+    hipLaunchKernelGGL(k_nn_packets, dim3(pkb), dim3(DL_BLOCK), 0, st, src_image4, src_ss, T, (const float4*)tgt_packed, tgt_ss / 4,
+                       (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, ws);
+#endif
+  hipLaunchKernelGGL(k_nn_pass_b, dim3(3 * 2048 + (NN_MERGED ? pkb : 0)), dim3(DL_BLOCK), 0, st, (const float4*)tgt_packed, tgt_ss / 4,
+                     (const float4*)tgt_normals_packed, tgtn_ss / 4, sen, nn_pix, match, visible, B, ws, 2048, src_image4, src_ss, T, pkb);
   return dl_check_launch("dl_nn_correspond");
 }
 

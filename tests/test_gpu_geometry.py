@@ -420,6 +420,54 @@ def test_nn_packet_walk_batched_random_poses():
         assert (m[:, ~ok] == 0).all()
 
 
+def test_nn_windowed_packets_batch_of_tilted_poses(monkeypatch):
+    """64x2048, batch 8, the true motion composed with a few degrees of roll / pitch error (a network in mid-training): thousands of
+    source tiles whose bound windows are large -- pass B takes them as WINDOWED packets (k_nn_pass_b's first workgroup range) and skips
+    their records in the lists.  Indices against the exhaustive kernel; the test reads the list counters to make sure the regime was met."""
+    sensor, img, nrm, T_true = _pair_images(999, 64, 2048, 64, 2250)
+    dev = img.device
+    B = 8
+    rng = np.random.default_rng(21)
+    Ts = []
+    for b in range(B):
+        e = rng.normal(0, 0.04, size=3)
+        q = torch.tensor([[e[0], e[1], 0.2 * e[2], 1.0]], dtype=torch.float32)
+        dT = orc.transformation_matrix(torch.tensor(rng.normal(0, 0.2, size=(1, 3)), dtype=torch.float32), q)
+        Ts.append(dT[0] @ torch.from_numpy(T_true).float())
+    T = torch.stack(Ts).to(dev)
+    imgs_t = img[0:1].expand(B, -1, -1, -1).contiguous()
+    imgs_s = img[1:2].expand(B, -1, -1, -1).contiguous()
+    nrm_s = nrm[1:2].expand(B, -1, -1, -1).contiguous()
+    kept = {}
+    real_empty = torch.empty
+
+    def spy(*a, **k):
+        t = real_empty(*a, **k)
+        if k.get("dtype") == torch.int64:
+            kept["ws"] = t
+        return t
+    monkeypatch.setattr(torch, "empty", spy)
+    nn, _, _ = _geo().nn_correspond(imgs_s, nrm_s, _geo().pack_image(imgs_t), None, T, sensor, need_without_normals=True)
+    monkeypatch.undo()
+    torch.cuda.synchronize()
+    counters = kept["ws"].view(torch.int32)[:6].tolist()
+    assert counters[5] >= 4096, f"the poses of this test no longer produce windowed packets: counters {counters}"
+    tflat = imgs_t[0, :3].reshape(3, -1).cpu().double()
+    tp, _, tpix = util.lists_from_images(imgs_t[0].cpu(), torch.zeros(3, 64, 2048))
+    sp, _, spix = util.lists_from_images(imgs_s[0].cpu(), nrm_s[0].cpu())
+    for b in range(B):
+        q = orc.transform_points(T[b:b + 1].cpu(), sp)
+        bf = _geo().nn_bruteforce(q[0].to(dev), tp[0].to(dev)).cpu().long()
+        got = nn[b].reshape(-1).cpu().long()[spix]
+        exp = tpix[bf]
+        if not torch.equal(got, exp):
+            bad = torch.nonzero(got != exp).reshape(-1)
+            d_got = (q[0][:, bad].double() - tflat[:, got[bad]]).norm(dim=0)
+            d_exp = (q[0][:, bad].double() - tflat[:, exp[bad]]).norm(dim=0)
+            assert torch.all(d_got <= d_exp + _q_slack(q[0][:, bad].double())), f"sample {b}: {len(bad)} non-tie mismatches"
+            assert len(bad) <= 1e-4 * len(got) + 1
+
+
 def test_nn_empty_target_and_empty_source():
     vf, hf = util.kitti_fov()
     sensor = gpu_sensor(16, 128, vf, hf)

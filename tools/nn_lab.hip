@@ -1,7 +1,7 @@
 // The exact nearest-neighbour search of csrc/nn.hip alone (no torch): a ray-cast street scene (ground, walls, pillars, boxes) seen from two
 // poses gives the target image and the source points; the search runs in the regimes the training loop meets and is checked against an
 // exhaustive fp64 search on the GPU (ties to the lower pixel index, as the kernels resolve them).
-//   nn_lab check            every regime at B=2 against the exhaustive search
+//   nn_lab check            every regime at B=8 against the exhaustive search (nn_lab check 0 -1 2: batch 2)
 //   nn_lab time [reps] [regime]   B=8, 64x2048: time per search, list sizes, uncertified share (per kernel: run one regime under
 //                           rocprofv3 --kernel-trace --stats)
 // Regimes: residual = true motion composed with a 0.4 m error (the bench's row), identity = T = I over 1 m / 2 deg of true motion,
@@ -233,7 +233,7 @@ int main(int argc, char** argv) {
   const bool check = argc > 1 && !strcmp(argv[1], "check");
   const int reps = argc > 2 ? atoi(argv[2]) : 20;
   const int only = argc > 3 ? atoi(argv[3]) : -1;
-  const int B = check ? 2 : 8, H = 64, W = 2048;
+  const int B = argc > 4 ? atoi(argv[4]) : 8, H = 64, W = 2048;      // (the windowed packets of pass B need thousands of source tiles: check at the full batch)
   Batch bt = make_batch(B, H, W, 1234);
   const int HW = bt.HW;
   int32_t *nn, *ref, *vis;
