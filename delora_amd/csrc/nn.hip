@@ -15,8 +15,8 @@
 //   pass B (k_nn_pass_b): windows of a few hundred pixels are scanned by 16 lanes per query; larger ones are walked tile
 //     by tile (bounding sphere and tight box per 4x16-pixel target tile, 16 lanes or a wave per query); a query without a
 //     bound walks a two-level pyramid over the whole image best first, so the result is exact in every regime.
-//   packets (k_nn_packets): the 64 queries of a source tile walk that pyramid together, one query per lane (an untrained
-//     network's random poses: every query is of this kind).
+//   packets (the first workgroup range of k_nn_pass_b): the 64 queries of a source tile walk that pyramid together, one query
+//     per lane (an untrained network's random poses: every query is of this kind; a tilted pose: the windowed packets).
 //
 // The target image is read in its packed form (one 16-byte load per candidate pixel).  Distances are accumulated
 // in fp64 from the fp32 coordinates, as the KD-tree does; ties resolve to the lower pixel index.  Bound: vector and scalar
@@ -1216,9 +1216,10 @@ __device__ __forceinline__ void nn_packets_few(const int vblock, const int vgrid
   }
 }
 
-// Pass B for the packets of pass A, a kernel of its own (inside k_nn_pass_b its registers cost the other lists two waves per SIMD): one
-// wave per packet.  q is re-derived from the source image (the same expression as in pass A),
-// pass A's best candidate comes back through nn_pix.
+// Pass B for the packets of pass A: one wave per packet, a static share of both kinds (the packets of waves without usable bounds, and --
+// when there are thousands -- the windowed packets).  q is re-derived from the source image (the same expression as in pass A), pass A's
+// best candidate comes back through nn_pix.  Runs as the first workgroup range of k_nn_pass_b (k_nn_packets below is the same code as a
+// kernel of its own, for A/B builds with -DNN_MERGED=0).
 __device__ __forceinline__ void nn_packets_run(const int vblock, const int vgrid, const float* __restrict__ src, int64_t src_ss,
                                                const float* __restrict__ T, const float4* __restrict__ tgt, int64_t tgt_ss4,
                                                const float4* __restrict__ tgtn, int64_t tgtn_ss4, const SensorK& sen,
