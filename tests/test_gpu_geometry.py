@@ -468,6 +468,37 @@ def test_nn_windowed_packets_batch_of_tilted_poses(monkeypatch):
             assert len(bad) <= 1e-4 * len(got) + 1
 
 
+@pytest.mark.parametrize("case", ["random", "true"])
+def test_nn_ragged_image_large_batch(case):
+    """30x500 (neither a multiple of the 4x16 tiles), batch 48: the tile-shaped waves of pass A hang over the image's edges, and with
+    random poses the batch has enough source tiles for the packet walk; indices against the exhaustive kernel."""
+    H, W = 30, 500
+    sensor, img, nrm, T_true = _pair_images(31, H, W, 30, 550)
+    dev = img.device
+    B = 48
+    rng = np.random.default_rng(5)
+    T = torch.cat([_random_T(rng) if case == "random" else torch.from_numpy(T_true).view(1, 4, 4).float() for _ in range(B)]).float().to(dev)
+    imgs_t = img[0:1].expand(B, -1, -1, -1).contiguous()
+    imgs_s = img[1:2].expand(B, -1, -1, -1).contiguous()
+    nrm_s = nrm[1:2].expand(B, -1, -1, -1).contiguous()
+    nn, _, _ = _geo().nn_correspond(imgs_s, nrm_s, _geo().pack_image(imgs_t), None, T, sensor, need_without_normals=True)
+    torch.cuda.synchronize()
+    tflat = imgs_t[0, :3].reshape(3, -1).cpu().double()
+    tp, _, tpix = util.lists_from_images(imgs_t[0].cpu(), torch.zeros(3, H, W))
+    sp, _, spix = util.lists_from_images(imgs_s[0].cpu(), nrm_s[0].cpu())
+    for b in range(0, B, 7):
+        q = orc.transform_points(T[b:b + 1].cpu(), sp)
+        bf = _geo().nn_bruteforce(q[0].to(dev), tp[0].to(dev)).cpu().long()
+        got = nn[b].reshape(-1).cpu().long()[spix]
+        exp = tpix[bf]
+        if not torch.equal(got, exp):
+            bad = torch.nonzero(got != exp).reshape(-1)
+            d_got = (q[0][:, bad].double() - tflat[:, got[bad]]).norm(dim=0)
+            d_exp = (q[0][:, bad].double() - tflat[:, exp[bad]]).norm(dim=0)
+            assert torch.all(d_got <= d_exp + _q_slack(q[0][:, bad].double())), f"sample {b}: {len(bad)} non-tie mismatches"
+            assert len(bad) <= 1e-4 * len(got) + 1
+
+
 def test_nn_empty_target_and_empty_source():
     vf, hf = util.kitti_fov()
     sensor = gpu_sensor(16, 128, vf, hf)
