@@ -109,7 +109,8 @@ int dl_normals(const float* image4, int64_t image_ss, int32_t S, int32_t H, int3
                int32_t half_rows, int32_t half_cols, float epsilon_range, int32_t min_neighbors,
                float* normals, float* packed_normals, dl_stream stream);
 
-/* Bytes of scratch dl_nn_correspond needs (hard-query list + counters). */
+/* Bytes of scratch dl_nn_correspond needs (list counters, the record lists of the uncertified queries, the two-level pyramid of the
+ * target tiles, packet descriptors; ~85 B per pixel of the batch). */
 size_t dl_nn_workspace_bytes(int32_t B, int32_t H, int32_t W);
 
 /*
@@ -125,7 +126,8 @@ size_t dl_nn_workspace_bytes(int32_t B, int32_t H, int32_t W);
  *   match      [B][6][H][W] out (may be NULL): per SOURCE pixel the matched target point (planes 0..2) and its
  *                         normal (planes 3..5), zeros where nn_pix is -1 -- what dl_icp_loss_* streams
  *   nn_pix     [B][H][W]  out: target pixel index of the nearest target point per source pixel
- *                         (-1 for empty source pixels or an empty target image)
+ *                         (-1 for empty source pixels or an empty target image); written twice for some pixels (the first
+ *                         pass hands its best candidate to the second through it): read it after the call, on `stream`
  *   visible    [B]        out (may be NULL): number of source points with round(v) < H and v > 0 in the
  *                         target frame (the visible_pixels metric, deployer.py:349-352,365-367)
  *   src_normals may be NULL; when given and need_without_normals == 0, source pixels without a normal
