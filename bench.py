@@ -59,7 +59,7 @@ def parse(argv=None):
     ap.add_argument("--autocast-steps", type=int, default=20, help="timed steps of the extra bf16-autocast leg of the fp32 run (0 = skip); N=1 only")
     ap.add_argument("--disk-pairs", type=int, default=32, help="scan pairs of the synthetic on-disk sequence of the `feed_disk` leg (0 = skip); N=1 only")
     ap.add_argument("--disk-workers", type=int, default=2, help="DataLoader worker processes of the `feed_disk` leg")
-    ap.add_argument("--variant-steps", type=int, default=10, help="timed steps of the extra fp32 legs `shipped_image` (64x720, the reference's "
+    ap.add_argument("--variant-steps", type=int, default=20, help="timed steps of the extra fp32 legs `shipped_image` (64x720, the reference's "
                     "default KITTI image) and `untrained_network` (randomly initialised heads: whole-image search) (0 = skip); N=1 only")
     ap.add_argument("--point-order", default="raster", choices=("raster", "firing", "shuffled"),
                     help="order of the points inside a raw scan: raster = ring after ring, the order of the reference's stored point lists "
@@ -811,6 +811,12 @@ def kernel_table(trainer, batch, reps):
     T_rand = GeometryHandler.get_transformation_matrix_quaternion(torch.randn((B, 3), generator=g), q, torch.device("cpu")).to(trainer.device)
     row("dl_nn_correspond/random-pose", timed(lambda: G.nn_correspond(img[:, 1], nrm[:, 1], tgt_pk, tgt_n_pk, T_rand, sensor)),
         28 * B * HW + 12 * B * HW, "l2+valu", "random rotations + 1 m translations (worst case of the exact search)")
+    # a network in mid-training: a few degrees of roll / pitch error and a few decimetres (most queries keep a bound, but a large one:
+    # the regime of the windowed packets of pass B)
+    q_tilt = torch.cat([0.03 * torch.randn((B, 3), generator=g), torch.ones((B, 1))], dim=1)
+    T_tilt = GeometryHandler.get_transformation_matrix_quaternion(0.2 * torch.randn((B, 3), generator=g), q_tilt, torch.device("cpu")).to(trainer.device)
+    row("dl_nn_correspond/tilted-pose", timed(lambda: G.nn_correspond(img[:, 1], nrm[:, 1], tgt_pk, tgt_n_pk, T_tilt, sensor)),
+        28 * B * HW + 12 * B * HW, "l2+valu", "rotations of a few degrees about random axes + 0.2 m translations (a network in mid-training)")
     # the pose the network itself produces at this point of the run (what the search of the timed steps sees): a network that
     # trains on unrelated random scenes does not converge to the true motion, so the residual the search faces is larger
     # than the 0.4 m of the row above
