@@ -691,6 +691,12 @@ static int dispatch_conv(const ConvArgs& a, hipStream_t st) {
       if (a.Wo % 64 == 0 && a.Ho % 4 == 0 && !launch_conv<256, 64, 8, 64, G, BT, 1>(a, st)) return 0;
     }
   }
+  if constexpr (G::WTAPS == 9 && !BIG && !BT && G::ISH == 1 && G::ISW == 2) {
+    // forward of the layers with stride (1,2) (layer2.0 / layer3.0 conv1): two output rows per workgroup share the middle rows of the
+    // 4 x 257-pixel input tile and one staging of the weights -- 232 -> 208 us and 423 -> 380 us at the bench's batch (round 6; the
+    // input-gradient phases and the (2,2) layer gain nothing from 256-pixel tiles, measured with tools/conv_harness)
+    if (a.C <= 256 && a.Wo % 128 == 0 && a.Ho % 2 == 0 && !launch_conv<256, 64, 8, 128, G, BT, 1>(a, st)) return 0;
+  }
   if constexpr (G::WTAPS == 9 && !BIG) {
     // strided 3x3 layers and their input-gradient phases: 8-channel chunks (half the LDS, two workgroups per CU) are
     // 5-9 % faster up to 256 reduction channels (tools/conv_harness time; the 512-channel phases and the 1x1 layers keep
