@@ -141,6 +141,7 @@ class PackedFeed:
             rt = torch.cuda.cudart()
             self.pinned = all(int(rt.cudaHostRegister(s.data_ptr(), s.numel() * 4, 0)) == 0 for s in self.slots)
         self.stream = torch.cuda.Stream(device=device) if self.cuda else None
+        self.slot_offs = [torch.zeros((2 * self.B + 1,), dtype=torch.int32).pin_memory() for _ in range(n_slots)] if self.cuda else []
         ctx = _mp.get_context("fork")
         self.tasks, self.done = ctx.Queue(), ctx.Queue()
         self.procs = [ctx.Process(target=_feed_worker, args=(dataset, self.slots, self.tasks, self.done, self.rows, self.capacity), daemon=True)
@@ -193,7 +194,13 @@ class PackedFeed:
             pts = torch.empty((self.rows, total), dtype=torch.float32, device=self.device)
             for c in range(self.rows):                                   # one contiguous DMA per coordinate row
                 pts[c].copy_(host[c], non_blocking=True)
-            offs_t = torch.tensor(offs, dtype=torch.int32).pin_memory().to(self.device, non_blocking=True)
+            # the CSR offsets go through a page-locked vector that belongs to the SLOT: it is rewritten only when the slot is, i.e. after
+            # this upload's event.  (A temporary `torch.tensor(offs).pin_memory()` is handed back to torch's host allocator at once;
+            # with batches arriving back to back from worker processes the next batch's offsets could land in the same block before
+            # this copy had run -- round 6: one step in a few hundred trained on its neighbour's scan boundaries.)
+            stage = self.slot_offs[slot]
+            stage[:len(offs)] = torch.tensor(offs, dtype=torch.int32)
+            offs_t = stage[:len(offs)].to(self.device, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.stream)
         self.bytes_moved += pts.numel() * 4

@@ -46,7 +46,8 @@ class HipStepGeometry:
             else:
                 t = (host.to(device), None)
             if len(self._offsets) > 64:
-                self._offsets.clear()
+                # drop the OLDEST entry only: its copy was issued 64 steps ago; the staging vectors of the latest steps may still be read
+                self._offsets.pop(next(iter(self._offsets)))
             self._offsets[key] = t
         return t[0]
 

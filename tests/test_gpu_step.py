@@ -332,7 +332,7 @@ def test_training_from_the_on_disk_format_through_the_packed_feed(tmp_path, with
         for k in m0:
             assert np.isclose(m0[k], m1[k], rtol=1e-6, atol=1e-9), (name, k, m0[k], m1[k])
         util.measured(f"packed feed ({name}) vs DataLoader ({'stored normals' if with_normals else 'xyz only'}): largest parameter difference after one epoch",
-                      max(float((a - b).abs().max()) for a, b in zip(p0, p1)), bound=1e-7)
+                      max(float((a - b).abs().max()) for a, b in zip(p0, p1)), bound=2.5e-7)     # (0.3 - 1.0e-7 from run to run: 1 % of ONE Adam step at this rate)
 
 
 @pytest.mark.parametrize("feed_kind", ["dataloader", "packed-in-process", "packed-2-workers", "packed-in-process-reverted"])
@@ -388,10 +388,16 @@ def test_product_loop_switches_to_graph_replay_and_keeps_the_trajectory(tmp_path
         assert tr.graph_probe_result[True]["decision"] == "graph" and tr._graphed.captured
         assert tr.graph_steps == 3 * 12 - probe and tr._graphed.fallback_steps == 0, (tr.graph_steps, tr._graphed.fallback_steps)
     assert runs[False][2].graph_steps == 0
-    worst = 0.0
-    for m_e, m_g in zip(runs[False][0], runs["auto"][0]):
+    worst, where = 0.0, None
+    for e, (m_e, m_g) in enumerate(zip(runs[False][0], runs["auto"][0])):
         for k in m_e:
-            worst = max(worst, abs(m_e[k] - m_g[k]) / max(abs(m_e[k]), 1e-12))
+            d = abs(m_e[k] - m_g[k]) / max(abs(m_e[k]), 1e-12)
+            if d > worst:
+                worst, where = d, (e, k, m_e[k], m_g[k])
+    if worst > 1e-5:
+        print("graph replay vs eager: worst metric", where, "largest parameter difference",
+              max(float((a - b).abs().max()) for a, b in zip(runs[False][1], runs["auto"][1])), "graph steps", tr.graph_steps,
+              "probe", tr.graph_probe_result)
     util.measured(f"product loop, graph replay vs eager ({feed_kind}): worst relative difference of an epoch metric "
                   "over three epochs", worst, bound=1e-5)
     util.measured(f"product loop, graph replay vs eager ({feed_kind}): largest parameter difference after 36 steps",
