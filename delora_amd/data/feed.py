@@ -24,13 +24,22 @@ class DevicePrefetcher:
                     if hasattr(v, "to"):
                         d[k] = v.to(self.device)
             return batch
+        keep = []
         with torch.cuda.stream(self.stream):
             for d in batch:
                 for k, v in d.items():
                     if torch.is_tensor(v):
                         if not v.is_cuda and not v.is_pinned():
                             v = v.pin_memory()
+                        if not v.is_cuda:
+                            keep.append(v)
                         d[k] = v.to(self.device, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.stream)
+        # the page-locked sources stay referenced until their copies have run (the same care as PackedFeed's per-slot offsets vector:
+        # a source handed back to the host allocator at once may be rewritten before an asynchronous copy has read it)
+        self._pending = [(e, k_) for e, k_ in getattr(self, "_pending", []) if not e.query()]
+        self._pending.append((ev, keep))
         return batch
 
     def __iter__(self):
